@@ -1,0 +1,111 @@
+/*
+ * gl_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the arithmetic on the zkevm-prover STARK hot path, used only as the
+ * checker for the HIP implementation: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it; nothing under merlin-zkevm-prover_amd/ may.
+ *
+ * Parity status: PINNED for Poseidon / linear_hash / Merkle layout / FRI fold / ext-field / w(n) /
+ * shift by the reference's golden STARK proofs (the .npz files under tests/golden, derived from
+ * testvectors/aggregatedProof/recursive1.zkin.proof_{0..3}.json and
+ * testvectors/finalProof/recursive2.zkin.proof_{01,03,23}.json).  Large NTT/LDE values are pinned by
+ * algebra (unique DFT for the pinned w(n); O(n^2) DFT and Horner cross-checks) because the
+ * arithmetic library itself (git submodule src/goldilocks -> 0xPolygonHermez/goldilocks, commit
+ * unknown) is absent from /root/reference and the reference cannot be built here.
+ *
+ * Every function cites the reference file:line it follows.  Elements are canonical u64 in [0,p),
+ * p = 2^64 - 2^32 + 1; non-canonical inputs (>= p) are accepted and reduced.
+ */
+#ifndef GL_ORACLE_H
+#define GL_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLO_P 0xFFFFFFFF00000001ULL
+
+/* ---- base field (upstream Goldilocks::{add,sub,mul,inv,exp,w,shift}) ---- */
+uint64_t glo_canon(uint64_t a);
+uint64_t glo_add(uint64_t a, uint64_t b);
+uint64_t glo_sub(uint64_t a, uint64_t b);
+uint64_t glo_mul(uint64_t a, uint64_t b);
+uint64_t glo_pow(uint64_t a, uint64_t e);
+uint64_t glo_inv(uint64_t a);            /* inv(0) = 0 */
+uint64_t glo_w(unsigned nbits);          /* primitive 2^nbits-th root: 7277203076849721926^(2^(32-nbits)) */
+uint64_t glo_shift(void);                /* 49 */
+
+/* ---- cubic extension F_p[x]/(x^3 - x - 1)  (polinomial.hpp:172-207) ---- */
+void glo3_mul(uint64_t out[3], const uint64_t a[3], const uint64_t b[3]);
+void glo3_mul1(uint64_t out[3], const uint64_t a[3], uint64_t b);
+void glo3_add(uint64_t out[3], const uint64_t a[3], const uint64_t b[3]);
+void glo3_sub(uint64_t out[3], const uint64_t a[3], const uint64_t b[3]);
+void glo3_inv(uint64_t out[3], const uint64_t a[3]);
+
+/* ---- Poseidon (poseidon_g_executor.cpp:174-205,297-303; .hpp:33-50) ---- */
+void glo_poseidon_perm(uint64_t st[12]);
+void glo_hash_full_result(uint64_t out[12], const uint64_t in[12]); /* transcript.cpp:23,46 */
+void glo_hash(uint64_t out[4], const uint64_t in[12]);
+void glo_linear_hash(uint64_t out[4], const uint64_t *in, uint64_t size); /* SURVEY 8(a) a6 */
+/* nodes: (2*nrows-1)*4 u64, level-0 digests first (merkleTreeGL.hpp:61-68) */
+void glo_merkletree(uint64_t *nodes, const uint64_t *src, uint64_t ncols, uint64_t nrows);
+/* proof = width row values followed by ceil(log2 height) siblings (merkleTreeGL.cpp:12-35) */
+void glo_merkle_group_proof(uint64_t *proof, const uint64_t *nodes, const uint64_t *src,
+                            uint64_t height, uint64_t width, uint64_t idx);
+/* climb leaf=linear_hash(vals) with siblings; returns 1 if equals root */
+int glo_merkle_verify(const uint64_t root[4], const uint64_t *vals, uint64_t width,
+                      const uint64_t *siblings, uint64_t nsib, uint64_t idx);
+
+/* ---- NTT / LDE, row-major n x ncols, natural order in and out
+ *      (semantics: build_const_tree.cpp:42-140,160-196,198-331; call sites starks.cpp:52,261,284,325) ---- */
+void glo_ntt(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t ncols, int inverse);
+void glo_extend_pol(uint64_t *out, const uint64_t *in, uint64_t n_ext, uint64_t n, uint64_t ncols);
+/* O(n^2) definition, one column, for tests: X[k] = sum x[i] w^(ik) */
+void glo_dft_naive(uint64_t *dst, const uint64_t *src, uint64_t n, int inverse);
+
+/* ---- Transcript (transcript.cpp:4-87) ---- */
+typedef struct {
+    uint64_t state[4], pending[8], out[12];
+    unsigned pending_cursor, out_cursor;
+} glo_transcript;
+void glo_transcript_init(glo_transcript *t);
+void glo_transcript_put(glo_transcript *t, const uint64_t *in, uint64_t size);
+uint64_t glo_transcript_get_fields1(glo_transcript *t);
+void glo_transcript_get_field(glo_transcript *t, uint64_t out[3]);
+void glo_transcript_get_permutations(glo_transcript *t, uint64_t *res, uint64_t n, uint64_t nbits);
+
+/* ---- FRI (friProve.cpp:20-126,201-217,252-271) ---- */
+/* pol: 2^prev_bits ext elements (stride 3) -> out: 2^cur_bits ext elements.
+ * sinv base = shift^-(2^(nbits_ext - prev_bits)) */
+void glo_fri_fold(uint64_t *out, const uint64_t *pol, unsigned prev_bits, unsigned cur_bits,
+                  unsigned nbits_ext, const uint64_t special_x[3]);
+/* aux[i*h+j] = pol[j*w+i], w = 2^transpose_bits (ext elements) */
+void glo_fri_transpose(uint64_t *aux, const uint64_t *pol, uint64_t degree, unsigned transpose_bits);
+/* one FRI query evaluation: fold a single group of nX ext values (the golden-proof check):
+ * returns sum_k INTT_nX(vals)[k] * (sinv_base * w(prev_bits)^-g)^k * x^k */
+void glo_fri_fold_group(uint64_t out[3], const uint64_t *vals, unsigned nx_bits, unsigned prev_bits,
+                        unsigned nbits_ext, uint64_t g, const uint64_t special_x[3]);
+
+/* ---- step-4 split (starks.cpp:265-280): qq2[(k*qdeg+p)*3..] = qq1[(p*N+k)*3..] * shift^(-N*p) ---- */
+void glo_q_split(uint64_t *qq2, const uint64_t *qq1, uint64_t n, unsigned qdeg);
+/* ---- evmap (starks.cpp:555-668): evals[i] = sum_k L[k] * pol_i[k << ext_bits]
+ *      pol i is described by (ptr, dim, stride); L = lpev if prime[i] else lev ---- */
+void glo_evmap(uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits,
+               const uint64_t *const *pol_ptr, const uint32_t *pol_dim, const uint64_t *pol_stride,
+               const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev);
+/* ---- element-wise ext inverse (polinomial.hpp:612-720 batchInverse*; exact field inverse) ---- */
+void glo_batch_inverse3(uint64_t *res, const uint64_t *src, uint64_t n);
+/* ---- tables: x_n / x_2ns geometric sequences (starks.hpp:149-160), ZhInv (zhInv.cpp:7-31) ---- */
+void glo_geom_seq(uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio);
+void glo_zhinv(uint64_t *out, unsigned nbits, unsigned nbits_ext);
+/* LEv: out[k] = xis^k (ext), k < n   (starks.cpp:305-323) */
+void glo_geom_seq3(uint64_t *out, uint64_t n, const uint64_t ratio[3]);
+
+int glo_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
