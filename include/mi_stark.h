@@ -1,0 +1,174 @@
+/*
+ * mi_stark.h -- C ABI of the MI355X-native STARK hot path (libmi_stark.so).
+ *
+ * This is the drop-in boundary for the zkevm-prover's batch-proof loop.  The reference has no FFI:
+ * its boundary is the link-time C++ surface of the (un-vendored) src/goldilocks submodule plus three
+ * src/starkpil classes.  Each entry point below names the reference interface it
+ * replaces; the C++ header shims in merlin-zkevm-prover_amd/host/ (NTT_Goldilocks, PoseidonGoldilocks,
+ * MerkleTreeGL, FRIProve, Transcript ...) forward to these, so src/starkpil compiles unchanged.
+ *
+ * Conventions
+ *   - Elements are uint64_t Goldilocks values (p = 2^64 - 2^32 + 1), row-major: element (row r, col c)
+ *     of a matrix lives at base[r * pitch + c] (commit_pols.hpp:1461, stark_info.cpp:473-482).
+ *     Inputs may be any u64 encoding; outputs are canonical (< p).
+ *   - "_dev" functions take HBM pointers (hipMalloc / torch device memory) and enqueue work on the
+ *     context's stream without synchronising.  Functions without the suffix take HOST pointers exactly
+ *     like the reference's methods, stage through HBM and return after the result is back in host memory.
+ *   - The caller owns every buffer; the library never frees or retains them.
+ *   - Return value: 0 on success, negative mi_status otherwise; mi_last_error() gives the message.
+ *     The reference's convention is log + exitProcess() (starks.hpp:99-100): the C++ shims map a
+ *     non-zero status onto that.  There is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with MI_ERR_NO_DEVICE.
+ */
+#ifndef MI_STARK_H
+#define MI_STARK_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx mi_ctx;
+
+typedef enum {
+    MI_OK = 0,
+    MI_ERR_NO_DEVICE = -1,
+    MI_ERR_INVALID = -2,   /* bad argument (non power-of-two size, null pointer, ...) */
+    MI_ERR_HIP = -3,       /* a HIP runtime call failed */
+    MI_ERR_NOMEM = -4,
+    MI_ERR_UNSUPPORTED = -5
+} mi_status;
+
+#define MI_HASH_SIZE 4        /* HASH_SIZE / CAPACITY   (merklehash_goldilocks.hpp) */
+#define MI_RATE 8
+#define MI_SPONGE_WIDTH 12
+#define MI_FIELD_EXTENSION 3  /* FIELD_EXTENSION        (goldilocks_cubic_extension.hpp) */
+
+/* ------------------------------------------------------------------ context */
+/* One context per GPU/process (one process per GPU).  device < 0 keeps the current device. */
+int mi_ctx_create(mi_ctx **out, int device);
+void mi_ctx_destroy(mi_ctx *ctx);
+/* Use a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int mi_ctx_set_stream(mi_ctx *ctx, void *hip_stream);
+int mi_ctx_sync(mi_ctx *ctx);
+/* Scratch HBM the library may allocate lazily for NTT/LDE ping-pong buffers (default 16 GiB,
+ * clamped to what the problem needs).  Wide LDEs are processed in column chunks that fit it. */
+int mi_ctx_set_workspace_limit(mi_ctx *ctx, uint64_t bytes);
+const char *mi_last_error(void);
+const char *mi_version(void);
+int mi_device_count(void);
+
+/* ------------------------------------------------------------------ NTT / LDE
+ * Replaces NTT_Goldilocks::{NTT, INTT, extendPol} (call sites starks.cpp:52,133,214,261,284,325-326;
+ * friProve.cpp:100-102).  Natural order in and out; columns independent; dst == src allowed.
+ * The reference's buffer / nphase / nblock arguments are CPU blocking hints and have no equivalent. */
+int mi_ntt_dev(mi_ctx *ctx, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch,
+               uint64_t n, uint64_t ncols, int inverse);
+/* out[i] = P_col(shift * w_ext^i), i < n_ext  (= INTT_n, scale by shift^k, zero-pad, NTT_n_ext) */
+int mi_lde_dev(mi_ctx *ctx, uint64_t *out, uint64_t out_pitch, const uint64_t *in, uint64_t in_pitch,
+               uint64_t n_ext, uint64_t n, uint64_t ncols);
+int mi_ntt(mi_ctx *ctx, uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t ncols, int inverse);
+int mi_lde(mi_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t n_ext, uint64_t n, uint64_t ncols);
+
+/* ------------------------------------------------------------------ Poseidon / Merkle
+ * Replaces PoseidonGoldilocks::{hash_full_result, hash, linear_hash, merkletree_avx, merkletree_avx512,
+ * merkletree} (transcript.cpp:23,46; merkleTreeGL.cpp:37-44; build_const_tree.cpp:382). */
+int mi_poseidon_hash_full_result(mi_ctx *ctx, uint64_t out[12], const uint64_t in[12]);          /* host ptrs */
+int mi_poseidon_hash(mi_ctx *ctx, uint64_t out[4], const uint64_t in[12]);                       /* host ptrs */
+int mi_poseidon_linear_hash(mi_ctx *ctx, uint64_t out[4], const uint64_t *in, uint64_t size);    /* host ptrs */
+/* count independent permutations, in/out: count x 12 (device) */
+int mi_poseidon_permute_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t count);
+/* digests[r*4..] = linear_hash(row r)  (device) */
+int mi_linear_hash_rows_dev(mi_ctx *ctx, uint64_t *digests, const uint64_t *src, uint64_t pitch,
+                            uint64_t ncols, uint64_t nrows);
+/* nodes: (2*nrows-1)*4 u64, leaves first then each level appended, root = last 4
+ * (merkleTreeGL.hpp:61-68).  nrows must be a power of two. */
+int mi_merkle_build_dev(mi_ctx *ctx, uint64_t *nodes, const uint64_t *src, uint64_t pitch,
+                        uint64_t ncols, uint64_t nrows);
+/* Finish a tree whose level-0 digests (nleaves*4) are already at nodes[0..]; used by the multi-GPU path
+ * to hash the top log2(G) levels over the all-gathered subtree roots. */
+int mi_merkle_levels_dev(mi_ctx *ctx, uint64_t *nodes, uint64_t nleaves);
+int mi_merkle_build(mi_ctx *ctx, uint64_t *nodes, const uint64_t *src, uint64_t ncols, uint64_t nrows);
+static inline uint64_t mi_merkle_num_nodes_elems(uint64_t nrows) { return (2 * nrows - 1) * MI_HASH_SIZE; }
+static inline uint64_t mi_merkle_proof_levels(uint64_t nrows)
+{
+    uint64_t l = 0;
+    while ((1ULL << l) < nrows) l++;
+    return l;
+}
+/* Replaces MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for a batch of queries:
+ * proofs[q] = row idx[q] (width values) followed by levels x 4 siblings; proof stride = width + 4*levels.
+ * idx is a HOST array; src/nodes/proofs are device pointers. */
+int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src,
+                               uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx,
+                               uint64_t nqueries);
+
+/* ------------------------------------------------------------------ FRI
+ * Replaces the fold loop of FRIProve::prove (friProve.cpp:44-108): pol holds 2^prev_bits cubic-extension
+ * elements (3 u64 each), out receives 2^cur_bits.  nbits_ext is the size of the first FRI domain, so the
+ * coset factor is shift^-(2^(nbits_ext - prev_bits)) (friProve.cpp:143-147). */
+int mi_fri_fold_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *pol, unsigned prev_bits, unsigned cur_bits,
+                    unsigned nbits_ext, const uint64_t special_x[3] /* host */);
+/* FRIProve::getTransposed (friProve.cpp:252-271): aux[i*h+j] = pol[j*w+i], w = 2^transpose_bits */
+int mi_fri_transpose_dev(mi_ctx *ctx, uint64_t *aux, const uint64_t *pol, uint64_t degree, unsigned transpose_bits);
+
+/* ------------------------------------------------------------------ the rest of Starks::genProof's
+ * device-friendly loops */
+/* step-4 split (starks.cpp:265-280): qq2 (n_ext x qdeg*3, zero-filled by the call) from qq1 (n_ext x 3) */
+int mi_q_split_dev(mi_ctx *ctx, uint64_t *qq2, const uint64_t *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg);
+/* evmap (starks.cpp:555-668): evals[i] = sum_k L[k] * pol_i[(k << ext_bits) * stride_i], L = lpev if
+ * prime[i] else lev.  pol_ptr are device pointers to element (row 0) of each polynomial; the four
+ * descriptor arrays are HOST arrays of length n_evals. */
+int mi_evmap_dev(mi_ctx *ctx, uint64_t *evals /* device, n_evals*3 */, uint64_t n_evals, uint64_t n,
+                 unsigned ext_bits, const uint64_t *const *pol_ptr, const uint32_t *pol_dim,
+                 const uint64_t *pol_stride, const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev);
+/* element-wise inverse of n cubic-extension elements (Polinomial::batchInverse[Parallel],
+ * polinomial.hpp:612-720); res == src allowed; inverse of 0 is 0 */
+int mi_batch_inverse3_dev(mi_ctx *ctx, uint64_t *res, const uint64_t *src, uint64_t n);
+/* out[i] = start * ratio^i  (x_n, x_2ns: starks.hpp:149-160,176-183) */
+int mi_geom_seq_dev(mi_ctx *ctx, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio);
+/* out[k] = ratio^k in the cubic extension (LEv / LpEv: starks.cpp:311-323) */
+int mi_geom_seq3_dev(mi_ctx *ctx, uint64_t *out, uint64_t n, const uint64_t ratio[3] /* host */);
+/* xDivXSubXi (starks.cpp:350-365): out[k] = x[k] / (x[k] - xi) in the cubic extension, x base field */
+int mi_x_div_x_sub_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *x, uint64_t n, const uint64_t xi[3] /* host */);
+/* ZhInv table (zhInv.cpp:7-31), HOST output of 2^(nbits_ext-nbits) values */
+int mi_zhinv(mi_ctx *ctx, uint64_t *out, unsigned nbits, unsigned nbits_ext);
+
+/* ------------------------------------------------------------------ utilities */
+/* Deterministic synthetic trace: out[i] = splitmix64(seed, i+1) reduced mod p. */
+int mi_fill_synthetic_dev(mi_ctx *ctx, uint64_t *out, uint64_t count, uint64_t seed);
+/* Column shard of the same synthetic matrix: out[r*out_pitch + c] = value of global element
+ * (r, col0 + c) of a matrix with global_cols columns, so any column partition reproduces one trace. */
+int mi_fill_synthetic_2d_dev(mi_ctx *ctx, uint64_t *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols,
+                             uint64_t global_cols, uint64_t col0, uint64_t seed);
+/* dst[r*dst_pitch + c] = canonical(src[r*src_pitch + c]): repacks the column slabs received in the
+ * multi-GPU columns->rows exchange into row-major rows. */
+int mi_copy_2d_dev(mi_ctx *ctx, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch,
+                   uint64_t nrows, uint64_t ncols);
+void *mi_dev_alloc(mi_ctx *ctx, uint64_t bytes);
+int mi_dev_free(mi_ctx *ctx, void *p);
+int mi_copy_h2d(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* Selects the Poseidon MDS code path (0 = 32-bit halves / v_mad_u64_u32, 1 = 22-bit limbs /
+ * v_mad_u32_u24).  Both are bit-identical; exposed for benchmarking. */
+int mi_set_poseidon_variant(mi_ctx *ctx, int variant);
+
+/* Timing hooks used by bench.py: HIP events recorded on the context's stream. */
+int mi_timer_start(mi_ctx *ctx, int slot);
+int mi_timer_stop(mi_ctx *ctx, int slot);
+int mi_timer_elapsed_ms(mi_ctx *ctx, int slot, float *ms); /* synchronises on the stop event */
+
+/* ------------------------------------------------------------------ debug hooks (tests only)
+ * Run the same inline arithmetic the kernels use on the HOST CPU so that it can be checked on machines
+ * without a GPU.  Not used by any entry point above. */
+void mi_dbg_host_poseidon_permute(uint64_t st[12], int variant);
+uint64_t mi_dbg_host_mul(uint64_t a, uint64_t b);
+void mi_dbg_host_e3_mul(uint64_t out[3], const uint64_t a[3], const uint64_t b[3]);
+void mi_dbg_host_e3_inv(uint64_t out[3], const uint64_t a[3]);
+void mi_dbg_host_dft16(uint64_t x[16], int log_size, int inverse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

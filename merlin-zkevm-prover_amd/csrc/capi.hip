@@ -1,0 +1,471 @@
+// capi.hip -- extern "C" entry points of libmi_stark.so (see include/mi_stark.h for the contract and the
+// reference interfaces each one replaces).  No CPU fallback exists: without a HIP device every compute
+// call returns MI_ERR_NO_DEVICE.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void mi_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *mi_last_error(void) { return g_err; }
+extern "C" const char *mi_version(void) { return "mi_stark 0.1 (gfx950)"; }
+
+extern "C" int mi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define CTX_OK(ctx)                                   \
+    do {                                              \
+        if (!(ctx)) {                                 \
+            mi_set_error("%s: null context", __func__); \
+            return MI_ERR_INVALID;                    \
+        }                                             \
+    } while (0)
+
+extern "C" int mi_ctx_create(mi_ctx **out, int device)
+{
+    if (!out) return MI_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        mi_set_error("no HIP device available: libmi_stark has no CPU fallback");
+        return MI_ERR_NO_DEVICE;
+    }
+    if (device >= n) {
+        mi_set_error("device %d out of range (%d devices)", device, n);
+        return MI_ERR_INVALID;
+    }
+    mi_ctx *c = new mi_ctx();
+    if (device >= 0) MI_HIP_CHECK(hipSetDevice(device));
+    MI_HIP_CHECK(hipGetDevice(&c->device));
+    hipDeviceProp_t prop;
+    MI_HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
+    c->cu_count = prop.multiProcessorCount;
+    MI_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    MI_HIP_CHECK(hipMalloc((void **)&c->small, 4096));
+    for (int i = 0; i < 8; i++) {
+        MI_HIP_CHECK(hipEventCreate(&c->ev_start[i]));
+        MI_HIP_CHECK(hipEventCreate(&c->ev_stop[i]));
+    }
+    *out = c;
+    return MI_OK;
+}
+
+extern "C" void mi_ctx_destroy(mi_ctx *c)
+{
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->owned) (void)hipFree(p);
+    if (c->workspace) (void)hipFree(c->workspace);
+    if (c->w256) (void)hipFree(c->w256);
+    if (c->small) (void)hipFree(c->small);
+    for (int i = 0; i < 8; i++) {
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+    }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mi_ctx_set_stream(mi_ctx *c, void *s)
+{
+    CTX_OK(c);
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (s) {
+        c->stream = (hipStream_t)s;
+        c->own_stream = false;
+    } else {
+        MI_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_sync(mi_ctx *c)
+{
+    CTX_OK(c);
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_ctx_set_workspace_limit(mi_ctx *c, uint64_t bytes)
+{
+    CTX_OK(c);
+    MI_REQUIRE(bytes >= (1ull << 20), "workspace limit must be at least 1 MiB");
+    c->workspace_limit = bytes;
+    return MI_OK;
+}
+
+int mi_ensure_workspace(mi_ctx *c, uint64_t bytes)
+{
+    if (bytes <= c->workspace_bytes) return MI_OK;
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->workspace) MI_HIP_CHECK(hipFree(c->workspace));
+    c->workspace = nullptr;
+    c->workspace_bytes = 0;
+    hipError_t e = hipMalloc((void **)&c->workspace, bytes);
+    if (e != hipSuccess) {
+        mi_set_error("cannot allocate %llu bytes of NTT workspace: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        return MI_ERR_NOMEM;
+    }
+    c->workspace_bytes = bytes;
+    return MI_OK;
+}
+
+extern "C" int mi_set_poseidon_variant(mi_ctx *c, int v)
+{
+    CTX_OK(c);
+    MI_REQUIRE(v == 0 || v == 1, "variant must be 0 or 1");
+    c->poseidon_variant = v;
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ NTT / LDE
+extern "C" int mi_ntt_dev(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch, uint64_t n,
+                          uint64_t ncols, int inverse)
+{
+    CTX_OK(c);
+    MI_REQUIRE((dst && src) || n == 0 || ncols == 0, "null buffer");
+    return launch_ntt(c, (u64 *)dst, dst_pitch, (const u64 *)src, src_pitch, n, ncols, inverse);
+}
+
+extern "C" int mi_lde_dev(mi_ctx *c, uint64_t *out, uint64_t out_pitch, const uint64_t *in, uint64_t in_pitch, uint64_t n_ext,
+                          uint64_t n, uint64_t ncols)
+{
+    CTX_OK(c);
+    MI_REQUIRE((out && in) || n == 0 || ncols == 0, "null buffer");
+    return launch_lde(c, (u64 *)out, out_pitch, (const u64 *)in, in_pitch, n_ext, n, ncols);
+}
+
+// host-pointer staging helper: device buffers owned for the duration of one call
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(uint64_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) {
+            mi_set_error("hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+            return MI_ERR_NOMEM;
+        }
+        return MI_OK;
+    }
+};
+
+extern "C" int mi_ntt(mi_ctx *c, uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t ncols, int inverse)
+{
+    CTX_OK(c);
+    if (n == 0 || ncols == 0) return MI_OK;
+    MI_REQUIRE(dst && src, "null buffer");
+    const uint64_t bytes = n * ncols * 8;
+    DevBuf d;
+    MI_TRY(d.alloc(bytes));
+    MI_HIP_CHECK(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_ntt(c, (u64 *)d.p, ncols, (const u64 *)d.p, ncols, n, ncols, inverse));
+    MI_HIP_CHECK(hipMemcpyAsync(dst, d.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_lde(mi_ctx *c, uint64_t *out, const uint64_t *in, uint64_t n_ext, uint64_t n, uint64_t ncols)
+{
+    CTX_OK(c);
+    if (n == 0 || ncols == 0) return MI_OK;
+    MI_REQUIRE(out && in, "null buffer");
+    DevBuf di, dout;
+    MI_TRY(di.alloc(n * ncols * 8));
+    MI_TRY(dout.alloc(n_ext * ncols * 8));
+    MI_HIP_CHECK(hipMemcpyAsync(di.p, in, n * ncols * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_lde(c, (u64 *)dout.p, ncols, (const u64 *)di.p, ncols, n_ext, n, ncols));
+    MI_HIP_CHECK(hipMemcpyAsync(out, dout.p, n_ext * ncols * 8, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ Poseidon / Merkle
+extern "C" int mi_poseidon_permute_dev(mi_ctx *c, uint64_t *out, const uint64_t *in, uint64_t count)
+{
+    CTX_OK(c);
+    MI_REQUIRE((out && in) || count == 0, "null buffer");
+    return launch_permute(c, (u64 *)out, (const u64 *)in, count);
+}
+
+extern "C" int mi_poseidon_hash_full_result(mi_ctx *c, uint64_t out[12], const uint64_t in[12])
+{
+    CTX_OK(c);
+    MI_REQUIRE(out && in, "null buffer");
+    MI_HIP_CHECK(hipMemcpyAsync(c->small, in, 96, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_permute(c, c->small + 16, c->small, 1));
+    MI_HIP_CHECK(hipMemcpyAsync(out, c->small + 16, 96, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_poseidon_hash(mi_ctx *c, uint64_t out[4], const uint64_t in[12])
+{
+    uint64_t full[12];
+    MI_TRY(mi_poseidon_hash_full_result(c, full, in));
+    memcpy(out, full, 32);
+    return MI_OK;
+}
+
+extern "C" int mi_linear_hash_rows_dev(mi_ctx *c, uint64_t *digests, const uint64_t *src, uint64_t pitch, uint64_t ncols,
+                                       uint64_t nrows)
+{
+    CTX_OK(c);
+    MI_REQUIRE((digests && (src || ncols == 0)) || nrows == 0, "null buffer");
+    MI_REQUIRE(pitch >= ncols, "pitch smaller than ncols");
+    return launch_linear_hash_rows(c, (u64 *)digests, (const u64 *)src, pitch, ncols, nrows);
+}
+
+extern "C" int mi_poseidon_linear_hash(mi_ctx *c, uint64_t out[4], const uint64_t *in, uint64_t size)
+{
+    CTX_OK(c);
+    MI_REQUIRE(out && (in || size == 0), "null buffer");
+    DevBuf d;
+    MI_TRY(d.alloc(size * 8 + 32));
+    if (size) MI_HIP_CHECK(hipMemcpyAsync((char *)d.p + 32, in, size * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_linear_hash_rows(c, (u64 *)d.p, (const u64 *)d.p + 4, size, size, 1));
+    MI_HIP_CHECK(hipMemcpyAsync(out, d.p, 32, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_merkle_levels_dev(mi_ctx *c, uint64_t *nodes, uint64_t nleaves)
+{
+    CTX_OK(c);
+    if (nleaves == 0) return MI_OK;
+    MI_REQUIRE(nodes, "null buffer");
+    return launch_merkle_levels(c, (u64 *)nodes, nleaves);
+}
+
+extern "C" int mi_merkle_build_dev(mi_ctx *c, uint64_t *nodes, const uint64_t *src, uint64_t pitch, uint64_t ncols,
+                                   uint64_t nrows)
+{
+    CTX_OK(c);
+    if (nrows == 0) return MI_OK; // merkletree() returns immediately on zero rows
+    MI_REQUIRE(nodes && (src || ncols == 0), "null buffer");
+    MI_REQUIRE(is_pow2(nrows), "number of rows must be a power of two");
+    MI_REQUIRE(pitch >= ncols, "pitch smaller than ncols");
+    MI_TRY(launch_linear_hash_rows(c, (u64 *)nodes, (const u64 *)src, pitch, ncols, nrows));
+    return launch_merkle_levels(c, (u64 *)nodes, nrows);
+}
+
+extern "C" int mi_merkle_build(mi_ctx *c, uint64_t *nodes, const uint64_t *src, uint64_t ncols, uint64_t nrows)
+{
+    CTX_OK(c);
+    if (nrows == 0) return MI_OK;
+    MI_REQUIRE(nodes && (src || ncols == 0), "null buffer");
+    DevBuf ds, dn;
+    MI_TRY(ds.alloc(nrows * ncols * 8));
+    MI_TRY(dn.alloc(mi_merkle_num_nodes_elems(nrows) * 8));
+    MI_HIP_CHECK(hipMemcpyAsync(ds.p, src, nrows * ncols * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(mi_merkle_build_dev(c, (uint64_t *)dn.p, (const uint64_t *)ds.p, ncols, ncols, nrows));
+    MI_HIP_CHECK(hipMemcpyAsync(nodes, dn.p, mi_merkle_num_nodes_elems(nrows) * 8, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src,
+                                          uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx, uint64_t nq)
+{
+    CTX_OK(c);
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(proofs && nodes && src && idx, "null buffer");
+    for (uint64_t q = 0; q < nq; q++) MI_REQUIRE(idx[q] < height, "query index out of range");
+    DevBuf di;
+    MI_TRY(di.alloc(nq * 8));
+    MI_HIP_CHECK(hipMemcpyAsync(di.p, idx, nq * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_group_proofs(c, (u64 *)proofs, (const u64 *)nodes, (const u64 *)src, pitch, height, width, (const u64 *)di.p, nq));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // di is released on return
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ FRI and the rest
+extern "C" int mi_fri_fold_dev(mi_ctx *c, uint64_t *out, const uint64_t *pol, unsigned prev_bits, unsigned cur_bits,
+                               unsigned nbits_ext, const uint64_t x[3])
+{
+    CTX_OK(c);
+    MI_REQUIRE(out && pol && x, "null buffer");
+    const u64 xe[3] = {x[0], x[1], x[2]};
+    return launch_fri_fold(c, (u64 *)out, (const u64 *)pol, prev_bits, cur_bits, nbits_ext, xe);
+}
+
+extern "C" int mi_fri_transpose_dev(mi_ctx *c, uint64_t *aux, const uint64_t *pol, uint64_t degree, unsigned tbits)
+{
+    CTX_OK(c);
+    MI_REQUIRE((aux && pol) || degree == 0, "null buffer");
+    return launch_fri_transpose(c, (u64 *)aux, (const u64 *)pol, degree, tbits);
+}
+
+extern "C" int mi_q_split_dev(mi_ctx *c, uint64_t *qq2, const uint64_t *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg)
+{
+    CTX_OK(c);
+    MI_REQUIRE(qq2 && qq1, "null buffer");
+    return launch_q_split(c, (u64 *)qq2, (const u64 *)qq1, n, n_ext, qdeg);
+}
+
+extern "C" int mi_evmap_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits,
+                            const uint64_t *const *pol_ptr, const uint32_t *pol_dim, const uint64_t *pol_stride,
+                            const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev)
+{
+    CTX_OK(c);
+    if (n_evals == 0) return MI_OK;
+    MI_REQUIRE(evals && pol_ptr && pol_dim && pol_stride && prime && lev && lpev, "null buffer");
+    return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
+                        prime, (const u64 *)lev, (const u64 *)lpev);
+}
+
+extern "C" int mi_batch_inverse3_dev(mi_ctx *c, uint64_t *res, const uint64_t *src, uint64_t n)
+{
+    CTX_OK(c);
+    MI_REQUIRE((res && src) || n == 0, "null buffer");
+    return launch_batch_inverse3(c, (u64 *)res, (const u64 *)src, n);
+}
+
+extern "C" int mi_geom_seq_dev(mi_ctx *c, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio)
+{
+    CTX_OK(c);
+    MI_REQUIRE(out || n == 0, "null buffer");
+    return launch_geom_seq(c, (u64 *)out, n, start, ratio);
+}
+
+extern "C" int mi_geom_seq3_dev(mi_ctx *c, uint64_t *out, uint64_t n, const uint64_t ratio[3])
+{
+    CTX_OK(c);
+    MI_REQUIRE((out || n == 0) && ratio, "null buffer");
+    const u64 r[3] = {ratio[0], ratio[1], ratio[2]};
+    return launch_geom_seq3(c, (u64 *)out, n, r);
+}
+
+extern "C" int mi_x_div_x_sub_dev(mi_ctx *c, uint64_t *out, const uint64_t *x, uint64_t n, const uint64_t xi[3])
+{
+    CTX_OK(c);
+    MI_REQUIRE(((out && x) || n == 0) && xi, "null buffer");
+    const u64 e[3] = {xi[0], xi[1], xi[2]};
+    return launch_x_div_x_sub(c, (u64 *)out, (const u64 *)x, n, e);
+}
+
+extern "C" int mi_zhinv(mi_ctx *c, uint64_t *out, unsigned nbits, unsigned nbits_ext)
+{
+    CTX_OK(c);
+    MI_REQUIRE(out && nbits > 0 && nbits < nbits_ext && nbits_ext - nbits <= 8, "need 0 < nbits < nbits_ext, blow-up <= 256");
+    // ZHInv[i] = 1 / (shift^(2^nbits) * w(extendBits)^i - 1)   (zhInv.cpp:7-31)
+    const unsigned ext = nbits_ext - nbits;
+    const uint64_t cnt = 1ull << ext;
+    u64 sn = 49;
+    for (unsigned i = 0; i < nbits; i++) sn = gl::mul(sn, sn);
+    u64 w = 7277203076849721926ULL;
+    for (unsigned i = ext; i < 32; i++) w = gl::mul(w, w);
+    MI_TRY(launch_zhinv(c, c->small, cnt, sn, w)); // cnt <= 256 values fit the 4 KiB scratch
+    MI_HIP_CHECK(hipMemcpyAsync(out, c->small, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ utilities
+extern "C" int mi_fill_synthetic_dev(mi_ctx *c, uint64_t *out, uint64_t count, uint64_t seed)
+{
+    CTX_OK(c);
+    MI_REQUIRE(out || count == 0, "null buffer");
+    return launch_fill_synthetic(c, (u64 *)out, count, seed);
+}
+
+extern "C" int mi_fill_synthetic_2d_dev(mi_ctx *c, uint64_t *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols,
+                                        uint64_t global_cols, uint64_t col0, uint64_t seed)
+{
+    CTX_OK(c);
+    MI_REQUIRE(out || nrows * ncols == 0, "null buffer");
+    MI_REQUIRE(out_pitch >= ncols && col0 + ncols <= global_cols, "bad column window");
+    return launch_fill_synthetic_2d(c, (u64 *)out, out_pitch, nrows, ncols, global_cols, col0, seed);
+}
+
+extern "C" int mi_copy_2d_dev(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch,
+                              uint64_t nrows, uint64_t ncols)
+{
+    CTX_OK(c);
+    MI_REQUIRE((dst && src) || nrows * ncols == 0, "null buffer");
+    MI_REQUIRE(dst_pitch >= ncols && src_pitch >= ncols, "pitch smaller than ncols");
+    return launch_copy_2d(c, (u64 *)dst, dst_pitch, (const u64 *)src, src_pitch, nrows, ncols);
+}
+
+extern "C" void *mi_dev_alloc(mi_ctx *c, uint64_t bytes)
+{
+    if (!c) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        mi_set_error("hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" int mi_dev_free(mi_ctx *c, void *p)
+{
+    CTX_OK(c);
+    if (p) {
+        MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+        MI_HIP_CHECK(hipFree(p));
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_copy_h2d(mi_ctx *c, void *dst, const void *src, uint64_t bytes)
+{
+    CTX_OK(c);
+    MI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_copy_d2h(mi_ctx *c, void *dst, const void *src, uint64_t bytes)
+{
+    CTX_OK(c);
+    MI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_timer_start(mi_ctx *c, int slot)
+{
+    CTX_OK(c);
+    MI_REQUIRE(slot >= 0 && slot < 8, "timer slot out of range");
+    MI_HIP_CHECK(hipEventRecord(c->ev_start[slot], c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_timer_stop(mi_ctx *c, int slot)
+{
+    CTX_OK(c);
+    MI_REQUIRE(slot >= 0 && slot < 8, "timer slot out of range");
+    MI_HIP_CHECK(hipEventRecord(c->ev_stop[slot], c->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_timer_elapsed_ms(mi_ctx *c, int slot, float *ms)
+{
+    CTX_OK(c);
+    MI_REQUIRE(slot >= 0 && slot < 8 && ms, "bad timer arguments");
+    MI_HIP_CHECK(hipEventSynchronize(c->ev_stop[slot]));
+    MI_HIP_CHECK(hipEventElapsedTime(ms, c->ev_start[slot], c->ev_stop[slot]));
+    return MI_OK;
+}

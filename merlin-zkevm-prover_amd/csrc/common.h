@@ -1,0 +1,102 @@
+// common.h -- context, error plumbing and internal launcher prototypes of libmi_stark.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <map>
+#include <vector>
+#include "../../include/mi_stark.h"
+#include "gl_math.h"
+
+void mi_set_error(const char *fmt, ...);
+
+#define MI_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            mi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MI_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define MI_REQUIRE(cond, msg)                                    \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            mi_set_error("%s: %s", __func__, msg);               \
+            return MI_ERR_INVALID;                               \
+        }                                                        \
+    } while (0)
+
+#define MI_TRY(expr)               \
+    do {                           \
+        int s_ = (expr);           \
+        if (s_ != MI_OK) return s_; \
+    } while (0)
+
+// Two-level power table: g^e = hi[e >> lo_bits] * lo[e & mask]   (lo[j] = s0 * g^j, hi[j] = g^(j << lo_bits))
+struct PowTable {
+    u64 *lo = nullptr, *hi = nullptr;
+    uint32_t lo_bits = 0;
+};
+
+struct NttPlan {
+    uint32_t log_n = 0;
+    PowTable tw;        // w_n^e, e < n
+    PowTable inv_scale; // 1/n (constant table, g = 1)
+    PowTable lde_scale; // shift^k / n
+};
+
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int poseidon_variant = 1;
+    uint64_t workspace_limit = 16ULL << 30;
+    u64 *workspace = nullptr;
+    uint64_t workspace_bytes = 0;
+    u64 *w256 = nullptr; // w_256^j, j < 256
+    u64 *small = nullptr; // 4 KiB device scratch for host-pointer single hashes
+    std::map<uint32_t, NttPlan> plans;
+    std::vector<void *> owned; // tables to free
+    hipEvent_t ev_start[8] = {}, ev_stop[8] = {};
+    int cu_count = 256;
+};
+
+int mi_ensure_workspace(mi_ctx *ctx, uint64_t bytes);
+int mi_get_plan(mi_ctx *ctx, uint32_t log_n, NttPlan **plan);
+int mi_make_pow_table(mi_ctx *ctx, PowTable *t, uint64_t count_log, u64 s0, u64 g);
+
+static inline uint32_t ilog2_u64(uint64_t n)
+{
+    uint32_t b = 0;
+    while ((1ULL << b) < n) b++;
+    return b;
+}
+static inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+
+// ---- internal launchers (defined in the .hip files)
+int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count);
+int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows);
+int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves);
+int launch_group_proofs(mi_ctx *ctx, u64 *proofs, const u64 *nodes, const u64 *src, uint64_t pitch, uint64_t height,
+                        uint64_t width, const u64 *idx_dev, uint64_t nq);
+int launch_ntt(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t n, uint64_t ncols,
+               int inverse);
+int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_t in_pitch, uint64_t n_ext, uint64_t n,
+               uint64_t ncols);
+int launch_fill_pow(mi_ctx *ctx, u64 *out, uint64_t count, u64 s0, u64 g, uint64_t stride_exp);
+int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, unsigned cur_bits, unsigned nbits_ext,
+                    const u64 x[3]);
+int launch_fri_transpose(mi_ctx *ctx, u64 *aux, const u64 *pol, uint64_t degree, unsigned tbits);
+int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg);
+int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,
+                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev);
+int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n);
+int launch_geom_seq(mi_ctx *ctx, u64 *out, uint64_t n, u64 start, u64 ratio);
+int launch_geom_seq3(mi_ctx *ctx, u64 *out, uint64_t n, const u64 ratio[3]);
+int launch_x_div_x_sub(mi_ctx *ctx, u64 *out, const u64 *x, uint64_t n, const u64 xi[3]);
+int launch_zhinv(mi_ctx *ctx, u64 *out, uint64_t cnt, u64 sn, u64 w);
+int launch_fill_synthetic(mi_ctx *ctx, u64 *out, uint64_t count, u64 seed);
+int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols, uint64_t global_cols,
+                             uint64_t col0, u64 seed);
+int launch_copy_2d(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols);

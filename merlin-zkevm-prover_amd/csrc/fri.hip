@@ -1,0 +1,381 @@
+// fri.hip -- FRI fold / transpose and the remaining device-friendly loops of Starks::genProof.
+//
+// Replaces: FRIProve::prove fold loop (friProve.cpp:44-108, polMulAxi :192-200, evalPol :201-217),
+// FRIProve::getTransposed (:252-271), the step-4 split (starks.cpp:265-280), Starks::evmap
+// (starks.cpp:555-668), Polinomial::batchInverse[Parallel] (polinomial.hpp:612-720), the x / x_n / x_2ns /
+// LEv tables (starks.hpp:149-183, starks.cpp:305-323), xDivXSubXi (starks.cpp:350-365), ZhInv (zhInv.cpp).
+// All of it is exact field arithmetic, so any evaluation order is bit-identical to the reference's.
+#include "common.h"
+#include "ntt_math.h"
+#include <algorithm>
+
+using gl::E3;
+
+// One folded element per lane.  Group g gathers pol[i * 2^cur + g], i < nX (consecutive lanes read
+// consecutive 24-byte elements: coalesced), INTT_nX in registers one extension component at a time,
+// coefficients parked in LDS ([k][d][lane], conflict free), then Horner in y = sinv_g * special_x, which
+// equals sum_k (c_k * sinv_g^k) * x^k of polMulAxi + evalPol.
+template <int LOG_NX>
+__global__ __launch_bounds__(64) void k_fri_fold(u64 *__restrict__ out, const u64 *__restrict__ pol, uint32_t cur_bits,
+                                                 u64 sinv0, u64 wi, E3 x, u64 nx_inv)
+{
+    constexpr int NX = 1 << LOG_NX;
+    extern __shared__ __attribute__((aligned(16))) u64 smem[]; // [NX][3][64]
+    const uint32_t lane = threadIdx.x;
+    const uint64_t g = (uint64_t)blockIdx.x * 64 + lane;
+    const uint64_t pol2n = 1ull << cur_bits;
+    if (g >= pol2n) return;
+#pragma unroll 1
+    for (int d = 0; d < 3; d++) {
+        u64 v[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) v[i] = gl::canon(pol[((uint64_t)i * pol2n + g) * 3 + d]);
+        nttm::dft_reg<LOG_NX, true>(v);
+#pragma unroll
+        for (int k = 0; k < NX; k++) smem[(k * 3 + d) * 64 + lane] = gl::mul(v[k], nx_inv);
+    }
+    const u64 sinv = gl::mul(sinv0, gl::pow(wi, g));
+    const E3 y = gl::e3_mul1(x, sinv);
+    E3 acc = {{smem[((NX - 1) * 3 + 0) * 64 + lane], smem[((NX - 1) * 3 + 1) * 64 + lane], smem[((NX - 1) * 3 + 2) * 64 + lane]}};
+#pragma unroll 1
+    for (int k = NX - 2; k >= 0; k--) {
+        const E3 c = {{smem[(k * 3 + 0) * 64 + lane], smem[(k * 3 + 1) * 64 + lane], smem[(k * 3 + 2) * 64 + lane]}};
+        acc = gl::e3_add(gl::e3_mul(acc, y), c);
+    }
+    out[g * 3 + 0] = acc.v[0];
+    out[g * 3 + 1] = acc.v[1];
+    out[g * 3 + 2] = acc.v[2];
+}
+
+__global__ __launch_bounds__(256) void k_copy_canon_flat(u64 *dst, const u64 *src, uint64_t count)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = gl::canon(src[i]);
+}
+
+int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, unsigned cur_bits, unsigned nbits_ext,
+                    const u64 x[3])
+{
+    MI_REQUIRE(prev_bits >= cur_bits && nbits_ext >= prev_bits && prev_bits <= 40, "bad FRI step sizes");
+    const unsigned lnx = prev_bits - cur_bits;
+    MI_REQUIRE(lnx <= 6, "FRI reduction of more than 6 bits per step is not supported");
+    const uint64_t pol2n = 1ull << cur_bits;
+    if (lnx == 0) { // friProve.cpp:82-85 (step 0 is a copy)
+        hipLaunchKernelGGL(k_copy_canon_flat, dim3((unsigned)((pol2n * 3 + 255) / 256)), dim3(256), 0, ctx->stream, out, pol,
+                           pol2n * 3);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+    u64 sinv0 = gl::inv(49); // Goldilocks::shift()^-1, squared once per bit already folded (friProve.cpp:143-147)
+    for (unsigned j = 0; j < nbits_ext - prev_bits; j++) sinv0 = gl::mul(sinv0, sinv0);
+    u64 w = 7277203076849721926ULL;
+    for (unsigned i = prev_bits; i < 32; i++) w = gl::mul(w, w);
+    const u64 wi = gl::inv(w);
+    const u64 nx_inv = gl::inv(1ull << lnx);
+    const E3 xe = {{gl::canon(x[0]), gl::canon(x[1]), gl::canon(x[2])}};
+    const unsigned grid = (unsigned)((pol2n + 63) / 64);
+    const size_t lds = (size_t)(1u << lnx) * 3 * 64 * 8;
+#define FOLD(Q)                                                                                                         \
+    case Q:                                                                                                             \
+        if (lds > 48 * 1024)                                                                                            \
+            MI_HIP_CHECK(hipFuncSetAttribute((const void *)k_fri_fold<Q>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                             (int)lds));                                                                \
+        hipLaunchKernelGGL(k_fri_fold<Q>, dim3(grid), dim3(64), lds, ctx->stream, out, pol, (uint32_t)cur_bits, sinv0,  \
+                           wi, xe, nx_inv);                                                                             \
+        break;
+    switch (lnx) {
+        FOLD(1) FOLD(2) FOLD(3) FOLD(4) FOLD(5) FOLD(6)
+    }
+#undef FOLD
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// aux[i*h + j] = pol[j*w + i]: 32x32 LDS tile of 24-byte elements, coalesced on both sides
+__global__ __launch_bounds__(256) void k_fri_transpose(u64 *__restrict__ aux, const u64 *__restrict__ pol, uint64_t w,
+                                                       uint64_t h)
+{
+    __shared__ u64 t[32][33][3];
+    const uint64_t i0 = (uint64_t)blockIdx.x * 32, j0 = (uint64_t)blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint64_t j = j0 + r, i = i0 + tx;
+        if (j < h && i < w) {
+            const u64 *p = pol + (j * w + i) * 3;
+            t[r][tx][0] = p[0]; t[r][tx][1] = p[1]; t[r][tx][2] = p[2];
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint64_t i = i0 + r, j = j0 + tx;
+        if (j < h && i < w) {
+            u64 *q = aux + (i * h + j) * 3;
+            q[0] = gl::canon(t[tx][r][0]); q[1] = gl::canon(t[tx][r][1]); q[2] = gl::canon(t[tx][r][2]);
+        }
+    }
+}
+
+int launch_fri_transpose(mi_ctx *ctx, u64 *aux, const u64 *pol, uint64_t degree, unsigned tbits)
+{
+    const uint64_t w = 1ull << tbits;
+    MI_REQUIRE(w && degree % w == 0, "degree must be a multiple of 2^transpose_bits");
+    const uint64_t h = degree / w;
+    if (!degree) return MI_OK;
+    dim3 grid((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32));
+    MI_REQUIRE(grid.y < 65536u * 1024u, "transpose grid too large");
+    hipLaunchKernelGGL(k_fri_transpose, grid, dim3(256), 0, ctx->stream, aux, pol, w, h);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---- step-4 split: qq2 viewed as n_ext rows of qdeg*3; rows >= n are zero (calloc at starks.cpp:232)
+__global__ __launch_bounds__(256) void k_q_split(u64 *__restrict__ qq2, const u64 *__restrict__ qq1, uint64_t n,
+                                                 uint64_t n_ext, uint32_t qdeg, u64 shift_in)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; // ext element index in qq2
+    if (e >= n_ext * qdeg) return;
+    const uint64_t k = e / qdeg;
+    const uint32_t p = (uint32_t)(e % qdeg);
+    u64 o0 = 0, o1 = 0, o2 = 0;
+    if (k < n) {
+        const u64 s = gl::pow(shift_in, p);
+        const u64 *src = qq1 + (p * n + k) * 3;
+        o0 = gl::mul(src[0], s); o1 = gl::mul(src[1], s); o2 = gl::mul(src[2], s);
+    }
+    qq2[e * 3 + 0] = o0; qq2[e * 3 + 1] = o1; qq2[e * 3 + 2] = o2;
+}
+
+int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg)
+{
+    MI_REQUIRE(qdeg >= 1 && (uint64_t)qdeg * n <= n_ext, "qdeg * n must not exceed n_ext");
+    const u64 shift_in = gl::pow(gl::inv(49), n);
+    const uint64_t tot = n_ext * qdeg;
+    hipLaunchKernelGGL(k_q_split, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq2, qq1, n, n_ext,
+                       (uint32_t)qdeg, shift_in);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---- evmap: a tall-skinny mat-vec.  Lane <-> evaluated polynomial (sorted by address on the host so
+// neighbouring lanes read neighbouring columns of one LDE row), block <-> slice of rows; partial sums
+// [slice][eval] are reduced by a second kernel.  Field addition is exact, so the order is free.
+struct EvDesc {
+    const u64 *ptr;
+    uint64_t stride;
+    uint32_t dim;
+    uint32_t prime;
+    uint32_t out_index;
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial, const EvDesc *__restrict__ desc,
+                                                       uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
+                                                       const u64 *__restrict__ lev, const u64 *__restrict__ lpev)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t k0 = (uint64_t)blockIdx.y * rows_per_slice;
+    uint64_t k1 = k0 + rows_per_slice;
+    if (k1 > n) k1 = n;
+    if (i >= n_evals) return;
+    const EvDesc d = desc[i];
+    const u64 *L = d.prime ? lpev : lev;
+    E3 acc = {{0, 0, 0}};
+    for (uint64_t k = k0; k < k1; k++) {
+        const E3 l = {{L[k * 3], L[k * 3 + 1], L[k * 3 + 2]}};
+        const u64 *b = d.ptr + (k << ext_bits) * d.stride;
+        E3 t;
+        if (d.dim == 1) t = gl::e3_mul1(l, gl::canon(b[0]));
+        else t = gl::e3_mul(l, E3{{gl::canon(b[0]), gl::canon(b[1]), gl::canon(b[2])}});
+        acc = gl::e3_add(acc, t);
+    }
+    u64 *o = partial + ((uint64_t)blockIdx.y * n_evals + i) * 3;
+    o[0] = acc.v[0]; o[1] = acc.v[1]; o[2] = acc.v[2];
+}
+
+__global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ partial,
+                                                      const EvDesc *__restrict__ desc, uint32_t n_evals, uint32_t n_slices)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_evals) return;
+    E3 acc = {{0, 0, 0}};
+    for (uint32_t s = 0; s < n_slices; s++) {
+        const u64 *p = partial + ((uint64_t)s * n_evals + i) * 3;
+        acc = gl::e3_add(acc, E3{{p[0], p[1], p[2]}});
+    }
+    u64 *o = evals + (uint64_t)desc[i].out_index * 3;
+    o[0] = acc.v[0]; o[1] = acc.v[1]; o[2] = acc.v[2];
+}
+
+int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,
+                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev)
+{
+    if (n_evals == 0) return MI_OK;
+    MI_REQUIRE(n_evals < (1u << 24), "too many evaluations");
+    std::vector<EvDesc> d(n_evals);
+    for (uint64_t i = 0; i < n_evals; i++) {
+        MI_REQUIRE(pol_dim[i] == 1 || pol_dim[i] == 3, "polynomial dim must be 1 or 3");
+        d[i] = EvDesc{pol_ptr[i], pol_stride[i], pol_dim[i], prime[i] ? 1u : 0u, (uint32_t)i, 0};
+    }
+    // order by address like the reference does (starks.cpp:560-607) -- here it buys coalescing
+    std::sort(d.begin(), d.end(), [](const EvDesc &a, const EvDesc &b) { return a.ptr < b.ptr; });
+    const uint32_t n_slices = (uint32_t)std::min<uint64_t>(n, 1024);
+    const uint64_t rows_per_slice = (n + n_slices - 1) / n_slices;
+    const uint64_t desc_bytes = n_evals * sizeof(EvDesc), part_bytes = (uint64_t)n_slices * n_evals * 3 * 8;
+    char *scratch = nullptr;
+    MI_HIP_CHECK(hipMallocAsync((void **)&scratch, desc_bytes + part_bytes + 64, ctx->stream));
+    EvDesc *ddesc = (EvDesc *)scratch;
+    u64 *partial = (u64 *)(scratch + ((desc_bytes + 63) & ~63ull));
+    MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // d is a stack-lifetime host buffer
+    const unsigned gx = (unsigned)((n_evals + 255) / 256);
+    hipLaunchKernelGGL(k_evmap_partial, dim3(gx, n_slices), dim3(256), 0, ctx->stream, partial, ddesc, (uint32_t)n_evals, n,
+                       (uint32_t)ext_bits, rows_per_slice, lev, lpev);
+    hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, partial, ddesc, (uint32_t)n_evals, n_slices);
+    MI_HIP_CHECK(hipGetLastError());
+    MI_HIP_CHECK(hipFreeAsync(scratch, ctx->stream));
+    return MI_OK;
+}
+
+// ---- element-wise inverse in F_p^3 (res == src allowed)
+__global__ __launch_bounds__(256) void k_batch_inverse3(u64 *res, const u64 *src, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const E3 a = {{gl::canon(src[i * 3]), gl::canon(src[i * 3 + 1]), gl::canon(src[i * 3 + 2])}};
+    const E3 r = gl::e3_inv(a);
+    res[i * 3] = r.v[0]; res[i * 3 + 1] = r.v[1]; res[i * 3 + 2] = r.v[2];
+}
+
+int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n)
+{
+    if (!n) return MI_OK;
+    hipLaunchKernelGGL(k_batch_inverse3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, res, src, n);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void k_geom_seq(u64 *out, uint64_t n, u64 start, u64 ratio)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = gl::mul(start, gl::pow(ratio, i));
+}
+
+int launch_geom_seq(mi_ctx *ctx, u64 *out, uint64_t n, u64 start, u64 ratio)
+{
+    if (!n) return MI_OK;
+    hipLaunchKernelGGL(k_geom_seq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, n, gl::canon(start),
+                       gl::canon(ratio));
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void k_geom_seq3(u64 *out, uint64_t n, E3 ratio)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    E3 r = {{1, 0, 0}}, b = ratio;
+    for (uint64_t e = i; e; e >>= 1) {
+        if (e & 1) r = gl::e3_mul(r, b);
+        b = gl::e3_mul(b, b);
+    }
+    out[i * 3] = r.v[0]; out[i * 3 + 1] = r.v[1]; out[i * 3 + 2] = r.v[2];
+}
+
+int launch_geom_seq3(mi_ctx *ctx, u64 *out, uint64_t n, const u64 ratio[3])
+{
+    if (!n) return MI_OK;
+    const E3 r = {{gl::canon(ratio[0]), gl::canon(ratio[1]), gl::canon(ratio[2])}};
+    hipLaunchKernelGGL(k_geom_seq3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, n, r);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// out[k] = x[k] * (x[k] - xi)^-1, x in the base field, xi in the extension
+__global__ __launch_bounds__(256) void k_x_div_x_sub(u64 *out, const u64 *x, uint64_t n, E3 xi)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 xv = gl::canon(x[i]);
+    const E3 d = {{gl::sub(xv, xi.v[0]), gl::neg(xi.v[1]), gl::neg(xi.v[2])}};
+    const E3 r = gl::e3_mul1(gl::e3_inv(d), xv);
+    out[i * 3] = r.v[0]; out[i * 3 + 1] = r.v[1]; out[i * 3 + 2] = r.v[2];
+}
+
+int launch_x_div_x_sub(mi_ctx *ctx, u64 *out, const u64 *x, uint64_t n, const u64 xi[3])
+{
+    if (!n) return MI_OK;
+    const E3 e = {{gl::canon(xi[0]), gl::canon(xi[1]), gl::canon(xi[2])}};
+    hipLaunchKernelGGL(k_x_div_x_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, x, n, e);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void k_zhinv(u64 *out, uint64_t cnt, u64 sn, u64 w)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < cnt) out[i] = gl::inv(gl::sub(gl::mul(sn, gl::pow(w, i)), 1));
+}
+
+int launch_zhinv(mi_ctx *ctx, u64 *out, uint64_t cnt, u64 sn, u64 w)
+{
+    hipLaunchKernelGGL(k_zhinv, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, out, cnt, sn, w);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void k_fill_synthetic(u64 *out, uint64_t count, u64 seed)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL; // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    out[i] = gl::canon(z);
+}
+
+int launch_fill_synthetic(mi_ctx *ctx, u64 *out, uint64_t count, u64 seed)
+{
+    if (!count) return MI_OK;
+    MI_REQUIRE(count < (1ull << 39), "count too large");
+    hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, out, count, seed);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void k_fill_synthetic_2d(u64 *out, uint64_t out_pitch, uint64_t nrows, uint32_t ncols,
+                                                           uint64_t global_cols, uint64_t col0, u64 seed)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * ncols) return;
+    const uint64_t r = i / ncols, c = i % ncols;
+    u64 z = seed + (r * global_cols + col0 + c + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    out[r * out_pitch + c] = gl::canon(z);
+}
+
+int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols, uint64_t global_cols,
+                             uint64_t col0, u64 seed)
+{
+    const uint64_t tot = nrows * ncols;
+    if (!tot) return MI_OK;
+    MI_REQUIRE(tot < (1ull << 39) && ncols < (1ull << 31), "matrix too large");
+    hipLaunchKernelGGL(k_fill_synthetic_2d, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, out, out_pitch, nrows,
+                       (uint32_t)ncols, global_cols, col0, seed);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+extern "C" uint64_t mi_dbg_host_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
+extern "C" void mi_dbg_host_e3_mul(uint64_t out[3], const uint64_t a[3], const uint64_t b[3])
+{
+    const E3 r = gl::e3_mul(E3{{gl::canon(a[0]), gl::canon(a[1]), gl::canon(a[2])}}, E3{{gl::canon(b[0]), gl::canon(b[1]), gl::canon(b[2])}});
+    out[0] = r.v[0]; out[1] = r.v[1]; out[2] = r.v[2];
+}
+extern "C" void mi_dbg_host_e3_inv(uint64_t out[3], const uint64_t a[3])
+{
+    const E3 r = gl::e3_inv(E3{{gl::canon(a[0]), gl::canon(a[1]), gl::canon(a[2])}});
+    out[0] = r.v[0]; out[1] = r.v[1]; out[2] = r.v[2];
+}

@@ -1,0 +1,147 @@
+// gl_math.h -- Goldilocks field / cubic-extension / Poseidon arithmetic for gfx950 kernels.
+//
+// p = 2^64 - 2^32 + 1.  Elements travel through HBM as canonical u64 in [0,p) (the reference's
+// Goldilocks::Element is a bare uint64_t fe: SURVEY 8(b) "Element representation"); inside a kernel
+// values are kept "weakly reduced" in [0,2^64) and canonicalised once, at the store.
+//
+// CDNA4 has no 64-bit integer multiplier: a 64x64 product is four v_mad_u64_u32, and the special
+// form of p turns the 128-bit reduction into adds (2^64 = 2^32-1, 2^96 = -1 mod p) -- no Montgomery
+// or Barrett constants.  Everything here is __host__ __device__ so the very same inline code can be
+// exercised on a machine without a GPU (mi_dbg_host_* in capi.hip; test use only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define MI_HD __host__ __device__ __forceinline__
+
+static constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
+static constexpr u64 GL_EPS = 0xFFFFFFFFULL; // 2^64 mod p = 2^32 - 1
+
+namespace gl {
+
+MI_HD u64 canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
+
+// a any u64, b canonical (< p)  ->  weakly reduced a + b
+MI_HD u64 add_wc(u64 a, u64 b)
+{
+    u64 s = a + b;
+    return s < a ? s + GL_EPS : s; // wrapped: true sum < 2^64 + p, so s < p and s + eps cannot wrap again
+}
+
+// both canonical -> canonical
+MI_HD u64 add(u64 a, u64 b)
+{
+    u64 s = a + b;
+    u64 t = s + GL_EPS; // s - p (mod 2^64)
+    return (s < a || s >= GL_P) ? t : s;
+}
+
+// both canonical -> canonical
+MI_HD u64 sub(u64 a, u64 b)
+{
+    u64 d = a - b;
+    return a < b ? d - GL_EPS : d; // d + p (mod 2^64)
+}
+
+MI_HD u64 neg(u64 a) { return a ? GL_P - a : 0; }
+
+// 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
+MI_HD u64 reduce128_w(u64 lo, u64 hi)
+{
+    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= GL_EPS; // borrowed 2^64 = p + eps
+    u64 t1 = ((u64)hl << 32) - hl; // hl * (2^32 - 1)
+    u64 r = t0 + t1;
+    return r < t1 ? r + GL_EPS : r;
+}
+
+MI_HD void mul64x64(u64 a, u64 b, u64 &lo, u64 &hi)
+{
+    // four 32x32->64 multiply-adds (v_mad_u64_u32)
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p10 = (u64)a1 * b0 + (p00 >> 32);          // < 2^64
+    u64 p01 = (u64)a0 * b1 + (u32)p10;             // < 2^64
+    u64 p11 = (u64)a1 * b1 + (p10 >> 32) + (p01 >> 32);
+    lo = (p01 << 32) | (u32)p00;
+    hi = p11;
+}
+
+MI_HD void sqr64(u64 a, u64 &lo, u64 &hi)
+{
+    // a^2 = p00 + 2*p01*2^32 + p11*2^64 : three multiplies instead of four
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+    u64 p00 = (u64)a0 * a0;
+    u64 p01 = (u64)a0 * a1;
+    u64 p11 = (u64)a1 * a1;
+    u64 mid = (p00 >> 32) + ((p01 << 1) & 0xFFFFFFFFULL); // word 1, < 2^33
+    lo = (mid << 32) | (u32)p00;
+    hi = p11 + (p01 >> 31) + (mid >> 32);
+}
+
+// any u64 inputs -> weakly reduced
+MI_HD u64 mul_w(u64 a, u64 b)
+{
+    u64 lo, hi;
+    mul64x64(a, b, lo, hi);
+    return reduce128_w(lo, hi);
+}
+MI_HD u64 sqr_w(u64 a)
+{
+    u64 lo, hi;
+    sqr64(a, lo, hi);
+    return reduce128_w(lo, hi);
+}
+// canonical result
+MI_HD u64 mul(u64 a, u64 b) { return canon(mul_w(a, b)); }
+
+MI_HD u64 pow(u64 a, u64 e)
+{
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = mul_w(r, a);
+        a = sqr_w(a);
+        e >>= 1;
+    }
+    return canon(r);
+}
+MI_HD u64 inv(u64 a) { return pow(a, GL_P - 2); } // inv(0) = 0
+
+// ---- cubic extension F_p[x]/(x^3 - x - 1); reference form: polinomial.hpp:195-205
+struct E3 { u64 v[3]; };
+
+MI_HD E3 e3_add(const E3 &a, const E3 &b) { return {{add(a.v[0], b.v[0]), add(a.v[1], b.v[1]), add(a.v[2], b.v[2])}}; }
+MI_HD E3 e3_sub(const E3 &a, const E3 &b) { return {{sub(a.v[0], b.v[0]), sub(a.v[1], b.v[1]), sub(a.v[2], b.v[2])}}; }
+MI_HD E3 e3_mul1(const E3 &a, u64 b) { return {{mul(a.v[0], b), mul(a.v[1], b), mul(a.v[2], b)}}; }
+MI_HD E3 e3_mul(const E3 &a, const E3 &b)
+{
+    u64 A = mul(add(a.v[0], a.v[1]), add(b.v[0], b.v[1]));
+    u64 B = mul(add(a.v[0], a.v[2]), add(b.v[0], b.v[2]));
+    u64 C = mul(add(a.v[1], a.v[2]), add(b.v[1], b.v[2]));
+    u64 D = mul(a.v[0], b.v[0]);
+    u64 E = mul(a.v[1], b.v[1]);
+    u64 F = mul(a.v[2], b.v[2]);
+    u64 G = sub(D, E);
+    return {{sub(add(C, G), F), sub(sub(sub(add(A, C), E), E), D), sub(B, G)}};
+}
+// exact inverse via the adjugate of the multiplication-by-a matrix (inv(0) = 0)
+MI_HD E3 e3_inv(const E3 &a)
+{
+    // columns a*1, a*x, a*x^2  (x^3 = x + 1)
+    u64 a0 = a.v[0], a1 = a.v[1], a2 = a.v[2];
+    u64 m00 = a0, m10 = a1, m20 = a2;                       // a*1
+    u64 m01 = a2, m11 = add(a0, a2), m21 = a1;              // a*x   = a2 + (a0+a2) x + a1 x^2
+    u64 m02 = a1, m12 = add(a1, a2), m22 = add(a0, a2);     // a*x^2 = a1 + (a1+a2) x + (a0+a2) x^2
+    u64 c00 = sub(mul(m11, m22), mul(m12, m21));
+    u64 c01 = sub(mul(m10, m22), mul(m12, m20));
+    u64 c02 = sub(mul(m10, m21), mul(m11, m20));
+    u64 det = add(sub(mul(m00, c00), mul(m01, c01)), mul(m02, c02));
+    u64 di = inv(det);
+    return {{mul(c00, di), mul(neg(c01), di), mul(c02, di)}};
+}
+
+} // namespace gl

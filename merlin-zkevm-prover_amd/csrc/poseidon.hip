@@ -1,0 +1,205 @@
+// poseidon.hip -- Poseidon sponge / Merkle-tree kernels for gfx950.
+//
+// Replaces PoseidonGoldilocks::{hash_full_result, hash, linear_hash, merkletree_avx} as called from
+// merkleTreeGL.cpp:37-44 and transcript.cpp:23,46, and MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35).
+//
+// Mapping: ONE ROW (one sponge) PER LANE.  A leaf of the 665-column trace is 84 chained permutations, so
+// the kernel is VALU-bound by three orders of magnitude (~3e4 integer ops per 64 B absorbed): each lane
+// streams its own row with plain 8-byte loads, prefetching the next 64-byte block while the current
+// permutation runs; neighbouring half-lines are picked up from L2 by the next absorb.  Tree levels read
+// two sibling digests (64 B contiguous per lane, fully coalesced) and write 32 B.
+#include "common.h"
+#include "poseidon_math.h"
+
+__constant__ u64 c_rc[360];
+
+static int upload_rc_once(mi_ctx *ctx)
+{
+    static int done_for_device = -1;
+    if (done_for_device == ctx->device) return MI_OK;
+    MI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), MI_POS_RC, sizeof(MI_POS_RC)));
+    done_for_device = ctx->device;
+    return MI_OK;
+}
+
+template <int MDS>
+__global__ __launch_bounds__(256) void k_permute(u64 *__restrict__ out, const u64 *__restrict__ in, uint64_t count)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    u64 s[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) s[j] = in[i * 12 + j];
+    pos::permute<MDS>(s, c_rc);
+#pragma unroll
+    for (int j = 0; j < 12; j++) out[i * 12 + j] = s[j];
+}
+
+// linear_hash of every row: ncols <= 4 -> copy + zero pad, else rate-8 sponge with the
+// previous block's out[0..4) carried in the capacity.
+template <int MDS>
+__global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ digests, const u64 *__restrict__ src,
+                                                          uint64_t pitch, uint32_t ncols, uint64_t nrows)
+{
+    uint64_t row = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    const u64 *p = src + row * pitch;
+    u64 *o = digests + row * 4;
+    if (ncols <= 4) {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) o[i] = i < ncols ? gl::canon(p[i]) : 0;
+        return;
+    }
+    u64 s[12], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[8 + i] = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) nxt[i] = i < ncols ? p[i] : 0;
+    for (uint32_t c = 0; c < ncols; c += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = nxt[i];
+        const uint32_t c2 = c + 8;
+        if (c2 < ncols) { // prefetch the next absorb while this permutation runs
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) nxt[i] = (c2 + i < ncols) ? p[c2 + i] : 0;
+        }
+        pos::permute<MDS>(s, c_rc);
+        if (c2 < ncols) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[8 + i] = s[i];
+        }
+    }
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(o);
+    o2[0] = make_ulonglong2(s[0], s[1]);
+    o2[1] = make_ulonglong2(s[2], s[3]);
+}
+
+// parent = hash(left || right || 0^4)[0..4)
+template <int MDS>
+__device__ __forceinline__ void hash_pair(u64 *__restrict__ out, const u64 *__restrict__ in)
+{
+    const ulonglong2 *i2 = reinterpret_cast<const ulonglong2 *>(in);
+    ulonglong2 a = i2[0], b = i2[1], c = i2[2], d = i2[3];
+    u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
+    pos::permute<MDS>(s, c_rc);
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(out);
+    o2[0] = make_ulonglong2(s[0], s[1]);
+    o2[1] = make_ulonglong2(s[2], s[3]);
+}
+
+template <int MDS>
+__global__ __launch_bounds__(256) void k_merkle_level(u64 *__restrict__ out, const u64 *__restrict__ in, uint64_t n_out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    hash_pair<MDS>(out + i * 4, in + i * 8);
+}
+
+// the last levels (n <= 512 nodes) in one workgroup: removes ~9 launch + drain latencies per tree
+template <int MDS>
+__global__ __launch_bounds__(256) void k_merkle_top(u64 *level, uint64_t n)
+{
+    while (n > 1) {
+        const uint64_t n_out = n >> 1;
+        u64 *nxt = level + n * 4;
+        for (uint64_t i = threadIdx.x; i < n_out; i += 256) hash_pair<MDS>(nxt + i * 4, level + i * 8);
+        __threadfence_block();
+        __syncthreads();
+        level = nxt;
+        n = n_out;
+    }
+}
+
+// one workgroup per query: row values then the sibling of every level (merkleTreeGL.cpp:12-35)
+__global__ __launch_bounds__(64) void k_group_proofs(u64 *__restrict__ proofs, const u64 *__restrict__ nodes,
+                                                     const u64 *__restrict__ src, uint64_t pitch, uint64_t height,
+                                                     uint32_t width, uint32_t levels, const u64 *__restrict__ idx)
+{
+    const uint64_t q = blockIdx.x;
+    const uint64_t id = idx[q];
+    u64 *out = proofs + q * ((uint64_t)width + 4ull * levels);
+    for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[id * pitch + i]);
+    for (uint32_t e = threadIdx.x; e < levels * 4; e += 64) {
+        const uint32_t l = e >> 2, k = e & 3;
+        // offset of level l = 4 * (h + h/2 + ... ) = 4 * (2h - (h >> (l-1)))   for l >= 1
+        const uint64_t off = l == 0 ? 0 : 4 * (2 * height - (height >> (l - 1)));
+        const uint64_t sib = (id >> l) ^ 1;
+        out[width + e] = nodes[off + sib * 4 + k];
+    }
+}
+
+template <typename F>
+static int by_variant(mi_ctx *ctx, F f)
+{
+    MI_TRY(upload_rc_once(ctx));
+    if (ctx->poseidon_variant == pos::MDS_HALF32) f(std::integral_constant<int, pos::MDS_HALF32>());
+    else f(std::integral_constant<int, pos::MDS_LIMB22>());
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count)
+{
+    if (count == 0) return MI_OK;
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    return by_variant(ctx, [&](auto v) {
+        hipLaunchKernelGGL((k_permute<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, out, in, count);
+    });
+}
+
+int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows)
+{
+    if (nrows == 0) return MI_OK;
+    MI_REQUIRE(ncols < (1ull << 31), "ncols too large");
+    MI_REQUIRE(nrows < (1ull << 39), "nrows too large");
+    const unsigned grid = (unsigned)((nrows + 255) / 256);
+    return by_variant(ctx, [&](auto v) {
+        hipLaunchKernelGGL((k_linear_hash_rows<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, digests, src, pitch,
+                           (uint32_t)ncols, nrows);
+    });
+}
+
+int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)
+{
+    MI_REQUIRE(is_pow2(nleaves), "number of leaves must be a power of two");
+    u64 *level = nodes;
+    uint64_t n = nleaves;
+    while (n > 512) {
+        const uint64_t n_out = n >> 1;
+        u64 *nxt = level + n * 4;
+        const unsigned grid = (unsigned)((n_out + 255) / 256);
+        MI_TRY(by_variant(ctx, [&](auto v) {
+            hipLaunchKernelGGL((k_merkle_level<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, nxt, level, n_out);
+        }));
+        level = nxt;
+        n = n_out;
+    }
+    if (n > 1) {
+        MI_TRY(by_variant(ctx, [&](auto v) {
+            hipLaunchKernelGGL((k_merkle_top<decltype(v)::value>), dim3(1), dim3(256), 0, ctx->stream, level, n);
+        }));
+    }
+    return MI_OK;
+}
+
+int launch_group_proofs(mi_ctx *ctx, u64 *proofs, const u64 *nodes, const u64 *src, uint64_t pitch, uint64_t height,
+                        uint64_t width, const u64 *idx_dev, uint64_t nq)
+{
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(is_pow2(height), "tree height must be a power of two");
+    const uint32_t levels = ilog2_u64(height);
+    hipLaunchKernelGGL(k_group_proofs, dim3((unsigned)nq), dim3(64), 0, ctx->stream, proofs, nodes, src, pitch, height,
+                       (uint32_t)width, levels, idx_dev);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---- host-side debug hook: the same inline permutation, run on the CPU (tests only)
+extern "C" void mi_dbg_host_poseidon_permute(uint64_t st[12], int variant)
+{
+    u64 s[12];
+    for (int i = 0; i < 12; i++) s[i] = st[i];
+    if (variant == pos::MDS_HALF32) pos::permute<pos::MDS_HALF32>(s, (const u64 *)MI_POS_RC);
+    else pos::permute<pos::MDS_LIMB22>(s, (const u64 *)MI_POS_RC);
+    for (int i = 0; i < 12; i++) st[i] = s[i];
+}

@@ -1,0 +1,132 @@
+// poseidon_math.h -- Poseidon-over-Goldilocks permutation (t=12, R_F=8, R_P=22, x^7), one state
+// per lane, all 12 words in VGPRs.
+//
+// Spec followed: src/sm/poseidon_g/poseidon_g_executor.cpp:174-205 (naive round form: add RC, S-box on
+// all lanes in rounds 0-3/26-29 else lane 0, state = M*state) with M = circ(MCIRC) + diag(MDIAG)
+// (poseidon_g_executor.hpp:37-50).  The upstream library uses the algebraically equal "optimised partial
+// round" form; on CDNA4 the naive form is the cheaper one: its MDS constants are < 2^6, so the
+// mat-vec needs no 64x64 multiplies at all (see mds_limb22), whereas the optimised form trades it for
+// 23 full 64-bit modular multiplies per partial round.
+//
+// Why one state per lane and not a wave-cooperative round with the state spread over 12 lanes: 22 of
+// the 30 rounds apply the S-box to lane 0 only, which would idle 11 of 12 cooperating lanes for ~2/3 of
+// the multiplies; with a whole state per lane every VALU slot does useful work and no LDS / cross-lane
+// traffic is needed.  (MFMA: not applicable -- exact 64-bit modular accumulation, 12x12 only.)
+#pragma once
+#include "gl_math.h"
+#include "poseidon_constants.h"
+
+namespace pos {
+
+static constexpr int MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20}; // == MI_POS_MCIRC
+static constexpr int MD0 = 8;                                                   // == MI_POS_MDIAG[0]
+
+enum { MDS_HALF32 = 0, MDS_LIMB22 = 1 };
+
+MI_HD u64 sbox(u64 x)
+{
+    u64 x2 = gl::sqr_w(x);
+    u64 x4 = gl::sqr_w(x2);
+    u64 x3 = gl::mul_w(x, x2);
+    return gl::mul_w(x3, x4);
+}
+
+// MDS on 32-bit halves: two 64-bit accumulators per output (v_mad_u64_u32).  Row sum of M is 264, so
+// each accumulator is < 2^41.
+MI_HD void mds_half32(u64 (&s)[12])
+{
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+#pragma unroll
+    for (int x = 0; x < 12; x++) {
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int y = 0; y < 12; y++) {
+            const u32 m = (u32)(MC[(y - x + 12) % 12] + ((x == 0 && y == 0) ? MD0 : 0));
+            al += (u64)lo[y] * m;
+            ah += (u64)hi[y] * m;
+        }
+        // value = al + ah*2^32 = al + (ah_lo << 32) + ah_hi * 2^64 ;  2^64 = 2^32 - 1
+        u64 ahh = ah >> 32;                          // < 2^9
+        u64 r = al + ((ahh << 32) - ahh);            // < 2^42, no wrap
+        u64 b = ah << 32;
+        u64 t = r + b;
+        s[x] = t < b ? t + GL_EPS : t;
+    }
+}
+
+// MDS on 22/22/20-bit limbs: three 32-bit accumulators per output, full-rate v_mad_u32_u24.
+// acc_k <= 264 * (2^22 - 1) < 2^31.
+MI_HD u32 mad24(u32 a, u32 b, u32 c)
+{
+    // both factors are provably < 2^24 (a is masked, b is a literal < 2^6): the AMDGPU backend selects
+    // the full-rate v_mad_u32_u24 for this expression (checked in the ISA)
+    return a * b + c;
+}
+
+MI_HD void mds_limb22(u64 (&s)[12])
+{
+    u32 l0[12], l1[12], l2[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        l0[i] = (u32)s[i] & 0x3FFFFFu;
+        l1[i] = (u32)(s[i] >> 22) & 0x3FFFFFu;
+        l2[i] = (u32)(s[i] >> 44);
+    }
+#pragma unroll
+    for (int x = 0; x < 12; x++) {
+        u32 a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int y = 0; y < 12; y++) {
+            const u32 m = (u32)(MC[(y - x + 12) % 12] + ((x == 0 && y == 0) ? MD0 : 0));
+            a0 = mad24(l0[y], m, a0);
+            a1 = mad24(l1[y], m, a1);
+            a2 = mad24(l2[y], m, a2);
+        }
+        // value = a0 + a1*2^22 + a2*2^44  (< 2^74)
+        u64 v = (u64)a0 + ((u64)a1 << 22);           // < 2^54
+        u64 b = (u64)a2 << 44;                       // low 20 bits of a2 land in bits 44..63
+        u64 lo = v + b;
+        u64 hi = (u64)(a2 >> 20) + (lo < b ? 1 : 0); // < 2^10, multiples of 2^64
+        u64 t1 = (hi << 32) - hi;
+        u64 r = lo + t1;
+        s[x] = r < t1 ? r + GL_EPS : r;
+    }
+}
+
+template <int MDS>
+MI_HD void mds(u64 (&s)[12])
+{
+    if (MDS == MDS_LIMB22) mds_limb22(s);
+    else mds_half32(s);
+}
+
+// rc: 360 round constants (canonical).  State in: any u64 encodings; out: canonical.
+template <int MDS>
+MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc)
+{
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_wc(s[i], rc[r * 12 + i]));
+        mds<MDS>(s);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc[r * 12 + i]);
+        s[0] = sbox(s[0]);
+        mds<MDS>(s);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_wc(s[i], rc[r * 12 + i]));
+        mds<MDS>(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+}
+
+} // namespace pos

@@ -1,0 +1,280 @@
+"""ctypes binding of libmi_stark.so (the C ABI declared in include/mi_stark.h).
+
+Plumbing only: device memory comes from torch (int64 tensors used as raw u64 containers), the stream is
+torch's current stream, and every call goes straight to the HIP library.  There is no fallback of any
+kind: if the shared library is missing or no GPU is usable, loading / context creation raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi_stark.so")
+P = 0xFFFFFFFF00000001
+
+u64 = ctypes.c_uint64
+_p64 = ctypes.POINTER(u64)
+
+
+class MiStarkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmi_stark.so (no GPU needed for loading; compute entry points need one)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiStarkError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+                "There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.mi_last_error.restype = ctypes.c_char_p
+        L.mi_version.restype = ctypes.c_char_p
+        L.mi_dev_alloc.restype = ctypes.c_void_p
+        L.mi_dbg_host_mul.restype = u64
+        L.mi_dbg_host_mul.argtypes = [u64, u64]
+        _lib = L
+    return _lib
+
+
+# every symbol include/mi_stark.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = [
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_set_stream", "mi_ctx_sync", "mi_ctx_set_workspace_limit",
+    "mi_last_error", "mi_version", "mi_device_count",
+    "mi_ntt_dev", "mi_lde_dev", "mi_ntt", "mi_lde",
+    "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
+    "mi_linear_hash_rows_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
+    "mi_merkle_group_proofs_dev",
+    "mi_fri_fold_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev",
+    "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
+    "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
+    "mi_set_poseidon_variant", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
+    "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
+    "mi_dbg_host_dft16",
+]
+
+
+def _check(status):
+    if status != 0:
+        raise MiStarkError(f"mi_stark status {status}: {lib().mi_last_error().decode()}")
+
+
+def _hp(a):
+    """host numpy uint64 array -> pointer"""
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_p64)
+
+
+def _dp(t, offset_elems=0):
+    """torch device tensor (int64 container) -> u64 pointer"""
+    return ctypes.cast(ctypes.c_void_p(t.data_ptr() + 8 * offset_elems), _p64)
+
+
+class Context:
+    """One context per process / GPU.  Work is enqueued on torch's current stream."""
+
+    def __init__(self, device=0, workspace_limit=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise MiStarkError("no GPU visible: mi_stark has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.h = ctypes.c_void_p()
+        _check(lib().mi_ctx_create(ctypes.byref(self.h), ctypes.c_int(device)))
+        self.use_torch_stream()
+        if workspace_limit:
+            _check(lib().mi_ctx_set_workspace_limit(self.h, u64(workspace_limit)))
+
+    def use_torch_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        _check(lib().mi_ctx_set_stream(self.h, ctypes.c_void_p(s)))
+
+    def close(self):
+        if self.h:
+            lib().mi_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def sync(self):
+        _check(lib().mi_ctx_sync(self.h))
+
+    # ---- memory helpers
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.int64, device=self.device)
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.int64, device=self.device)
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        return self.torch.from_numpy(a.view(np.int64)).to(self.device)
+
+    def to_host(self, t):
+        return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+    def set_poseidon_variant(self, v):
+        _check(lib().mi_set_poseidon_variant(self.h, ctypes.c_int(v)))
+
+    # ---- NTT / LDE (device resident)
+    def ntt(self, dst, src, n, ncols, inverse=False, dst_pitch=None, src_pitch=None, dst_off=0, src_off=0):
+        _check(lib().mi_ntt_dev(self.h, _dp(dst, dst_off), u64(dst_pitch or ncols), _dp(src, src_off),
+                                u64(src_pitch or ncols), u64(n), u64(ncols), ctypes.c_int(int(inverse))))
+
+    def lde(self, out, inp, n_ext, n, ncols, out_pitch=None, in_pitch=None, out_off=0, in_off=0):
+        _check(lib().mi_lde_dev(self.h, _dp(out, out_off), u64(out_pitch or ncols), _dp(inp, in_off),
+                                u64(in_pitch or ncols), u64(n_ext), u64(n), u64(ncols)))
+
+    # ---- Poseidon / Merkle
+    def permute(self, out, inp, count):
+        _check(lib().mi_poseidon_permute_dev(self.h, _dp(out), _dp(inp), u64(count)))
+
+    def linear_hash_rows(self, digests, src, ncols, nrows, pitch=None, src_off=0):
+        _check(lib().mi_linear_hash_rows_dev(self.h, _dp(digests), _dp(src, src_off), u64(pitch or ncols), u64(ncols), u64(nrows)))
+
+    def merkle_build(self, nodes, src, ncols, nrows, pitch=None, src_off=0):
+        _check(lib().mi_merkle_build_dev(self.h, _dp(nodes), _dp(src, src_off), u64(pitch or ncols), u64(ncols), u64(nrows)))
+
+    def merkle_levels(self, nodes, nleaves):
+        _check(lib().mi_merkle_levels_dev(self.h, _dp(nodes), u64(nleaves)))
+
+    def merkle_group_proofs(self, proofs, nodes, src, height, width, idx, pitch=None):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        _check(lib().mi_merkle_group_proofs_dev(self.h, _dp(proofs), _dp(nodes), _dp(src), u64(pitch or width),
+                                                u64(height), u64(width), _hp(idx), u64(idx.size)))
+
+    # ---- host-pointer (drop-in) variants
+    def ntt_host(self, src, n, ncols, inverse=False):
+        src = np.ascontiguousarray(src, dtype=np.uint64)
+        dst = np.empty(n * ncols, dtype=np.uint64)
+        _check(lib().mi_ntt(self.h, _hp(dst), _hp(src.reshape(-1)), u64(n), u64(ncols), ctypes.c_int(int(inverse))))
+        return dst.reshape(n, ncols)
+
+    def lde_host(self, src, n_ext, n, ncols):
+        src = np.ascontiguousarray(src, dtype=np.uint64)
+        out = np.empty(n_ext * ncols, dtype=np.uint64)
+        _check(lib().mi_lde(self.h, _hp(out), _hp(src.reshape(-1)), u64(n_ext), u64(n), u64(ncols)))
+        return out.reshape(n_ext, ncols)
+
+    def merkle_build_host(self, src, ncols, nrows):
+        src = np.ascontiguousarray(src, dtype=np.uint64)
+        nodes = np.empty((2 * nrows - 1) * 4, dtype=np.uint64)
+        _check(lib().mi_merkle_build(self.h, _hp(nodes), _hp(src.reshape(-1)), u64(ncols), u64(nrows)))
+        return nodes
+
+    def hash_full_result(self, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.uint64)
+        out = np.empty(12, dtype=np.uint64)
+        _check(lib().mi_poseidon_hash_full_result(self.h, _hp(out), _hp(inp)))
+        return out
+
+    def hash(self, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.uint64)
+        out = np.empty(4, dtype=np.uint64)
+        _check(lib().mi_poseidon_hash(self.h, _hp(out), _hp(inp)))
+        return out
+
+    def linear_hash(self, vals):
+        vals = np.ascontiguousarray(vals, dtype=np.uint64)
+        out = np.empty(4, dtype=np.uint64)
+        _check(lib().mi_poseidon_linear_hash(self.h, _hp(out), _hp(vals) if vals.size else None, u64(vals.size)))
+        return out
+
+    # ---- FRI and the rest
+    def fri_fold(self, out, pol, prev_bits, cur_bits, nbits_ext, x):
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        _check(lib().mi_fri_fold_dev(self.h, _dp(out), _dp(pol), ctypes.c_uint(prev_bits), ctypes.c_uint(cur_bits),
+                                     ctypes.c_uint(nbits_ext), _hp(x)))
+
+    def fri_transpose(self, aux, pol, degree, tbits):
+        _check(lib().mi_fri_transpose_dev(self.h, _dp(aux), _dp(pol), u64(degree), ctypes.c_uint(tbits)))
+
+    def q_split(self, qq2, qq1, n, n_ext, qdeg):
+        _check(lib().mi_q_split_dev(self.h, _dp(qq2), _dp(qq1), u64(n), u64(n_ext), ctypes.c_uint(qdeg)))
+
+    def evmap(self, evals, pols, prime, lev, lpev, n, ext_bits):
+        """pols: list of (tensor, offset_elems, dim, stride)"""
+        k = len(pols)
+        ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() + 8 * off for (t, off, _, _) in pols])
+        dims = np.array([d for (_, _, d, _) in pols], dtype=np.uint32)
+        strides = np.array([s for (_, _, _, s) in pols], dtype=np.uint64)
+        pr = np.ascontiguousarray(prime, dtype=np.uint8)
+        _check(lib().mi_evmap_dev(self.h, _dp(evals), u64(k), u64(n), ctypes.c_uint(ext_bits), ptrs,
+                                  dims.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _hp(strides),
+                                  pr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dp(lev), _dp(lpev)))
+
+    def batch_inverse3(self, res, src, n):
+        _check(lib().mi_batch_inverse3_dev(self.h, _dp(res), _dp(src), u64(n)))
+
+    def geom_seq(self, out, n, start, ratio):
+        _check(lib().mi_geom_seq_dev(self.h, _dp(out), u64(n), u64(start), u64(ratio)))
+
+    def geom_seq3(self, out, n, ratio):
+        r = np.ascontiguousarray(ratio, dtype=np.uint64)
+        _check(lib().mi_geom_seq3_dev(self.h, _dp(out), u64(n), _hp(r)))
+
+    def x_div_x_sub(self, out, x, n, xi):
+        e = np.ascontiguousarray(xi, dtype=np.uint64)
+        _check(lib().mi_x_div_x_sub_dev(self.h, _dp(out), _dp(x), u64(n), _hp(e)))
+
+    def zhinv(self, nbits, nbits_ext):
+        out = np.empty(1 << (nbits_ext - nbits), dtype=np.uint64)
+        _check(lib().mi_zhinv(self.h, _hp(out), ctypes.c_uint(nbits), ctypes.c_uint(nbits_ext)))
+        return out
+
+    def fill_synthetic(self, out, count, seed, off=0):
+        _check(lib().mi_fill_synthetic_dev(self.h, _dp(out, off), u64(count), u64(seed)))
+
+    def fill_synthetic_2d(self, out, nrows, ncols, global_cols, col0, seed, out_pitch=None):
+        _check(lib().mi_fill_synthetic_2d_dev(self.h, _dp(out), u64(out_pitch or ncols), u64(nrows), u64(ncols),
+                                              u64(global_cols), u64(col0), u64(seed)))
+
+    def copy_2d(self, dst, src, nrows, ncols, dst_pitch, src_pitch, dst_off=0, src_off=0):
+        _check(lib().mi_copy_2d_dev(self.h, _dp(dst, dst_off), u64(dst_pitch), _dp(src, src_off), u64(src_pitch),
+                                    u64(nrows), u64(ncols)))
+
+    # ---- timers (HIP events on the context's stream)
+    def timer_start(self, slot=0):
+        _check(lib().mi_timer_start(self.h, ctypes.c_int(slot)))
+
+    def timer_stop(self, slot=0):
+        _check(lib().mi_timer_stop(self.h, ctypes.c_int(slot)))
+
+    def timer_ms(self, slot=0):
+        ms = ctypes.c_float()
+        _check(lib().mi_timer_elapsed_ms(self.h, ctypes.c_int(slot), ctypes.byref(ms)))
+        return ms.value
+
+
+# ---- host debug hooks (same inline math as the kernels, run on the CPU; tests only)
+def dbg_host_permute(state, variant):
+    s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    lib().mi_dbg_host_poseidon_permute(_hp(s), ctypes.c_int(variant))
+    return s
+
+
+def dbg_host_mul(a, b):
+    return int(lib().mi_dbg_host_mul(u64(a), u64(b)))
+
+
+def dbg_host_e3_mul(a, b):
+    out = np.empty(3, dtype=np.uint64)
+    lib().mi_dbg_host_e3_mul(_hp(out), _hp(np.ascontiguousarray(a, dtype=np.uint64)), _hp(np.ascontiguousarray(b, dtype=np.uint64)))
+    return out
+
+
+def dbg_host_e3_inv(a):
+    out = np.empty(3, dtype=np.uint64)
+    lib().mi_dbg_host_e3_inv(_hp(out), _hp(np.ascontiguousarray(a, dtype=np.uint64)))
+    return out
+
+
+def dbg_host_dft(x, log_size, inverse):
+    v = np.zeros(16, dtype=np.uint64)
+    v[:1 << log_size] = x
+    lib().mi_dbg_host_dft16(_hp(v), ctypes.c_int(log_size), ctypes.c_int(int(inverse)))
+    return v[:1 << log_size].copy()

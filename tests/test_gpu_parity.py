@@ -1,0 +1,389 @@
+"""GPU parity tests proper: every call goes through the C ABI (libmi_stark.so) and is compared
+bit-for-bit with the CPU oracle on the same seeded inputs, with the golden fixtures of the reference,
+and -- at BASELINE sizes -- through size-independent properties (round trips, linearity, Merkle paths)."""
+import glob, os
+import numpy as np
+import pytest
+import glo
+
+pytestmark = pytest.mark.gpu
+P = glo.P
+BITS = [20, 16, 12, 9, 6]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import mi_stark
+    c = mi_stark.Context(0)
+    yield c
+    c.close()
+
+
+def dev_roundtrip(ctx, a):
+    return ctx.to_host(ctx.to_device(a))
+
+
+# ------------------------------------------------------------------ Poseidon
+@pytest.mark.parametrize("variant", [0, 1])
+def test_permute_matches_oracle(ctx, variant):
+    ctx.set_poseidon_variant(variant)
+    rng = np.random.default_rng(10 + variant)
+    st = glo.rand_fe(rng, (1000, 12), canonical=False)
+    st[0] = 0
+    st[1] = np.arange(12)
+    st[2] = P - 1
+    st[3] = 2**64 - 1
+    d_in = ctx.to_device(st)
+    d_out = ctx.empty(st.size)
+    ctx.permute(d_out, d_in, 1000)
+    got = ctx.to_host(d_out).reshape(-1, 12)
+    for i in range(1000):
+        assert np.array_equal(got[i], glo.perm(st[i])), i
+    assert [hex(x) for x in got[0][:4]] == ["0x3c18a9786cb0b359", "0xc4055e3364a246c3", "0x7953db0ab48808f4", "0xc71603f33a1144ca"]
+    ctx.set_poseidon_variant(1)
+
+
+def test_host_pointer_hashes(ctx):
+    rng = np.random.default_rng(11)
+    x = glo.rand_fe(rng, 12)
+    assert np.array_equal(ctx.hash_full_result(x), glo.perm(x))
+    assert np.array_equal(ctx.hash(x), glo.perm(x)[:4])
+    for size in (0, 1, 3, 4, 5, 8, 9, 16, 17, 18, 39, 52, 665):
+        v = glo.rand_fe(rng, size)
+        assert np.array_equal(ctx.linear_hash(v), glo.linear_hash(v)), size
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_linear_hash_rows_all_widths(ctx, variant):
+    ctx.set_poseidon_variant(variant)
+    rng = np.random.default_rng(12)
+    for w in list(range(0, 26)) + [39, 48, 52, 96, 128, 371, 665]:
+        h = 70 if w < 100 else 9
+        pitch = w + 3
+        src = glo.rand_fe(rng, (h, pitch), canonical=(w % 2 == 0))
+        d = ctx.to_device(src)
+        out = ctx.empty(h * 4)
+        ctx.linear_hash_rows(out, d, w, h, pitch=pitch)
+        got = ctx.to_host(out).reshape(h, 4)
+        for r in range(h):
+            assert np.array_equal(got[r], glo.linear_hash(src[r, :w])), (w, r)
+    ctx.set_poseidon_variant(1)
+
+
+@pytest.mark.parametrize("h,w", [(1, 5), (2, 3), (4, 1), (8, 9), (64, 18), (512, 21), (1024, 6), (2048, 39), (4096, 4), (1 << 13, 12)])
+def test_merkle_tree_matches_oracle(ctx, h, w):
+    rng = np.random.default_rng(h + w)
+    src = glo.rand_fe(rng, (h, w))
+    nodes = ctx.empty((2 * h - 1) * 4)
+    ctx.merkle_build(nodes, ctx.to_device(src), w, h)
+    got = ctx.to_host(nodes)
+    want = glo.merkletree(src, w, h)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ctx.merkle_build_host(src, w, h), want)
+
+
+def test_merkle_rejects_bad_sizes(ctx):
+    import mi_stark
+    nodes = ctx.empty(64)
+    with pytest.raises(mi_stark.MiStarkError):
+        ctx.merkle_build(nodes, ctx.zeros(30), 5, 6)          # height must be a power of two
+    ctx.merkle_build(nodes, ctx.zeros(8), 5, 0)                # zero rows: returns immediately like merkletree()
+
+
+def test_group_proofs_match_oracle_and_verify(ctx):
+    rng = np.random.default_rng(14)
+    h, w = 1 << 10, 18
+    src = glo.rand_fe(rng, (h, w))
+    d_src = ctx.to_device(src)
+    nodes = ctx.empty((2 * h - 1) * 4)
+    ctx.merkle_build(nodes, d_src, w, h)
+    idx = np.array([0, 1, 2, 511, 512, 1023, 700], dtype=np.uint64)
+    stride = w + 4 * 10
+    proofs = ctx.empty(idx.size * stride)
+    ctx.merkle_group_proofs(proofs, nodes, d_src, h, w, idx)
+    got = ctx.to_host(proofs).reshape(idx.size, stride)
+    h_nodes = ctx.to_host(nodes)
+    for q, i in enumerate(idx):
+        assert np.array_equal(got[q], glo.merkle_group_proof(h_nodes, src, h, w, int(i)))
+        assert glo.merkle_verify(h_nodes[-4:], got[q][:w], got[q][w:], int(i))
+
+
+FILES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_golden_merkle_paths_on_gpu(ctx, path):
+    """Replays the reference's golden proofs with GPU hashing only: linear_hash of the opened row, then the
+    2->1 climb with mi_poseidon_hash, must land on the roots stored in the proof."""
+    d = np.load(path)
+    for q in range(min(3, len(d["q_index"]))):
+        idx0 = int(d["q_index"][q])
+        trees = [(d["root1"], d["s0_vals1"][q], d["s0_siblings1"][q], idx0),
+                 (d["root3"], d["s0_vals3"][q], d["s0_siblings3"][q], idx0),
+                 (d["root4"], d["s0_vals4"][q], d["s0_siblings4"][q], idx0)]
+        for s in range(1, 5):
+            trees.append((d[f"s{s}_root"], d[f"s{s}_vals"][q], d[f"s{s}_siblings"][q], idx0 % (1 << BITS[s])))
+        for root, vals, sibs, idx in trees:
+            cur = ctx.linear_hash(vals)
+            for lvl in range(sibs.shape[0]):
+                inp = np.zeros(12, dtype=np.uint64)
+                if idx & 1:
+                    inp[:4], inp[4:8] = sibs[lvl], cur
+                else:
+                    inp[:4], inp[4:8] = cur, sibs[lvl]
+                cur = ctx.hash(inp)
+                idx >>= 1
+            assert np.array_equal(cur, root)
+
+
+# ------------------------------------------------------------------ NTT / LDE
+NTT_CASES = [(1, 1), (1, 5), (2, 1), (2, 3), (4, 6), (8, 1), (16, 3), (32, 7), (64, 33), (128, 2), (256, 37), (512, 3),
+             (1024, 1), (1024, 65), (2048, 6), (4096, 32), (1 << 13, 5), (1 << 16, 3), (1 << 17, 1)]
+
+
+@pytest.mark.parametrize("n,ncols", NTT_CASES)
+def test_ntt_matches_oracle(ctx, n, ncols):
+    rng = np.random.default_rng(n * 131 + ncols)
+    x = glo.rand_fe(rng, (n, ncols), canonical=(ncols % 2 == 1))
+    d = ctx.to_device(x)
+    out = ctx.empty(n * ncols)
+    for inverse in (False, True):
+        ctx.ntt(out, d, n, ncols, inverse=inverse)
+        assert np.array_equal(ctx.to_host(out).reshape(n, ncols), glo.ntt(x, n, ncols, inverse=inverse)), inverse
+
+
+def test_ntt_in_place_pitched_and_host_variant(ctx):
+    rng = np.random.default_rng(21)
+    n, ncols, pitch = 1 << 12, 3, 7
+    buf = glo.rand_fe(rng, (n, pitch))
+    d = ctx.to_device(buf)
+    ctx.ntt(d, d, n, ncols, inverse=True, dst_pitch=pitch, src_pitch=pitch)       # LEv-style in-place INTT (starks.cpp:325)
+    got = ctx.to_host(d).reshape(n, pitch)
+    assert np.array_equal(got[:, :ncols], glo.ntt(np.ascontiguousarray(buf[:, :ncols]), n, ncols, inverse=True))
+    assert np.array_equal(got[:, ncols:], buf[:, ncols:])                           # untouched columns
+    x = glo.rand_fe(rng, (1 << 9, 4))
+    assert np.array_equal(ctx.ntt_host(x, 1 << 9, 4), glo.ntt(x, 1 << 9, 4))
+
+
+def test_ntt_identities(ctx):
+    n = 1 << 14
+    imp = np.zeros(n, dtype=np.uint64); imp[0] = 1
+    out = ctx.empty(n)
+    ctx.ntt(out, ctx.to_device(imp), n, 1)
+    assert np.all(ctx.to_host(out) == 1)
+    w = glo.lib().glo_w(14)
+    geo = glo.geom_seq(n, 1, glo.lib().glo_inv(w))
+    ctx.ntt(out, ctx.to_device(geo), n, 1)
+    want = np.zeros(n, dtype=np.uint64); want[1] = n
+    assert np.array_equal(ctx.to_host(out), want)
+    for fill in (0, P - 1):
+        c = np.full(n, fill, dtype=np.uint64)
+        ctx.ntt(out, ctx.to_device(c), n, 1)
+        assert np.array_equal(ctx.to_host(out), glo.ntt(c, n, 1)[:, 0])
+
+
+def test_config1_forward_ntt_2pow20(ctx):
+    """BASELINE config 1 on the GPU: forward NTT over 2^20 elements, 1 column, bit-exact vs the CPU oracle."""
+    n = 1 << 20
+    x = glo.splitmix64(0x5EED0001, n)
+    out = ctx.empty(n)
+    ctx.ntt(out, ctx.to_device(x), n, 1)
+    assert np.array_equal(ctx.to_host(out), glo.ntt(x, n, 1)[:, 0])
+
+
+def test_config2_roundtrip_2pow23(ctx):
+    """BASELINE config 2: 2^23-row x 1-column NTT + iNTT round trip returns the input bit-exactly."""
+    n = 1 << 23
+    d = ctx.empty(n)
+    ctx.fill_synthetic(d, n, 0x5EED0002)
+    x = ctx.to_host(d).copy()
+    assert np.array_equal(x[:1000], glo.splitmix64(0x5EED0002, 1000))
+    y = ctx.empty(n)
+    ctx.ntt(y, d, n, 1)
+    hy = ctx.to_host(y)
+    # spot-check a few outputs against the definition X[k] = sum x[i] w^(ik) via Horner on the host
+    w = glo.lib().glo_w(23)
+    xi = [int(v) for v in x]
+    assert sum(xi) % P == int(hy[0])
+    wk, acc = pow(w, 12345, P), 0
+    for v in reversed(xi):
+        acc = (acc * wk + v) % P
+    assert acc == int(hy[12345])
+    ctx.ntt(y, y, n, 1, inverse=True)
+    assert np.array_equal(ctx.to_host(y), x)
+
+
+LDE_CASES = [(1, 2, 3), (2, 4, 1), (4, 8, 5), (16, 32, 37), (256, 512, 3), (256, 1024, 6), (512, 1024, 70), (1024, 2048, 1),
+             (1 << 12, 1 << 13, 33), (1 << 15, 1 << 16, 6), (1 << 16, 1 << 17, 2), (8, 8, 4)]
+
+
+@pytest.mark.parametrize("n,n_ext,ncols", LDE_CASES)
+def test_lde_matches_oracle(ctx, n, n_ext, ncols):
+    rng = np.random.default_rng(n + n_ext + ncols)
+    x = glo.rand_fe(rng, (n, ncols))
+    out = ctx.empty(n_ext * ncols)
+    ctx.lde(out, ctx.to_device(x), n_ext, n, ncols)
+    assert np.array_equal(ctx.to_host(out).reshape(n_ext, ncols), glo.extend_pol(x, n_ext, n, ncols))
+
+
+def test_lde_column_chunks_and_pitches(ctx):
+    """Wide traces are processed in column chunks sized to the workspace; chunking must not change results."""
+    import mi_stark
+    rng = np.random.default_rng(33)
+    n, n_ext, ncols, in_pitch, out_pitch = 1 << 10, 1 << 11, 100, 103, 101
+    src = glo.rand_fe(rng, (n, in_pitch))
+    small = mi_stark.Context(0, workspace_limit=1 << 20)      # 1 MiB -> chunks of 32 columns
+    out = small.zeros(n_ext * out_pitch)
+    small.lde(out, small.to_device(src), n_ext, n, ncols, out_pitch=out_pitch, in_pitch=in_pitch)
+    got = small.to_host(out).reshape(n_ext, out_pitch)
+    assert np.array_equal(got[:, :ncols], glo.extend_pol(np.ascontiguousarray(src[:, :ncols]), n_ext, n, ncols))
+    assert not got[:, ncols:].any()
+    x = glo.rand_fe(rng, (1 << 11, 70))
+    o2 = small.empty(x.size)
+    small.ntt(o2, small.to_device(x), 1 << 11, 70)
+    assert np.array_equal(small.to_host(o2).reshape(1 << 11, 70), glo.ntt(x, 1 << 11, 70))
+    assert np.array_equal(small.lde_host(x[:256, :5], 512, 256, 5), glo.extend_pol(np.ascontiguousarray(x[:256, :5]), 512, 256, 5))
+    small.close()
+
+
+def test_lde_merkle_large_properties(ctx):
+    """2^20 x 32 LDE + tree: linearity of the LDE, even rows reproduce the trace's coset-free part, and a
+    Merkle path opened from the device tree verifies on the CPU against the device root."""
+    n, n_ext, ncols = 1 << 20, 1 << 21, 32
+    a, b = ctx.empty(n * ncols), ctx.empty(n * ncols)
+    ctx.fill_synthetic(a, n * ncols, 1)
+    ctx.fill_synthetic(b, n * ncols, 2)
+    ea, eb, es = ctx.empty(n_ext * ncols), ctx.empty(n_ext * ncols), ctx.empty(n_ext * ncols)
+    ctx.lde(ea, a, n_ext, n, ncols)
+    ctx.lde(eb, b, n_ext, n, ncols)
+    ha, hb = ctx.to_host(a), ctx.to_host(b)
+    hs = np.array([(int(u) + int(v)) % P for u, v in zip(ha[:4096], hb[:4096])], dtype=np.uint64)
+    # full-size modular sum with uint64 wrap-around arithmetic (python ints would take minutes)
+    sw = ha + hb
+    carry = sw < ha
+    sw = np.where(carry, sw + np.uint64(0xFFFFFFFF), sw)
+    sw = np.where(sw >= np.uint64(P), sw - np.uint64(P), sw)
+    assert np.array_equal(sw[:4096], hs)
+    ctx.lde(es, ctx.to_device(sw), n_ext, n, ncols)
+    hea, heb, hes = ctx.to_host(ea), ctx.to_host(eb), ctx.to_host(es)
+    t = hea + heb
+    t = np.where(t < hea, t + np.uint64(0xFFFFFFFF), t)
+    t = np.where(t >= np.uint64(P), t - np.uint64(P), t)
+    assert np.array_equal(t, hes)                                    # LDE(a+b) = LDE(a) + LDE(b)
+    # tree + path
+    nodes = ctx.empty((2 * n_ext - 1) * 4)
+    ctx.merkle_build(nodes, ea, ncols, n_ext)
+    idx = np.array([0, 123456, n_ext - 1], dtype=np.uint64)
+    stride = ncols + 4 * 21
+    proofs = ctx.empty(idx.size * stride)
+    ctx.merkle_group_proofs(proofs, nodes, ea, n_ext, ncols, idx)
+    pr = ctx.to_host(proofs).reshape(idx.size, stride)
+    root = ctx.to_host(nodes[-4:])
+    rows = hea.reshape(n_ext, ncols)
+    for q, i in enumerate(idx):
+        assert np.array_equal(pr[q][:ncols], rows[int(i)])
+        assert glo.merkle_verify(root, pr[q][:ncols], pr[q][ncols:], int(i))
+
+
+# ------------------------------------------------------------------ FRI
+@pytest.mark.parametrize("prev,cur", [(6, 5), (8, 6), (9, 6), (10, 6), (12, 7), (14, 8), (10, 10)])
+def test_fri_fold_matches_oracle(ctx, prev, cur):
+    rng = np.random.default_rng(prev * 17 + cur)
+    pol = glo.rand_fe(rng, (1 << prev, 3))
+    x = glo.rand_fe(rng, 3)
+    out = ctx.empty((1 << cur) * 3)
+    ctx.fri_fold(out, ctx.to_device(pol), prev, cur, 16, x)
+    assert np.array_equal(ctx.to_host(out).reshape(-1, 3), glo.fri_fold(pol, prev, cur, 16, x))
+
+
+def test_fri_transpose_and_step_tree(ctx):
+    rng = np.random.default_rng(40)
+    prev, nxt = 12, 8
+    pol = glo.rand_fe(rng, (1 << prev) * 3)
+    aux = ctx.empty(pol.size)
+    ctx.fri_transpose(aux, ctx.to_device(pol), 1 << prev, nxt)
+    want = glo.fri_transpose(pol, 1 << prev, nxt)
+    assert np.array_equal(ctx.to_host(aux), want)
+    # friProve.cpp:110-126: MerkleTreeGL(nGroups, groupSize*3) over the transposed polynomial
+    groups, gsize = 1 << nxt, (1 << (prev - nxt)) * 3
+    nodes = ctx.empty((2 * groups - 1) * 4)
+    ctx.merkle_build(nodes, aux, gsize, groups)
+    assert np.array_equal(ctx.to_host(nodes), glo.merkletree(want, gsize, groups))
+
+
+def test_golden_fri_fold_on_gpu(ctx, golden_dir):
+    """The reference's own proofs, folded on the GPU: plant the 43 opened groups of a step into an otherwise
+    random polynomial, fold, and the planted outputs must equal the next step's opened values / finalPol."""
+    d = np.load(os.path.join(golden_dir, "recursive1_proof_0.npz"))
+    rng = np.random.default_rng(41)
+    for s in range(1, 5):
+        prev, cur = BITS[s - 1], BITS[s]
+        nx = 1 << (prev - cur)
+        pol = glo.rand_fe(rng, (1 << prev, 3))
+        gs = []
+        for q in range(len(d["q_index"])):
+            g = int(d["q_index"][q]) % (1 << cur)
+            vals = d[f"s{s}_vals"][q].reshape(nx, 3)
+            for i in range(nx):
+                pol[i * (1 << cur) + g] = vals[i]
+            gs.append(g)
+        out = ctx.empty((1 << cur) * 3)
+        ctx.fri_fold(out, ctx.to_device(pol), prev, cur, 20, d["special_x"][s - 1])
+        got = ctx.to_host(out).reshape(-1, 3)
+        for q, g in enumerate(gs):
+            if s < 4:
+                j = g >> BITS[s + 1]
+                want = d[f"s{s + 1}_vals"][q][3 * j:3 * j + 3]
+            else:
+                want = d["finalPol"][g]
+            assert np.array_equal(got[g], want), (s, q)
+
+
+# ------------------------------------------------------------------ the rest of genProof's loops
+def test_q_split_batch_inverse_tables(ctx):
+    rng = np.random.default_rng(50)
+    n, qdeg = 1 << 10, 2
+    qq1 = glo.rand_fe(rng, (2 * n) * 3)
+    qq2 = ctx.empty(2 * n * qdeg * 3)
+    ctx.q_split(qq2, ctx.to_device(qq1), n, 2 * n, qdeg)
+    assert np.array_equal(ctx.to_host(qq2), glo.q_split(qq1, n, qdeg))
+    src = glo.rand_fe(rng, 999 * 3)
+    src[:3] = 0
+    d = ctx.to_device(src)
+    ctx.batch_inverse3(d, d, 999)
+    assert np.array_equal(ctx.to_host(d), glo.batch_inverse3(src))
+    w = glo.lib().glo_w(13)
+    out = ctx.empty(1 << 13)
+    ctx.geom_seq(out, 1 << 13, 49, w)                                 # x_2ns (starks.hpp:154-159)
+    assert np.array_equal(ctx.to_host(out), glo.geom_seq(1 << 13, 49, w))
+    r = glo.rand_fe(rng, 3)
+    o3 = ctx.empty(3 * 5000)
+    ctx.geom_seq3(o3, 5000, r)                                        # LEv (starks.cpp:311-323)
+    assert np.array_equal(ctx.to_host(o3), glo.geom_seq3(5000, r))
+    assert np.array_equal(ctx.zhinv(10, 11), glo.zhinv(10, 11))
+    assert np.array_equal(ctx.zhinv(8, 11), glo.zhinv(8, 11))
+    # xDivXSubXi (starks.cpp:350-365)
+    xs = glo.geom_seq(4096, 49, glo.lib().glo_w(12))
+    xi = glo.rand_fe(rng, 3)
+    o = ctx.empty(4096 * 3)
+    ctx.x_div_x_sub(o, ctx.to_device(xs), 4096, xi)
+    got = ctx.to_host(o).reshape(-1, 3)
+    for k in (0, 1, 4095):
+        den = np.array([(int(xs[k]) - int(xi[0])) % P, (-int(xi[1])) % P, (-int(xi[2])) % P], dtype=np.uint64)
+        want = glo.e3_mul(glo.e3_inv(den), np.array([xs[k], 0, 0], dtype=np.uint64))
+        assert np.array_equal(got[k], want)
+
+
+def test_evmap_matches_oracle(ctx):
+    rng = np.random.default_rng(51)
+    n, ext_bits, width = 1 << 12, 1, 23
+    cm = glo.rand_fe(rng, ((n << ext_bits), width))
+    q = glo.rand_fe(rng, ((n << ext_bits), 3))
+    lev, lpev = glo.rand_fe(rng, (n, 3)), glo.rand_fe(rng, (n, 3))
+    d_cm, d_q = ctx.to_device(cm), ctx.to_device(q)
+    pols_h = [(cm, c, 1, width) for c in (0, 5, 5, 22, 7)] + [(cm, 10, 3, width), (q, 0, 3, 3)]
+    pols_d = [(d_cm, c, 1, width) for c in (0, 5, 5, 22, 7)] + [(d_cm, 10, 3, width), (d_q, 0, 3, 3)]
+    prime = [0, 1, 0, 1, 1, 0, 1]
+    ev = ctx.empty(len(pols_d) * 3)
+    ctx.evmap(ev, pols_d, prime, ctx.to_device(lev), ctx.to_device(lpev), n, ext_bits)
+    assert np.array_equal(ctx.to_host(ev).reshape(-1, 3), glo.evmap(pols_h, prime, lev, lpev, n, ext_bits))
