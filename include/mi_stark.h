@@ -49,7 +49,8 @@ typedef enum {
 /* One context per GPU/process (one process per GPU).  device < 0 keeps the current device. */
 int mi_ctx_create(mi_ctx **out, int device);
 void mi_ctx_destroy(mi_ctx *ctx);
-/* Use a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* Use a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL (the initial
+ * value) is the device's default stream. */
 int mi_ctx_set_stream(mi_ctx *ctx, void *hip_stream);
 int mi_ctx_sync(mi_ctx *ctx);
 /* Scratch HBM the library may allocate lazily for NTT/LDE ping-pong buffers (default 16 GiB,

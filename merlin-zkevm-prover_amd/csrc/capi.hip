@@ -54,8 +54,8 @@ extern "C" int mi_ctx_create(mi_ctx **out, int device)
     hipDeviceProp_t prop;
     MI_HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
     c->cu_count = prop.multiProcessorCount;
-    MI_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
+    c->stream = nullptr; // the device's default stream until the caller hands one over
+    c->own_stream = false;
     MI_HIP_CHECK(hipMalloc((void **)&c->small, 4096));
     for (int i = 0; i < 8; i++) {
         MI_HIP_CHECK(hipEventCreate(&c->ev_start[i]));
@@ -85,14 +85,10 @@ extern "C" int mi_ctx_set_stream(mi_ctx *c, void *s)
 {
     CTX_OK(c);
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    if (s) {
-        c->stream = (hipStream_t)s;
-        c->own_stream = false;
-    } else {
-        MI_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    // NULL is a valid handle: it names the device's default stream (what torch.cuda.current_stream()
+    // returns as 0 unless a side stream is active), which orders with every other stream's work.
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
     return MI_OK;
 }
 
