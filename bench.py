@@ -28,6 +28,9 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 7
 def cpu_baseline(log_n, ncols):
     """CPU oracle ("port", OpenMP) on a bounded sample of the same workload: LDE + Merkle tree of a
     2^log_n x ncols trace.  tests/glo.py is the oracle binding; it is used here only as the timed baseline."""
+    # threads = this process's CPU share (the GPU box gives 16 cores per GPU), set before libgomp starts
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(share, 16))))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import glo
     n, n_ext = 1 << log_n, 2 << log_n
@@ -55,8 +58,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=23, help="log2 of trace rows (BASELINE: 23)")
     ap.add_argument("--cols", type=int, default=665, help="committed columns (BASELINE: 665)")
     ap.add_argument("--workspace-gib", type=float, default=16.0)
-    ap.add_argument("--poseidon-variant", type=int, default=1)
-    ap.add_argument("--cpu-log-n", type=int, default=14, help="log2 rows of the CPU-baseline sample")
+    ap.add_argument("--poseidon-variant", type=int, default=0)
+    ap.add_argument("--cpu-log-n", type=int, default=16, help="log2 rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

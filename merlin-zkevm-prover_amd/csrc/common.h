@@ -50,7 +50,7 @@ struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int poseidon_variant = 1;
+    int poseidon_variant = 0; // 0 = 32-bit halves / v_mad_u64_u32 (fewer instructions; all int multiplies issue at the same rate on gfx950)
     uint64_t workspace_limit = 16ULL << 30;
     u64 *workspace = nullptr;
     uint64_t workspace_bytes = 0;

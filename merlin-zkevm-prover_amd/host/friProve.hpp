@@ -1,0 +1,159 @@
+// friProve.hpp -- FRIProve::prove with the reference's control flow (friProve.cpp:5-190) on device-resident
+// data: the FRI polynomial stays in HBM across steps (fold -> transpose -> step tree), only step roots, the
+// final polynomial and the query openings come back.  StarkInfo / FRIProof carry just the fields this path
+// reads (stark_info.hpp:21-35, friProof.hpp:9-236 minus the JSON writers).
+#ifndef FRI_PROVE
+#define FRI_PROVE
+#include <vector>
+#include "transcript.hpp"
+#include "polinomial.hpp"
+#include "merkleTreeGL.hpp"
+#include "ntt_goldilocks.hpp"
+
+class StepStruct { public: uint64_t nBits; };
+class StarkStruct { public: uint64_t nBits = 0, nBitsExt = 0, nQueries = 0; std::vector<StepStruct> steps; };
+class StarkInfo { public: StarkStruct starkStruct; };
+
+class MerkleProof
+{
+public:
+    std::vector<std::vector<Goldilocks::Element>> v;
+    std::vector<std::vector<Goldilocks::Element>> mp;
+    MerkleProof(uint64_t nLinears, uint64_t elementsTree, Goldilocks::Element *pointer)
+        : v(nLinears, std::vector<Goldilocks::Element>(1, Goldilocks::zero())), mp(elementsTree, std::vector<Goldilocks::Element>(HASH_SIZE, Goldilocks::zero()))
+    {
+        for (uint64_t i = 0; i < nLinears; i++) v[i][0] = pointer[i];
+        for (uint64_t j = 0; j < elementsTree; j++) std::memcpy(&mp[j][0], &pointer[nLinears + j * HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+    };
+};
+class ProofTree
+{
+public:
+    std::vector<Goldilocks::Element> root;
+    std::vector<std::vector<MerkleProof>> polQueries;
+    ProofTree() : root(HASH_SIZE){};
+    void setRoot(Goldilocks::Element *_root) { std::memcpy(&root[0], _root, HASH_SIZE * sizeof(Goldilocks::Element)); };
+};
+class Fri
+{
+public:
+    std::vector<std::vector<Goldilocks::Element>> pol;
+    std::vector<ProofTree> trees;
+    Fri(uint64_t polN, uint64_t dim, uint64_t numSteps) : pol(polN, std::vector<Goldilocks::Element>(dim, Goldilocks::zero())), trees(numSteps){};
+    void setPol(Goldilocks::Element *pPol)
+    {
+        for (uint64_t i = 0; i < pol.size(); i++) std::memcpy(&pol[i][0], &pPol[i * pol[i].size()], pol[i].size() * sizeof(Goldilocks::Element));
+    }
+};
+class Proofs
+{
+public:
+    Fri fri;
+    Proofs(StarkInfo &starkInfo)
+        : fri(1ULL << starkInfo.starkStruct.steps[starkInfo.starkStruct.steps.size() - 1].nBits, FIELD_EXTENSION, starkInfo.starkStruct.steps.size()){};
+};
+class FRIProof
+{
+public:
+    Proofs proofs;
+    FRIProof(StarkInfo &starkInfo) : proofs(starkInfo){};
+};
+
+class FRIProve
+{
+public:
+    // treesGL: the 5 commitment trees opened at step 0 (null entries are skipped); friPol: 2^polBits cubic-extension
+    // elements in HOST memory (as in the reference) -- it is uploaded once and folded in HBM.
+    static void prove(FRIProof &fproof, MerkleTreeGL **treesGL, Transcript transcript, Polinomial &friPol, uint64_t polBits, StarkInfo starkInfo,
+                      uint64_t nTrees = 5)
+    {
+        mi_ctx *c = mi::ctx();
+        const std::vector<StepStruct> &steps = starkInfo.starkStruct.steps;
+        const uint64_t nBitsExt = polBits;
+        uint64_t *d_pol = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8), *d_next = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8);
+        uint64_t *d_aux = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8);
+        if (!d_pol || !d_next || !d_aux) mi::fail("FRIProve::prove (alloc)");
+        mi::check(mi_copy_h2d(c, d_pol, friPol.address(), (3ULL << polBits) * 8), "FRIProve::prove (h2d)");
+        std::vector<MerkleTreeGL *> treesFRIGL(steps.size(), nullptr);
+        uint64_t pol2N = 0;
+        for (uint64_t si = 0; si < steps.size(); si++) {
+            const uint64_t curBits = steps[si].nBits;
+            pol2N = 1ULL << curBits;
+            Goldilocks::Element special_x[FIELD_EXTENSION];
+            transcript.getField(special_x); // friProve.cpp:30
+            mi::check(mi_fri_fold_dev(c, d_next, d_pol, (unsigned)polBits, (unsigned)curBits, (unsigned)nBitsExt, (const uint64_t *)special_x),
+                      "FRIProve::prove (fold)"); // friProve.cpp:44-108 (a copy when si == 0)
+            if (si < steps.size() - 1) { // friProve.cpp:110-126
+                const uint64_t nGroups = 1ULL << steps[si + 1].nBits, groupSize = pol2N / nGroups;
+                mi::check(mi_fri_transpose_dev(c, d_aux, d_next, pol2N, (unsigned)steps[si + 1].nBits), "FRIProve::prove (transpose)");
+                MerkleTreeGL *t = new MerkleTreeGL(nGroups, groupSize * FIELD_EXTENSION, NULL);
+                uint64_t *d_src = (uint64_t *)mi_dev_alloc(c, pol2N * 3 * 8); // the tree keeps its own leaves for the query phase
+                if (!d_src) mi::fail("FRIProve::prove (alloc tree source)");
+                mi::check(mi_copy_2d_dev(c, d_src, groupSize * 3, d_aux, groupSize * 3, nGroups, groupSize * 3), "FRIProve::prove (copySource)");
+                t->setDeviceSource(d_src);
+                t->merkelize();
+                Goldilocks::Element rootGL[HASH_SIZE];
+                t->getRoot(rootGL);
+                transcript.put(rootGL, HASH_SIZE);
+                fproof.proofs.fri.trees[si + 1].setRoot(rootGL);
+                treesFRIGL[si + 1] = t;
+                owned_sources().push_back(d_src);
+            } else { // friProve.cpp:128-134: the last polynomial goes into the transcript and the proof
+                std::vector<Goldilocks::Element> last(pol2N * 3);
+                mi::check(mi_copy_d2h(c, last.data(), d_next, pol2N * 3 * 8), "FRIProve::prove (final pol)");
+                for (uint64_t i = 0; i < pol2N; i++) transcript.put(&last[i * 3], FIELD_EXTENSION);
+                fproof.proofs.fri.setPol(last.data());
+                std::memcpy(friPol.address(), last.data(), pol2N * 3 * 8); // the reference leaves the folded pol in friPol
+            }
+            std::swap(d_pol, d_next);
+            polBits = curBits;
+        }
+        // ---- query phase (friProve.cpp:155-187)
+        std::vector<uint64_t> ys(starkInfo.starkStruct.nQueries);
+        transcript.getPermutations(ys.data(), starkInfo.starkStruct.nQueries, steps[0].nBits);
+        for (uint64_t si = 0; si < steps.size(); si++) {
+            if (si == 0) {
+                std::vector<std::vector<Goldilocks::Element>> buffs(nTrees);
+                for (uint64_t t = 0; t < nTrees; t++) {
+                    if (!treesGL[t]) continue;
+                    const uint64_t stride = treesGL[t]->width + treesGL[t]->MerkleProofSize() * HASH_SIZE;
+                    buffs[t].resize(stride * ys.size());
+                    treesGL[t]->getGroupProofs(buffs[t].data(), ys.data(), ys.size());
+                }
+                for (uint64_t i = 0; i < ys.size(); i++) {
+                    std::vector<MerkleProof> vMkProof;
+                    for (uint64_t t = 0; t < nTrees; t++) {
+                        if (!treesGL[t]) continue;
+                        const uint64_t stride = treesGL[t]->width + treesGL[t]->MerkleProofSize() * HASH_SIZE;
+                        vMkProof.push_back(MerkleProof(treesGL[t]->width, treesGL[t]->MerkleProofSize(), &buffs[t][i * stride]));
+                    }
+                    fproof.proofs.fri.trees[0].polQueries.push_back(vMkProof);
+                }
+            } else {
+                MerkleTreeGL *t = treesFRIGL[si];
+                const uint64_t stride = t->width + t->MerkleProofSize() * HASH_SIZE;
+                std::vector<Goldilocks::Element> buff(stride * ys.size());
+                t->getGroupProofs(buff.data(), ys.data(), ys.size());
+                for (uint64_t i = 0; i < ys.size(); i++) {
+                    std::vector<MerkleProof> vMkProof;
+                    vMkProof.push_back(MerkleProof(t->width, t->MerkleProofSize(), &buff[i * stride]));
+                    fproof.proofs.fri.trees[si].polQueries.push_back(vMkProof);
+                }
+            }
+            if (si < steps.size() - 1)
+                for (uint64_t i = 0; i < ys.size(); i++) ys[i] = ys[i] % (1ULL << steps[si + 1].nBits);
+        }
+        for (MerkleTreeGL *t : treesFRIGL) delete t;
+        for (uint64_t *p : owned_sources()) mi_dev_free(c, p);
+        owned_sources().clear();
+        mi_dev_free(c, d_pol); mi_dev_free(c, d_next); mi_dev_free(c, d_aux);
+    }
+
+private:
+    static std::vector<uint64_t *> &owned_sources()
+    {
+        static std::vector<uint64_t *> v;
+        return v;
+    }
+};
+#endif

@@ -1,0 +1,128 @@
+// merkleTreeGL.hpp -- MerkleTreeGL with the reference's public surface (merkleTreeGL.hpp:9-79,
+// merkleTreeGL.cpp:5-44): height, width, source, nodes, copySource, merkelize, getTreeNumElements, getRoot,
+// getGroupProof, MerkleProofSize.  Level-1 re-implementation: merkelize() builds the tree in HBM
+// and keeps source + nodes device-resident; getRoot / getGroupProof fetch 4 / width+4*levels elements.  The
+// host `nodes` array of the reference is still allocated (same ownership rules) and filled on demand by
+// syncNodesToHost() for callers that walk it directly.
+#ifndef MERKLETREEGL
+#define MERKLETREEGL
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include "goldilocks_base_field.hpp"
+#include "poseidon_goldilocks.hpp"
+#include "merklehash_goldilocks.hpp"
+#include "mi_runtime.hpp"
+
+#define MERKLEHASHGL_ARITY 2
+class MerkleTreeGL
+{
+    uint64_t *d_source = nullptr, *d_nodes = nullptr; // HBM copies
+    bool d_source_borrowed = false;
+    void releaseDevice()
+    {
+        if (d_source && !d_source_borrowed) mi_dev_free(mi::ctx(), d_source);
+        if (d_nodes) mi_dev_free(mi::ctx(), d_nodes);
+        d_source = d_nodes = nullptr;
+        d_source_borrowed = false;
+    }
+
+public:
+    uint64_t height = 0;
+    uint64_t width = 0;
+    Goldilocks::Element *source = NULL;
+    Goldilocks::Element *nodes = NULL;
+    bool isSourceAllocated = false;
+    bool isNodesAllocated = false;
+    MerkleTreeGL(){};
+    MerkleTreeGL(Goldilocks::Element *tree) // constant tree mapped from a file: [width, height, source, nodes]
+    {
+        width = Goldilocks::toU64(tree[0]);
+        height = Goldilocks::toU64(tree[1]);
+        source = &tree[2];
+        nodes = &tree[2 + height * width];
+    };
+    MerkleTreeGL(uint64_t _height, uint64_t _width, Goldilocks::Element *_source) : height(_height), width(_width), source(_source)
+    {
+        if (source == NULL) {
+            source = (Goldilocks::Element *)calloc(height * width, sizeof(Goldilocks::Element));
+            isSourceAllocated = true;
+        }
+        nodes = (Goldilocks::Element *)calloc(getTreeNumElements(), sizeof(Goldilocks::Element));
+        isNodesAllocated = true;
+    };
+    MerkleTreeGL(const MerkleTreeGL &) = delete;
+    MerkleTreeGL &operator=(const MerkleTreeGL &) = delete;
+    ~MerkleTreeGL()
+    {
+        releaseDevice();
+        if (isSourceAllocated) free(source);
+        if (isNodesAllocated) free(nodes);
+    };
+    void copySource(Goldilocks::Element *_source) { std::memcpy(source, _source, height * width * sizeof(Goldilocks::Element)); }
+    // device-resident source (e.g. an LDE output that never left HBM): borrowed, pitch == width
+    void setDeviceSource(uint64_t *dev_source)
+    {
+        releaseDevice();
+        d_source = dev_source;
+        d_source_borrowed = true;
+    }
+    uint64_t *deviceNodes() { return d_nodes; }
+    uint64_t *deviceSource() { return d_source; }
+
+    void merkelize() // merkleTreeGL.cpp:37-44
+    {
+        mi_ctx *c = mi::ctx();
+        if (!d_source) {
+            d_source = (uint64_t *)mi_dev_alloc(c, height * width * 8);
+            if (!d_source) mi::fail("MerkleTreeGL::merkelize (alloc source)");
+        }
+        if (!d_source_borrowed) mi::check(mi_copy_h2d(c, d_source, source, height * width * 8), "MerkleTreeGL::merkelize (h2d)");
+        if (!d_nodes) {
+            d_nodes = (uint64_t *)mi_dev_alloc(c, getTreeNumElements() * 8);
+            if (!d_nodes) mi::fail("MerkleTreeGL::merkelize (alloc nodes)");
+        }
+        mi::check(mi_merkle_build_dev(c, d_nodes, d_source, width, width, height), "MerkleTreeGL::merkelize");
+    }
+    void syncNodesToHost()
+    {
+        if (d_nodes) mi::check(mi_copy_d2h(mi::ctx(), nodes, d_nodes, getTreeNumElements() * 8), "MerkleTreeGL::syncNodesToHost");
+    }
+    uint64_t getTreeNumElements() { return height * HASH_SIZE + (height - 1) * HASH_SIZE; }
+    void getRoot(Goldilocks::Element *root)
+    {
+        if (d_nodes) mi::check(mi_copy_d2h(mi::ctx(), root, d_nodes + getTreeNumElements() - HASH_SIZE, HASH_SIZE * 8), "MerkleTreeGL::getRoot");
+        else std::memcpy(root, &nodes[getTreeNumElements() - HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+    }
+    uint64_t MerkleProofSize()
+    {
+        if (height > 1) return (uint64_t)ceil(log10(height) / log10(MERKLEHASHGL_ARITY));
+        return 0;
+    }
+    // proof = width values of row idx, then the sibling of every level (merkleTreeGL.cpp:12-35)
+    void getGroupProof(Goldilocks::Element *proof, uint64_t idx) { getGroupProofs(proof, &idx, 1); }
+    void getGroupProofs(Goldilocks::Element *proofs, const uint64_t *idx, uint64_t nq)
+    {
+        const uint64_t stride = width + MerkleProofSize() * HASH_SIZE;
+        if (d_nodes && d_source) {
+            mi_ctx *c = mi::ctx();
+            uint64_t *d_out = (uint64_t *)mi_dev_alloc(c, nq * stride * 8);
+            if (!d_out) mi::fail("MerkleTreeGL::getGroupProofs (alloc)");
+            mi::check(mi_merkle_group_proofs_dev(c, d_out, d_nodes, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs");
+            mi::check(mi_copy_d2h(c, proofs, d_out, nq * stride * 8), "MerkleTreeGL::getGroupProofs (d2h)");
+            mi_dev_free(c, d_out);
+            return;
+        }
+        for (uint64_t q = 0; q < nq; q++) { // tree loaded from a file (constant tree): plain copies, no arithmetic
+            Goldilocks::Element *p = proofs + q * stride;
+            std::memcpy(p, &source[idx[q] * width], width * sizeof(Goldilocks::Element));
+            uint64_t id = idx[q], offset = 0, n = height;
+            p += width;
+            while (n > 1) {
+                std::memcpy(p, &nodes[offset + (id ^ 1) * HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+                p += HASH_SIZE; offset += n * HASH_SIZE; n >>= 1; id >>= 1;
+            }
+        }
+    }
+};
+#endif

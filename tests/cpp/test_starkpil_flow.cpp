@@ -1,0 +1,186 @@
+// test_starkpil_flow.cpp -- drives the header shims (merlin-zkevm-prover_amd/host) the way src/starkpil does
+// (starks.cpp:48-59,261-292,325; friProve.cpp:5-190) and checks every result bit-for-bit against the CPU oracle.
+// Built by tests/test_cpp_shims.py with g++ against libmi_stark.so + liboracle; needs a GPU to run.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "goldilocks_base_field.hpp"
+#include "goldilocks_cubic_extension.hpp"
+#include "ntt_goldilocks.hpp"
+#include "poseidon_goldilocks.hpp"
+#include "merkleTreeGL.hpp"
+#include "transcript.hpp"
+#include "polinomial.hpp"
+#include "friProve.hpp"
+#include "../../oracle/gl_oracle.h"
+
+static int failures = 0;
+#define EXPECT(cond, what)                                            \
+    do {                                                              \
+        if (!(cond)) { std::printf("FAIL: %s (line %d)\n", what, __LINE__); failures++; } \
+        else std::printf("ok: %s\n", what);                           \
+    } while (0)
+
+static uint64_t splitmix(uint64_t seed, uint64_t i)
+{
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z >= GLO_P ? z - GLO_P : z;
+}
+static bool same(const void *a, const void *b, size_t n_elems) { return std::memcmp(a, b, n_elems * 8) == 0; }
+
+int main()
+{
+    const uint64_t nBits = 12, nBitsExt = 13, N = 1ULL << nBits, NExtended = 1ULL << nBitsExt, nCols = 37;
+    // ---- STEP 1 of Starks::genProof (starks.cpp:48-59)
+    std::vector<Goldilocks::Element> cm1_n(N * nCols), cm1_2ns(NExtended * nCols), want_2ns(NExtended * nCols);
+    for (uint64_t i = 0; i < N * nCols; i++) cm1_n[i] = Goldilocks::fromU64(splitmix(1, i));
+    NTT_Goldilocks ntt(N), nttExtended(NExtended);
+    ntt.extendPol(cm1_2ns.data(), cm1_n.data(), NExtended, N, nCols, NULL);
+    glo_extend_pol((uint64_t *)want_2ns.data(), (const uint64_t *)cm1_n.data(), NExtended, N, nCols);
+    EXPECT(same(cm1_2ns.data(), want_2ns.data(), NExtended * nCols), "extendPol == oracle");
+
+    MerkleTreeGL *treesGL[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    treesGL[0] = new MerkleTreeGL(NExtended, nCols, cm1_2ns.data());
+    treesGL[0]->merkelize();
+    Goldilocks::Element root0[HASH_SIZE];
+    treesGL[0]->getRoot(root0);
+    std::vector<uint64_t> want_nodes((2 * NExtended - 1) * 4);
+    glo_merkletree(want_nodes.data(), (const uint64_t *)want_2ns.data(), nCols, NExtended);
+    EXPECT(same(root0, &want_nodes[want_nodes.size() - 4], 4), "MerkleTreeGL root == oracle");
+    treesGL[0]->syncNodesToHost();
+    EXPECT(same(treesGL[0]->nodes, want_nodes.data(), want_nodes.size()), "MerkleTreeGL nodes == oracle");
+    {
+        std::vector<Goldilocks::Element> proof(nCols + treesGL[0]->MerkleProofSize() * HASH_SIZE), wantp(proof.size());
+        treesGL[0]->getGroupProof(proof.data(), 777);
+        glo_merkle_group_proof((uint64_t *)wantp.data(), want_nodes.data(), (const uint64_t *)want_2ns.data(), NExtended, nCols, 777);
+        EXPECT(treesGL[0]->MerkleProofSize() == nBitsExt && same(proof.data(), wantp.data(), proof.size()), "getGroupProof == oracle");
+    }
+
+    Transcript transcript;
+    glo_transcript otr;
+    glo_transcript_init(&otr);
+    Goldilocks::Element publics[3] = {{11}, {22}, {33}};
+    transcript.put(publics, 3);
+    glo_transcript_put(&otr, (const uint64_t *)publics, 3);
+    transcript.put(root0, HASH_SIZE);
+    glo_transcript_put(&otr, (const uint64_t *)root0, HASH_SIZE);
+    Goldilocks::Element ch[3];
+    uint64_t och[3];
+    transcript.getField(ch);
+    glo_transcript_get_field(&otr, och);
+    EXPECT(same(ch, och, 3), "Transcript challenge == oracle");
+
+    // ---- STEP 4 shapes (starks.cpp:261,284): INTT with the positional (NULL, 2, 1) hints, NTT over 6 columns
+    std::vector<Goldilocks::Element> q_2ns(NExtended * 3), qq1(NExtended * 3), wq(NExtended * 3);
+    for (uint64_t i = 0; i < q_2ns.size(); i++) q_2ns[i] = Goldilocks::fromU64(splitmix(2, i));
+    nttExtended.INTT(qq1.data(), q_2ns.data(), NExtended, 3, NULL, 2, 1);
+    glo_ntt((uint64_t *)wq.data(), (const uint64_t *)q_2ns.data(), NExtended, 3, 1);
+    EXPECT(same(qq1.data(), wq.data(), NExtended * 3), "nttExtended.INTT(.., 3, NULL, 2, 1) == oracle");
+    std::vector<Goldilocks::Element> qq2(NExtended * 6), cm4(NExtended * 6), w4(NExtended * 6);
+    for (uint64_t i = 0; i < qq2.size(); i++) qq2[i] = Goldilocks::fromU64(splitmix(3, i));
+    nttExtended.NTT(cm4.data(), qq2.data(), NExtended, 6);
+    glo_ntt((uint64_t *)w4.data(), (const uint64_t *)qq2.data(), NExtended, 6, 0);
+    EXPECT(same(cm4.data(), w4.data(), NExtended * 6), "nttExtended.NTT(.., 6) == oracle");
+
+    // ---- STEP 5: LEv geometric series + in-place INTT (starks.cpp:311-326), batchInverse (polinomial.hpp:612)
+    Polinomial LEv(N, 3, "LEv");
+    Polinomial xis(1, 3);
+    xis[0][0] = ch[0]; xis[0][1] = ch[1]; xis[0][2] = ch[2];
+    Goldilocks3::one((Goldilocks3::Element &)*LEv[0]);
+    for (uint64_t k = 1; k < N; k++) Polinomial::mulElement(LEv, k, LEv, k - 1, xis, 0);
+    std::vector<uint64_t> wlev(N * 3), wlev2(N * 3);
+    glo_geom_seq3(wlev.data(), N, och);
+    EXPECT(same(LEv.address(), wlev.data(), N * 3), "LEv series == oracle");
+    ntt.INTT(LEv.address(), LEv.address(), N, 3);
+    glo_ntt(wlev2.data(), wlev.data(), N, 3, 1);
+    EXPECT(same(LEv.address(), wlev2.data(), N * 3), "in-place ntt.INTT(LEv, LEv, N, 3) == oracle");
+    Polinomial inv(N, 3);
+    Polinomial::batchInverseParallel(inv, LEv);
+    std::vector<uint64_t> winv(N * 3);
+    glo_batch_inverse3(winv.data(), wlev2.data(), N);
+    EXPECT(same(inv.address(), winv.data(), N * 3), "batchInverseParallel == oracle");
+
+    // ---- FRI (friProve.cpp:5-190) with steps 13 -> 9 -> 6 -> 3, 11 queries; oracle mirror alongside
+    StarkInfo starkInfo;
+    starkInfo.starkStruct.nBits = nBits;
+    starkInfo.starkStruct.nBitsExt = nBitsExt;
+    starkInfo.starkStruct.nQueries = 11;
+    for (uint64_t b : {13, 9, 6, 3}) starkInfo.starkStruct.steps.push_back(StepStruct{b});
+    std::vector<Goldilocks::Element> f_2ns(NExtended * 3);
+    for (uint64_t i = 0; i < f_2ns.size(); i++) f_2ns[i] = Goldilocks::fromU64(splitmix(4, i));
+    std::vector<uint64_t> opol((const uint64_t *)f_2ns.data(), (const uint64_t *)f_2ns.data() + f_2ns.size());
+    Polinomial friPol(f_2ns.data(), NExtended, 3, 3, "friPol");
+    FRIProof fproof(starkInfo);
+    FRIProve::prove(fproof, treesGL, transcript, friPol, nBitsExt, starkInfo);
+
+    // oracle mirror of FRIProve::prove
+    std::vector<std::vector<uint64_t>> otrees(4), osrc(4);
+    uint64_t polBits = nBitsExt;
+    bool roots_ok = true;
+    for (size_t si = 0; si < 4; si++) {
+        uint64_t cur = starkInfo.starkStruct.steps[si].nBits, x[3];
+        glo_transcript_get_field(&otr, x);
+        std::vector<uint64_t> nxt((1ULL << cur) * 3);
+        glo_fri_fold(nxt.data(), opol.data(), (unsigned)polBits, (unsigned)cur, (unsigned)nBitsExt, x);
+        if (si < 3) {
+            uint64_t nb = starkInfo.starkStruct.steps[si + 1].nBits, groups = 1ULL << nb, gsz = ((1ULL << cur) / groups) * 3;
+            osrc[si + 1].resize(nxt.size());
+            glo_fri_transpose(osrc[si + 1].data(), nxt.data(), 1ULL << cur, (unsigned)nb);
+            otrees[si + 1].resize((2 * groups - 1) * 4);
+            glo_merkletree(otrees[si + 1].data(), osrc[si + 1].data(), gsz, groups);
+            const uint64_t *r = &otrees[si + 1][otrees[si + 1].size() - 4];
+            glo_transcript_put(&otr, r, 4);
+            roots_ok = roots_ok && same(r, fproof.proofs.fri.trees[si + 1].root.data(), 4);
+        } else {
+            for (uint64_t i = 0; i < (1ULL << cur); i++) glo_transcript_put(&otr, &nxt[i * 3], 3);
+            bool pol_ok = true;
+            for (uint64_t i = 0; i < (1ULL << cur); i++) pol_ok = pol_ok && same(fproof.proofs.fri.pol[i].data(), &nxt[i * 3], 3);
+            EXPECT(pol_ok, "FRI final polynomial == oracle");
+        }
+        opol = nxt;
+        polBits = cur;
+    }
+    EXPECT(roots_ok, "FRI step roots == oracle");
+    std::vector<uint64_t> ys(11);
+    glo_transcript_get_permutations(&otr, ys.data(), 11, 13);
+    bool q_ok = fproof.proofs.fri.trees[0].polQueries.size() == 11;
+    for (size_t si = 0; si < 4 && q_ok; si++) {
+        for (size_t i = 0; i < 11 && q_ok; i++) {
+            const std::vector<MerkleProof> &mk = fproof.proofs.fri.trees[si].polQueries[i];
+            uint64_t w, h;
+            const uint64_t *nodes, *src;
+            if (si == 0) { w = nCols; h = NExtended; nodes = want_nodes.data(); src = (const uint64_t *)want_2ns.data(); }
+            else { h = 1ULL << starkInfo.starkStruct.steps[si].nBits; w = osrc[si].size() / h; nodes = otrees[si].data(); src = osrc[si].data(); }
+            uint64_t levels = 0;
+            while ((1ULL << levels) < h) levels++;
+            std::vector<uint64_t> wp(w + 4 * levels);
+            glo_merkle_group_proof(wp.data(), nodes, src, h, w, ys[i]);
+            q_ok = mk.size() == 1 && mk[0].v.size() == w && mk[0].mp.size() == levels;
+            for (uint64_t k = 0; k < w && q_ok; k++) q_ok = mk[0].v[k][0].fe == wp[k];
+            for (uint64_t l = 0; l < levels && q_ok; l++) q_ok = same(mk[0].mp[l].data(), &wp[w + 4 * l], 4);
+            q_ok = q_ok && glo_merkle_verify(si == 0 ? (const uint64_t *)root0 : &otrees[si][otrees[si].size() - 4], wp.data(), w, &wp[w], levels, ys[i]);
+        }
+        for (auto &y : ys) if (si < 3) y %= (1ULL << starkInfo.starkStruct.steps[si + 1].nBits);
+    }
+    EXPECT(q_ok, "FRI query openings == oracle and verify against the roots");
+
+    // ---- scalar API spot checks used by the reference (zhInv.cpp, starks.hpp:149-160)
+    EXPECT(Goldilocks::toU64(Goldilocks::w(3)) == glo_w(3) && Goldilocks::toU64(Goldilocks::w(24)) == glo_w(24), "Goldilocks::w");
+    EXPECT(Goldilocks::toU64(Goldilocks::inv(Goldilocks::shift())) == glo_inv(49), "Goldilocks::inv(shift)");
+    Goldilocks3::Element a = {{5}, {6}, {7}}, ai, prod;
+    Goldilocks3::inv(ai, a);
+    Goldilocks3::mul(prod, a, ai);
+    EXPECT(Goldilocks3::isOne(prod), "Goldilocks3::inv");
+    Goldilocks::Element lh[4];
+    uint64_t wlh[4];
+    PoseidonGoldilocks::linear_hash(lh, cm1_n.data(), 18);
+    glo_linear_hash(wlh, (const uint64_t *)cm1_n.data(), 18);
+    EXPECT(same(lh, wlh, 4), "PoseidonGoldilocks::linear_hash == oracle");
+
+    delete treesGL[0];
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL OK", failures);
+    return failures ? 1 : 0;
+}
