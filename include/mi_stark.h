@@ -154,6 +154,9 @@ int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* Selects the Poseidon MDS code path (0 = 32-bit halves / v_mad_u64_u32, 1 = 22-bit limbs /
  * v_mad_u32_u24).  Both are bit-identical; exposed for benchmarking. */
 int mi_set_poseidon_variant(mi_ctx *ctx, int variant);
+/* NTT tile width in elements per row segment: log_b = 4 (128-byte segments, 4 workgroups per CU) or 5
+ * (256-byte segments, 2 per CU).  Results are identical; exposed for benchmarking. */
+int mi_set_ntt_tile(mi_ctx *ctx, int log_b);
 
 /* Timing hooks used by bench.py: HIP events recorded on the context's stream. */
 int mi_timer_start(mi_ctx *ctx, int slot);

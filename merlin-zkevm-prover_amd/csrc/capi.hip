@@ -123,6 +123,14 @@ int mi_ensure_workspace(mi_ctx *c, uint64_t bytes)
     return MI_OK;
 }
 
+extern "C" int mi_set_ntt_tile(mi_ctx *c, int log_b)
+{
+    CTX_OK(c);
+    MI_REQUIRE(log_b == 4 || log_b == 5, "log_b must be 4 or 5");
+    c->ntt_log_b = (uint32_t)log_b;
+    return MI_OK;
+}
+
 extern "C" int mi_set_poseidon_variant(mi_ctx *c, int v)
 {
     CTX_OK(c);

@@ -60,6 +60,7 @@ struct mi_ctx {
     std::vector<void *> owned; // tables to free
     hipEvent_t ev_start[8] = {}, ev_stop[8] = {};
     int cu_count = 256;
+    uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
 };
 
 int mi_ensure_workspace(mi_ctx *ctx, uint64_t bytes);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64) void k_fri_fold(u64 *__restrict__ out, const u6
         for (int i = 0; i < NX; i++) v[i] = gl::canon(pol[((uint64_t)i * pol2n + g) * 3 + d]);
         nttm::dft_reg<LOG_NX, true>(v);
 #pragma unroll
-        for (int k = 0; k < NX; k++) smem[(k * 3 + d) * 64 + lane] = gl::mul(v[k], nx_inv);
+        for (int k = 0; k < NX; k++) smem[(k * 3 + d) * 64 + lane] = gl::mul(v[k], nx_inv); // dft_reg output is weak; mul canonicalises
     }
     const u64 sinv = gl::mul(sinv0, gl::pow(wi, g));
     const E3 y = gl::e3_mul1(x, sinv);

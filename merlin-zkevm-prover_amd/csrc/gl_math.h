@@ -48,6 +48,15 @@ MI_HD u64 sub(u64 a, u64 b)
 
 MI_HD u64 neg(u64 a) { return a ? GL_P - a : 0; }
 
+// a any u64, b canonical (< p)  ->  weakly reduced a - b
+MI_HD u64 sub_wc(u64 a, u64 b)
+{
+    u64 d = a - b;
+    return a < b ? d - GL_EPS : d; // borrowed: d >= 2^64 - p + 1 > eps, so d - eps cannot borrow again
+}
+// any u64 -> weakly reduced -a
+MI_HD u64 neg_w(u64 a) { return GL_P - canon(a); }
+
 // 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
 MI_HD u64 reduce128_w(u64 lo, u64 hi)
 {

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "ntt_math.h"
 
+
 struct NttPass {
     const u64 *src;
     u64 *dst;
@@ -43,16 +44,18 @@ struct NttPass {
     const u64 *w256;
 };
 
-template <int LOG_R, bool INV>
-__global__ __launch_bounds__(256) void k_ntt_pass(const NttPass a)
+template <int LOG_R, bool INV, int LOG_B>
+__global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
 {
+    constexpr int B = 1 << LOG_B;               // batch elements per tile row (B * 8 bytes contiguous in HBM)
+    constexpr int NTT_THREADS = 16 * B;         // one radix-16 work item per thread and step at r = 256
     constexpr int R = 1 << LOG_R;
     constexpr int LB = LOG_R >= 4 ? 4 : LOG_R; // second in-register step
     constexpr int LA = LOG_R - LB;             // first in-register step (0..4 bits)
     constexpr int RA = 1 << LA, RB = 1 << LB;
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
-    u64 *tile = smem;          // [R][32]
-    u64 *w256 = tile + R * 32; // [256]
+    u64 *tile = smem;          // [R][B]
+    u64 *w256 = tile + R * B;  // [256]
     u64 *tw = w256 + 256;      // [R][TJ]
 
     const uint32_t tid = threadIdx.x;
@@ -68,8 +71,8 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const NttPass a)
     const uint64_t beta0 = (lt / a.n_col_tiles) << a.tj_log;
     const uint32_t c0 = (uint32_t)(lt % a.n_col_tiles) << a.tcp_log;
 
-    w256[tid] = a.w256[tid];
-    for (uint32_t e = tid; e < (uint32_t)R * TJ; e += 256) {
+    if (tid < 256) w256[tid] = a.w256[tid];
+    for (uint32_t e = tid; e < (uint32_t)R * TJ; e += NTT_THREADS) {
         const uint32_t k1 = e >> a.tj_log, tj = e & (TJ - 1);
         const uint64_t beta = beta0 + tj;
         const uint64_t ip = beta >> a.log_K, kappa = beta & (K - 1);
@@ -84,50 +87,50 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const NttPass a)
         tw[e] = t;
     }
 
-    // ---- load: lanes run along the 32 batch elements (contiguous in HBM), 8 rows per sweep
+    // ---- load: lanes run along the 32 batch elements (contiguous in HBM), 16 rows per sweep
     {
-        const uint32_t b = tid & 31, tj = b >> a.tcp_log, c = b & (TCP - 1);
+        const uint32_t b = tid & (B - 1), tj = b >> a.tcp_log, c = b & (TCP - 1);
         const uint32_t col = c0 + c;
         const bool active = col < a.ncols;
         const u64 *p = a.src + (beta0 + tj) * a.src_pitch + col;
 #pragma unroll 8
-        for (uint32_t i1 = tid >> 5; i1 < (uint32_t)R; i1 += 8) {
+        for (uint32_t i1 = tid >> LOG_B; i1 < (uint32_t)R; i1 += NTT_THREADS / B) {
             const uint64_t row = (uint64_t)i1 * mK + beta0 + tj;
             u64 v = 0;
-            if (active && row < a.in_valid_rows) v = gl::canon(p[(uint64_t)i1 * mK * a.src_pitch]);
-            tile[i1 * 32 + b] = v;
+            if (active && row < a.in_valid_rows) v = p[(uint64_t)i1 * mK * a.src_pitch]; // any encoding; dft_reg accepts it
+            tile[i1 * B + b] = v;
         }
     }
     __syncthreads();
 
     // ---- step A: RA-point DFTs over the high bits, in place, then twiddle by w_r^(p' ka)
     if (LA > 0) {
-        for (uint32_t item = tid; item < (uint32_t)RB * 32; item += 256) {
-            const uint32_t b = item & 31, pp = item >> 5;
+        for (uint32_t item = tid; item < (uint32_t)RB * B; item += NTT_THREADS) {
+            const uint32_t b = item & (B - 1), pp = item >> LOG_B;
             u64 x[RA];
 #pragma unroll
-            for (int i = 0; i < RA; i++) x[i] = tile[(i * RB + pp) * 32 + b];
+            for (int i = 0; i < RA; i++) x[i] = tile[(i * RB + pp) * B + b];
             nttm::dft_reg<LA, INV>(x);
 #pragma unroll
             for (int ka = 1; ka < RA; ka++) {
                 uint32_t idx = (pp * ka) << (8 - LOG_R);
                 if (INV) idx = (256 - idx) & 255;
-                x[ka] = gl::mul(x[ka], w256[idx]);
+                x[ka] = gl::mul_w(x[ka], w256[idx]);
             }
 #pragma unroll
-            for (int ka = 0; ka < RA; ka++) tile[(ka * RB + pp) * 32 + b] = x[ka];
+            for (int ka = 0; ka < RA; ka++) tile[(ka * RB + pp) * B + b] = x[ka];
         }
         __syncthreads();
     }
 
     // ---- step B: RB-point DFTs over the low bits, inter-pass twiddle / scale, store in natural order
-    for (uint32_t item = tid; item < (uint32_t)RA * 32; item += 256) {
-        const uint32_t b = item & 31, kap = item >> 5;
+    for (uint32_t item = tid; item < (uint32_t)RA * B; item += NTT_THREADS) {
+        const uint32_t b = item & (B - 1), kap = item >> LOG_B;
         const uint32_t tj = b >> a.tcp_log, c = b & (TCP - 1);
         const uint32_t col = c0 + c;
         u64 x[RB];
 #pragma unroll
-        for (int i = 0; i < RB; i++) x[i] = tile[(kap * RB + i) * 32 + b];
+        for (int i = 0; i < RB; i++) x[i] = tile[(kap * RB + i) * B + b];
         nttm::dft_reg<LB, INV>(x);
         if (col < a.ncols) {
             const uint64_t beta = beta0 + tj;
@@ -202,29 +205,37 @@ int mi_get_plan(mi_ctx *ctx, uint32_t log_n, NttPlan **plan)
     return MI_OK;
 }
 
-template <int LOG_R>
-static int launch_pass_r(mi_ctx *ctx, const NttPass &a, bool inv, size_t lds)
+template <int LOG_R, int LOG_B>
+static int launch_pass_rb(mi_ctx *ctx, const NttPass &a, bool inv, size_t lds)
 {
-    auto kf = k_ntt_pass<LOG_R, false>;
-    auto ki = k_ntt_pass<LOG_R, true>;
+    auto kf = k_ntt_pass<LOG_R, false, LOG_B>;
+    auto ki = k_ntt_pass<LOG_R, true, LOG_B>;
     if (lds > 48 * 1024) {
         MI_HIP_CHECK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         MI_HIP_CHECK(hipFuncSetAttribute((const void *)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)a.n_tiles), dim3(256), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(kf, dim3((unsigned)a.n_tiles), dim3(256), lds, ctx->stream, a);
+    if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)a.n_tiles), dim3(16 << LOG_B), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(kf, dim3((unsigned)a.n_tiles), dim3(16 << LOG_B), lds, ctx->stream, a);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
+}
+
+template <int LOG_R>
+static int launch_pass_r(mi_ctx *ctx, const NttPass &a, bool inv, size_t lds, uint32_t log_b)
+{
+    return log_b == 4 ? launch_pass_rb<LOG_R, 4>(ctx, a, inv, lds) : launch_pass_rb<LOG_R, 5>(ctx, a, inv, lds);
 }
 
 static int launch_pass(mi_ctx *ctx, NttPass &a, uint32_t log_r, bool inv)
 {
     const uint64_t n = 1ull << a.log_n;
     const uint64_t mK = n >> log_r;
-    // tile geometry: TCP = columns per tile (power of two <= 32), TJ = 32 / TCP beta rows (<= mK)
+    // tile geometry: B = batch elements per tile row (16 or 32), TCP = columns per tile (power of two <= B),
+    // TJ = B / TCP consecutive beta rows (<= mK)
+    const uint32_t log_b = ctx->ntt_log_b;
     uint32_t tcp_log = 0;
-    while ((1u << tcp_log) < a.ncols && tcp_log < 5) tcp_log++;
-    uint32_t tj_log = 5 - tcp_log;
+    while ((1u << tcp_log) < a.ncols && tcp_log < log_b) tcp_log++;
+    uint32_t tj_log = log_b - tcp_log;
     while ((1ull << tj_log) > mK) tj_log--;
     a.tcp_log = tcp_log;
     a.tj_log = tj_log;
@@ -232,16 +243,16 @@ static int launch_pass(mi_ctx *ctx, NttPass &a, uint32_t log_r, bool inv)
     a.n_tiles = (mK >> tj_log) * a.n_col_tiles;
     MI_REQUIRE(a.n_tiles < (1ull << 31), "NTT grid too large");
     a.w256 = ctx->w256;
-    const size_t lds = ((size_t)(1u << log_r) * 32 + 256 + ((size_t)(1u << log_r) << tj_log)) * 8;
+    const size_t lds = (((size_t)(1u << log_r) << log_b) + 256 + ((size_t)(1u << log_r) << tj_log)) * 8;
     switch (log_r) {
-    case 1: return launch_pass_r<1>(ctx, a, inv, lds);
-    case 2: return launch_pass_r<2>(ctx, a, inv, lds);
-    case 3: return launch_pass_r<3>(ctx, a, inv, lds);
-    case 4: return launch_pass_r<4>(ctx, a, inv, lds);
-    case 5: return launch_pass_r<5>(ctx, a, inv, lds);
-    case 6: return launch_pass_r<6>(ctx, a, inv, lds);
-    case 7: return launch_pass_r<7>(ctx, a, inv, lds);
-    case 8: return launch_pass_r<8>(ctx, a, inv, lds);
+    case 1: return launch_pass_r<1>(ctx, a, inv, lds, log_b);
+    case 2: return launch_pass_r<2>(ctx, a, inv, lds, log_b);
+    case 3: return launch_pass_r<3>(ctx, a, inv, lds, log_b);
+    case 4: return launch_pass_r<4>(ctx, a, inv, lds, log_b);
+    case 5: return launch_pass_r<5>(ctx, a, inv, lds, log_b);
+    case 6: return launch_pass_r<6>(ctx, a, inv, lds, log_b);
+    case 7: return launch_pass_r<7>(ctx, a, inv, lds, log_b);
+    case 8: return launch_pass_r<8>(ctx, a, inv, lds, log_b);
     }
     mi_set_error("bad radix");
     return MI_ERR_INVALID;
@@ -419,5 +430,5 @@ extern "C" void mi_dbg_host_dft16(uint64_t x[16], int log_size, int inverse)
     case 4: RUN(4) break;
     }
 #undef RUN
-    for (int i = 0; i < 16; i++) x[i] = v[i];
+    for (int i = 0; i < 16; i++) x[i] = gl::canon(v[i]);
 }

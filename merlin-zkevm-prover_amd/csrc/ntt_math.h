@@ -1,41 +1,44 @@
 // ntt_math.h -- in-register small DFTs over Goldilocks used by the Stockham NTT passes and the FRI fold.
 //
 // In Goldilocks 2 has multiplicative order 192 (2^96 = -1), and the reference's root table
-// (w(4) = 4096 = 2^12, w(5) = 64, w(6) = 8) makes every twiddle of a 16-point DFT a
-// power of two: w_64^j = 2^(3 j), w_16^j = 2^(12 j).
+// (w(4) = 4096 = 2^12, w(5) = 64, w(6) = 8) makes every twiddle of a 64-point DFT a
+// power of two: w_64^j = 2^(3 j).  A butterfly inside a radix-16/64 step therefore costs shifts and adds
+// only -- no 64x64 multiply, no table.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "gl_math.h"
 
 namespace nttm {
 
-// 2^e mod p for 0 <= e < 192, evaluated at compile time
-constexpr u64 cpow2(int e)
+template <int I, int N, typename F>
+MI_HD void static_for(F &&f)
 {
-    unsigned __int128 r = 1;
-    for (int i = 0; i < e; i++) {
-        r <<= 1;
-        if (r >= (unsigned __int128)GL_P) r -= GL_P;
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
-    return (u64)r;
 }
 
-// w_64^j (forward) and w_64^-j (inverse), j < 32.  w_64 = 8 = 2^3; 2^-3j = 2^(192 - 3 j).
-struct W64Table { u64 fwd[32], inv[32]; };
-constexpr W64Table make_w64()
+// x * 2^E mod p for a compile-time 0 <= E < 192; any u64 in, weakly reduced out.
+template <int E>
+MI_HD u64 mul_pow2(u64 x)
 {
-    W64Table t{};
-    for (int j = 0; j < 32; j++) {
-        t.fwd[j] = cpow2(3 * j);
-        t.inv[j] = cpow2((192 - 3 * j) % 192);
+    static_assert(E >= 0 && E < 192, "exponent out of range");
+    if constexpr (E == 0) {
+        return x;
+    } else if constexpr (E >= 96) {
+        return mul_pow2<E - 96>(gl::neg_w(x)); // 2^96 = -1
+    } else if constexpr (E >= 64) {
+        return mul_pow2<E - 48>(mul_pow2<48>(x));
+    } else if constexpr (E < 32) {
+        const u64 lo = x << E, hi = x >> (64 - E); // hi < 2^31: hi * 2^64 = hi * (2^32 - 1)
+        const u64 t1 = (hi << 32) - hi;
+        const u64 r = lo + t1;
+        return r < t1 ? r + GL_EPS : r;
+    } else {
+        return gl::reduce128_w(x << E, x >> (64 - E));
     }
-    return t;
-}
-static constexpr W64Table W64 = make_w64(); // built at compile time; indices below are constants after unrolling
-
-template <bool INV>
-MI_HD constexpr u64 w64(int j)
-{
-    return INV ? W64.inv[j] : W64.fwd[j];
 }
 
 template <int Q>
@@ -46,26 +49,28 @@ MI_HD constexpr int bitrev(int k)
     return r;
 }
 
-// 2^Q-point DFT (Q <= 6) in registers, natural order in and out, canonical values in and out.
-// DIF radix-2 layers; the closing bit-reversal is a compile-time register renaming.
+// 2^Q-point DFT (Q <= 6) in registers, natural order in and out.  Inputs: any u64 encodings; outputs weakly
+// reduced (callers canonicalise at the store).  DIF radix-2 layers with shift-only twiddles; the closing
+// bit-reversal is a compile-time register renaming.
 template <int Q, bool INV>
 MI_HD void dft_reg(u64 (&x)[1 << Q])
 {
     constexpr int N = 1 << Q;
-#pragma unroll
-    for (int len = N; len >= 2; len >>= 1) {
-        const int half = len >> 1;
-#pragma unroll
-        for (int s = 0; s < N; s += len) {
-#pragma unroll
-            for (int j = 0; j < half; j++) {
-                u64 u = x[s + j], v = x[s + j + half];
-                x[s + j] = gl::add(u, v);
-                u64 d = gl::sub(u, v);
-                x[s + j + half] = (j == 0) ? d : gl::mul(d, w64<INV>(j * (64 / len)));
-            }
-        }
-    }
+    static_for<0, Q>([&](auto L) {
+        constexpr int len = N >> decltype(L)::value;
+        constexpr int half = len / 2;
+        static_for<0, N / len>([&](auto B) {
+            constexpr int s = decltype(B)::value * len;
+            static_for<0, half>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int e0 = 3 * j * (64 / len);              // w_len^j = w_64^(j * 64/len) = 2^e0
+                constexpr int e = INV ? (192 - e0) % 192 : e0;
+                const u64 u = x[s + j], v = gl::canon(x[s + j + half]);
+                x[s + j] = gl::add_wc(u, v);
+                x[s + j + half] = mul_pow2<e>(gl::sub_wc(u, v));
+            });
+        });
+    });
     u64 y[N];
 #pragma unroll
     for (int k = 0; k < N; k++) y[k] = x[bitrev<Q>(k)];

@@ -152,6 +152,25 @@ def test_ntt_matches_oracle(ctx, n, ncols):
         assert np.array_equal(ctx.to_host(out).reshape(n, ncols), glo.ntt(x, n, ncols, inverse=inverse)), inverse
 
 
+def test_ntt_and_lde_with_16_wide_tiles(ctx):
+    """The NTT tile width is a tuning knob (128-byte or 256-byte row segments); results must not depend on it."""
+    ctx.set_ntt_tile(4)
+    try:
+        rng = np.random.default_rng(77)
+        for n, ncols in ((64, 33), (1024, 1), (4096, 17), (1 << 13, 5), (1 << 16, 3)):
+            x = glo.rand_fe(rng, (n, ncols))
+            out = ctx.empty(n * ncols)
+            for inverse in (False, True):
+                ctx.ntt(out, ctx.to_device(x), n, ncols, inverse=inverse)
+                assert np.array_equal(ctx.to_host(out).reshape(n, ncols), glo.ntt(x, n, ncols, inverse=inverse)), (n, ncols, inverse)
+        x = glo.rand_fe(rng, (1 << 12, 37))
+        out = ctx.empty((1 << 13) * 37)
+        ctx.lde(out, ctx.to_device(x), 1 << 13, 1 << 12, 37)
+        assert np.array_equal(ctx.to_host(out).reshape(1 << 13, 37), glo.extend_pol(x, 1 << 13, 1 << 12, 37))
+    finally:
+        ctx.set_ntt_tile(5)
+
+
 def test_ntt_in_place_pitched_and_host_variant(ctx):
     rng = np.random.default_rng(21)
     n, ncols, pitch = 1 << 12, 3, 7
