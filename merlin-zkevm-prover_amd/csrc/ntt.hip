@@ -135,13 +135,13 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
         if (col < a.ncols) {
             const uint64_t beta = beta0 + tj;
             const uint64_t ip = beta >> a.log_K, kappa = beta & (K - 1);
-            u64 *q = a.dst + col;
+            // output row of k1 = kap + RA*kb is ((ip << LOG_R) + k1) * K + kappa: a constant stride in kb
+            u64 *q = a.dst + col + ((((ip << LOG_R) + kap) << a.log_K) + kappa) * a.dst_pitch;
+            const uint64_t qstride = ((uint64_t)RA << a.log_K) * a.dst_pitch;
+            const u64 *t = tw + ((kap << a.tj_log) + tj);
+            const uint32_t tstride = (uint32_t)RA << a.tj_log;
 #pragma unroll
-            for (int kb = 0; kb < RB; kb++) {
-                const uint32_t k1 = kap + RA * kb;
-                const uint64_t ro = (((ip << LOG_R) + k1) << a.log_K) + kappa;
-                q[ro * a.dst_pitch] = gl::mul(x[kb], tw[(k1 << a.tj_log) + tj]);
-            }
+            for (int kb = 0; kb < RB; kb++) q[kb * qstride] = gl::mul(x[kb], t[kb * tstride]);
         }
     }
 }

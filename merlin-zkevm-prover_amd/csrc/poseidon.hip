@@ -50,24 +50,35 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
         for (uint32_t i = 0; i < 4; i++) o[i] = i < ncols ? gl::canon(p[i]) : 0;
         return;
     }
-    u64 s[12], nxt[8];
+    // Two 64-byte blocks are fetched back to back every second absorb (128 contiguous bytes per lane), so the
+    // 128-byte line that straddles them is touched twice within one burst instead of one permutation apart.
+    u64 s[12], b0[8], b1[8];
 #pragma unroll
     for (int i = 0; i < 4; i++) s[8 + i] = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 8; i++) nxt[i] = i < ncols ? p[i] : 0;
-    for (uint32_t c = 0; c < ncols; c += 8) {
+    for (uint32_t i = 0; i < 8; i++) b0[i] = i < ncols ? p[i] : 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) s[i] = nxt[i];
-        const uint32_t c2 = c + 8;
-        if (c2 < ncols) { // prefetch the next absorb while this permutation runs
+    for (uint32_t i = 0; i < 8; i++) b1[i] = 8 + i < ncols ? p[8 + i] : 0;
+    for (uint32_t c = 0; c < ncols; c += 16) {
 #pragma unroll
-            for (uint32_t i = 0; i < 8; i++) nxt[i] = (c2 + i < ncols) ? p[c2 + i] : 0;
+        for (int i = 0; i < 8; i++) s[i] = b0[i];
+        pos::permute<MDS>(s, c_rc);
+        if (c + 8 >= ncols) break;
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[8 + i] = s[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = b1[i];
+        const uint32_t c2 = c + 16;
+        if (c2 < ncols) { // prefetch the next two absorbs while this permutation runs
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) b0[i] = (c2 + i < ncols) ? p[c2 + i] : 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) b1[i] = (c2 + 8 + i < ncols) ? p[c2 + 8 + i] : 0;
         }
         pos::permute<MDS>(s, c_rc);
-        if (c2 < ncols) {
+        if (c2 >= ncols) break;
 #pragma unroll
-            for (int i = 0; i < 4; i++) s[8 + i] = s[i];
-        }
+        for (int i = 0; i < 4; i++) s[8 + i] = s[i];
     }
     ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(o);
     o2[0] = make_ulonglong2(s[0], s[1]);
