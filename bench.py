@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--poseidon-variant", type=int, default=0)
     ap.add_argument("--cpu-log-n", type=int, default=16, help="log2 rows of the CPU-baseline sample")
     ap.add_argument("--ntt-log-b", type=int, default=5)
+    ap.add_argument("--leaf-mode", type=int, default=1, help="1 = line-aligned leaf fetch (default), 0 = per-block loads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,6 +86,7 @@ def main():
     ctx = mi_stark.Context(local_rank, workspace_limit=int(args.workspace_gib * (1 << 30)))
     ctx.set_poseidon_variant(args.poseidon_variant)
     ctx.set_ntt_tile(args.ntt_log_b)
+    ctx.set_leaf_mode(args.leaf_mode)
     n, n_ext, ncols = 1 << args.log_n, 2 << args.log_n, args.cols
     plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=rank)
 
@@ -169,7 +171,7 @@ def main():
                        "rows": n, "cols": ncols, "rows_ext": n_ext, "parallelism": "col-shard LDE -> all-to-all -> row-shard Merkle x%d" % world,
                        "poseidon_variant": args.poseidon_variant},
             "root": root_host,
-            "roofline": {"kernel": "k_linear_hash_rows", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_linear_hash_rows_lines" if args.leaf_mode else "k_linear_hash_rows", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": leaf_bytes, "avg_launch_ms": leaf_ms,
                          "note": "VALU-bound kernel (~3e4 integer ops per 64 B absorbed): see valu + DESIGN.md"},

@@ -157,6 +157,9 @@ int mi_set_poseidon_variant(mi_ctx *ctx, int variant);
 /* NTT tile width in elements per row segment: log_b = 4 (128-byte segments, 4 workgroups per CU) or 5
  * (256-byte segments, 2 per CU).  Results are identical; exposed for benchmarking. */
 int mi_set_ntt_tile(mi_ctx *ctx, int log_b);
+/* Leaf sponge memory access: 1 (default) = every lane fetches whole aligned 128-byte lines into a register
+ * ring, 0 = plain per-block loads.  Results are identical; exposed for benchmarking. */
+int mi_set_leaf_mode(mi_ctx *ctx, int line_aligned);
 
 /* Timing hooks used by bench.py: HIP events recorded on the context's stream. */
 int mi_timer_start(mi_ctx *ctx, int slot);

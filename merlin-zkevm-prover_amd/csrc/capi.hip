@@ -123,6 +123,13 @@ int mi_ensure_workspace(mi_ctx *c, uint64_t bytes)
     return MI_OK;
 }
 
+extern "C" int mi_set_leaf_mode(mi_ctx *c, int line_aligned)
+{
+    CTX_OK(c);
+    c->leaf_line_aligned = line_aligned != 0;
+    return MI_OK;
+}
+
 extern "C" int mi_set_ntt_tile(mi_ctx *c, int log_b)
 {
     CTX_OK(c);

@@ -60,6 +60,7 @@ struct mi_ctx {
     std::vector<void *> owned; // tables to free
     hipEvent_t ev_start[8] = {}, ev_stop[8] = {};
     int cu_count = 256;
+    bool leaf_line_aligned = true; // leaf sponge fetches whole aligned 128-byte lines (k_linear_hash_rows_lines)
     uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
 };
 
