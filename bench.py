@@ -25,6 +25,20 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T full-rate lane-ops/s
 
 
+def valu_roofline(perms, leaf_ms):
+    """Issue-rate roofline of the Poseidon leaf kernel.  Static instruction counts per permutation come from the
+    gfx950 ISA of pos::permute<MDS_HALF32> (8 full rounds x 1715 + 22 partial rounds x 629 instructions, of which
+    11348 VALU instructions issue at 2 clk per wave64 and 14864 at 4 clk: DESIGN.md section 4); the two issue rates
+    are the best chip-wide rates measured by tools/ubench_int2.hip on this chip
+    (profiles/r01_ubench_int_issue_rates2.txt: 1047 G wave-instr/s for the 2-clk class, 592 G for the 4-clk class)."""
+    full_rate, half_rate = 8 * 830 + 22 * 214, 8 * 802 + 22 * 384   # VOP1/VOP2 (e32) class / VOP3 integer class, per permutation
+    t_min_per_wave_perm = full_rate / 1047e9 + half_rate / 592e9    # seconds of chip-wide issue time per wave-permutation
+    peak_perms = 64.0 / t_min_per_wave_perm
+    ach = perms / (leaf_ms * 1e-3) if leaf_ms > 0 else 0.0
+    return {"kernel": "k_linear_hash_rows_lines", "bound": "valu-issue", "perms_per_launch": perms, "achieved": ach, "peak": peak_perms,
+            "unit": "permutations/s", "frac": ach / peak_perms, "instructions_per_permutation": full_rate + half_rate}
+
+
 def cpu_baseline(log_n, ncols):
     """CPU oracle ("port", OpenMP) on a bounded sample of the same workload: LDE + Merkle tree of a
     2^log_n x ncols trace.  tests/glo.py is the oracle binding; it is used here only as the timed baseline."""
@@ -175,15 +189,20 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": leaf_bytes, "avg_launch_ms": leaf_ms,
                          "note": "VALU-bound kernel (~3e4 integer ops per 64 B absorbed): see valu + DESIGN.md"},
-            "valu": {"kernel": "k_linear_hash_rows", "perms_per_launch": perms,
-                     "perms_per_s": perms / (leaf_ms * 1e-3) if leaf_ms > 0 else 0.0,
-                     "full_rate_lane_ops_per_s_peak": VALU_LANE_OPS_PER_S},
+            "valu": valu_roofline(perms, leaf_ms),
             "roofline_lde": {"kernel": "k_ntt_pass (9 launches per column chunk)", "bound": "hbm",
                              "achieved": lde_bytes / (lde_ms * 1e-3) / 1e9 if lde_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "algorithmic_bytes": lde_bytes, "avg_ms": lde_ms},
             "phase_ms": {"STARK_STEP_1_LDE": lde_ms, "STARK_STEP_1_MERKLETREE_leaves": leaf_ms, "STARK_STEP_1_MERKLETREE_levels": t_lvls / K},
         }
         out["roofline_lde"]["frac"] = out["roofline_lde"]["achieved"] / HBM_PEAK_GBS
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (they cannot run inside the
+        # timed process); the committed summary of the same command is read back here when the workload matches
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.log_n == 23 and ncols == 665 and args.leaf_mode == 1 and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))["kernels"]["k_linear_hash_rows_lines"]
+            out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols)
         else:
