@@ -151,8 +151,9 @@ void *mi_dev_alloc(mi_ctx *ctx, uint64_t bytes);
 int mi_dev_free(mi_ctx *ctx, void *p);
 int mi_copy_h2d(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
-/* Selects the Poseidon MDS code path (0 = 32-bit halves / v_mad_u64_u32, 1 = 22-bit limbs /
- * v_mad_u32_u24).  Both are bit-identical; exposed for benchmarking. */
+/* Selects the Poseidon code path: 0 = naive rounds, MDS on 32-bit halves (v_mad_u64_u32); 1 = naive rounds, MDS on
+ * 22-bit limbs (v_mad_u32_u24); 2 = optimised partial rounds (sparse matrices, tools/gen_poseidon_sparse.py).
+ * All are bit-identical; exposed for benchmarking. */
 int mi_set_poseidon_variant(mi_ctx *ctx, int variant);
 /* NTT tile width in elements per row segment: log_b = 4 (128-byte segments, 4 workgroups per CU) or 5
  * (256-byte segments, 2 per CU).  Results are identical; exposed for benchmarking. */

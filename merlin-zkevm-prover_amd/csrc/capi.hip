@@ -141,7 +141,7 @@ extern "C" int mi_set_ntt_tile(mi_ctx *c, int log_b)
 extern "C" int mi_set_poseidon_variant(mi_ctx *c, int v)
 {
     CTX_OK(c);
-    MI_REQUIRE(v == 0 || v == 1, "variant must be 0 or 1");
+    MI_REQUIRE(v >= 0 && v <= 2, "variant must be 0, 1 or 2");
     c->poseidon_variant = v;
     return MI_OK;
 }

@@ -12,12 +12,16 @@
 #include "poseidon_math.h"
 
 __constant__ u64 c_rc[360];
+__constant__ pos::SparseTables c_sparse;
 
 static int upload_rc_once(mi_ctx *ctx)
 {
     static int done_for_device = -1;
     if (done_for_device == ctx->device) return MI_OK;
     MI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), MI_POS_RC, sizeof(MI_POS_RC)));
+    static pos::SparseTables host_tables;
+    pos::fill_sparse_tables(host_tables);
+    MI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_sparse), &host_tables, sizeof(host_tables)));
     done_for_device = ctx->device;
     return MI_OK;
 }
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(256) void k_permute(u64 *__restrict__ out, const u6
     u64 s[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) s[j] = in[i * 12 + j];
-    pos::permute<MDS>(s, c_rc);
+    pos::permute<MDS>(s, c_rc, &c_sparse);
 #pragma unroll
     for (int j = 0; j < 12; j++) out[i * 12 + j] = s[j];
 }
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
     for (uint32_t c = 0; c < ncols; c += 16) {
 #pragma unroll
         for (int i = 0; i < 8; i++) s[i] = b0[i];
-        pos::permute<MDS>(s, c_rc);
+        pos::permute<MDS>(s, c_rc, &c_sparse);
         if (c + 8 >= ncols) break;
 #pragma unroll
         for (int i = 0; i < 4; i++) s[8 + i] = s[i];
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) b1[i] = (c2 + 8 + i < ncols) ? p[c2 + 8 + i] : 0;
         }
-        pos::permute<MDS>(s, c_rc);
+        pos::permute<MDS>(s, c_rc, &c_sparse);
         if (c2 >= ncols) break;
 #pragma unroll
         for (int i = 0; i < 4; i++) s[8 + i] = s[i];
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows_lines(u64 *__restrict_
                 else ring_load_line<0>(win, lp + (uint64_t)(dead + 2) * 16, lo, hi);
             }
         }
-        pos::permute<MDS>(s, c_rc);
+        pos::permute<MDS>(s, c_rc, &c_sparse);
         if (pos + 8 < end) {
 #pragma unroll
             for (int i = 0; i < 4; i++) s[8 + i] = s[i];
@@ -177,7 +181,7 @@ __device__ __forceinline__ void hash_pair(u64 *__restrict__ out, const u64 *__re
     const ulonglong2 *i2 = reinterpret_cast<const ulonglong2 *>(in);
     ulonglong2 a = i2[0], b = i2[1], c = i2[2], d = i2[3];
     u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
-    pos::permute<MDS>(s, c_rc);
+    pos::permute<MDS>(s, c_rc, &c_sparse);
     ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(out);
     o2[0] = make_ulonglong2(s[0], s[1]);
     o2[1] = make_ulonglong2(s[2], s[3]);
@@ -229,6 +233,7 @@ static int by_variant(mi_ctx *ctx, F f)
 {
     MI_TRY(upload_rc_once(ctx));
     if (ctx->poseidon_variant == pos::MDS_HALF32) f(std::integral_constant<int, pos::MDS_HALF32>());
+    else if (ctx->poseidon_variant == pos::MDS_SPARSE) f(std::integral_constant<int, pos::MDS_SPARSE>());
     else f(std::integral_constant<int, pos::MDS_LIMB22>());
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -303,7 +308,11 @@ extern "C" void mi_dbg_host_poseidon_permute(uint64_t st[12], int variant)
 {
     u64 s[12];
     for (int i = 0; i < 12; i++) s[i] = st[i];
+    static pos::SparseTables tables;
+    static bool filled = false;
+    if (!filled) { pos::fill_sparse_tables(tables); filled = true; }
     if (variant == pos::MDS_HALF32) pos::permute<pos::MDS_HALF32>(s, (const u64 *)MI_POS_RC);
+    else if (variant == pos::MDS_SPARSE) pos::permute<pos::MDS_SPARSE>(s, (const u64 *)MI_POS_RC, &tables);
     else pos::permute<pos::MDS_LIMB22>(s, (const u64 *)MI_POS_RC);
     for (int i = 0; i < 12; i++) st[i] = s[i];
 }

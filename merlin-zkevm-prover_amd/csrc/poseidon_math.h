@@ -15,13 +15,14 @@
 #pragma once
 #include "gl_math.h"
 #include "poseidon_constants.h"
+#include "poseidon_sparse_constants.h"
 
 namespace pos {
 
 static constexpr int MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20}; // == MI_POS_MCIRC
 static constexpr int MD0 = 8;                                                   // == MI_POS_MDIAG[0]
 
-enum { MDS_HALF32 = 0, MDS_LIMB22 = 1 };
+enum { MDS_HALF32 = 0, MDS_LIMB22 = 1, MDS_SPARSE = 2 };
 
 MI_HD u64 sbox(u64 x)
 {
@@ -95,6 +96,102 @@ MI_HD void mds_limb22(u64 (&s)[12])
     }
 }
 
+// ---- optimised partial rounds (variant MDS_SPARSE): tables derived and verified by tools/gen_poseidon_sparse.py.
+// A partial round becomes: S-box on s0, one 12-term dot product with 64-bit constants for the new s0 and eleven
+// "s_i += w_i * s0".  The dot product is accumulated WITHOUT carries: each constant is pre-split into 22/22/20-bit
+// limbs, so the six 64-bit accumulators (2 halves of s_j x 3 limbs) stay below 2^58 over 12 terms and a single
+// reduction closes the row.
+struct SparseTables {
+    u64 first_rc[12];
+    u64 k[22];            // k[21] unused (0)
+    u64 w[22][11];
+    u32 vhat_l[22][11][3];
+    u32 pre_l[11][11][3];
+};
+
+inline void fill_sparse_tables(SparseTables &t)
+{
+    for (int i = 0; i < 12; i++) t.first_rc[i] = MI_POS_FIRST_RC[i];
+    for (int r = 0; r < 22; r++) {
+        t.k[r] = r < 21 ? MI_POS_K[r] : 0;
+        for (int j = 0; j < 11; j++) {
+            t.w[r][j] = MI_POS_W[r * 11 + j];
+            const u64 v = MI_POS_VHAT[r * 11 + j];
+            t.vhat_l[r][j][0] = (u32)(v & 0x3FFFFF); t.vhat_l[r][j][1] = (u32)((v >> 22) & 0x3FFFFF); t.vhat_l[r][j][2] = (u32)(v >> 44);
+        }
+    }
+    for (int i = 0; i < 11; i++)
+        for (int j = 0; j < 11; j++) {
+            const u64 v = MI_POS_PRE[i * 11 + j];
+            t.pre_l[i][j][0] = (u32)(v & 0x3FFFFF); t.pre_l[i][j][1] = (u32)((v >> 22) & 0x3FFFFF); t.pre_l[i][j][2] = (u32)(v >> 44);
+        }
+}
+
+struct DotAcc { u64 a[2][3]; };
+
+MI_HD void dot_acc(DotAcc &d, u64 x, const u32 (&c)[3])
+{
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        d.a[0][l] += (u64)lo * c[l];
+        d.a[1][l] += (u64)hi * c[l];
+    }
+}
+
+// value = sum_{h,l} a[h][l] * 2^(32h + 22l), every a < 2^60  ->  weakly reduced
+MI_HD u64 dot_close(const DotAcc &d)
+{
+    typedef unsigned __int128 u128;
+    const u128 X = (u128)d.a[0][0] + ((u128)d.a[0][1] << 22) + ((u128)d.a[0][2] << 44); // < 2^105
+    const u128 Y = (u128)d.a[1][0] + ((u128)d.a[1][1] << 22) + ((u128)d.a[1][2] << 44);
+    const u64 ylo = (u64)Y, yhi = (u64)(Y >> 64);                                        // yhi < 2^41
+    // Y * 2^32 = (ylo mod 2^32) * 2^32 + (ylo >> 32) * 2^64 + yhi * 2^96  ==  ... + (ylo >> 32) * eps - yhi
+    const u128 T = (u128)(u64)X + (u128)(u64)(X >> 64) * GL_EPS + ((u128)(ylo & GL_EPS) << 32) + (u128)(ylo >> 32) * GL_EPS;
+    const u64 r = gl::reduce128_w((u64)T, (u64)(T >> 64));
+    return gl::sub_wc(r, yhi);
+}
+
+// s_i + w * s0 (all 64-bit, any encodings) -> weakly reduced
+MI_HD u64 axpy_w(u64 si, u64 w, u64 s0)
+{
+    u64 lo, hi;
+    gl::mul64x64(w, s0, lo, hi);
+    const u64 l2 = lo + si;
+    hi += l2 < lo ? 1 : 0; // (2^64-1)^2 + 2^64 - 1 < 2^128: no overflow of hi
+    return gl::reduce128_w(l2, hi);
+}
+
+MI_HD void partial_rounds_sparse(u64 (&s)[12], const SparseTables &t)
+{
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], t.first_rc[i]);
+    { // s[1:] = PRE * s[1:]
+        u64 o[11];
+#pragma unroll 1
+        for (int i = 0; i < 11; i++) {
+            DotAcc d = {};
+#pragma unroll
+            for (int j = 0; j < 11; j++) dot_acc(d, s[1 + j], t.pre_l[i][j]);
+            o[i] = dot_close(d);
+        }
+#pragma unroll
+        for (int i = 0; i < 11; i++) s[1 + i] = o[i];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        u64 s0 = gl::add_wc(sbox(s[0]), t.k[r]);
+        DotAcc d = {};
+        d.a[0][0] = (u64)(u32)s0 * MI_POS_M00;
+        d.a[1][0] = (u64)(u32)(s0 >> 32) * MI_POS_M00;
+#pragma unroll
+        for (int j = 0; j < 11; j++) dot_acc(d, s[1 + j], t.vhat_l[r][j]);
+#pragma unroll
+        for (int i = 0; i < 11; i++) s[1 + i] = axpy_w(s[1 + i], t.w[r][i], s0);
+        s[0] = dot_close(d);
+    }
+}
+
 template <int MDS>
 MI_HD void mds(u64 (&s)[12])
 {
@@ -102,28 +199,34 @@ MI_HD void mds(u64 (&s)[12])
     else mds_half32(s);
 }
 
-// rc: 360 round constants (canonical).  State in: any u64 encodings; out: canonical.
+// rc: 360 round constants (canonical); sp: tables of the optimised partial rounds (only read by MDS_SPARSE).
+// State in: any u64 encodings; out: canonical.
 template <int MDS>
-MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc)
+MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables *__restrict__ sp = nullptr)
 {
+    constexpr int FULL_MDS = (MDS == MDS_SPARSE) ? MDS_HALF32 : MDS;
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_wc(s[i], rc[r * 12 + i]));
-        mds<MDS>(s);
+        mds<FULL_MDS>(s);
     }
+    if (MDS == MDS_SPARSE) {
+        partial_rounds_sparse(s, *sp);
+    } else {
 #pragma unroll 1
-    for (int r = 4; r < 26; r++) {
+        for (int r = 4; r < 26; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc[r * 12 + i]);
-        s[0] = sbox(s[0]);
-        mds<MDS>(s);
+            for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc[r * 12 + i]);
+            s[0] = sbox(s[0]);
+            mds<FULL_MDS>(s);
+        }
     }
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_wc(s[i], rc[r * 12 + i]));
-        mds<MDS>(s);
+        mds<FULL_MDS>(s);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);

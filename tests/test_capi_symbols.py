@@ -34,7 +34,7 @@ def test_no_cpu_fallback_without_gpu():
         mi_stark.Context(0)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_device_poseidon_math_on_host_matches_oracle(variant):
     rng = np.random.default_rng(variant)
     cases = [np.zeros(12, dtype=np.uint64), np.arange(12, dtype=np.uint64), np.full(12, P - 1, dtype=np.uint64),

@@ -24,7 +24,7 @@ def dev_roundtrip(ctx, a):
 
 
 # ------------------------------------------------------------------ Poseidon
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_permute_matches_oracle(ctx, variant):
     ctx.set_poseidon_variant(variant)
     rng = np.random.default_rng(10 + variant)
@@ -53,7 +53,7 @@ def test_host_pointer_hashes(ctx):
         assert np.array_equal(ctx.linear_hash(v), glo.linear_hash(v)), size
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_linear_hash_rows_all_widths(ctx, variant):
     ctx.set_poseidon_variant(variant)
     rng = np.random.default_rng(12)
