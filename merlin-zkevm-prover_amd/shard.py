@@ -58,30 +58,46 @@ class ShardPlan:
         return max(w for (_, w) in self.cols)
 
 
-def lde_merkle_sharded(plan: ShardPlan, ops, dist, trace_shard, bufs):
-    """Runs steps 1-4.  `ops` provides lde / copy_2d / merkle_build / merkle_levels / root helpers on the
-    device the tensors live on; `dist` is torch.distributed (or None when world == 1).
-    bufs: dict with 'ext' (n_ext*max_cols), 'recv' (rows_per_rank*ncols), 'nodes' ((2*rows_per_rank-1)*4),
-    'roots' (world*4 + tree above them).  Returns the tensor holding the global root (4 u64)."""
+def phase_lde(plan: ShardPlan, ops, trace_shard, bufs):
+    """Step 1: extend my column range.  bufs['ext'] receives [n_ext x my_cols] (pitch my_cols)."""
+    ops.lde(bufs["ext"], trace_shard, plan.n_ext, plan.n, plan.my_cols)
+
+
+def phase_exchange(plan: ShardPlan, dist, bufs):
+    """Step 2: columns -> rows.  After it bufs['recv'] holds G slabs [rows_per_rank x cols_g], in rank order."""
     p = plan
-    ext, nodes = bufs["ext"], bufs["nodes"]
-    ops.lde(ext, trace_shard, p.n_ext, p.n, p.my_cols)                     # [n_ext x my_cols], pitch my_cols
-    if p.world == 1:
-        ops.merkle_build(nodes, ext, p.ncols, p.n_ext)
-        return nodes[(2 * p.n_ext - 2) * 4:(2 * p.n_ext - 1) * 4]
-    recv = bufs["recv"]
-    send = ext[:p.n_ext * p.my_cols]
-    dist.all_to_all_single(recv[:p.rows_per_rank * p.ncols], send, output_split_sizes=p.recv_splits,
-                           input_split_sizes=p.send_splits)
-    # recv holds G column slabs [rows_per_rank x cols_g]; repack into row-major rows (reuses `ext`)
-    rows = ext
-    off = 0
+    dist.all_to_all_single(bufs["recv"][:p.rows_per_rank * p.ncols], bufs["ext"][:p.n_ext * p.my_cols],
+                           output_split_sizes=p.recv_splits, input_split_sizes=p.send_splits)
+
+
+def phase_merkle_local(plan: ShardPlan, ops, bufs):
+    """Step 3: repack the slabs into row-major rows (reusing bufs['ext']) and build my subtree.  Returns my root."""
+    p = plan
+    rows, recv, off = bufs["ext"], bufs["recv"], 0
     for (c0, w) in p.cols:
         ops.copy_2d(rows, recv, p.rows_per_rank, w, dst_pitch=p.ncols, src_pitch=w, dst_off=c0, src_off=off)
         off += p.rows_per_rank * w
-    ops.merkle_build(nodes, rows, p.ncols, p.rows_per_rank)
-    my_root = nodes[(2 * p.rows_per_rank - 2) * 4:(2 * p.rows_per_rank - 1) * 4]
-    roots = bufs["roots"]
-    dist.all_gather_into_tensor(roots[:p.world * 4], my_root.contiguous())
-    ops.merkle_levels(roots, p.world)                                      # top log2(G) levels, same on every rank
-    return roots[(2 * p.world - 2) * 4:(2 * p.world - 1) * 4]
+    ops.merkle_build(bufs["nodes"], rows, p.ncols, p.rows_per_rank)
+    return bufs["nodes"][(2 * p.rows_per_rank - 2) * 4:(2 * p.rows_per_rank - 1) * 4]
+
+
+def phase_top(plan: ShardPlan, ops, bufs):
+    """Step 4b: bufs['roots'][:G*4] holds the G subtree roots in rank order; hash the top log2(G) levels."""
+    ops.merkle_levels(bufs["roots"], plan.world)
+    return bufs["roots"][(2 * plan.world - 2) * 4:(2 * plan.world - 1) * 4]
+
+
+def lde_merkle_sharded(plan: ShardPlan, ops, dist, trace_shard, bufs):
+    """Runs steps 1-4.  `ops` provides lde / copy_2d / merkle_build / merkle_levels on the device the tensors live
+    on; `dist` is torch.distributed (or None when world == 1).
+    bufs: dict with 'ext' (max(n_ext*max_cols, rows_per_rank*ncols)), 'recv' (rows_per_rank*ncols),
+    'nodes' ((2*rows_per_rank-1)*4), 'roots' ((2*world-1)*4).  Returns the tensor holding the global root (4 u64)."""
+    p = plan
+    phase_lde(p, ops, trace_shard, bufs)
+    if p.world == 1:
+        ops.merkle_build(bufs["nodes"], bufs["ext"], p.ncols, p.n_ext)
+        return bufs["nodes"][(2 * p.n_ext - 2) * 4:(2 * p.n_ext - 1) * 4]
+    phase_exchange(p, dist, bufs)
+    my_root = phase_merkle_local(p, ops, bufs)
+    dist.all_gather_into_tensor(bufs["roots"][:p.world * 4], my_root.contiguous())
+    return phase_top(p, ops, bufs)

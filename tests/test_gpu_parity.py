@@ -420,3 +420,52 @@ def test_genproof_shaped_flow_small():
     assert out["checks"] == {"step0_merkle_paths_verify": True, "fri_merkle_paths_verify": True,
                              "fri_fold_relation_on_openings": True, "evmap_spot_check": True}
     assert out["config"]["fri_steps_bits"] == [13, 8, 3]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_path_emulated_on_one_gpu(ctx, world):
+    """The multi-GPU orchestration (shard.py) with the REAL device ops, all ranks emulated one after the other on
+    this GPU and the all-to-all / all-gather done by tensor copies: the root must equal the single-GPU root."""
+    import torch
+    from shard import ShardPlan, phase_lde, phase_merkle_local, phase_top
+    n, ncols = 1 << 10, 37
+    n_ext = 2 * n
+
+    class Ops:
+        lde = staticmethod(lambda out, inp, ne, nn, c: ctx.lde(out, inp, ne, nn, c))
+        copy_2d = staticmethod(ctx.copy_2d)
+        merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
+        merkle_levels = staticmethod(ctx.merkle_levels)
+
+    # single-GPU reference
+    full = ctx.empty(n * ncols)
+    ctx.fill_synthetic_2d(full, n, ncols, ncols, 0, 0x5EED0003)
+    ext1, nodes1 = ctx.empty(n_ext * ncols), ctx.empty((2 * n_ext - 1) * 4)
+    ctx.lde(ext1, full, n_ext, n, ncols)
+    ctx.merkle_build(nodes1, ext1, ncols, n_ext)
+    want_root = ctx.to_host(nodes1[-4:])
+    assert np.array_equal(ctx.to_host(nodes1), glo.merkletree(glo.extend_pol(ctx.to_host(full).reshape(n, ncols), n_ext, n, ncols), ncols, n_ext))
+    # emulated ranks
+    plans = [ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=r) for r in range(world)]
+    bufs = []
+    for p in plans:
+        trace = ctx.empty(n * p.my_cols)
+        ctx.fill_synthetic_2d(trace, n, p.my_cols, ncols, p.col0, 0x5EED0003)     # column shard of the same trace
+        b = {"ext": ctx.empty(max(n_ext * p.max_cols, p.rows_per_rank * ncols)), "nodes": ctx.empty((2 * p.rows_per_rank - 1) * 4),
+             "recv": ctx.empty(p.rows_per_rank * ncols), "roots": ctx.empty((2 * world - 1) * 4)}
+        phase_lde(p, Ops, trace, b)
+        bufs.append(b)
+    torch.cuda.synchronize()
+    for dst in plans:                                                                # all-to-all by copies
+        off = 0
+        for src in plans:
+            cnt = dst.rows_per_rank * src.my_cols
+            start = dst.rank * dst.rows_per_rank * src.my_cols
+            bufs[dst.rank]["recv"][off:off + cnt] = bufs[src.rank]["ext"][start:start + cnt]
+            off += cnt
+    roots = [phase_merkle_local(p, Ops, bufs[p.rank]).clone() for p in plans]
+    for p in plans:                                                                  # all-gather by copies
+        for r in range(world):
+            bufs[p.rank]["roots"][4 * r:4 * r + 4] = roots[r]
+        got = phase_top(p, Ops, bufs[p.rank])
+        assert np.array_equal(ctx.to_host(got), want_root), p.rank
