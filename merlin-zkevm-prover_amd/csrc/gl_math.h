@@ -22,7 +22,33 @@ static constexpr u64 GL_EPS = 0xFFFFFFFFULL; // 2^64 mod p = 2^32 - 1
 
 namespace gl {
 
-MI_HD u64 canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
+// true in at least one lane of the wave?  A correction that is needed with probability ~2^-32 per value (x >= p,
+// lo < hh after a multiply) is put behind a wave-uniform branch: the common path pays one compare instead of a
+// compare, two selects and a 64-bit add.  Host build: plain condition.
+MI_HD bool rare(bool c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(c) != 0;
+#else
+    return c;
+#endif
+}
+
+// keeps the compiler from turning a rare() block back into selects
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_KEEP_BRANCH() asm volatile("" ::: "memory")
+#else
+#define MI_KEEP_BRANCH() do { } while (0)
+#endif
+
+MI_HD u64 canon(u64 a)
+{
+    if (rare(a >= GL_P)) {
+        MI_KEEP_BRANCH();
+        a = a >= GL_P ? a - GL_P : a;
+    }
+    return a;
+}
 
 // a any u64, b canonical (< p)  ->  weakly reduced a + b
 MI_HD u64 add_wc(u64 a, u64 b)
@@ -62,7 +88,10 @@ MI_HD u64 reduce128_w(u64 lo, u64 hi)
 {
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u64 t0 = lo - hh;
-    if (lo < hh) t0 -= GL_EPS; // borrowed 2^64 = p + eps
+    if (rare(lo < hh)) { // borrowed 2^64 = p + eps (needs lo < 2^32: ~never)
+        MI_KEEP_BRANCH();
+        t0 = lo < hh ? t0 - GL_EPS : t0;
+    }
     u64 t1 = ((u64)hl << 32) - hl; // hl * (2^32 - 1)
     u64 r = t0 + t1;
     return r < t1 ? r + GL_EPS : r;

@@ -34,7 +34,14 @@ MI_HD u64 mul_pow2(u64 x)
     } else if constexpr (E < 32) {
         const u64 lo = x << E, hi = x >> (64 - E); // hi < 2^31: hi * 2^64 = hi * (2^32 - 1)
         const u64 t1 = (hi << 32) - hi;
-        const u64 r = lo + t1;
+        u64 r = lo + t1;
+        if (E <= 20) { // t1 < 2^(32+E): the wrap has probability ~2^(E-32) per value
+            if (gl::rare(r < t1)) {
+                MI_KEEP_BRANCH();
+                r = r < t1 ? r + GL_EPS : r;
+            }
+            return r;
+        }
         return r < t1 ? r + GL_EPS : r;
     } else {
         return gl::reduce128_w(x << E, x >> (64 - E));

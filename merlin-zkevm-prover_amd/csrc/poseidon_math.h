@@ -53,7 +53,11 @@ MI_HD void mds_half32(u64 (&s)[12])
         u64 r = al + ((ahh << 32) - ahh);            // < 2^42, no wrap
         u64 b = ah << 32;
         u64 t = r + b;
-        s[x] = t < b ? t + GL_EPS : t;
+        if (gl::rare(t < b)) { // r < 2^42: wraps with probability ~2^-22
+            MI_KEEP_BRANCH();
+            t = t < b ? t + GL_EPS : t;
+        }
+        s[x] = t;
     }
 }
 

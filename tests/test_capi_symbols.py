@@ -40,6 +40,7 @@ def test_device_poseidon_math_on_host_matches_oracle(variant):
     cases = [np.zeros(12, dtype=np.uint64), np.arange(12, dtype=np.uint64), np.full(12, P - 1, dtype=np.uint64),
              np.full(12, 2**64 - 1, dtype=np.uint64),                 # non-canonical encodings
              np.array([P, P + 1, 2**64 - 1, 0, 1, 2, 3, 2**32 - 1, 2**32, 2**63, P - 2, 5], dtype=np.uint64)]
+    cases += [np.array([(1 << ((k + 5 * j) % 64)) for j in range(12)], dtype=np.uint64) for k in range(64)]
     cases += [glo.rand_fe(rng, 12, canonical=False) for _ in range(200)]
     for c in cases:
         assert np.array_equal(mi_stark.dbg_host_permute(c, variant), glo.perm(c))
@@ -48,7 +49,7 @@ def test_device_poseidon_math_on_host_matches_oracle(variant):
 def test_device_field_math_on_host_matches_oracle():
     rng = np.random.default_rng(7)
     L = glo.lib()
-    edge = [0, 1, 2, P - 1, P - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**63, 2**64 - 1, P, P + 1]
+    edge = [0, 1, 2, P - 1, P - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**48, 2**63, 2**64 - 1, P, P + 1]
     for a in edge:
         for b in edge:
             assert mi_stark.dbg_host_mul(a, b) == L.glo_mul(a, b)

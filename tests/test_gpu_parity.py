@@ -33,6 +33,12 @@ def test_permute_matches_oracle(ctx, variant):
     st[1] = np.arange(12)
     st[2] = P - 1
     st[3] = 2**64 - 1
+    # powers of two: their squares / 4th powers have all-zero low words, which drives the rarely-taken
+    # "lo < hh" and "x >= p" correction branches of the device arithmetic
+    for k in range(64):
+        st[4 + k] = np.uint64(1) << np.uint64(k)
+        st[68 + k] = [(1 << ((k + 5 * j) % 64)) for j in range(12)]
+        st[132 + k] = [P - (1 << ((k + 3 * j) % 63)) for j in range(12)]
     d_in = ctx.to_device(st)
     d_out = ctx.empty(st.size)
     ctx.permute(d_out, d_in, 1000)
@@ -199,6 +205,11 @@ def test_ntt_identities(ctx):
         c = np.full(n, fill, dtype=np.uint64)
         ctx.ntt(out, ctx.to_device(c), n, 1)
         assert np.array_equal(ctx.to_host(out), glo.ntt(c, n, 1)[:, 0])
+    # sparse power-of-two inputs (rare correction branches), forward and inverse
+    c = np.array([(1 << (i % 64)) if i % 7 == 0 else 0 for i in range(n)], dtype=np.uint64)
+    for inverse in (False, True):
+        ctx.ntt(out, ctx.to_device(c), n, 1, inverse=inverse)
+        assert np.array_equal(ctx.to_host(out), glo.ntt(c, n, 1, inverse=inverse)[:, 0])
 
 
 def test_config1_forward_ntt_2pow20(ctx):
