@@ -32,16 +32,19 @@ MI_HD u64 sbox(u64 x)
     return gl::mul_w(x3, x4);
 }
 
-// MDS on 32-bit halves: two 64-bit accumulators per output (v_mad_u64_u32).  Row sum of M is 264, so
-// each accumulator is < 2^41.
-MI_HD void mds_half32(u64 (&s)[12])
+// MDS on 32-bit halves: two 64-bit accumulators per output (v_mad_u64_u32).  Row sum of M is 264, so each
+// accumulator stays below 2^41 + 2^32.  The NEXT round's constants are folded in for free: the accumulators start
+// at the two halves of rc_next[x] instead of zero (exact integer identity), which removes the 12 modular additions
+// of the following "add round constants" layer.  rc_next == nullptr: plain M * s.
+MI_HD void mds_half32(u64 (&s)[12], const u64 *__restrict__ rc_next = nullptr)
 {
     u32 lo[12], hi[12];
+    u64 rcn[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); rcn[i] = rc_next ? rc_next[i] : 0; }
 #pragma unroll
     for (int x = 0; x < 12; x++) {
-        u64 al = 0, ah = 0;
+        u64 al = (u64)(u32)rcn[x], ah = rcn[x] >> 32;
 #pragma unroll
         for (int y = 0; y < 12; y++) {
             const u32 m = (u32)(MC[(y - x + 12) % 12] + ((x == 0 && y == 0) ? MD0 : 0));
@@ -49,15 +52,11 @@ MI_HD void mds_half32(u64 (&s)[12])
             ah += (u64)hi[y] * m;
         }
         // value = al + ah*2^32 = al + (ah_lo << 32) + ah_hi * 2^64 ;  2^64 = 2^32 - 1
-        u64 ahh = ah >> 32;                          // < 2^9
-        u64 r = al + ((ahh << 32) - ahh);            // < 2^42, no wrap
+        u64 ahh = ah >> 32;                          // < 2^10
+        u64 r = al + ((ahh << 32) - ahh);            // < 2^43, no wrap
         u64 b = ah << 32;
         u64 t = r + b;
-        if (gl::rare(t < b)) { // r < 2^42: wraps with probability ~2^-22
-            MI_KEEP_BRANCH();
-            t = t < b ? t + GL_EPS : t;
-        }
-        s[x] = t;
+        s[x] = t < b ? t + GL_EPS : t; // (a wave-uniform branch here splits the block and un-hoists the constant loads)
     }
 }
 
@@ -196,11 +195,19 @@ MI_HD void partial_rounds_sparse(u64 (&s)[12], const SparseTables &t)
     }
 }
 
+// s <- M * s + rc_next (rc_next may be null).  Only the half32 path folds the constants; the others add them.
 template <int MDS>
-MI_HD void mds(u64 (&s)[12])
+MI_HD void mds(u64 (&s)[12], const u64 *__restrict__ rc_next)
 {
-    if (MDS == MDS_LIMB22) mds_limb22(s);
-    else mds_half32(s);
+    if (MDS == MDS_LIMB22) {
+        mds_limb22(s);
+        if (rc_next) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc_next[i]);
+        }
+    } else {
+        mds_half32(s, rc_next);
+    }
 }
 
 // rc: 360 round constants (canonical); sp: tables of the optimised partial rounds (only read by MDS_SPARSE).
@@ -209,28 +216,31 @@ template <int MDS>
 MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables *__restrict__ sp = nullptr)
 {
     constexpr int FULL_MDS = (MDS == MDS_SPARSE) ? MDS_HALF32 : MDS;
+    // round r: s <- M * S(s + rc_r).  The "+ rc_{r+1}" of the next round rides in the MDS of round r.
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc[i]);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_wc(s[i], rc[r * 12 + i]));
-        mds<FULL_MDS>(s);
+        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        mds<FULL_MDS>(s, (MDS == MDS_SPARSE && r == 3) ? nullptr : rc + (r + 1) * 12);
     }
     if (MDS == MDS_SPARSE) {
         partial_rounds_sparse(s, *sp);
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc[26 * 12 + i]);
     } else {
 #pragma unroll 1
         for (int r = 4; r < 26; r++) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], rc[r * 12 + i]);
             s[0] = sbox(s[0]);
-            mds<FULL_MDS>(s);
+            mds<FULL_MDS>(s, rc + (r + 1) * 12);
         }
     }
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_wc(s[i], rc[r * 12 + i]));
-        mds<FULL_MDS>(s);
+        for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+        mds<FULL_MDS>(s, r < 29 ? rc + (r + 1) * 12 : nullptr);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
