@@ -41,6 +41,8 @@ MI_HD bool rare(bool c)
 #define MI_KEEP_BRANCH() do { } while (0)
 #endif
 
+MI_HD u64 canon_sel(u64 a) { return a >= GL_P ? a - GL_P : a; } // select form (no branch)
+
 MI_HD u64 canon(u64 a)
 {
     if (rare(a >= GL_P)) {

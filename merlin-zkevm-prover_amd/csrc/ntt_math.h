@@ -9,6 +9,10 @@
 #include <utility>
 #include "gl_math.h"
 
+#ifndef MI_DFT_CANON
+#define MI_DFT_CANON(x) gl::canon(x)
+#endif
+
 namespace nttm {
 
 template <int I, int N, typename F>
@@ -72,7 +76,7 @@ MI_HD void dft_reg(u64 (&x)[1 << Q])
                 constexpr int j = decltype(J)::value;
                 constexpr int e0 = 3 * j * (64 / len);              // w_len^j = w_64^(j * 64/len) = 2^e0
                 constexpr int e = INV ? (192 - e0) % 192 : e0;
-                const u64 u = x[s + j], v = gl::canon(x[s + j + half]);
+                const u64 u = x[s + j], v = MI_DFT_CANON(x[s + j + half]);
                 x[s + j] = gl::add_wc(u, v);
                 x[s + j + half] = mul_pow2<e>(gl::sub_wc(u, v));
             });

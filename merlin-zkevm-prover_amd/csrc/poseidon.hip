@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
     for (uint32_t c = 0; c < ncols; c += 16) {
 #pragma unroll
         for (int i = 0; i < 8; i++) s[i] = b0[i];
-        pos::permute<MDS>(s, c_rc, &c_sparse);
+        pos::permute<MDS, 0>(s, c_rc, &c_sparse);
         if (c + 8 >= ncols) break;
 #pragma unroll
         for (int i = 0; i < 4; i++) s[8 + i] = s[i];
@@ -79,14 +79,14 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) b1[i] = (c2 + 8 + i < ncols) ? p[c2 + 8 + i] : 0;
         }
-        pos::permute<MDS>(s, c_rc, &c_sparse);
+        pos::permute<MDS, 0>(s, c_rc, &c_sparse);
         if (c2 >= ncols) break;
 #pragma unroll
         for (int i = 0; i < 4; i++) s[8 + i] = s[i];
     }
     ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(o);
-    o2[0] = make_ulonglong2(s[0], s[1]);
-    o2[1] = make_ulonglong2(s[2], s[3]);
+    o2[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+    o2[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
 // ---- line-aligned variant of the leaf sponge (default).
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows_lines(u64 *__restrict_
                 else ring_load_line<0>(win, lp + (uint64_t)(dead + 2) * 16, lo, hi);
             }
         }
-        pos::permute<MDS>(s, c_rc, &c_sparse);
+        pos::permute<MDS, 0>(s, c_rc, &c_sparse);
         if (pos + 8 < end) {
 #pragma unroll
             for (int i = 0; i < 4; i++) s[8 + i] = s[i];
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows_lines(u64 *__restrict_
     }
     if (active) {
         ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(digests + row * 4);
-        o2[0] = make_ulonglong2(s[0], s[1]);
-        o2[1] = make_ulonglong2(s[2], s[3]);
+        o2[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+        o2[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
     }
 }
 
@@ -181,7 +181,7 @@ __device__ __forceinline__ void hash_pair(u64 *__restrict__ out, const u64 *__re
     const ulonglong2 *i2 = reinterpret_cast<const ulonglong2 *>(in);
     ulonglong2 a = i2[0], b = i2[1], c = i2[2], d = i2[3];
     u64 s[12] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, 0, 0, 0, 0};
-    pos::permute<MDS>(s, c_rc, &c_sparse);
+    pos::permute<MDS, 4>(s, c_rc, &c_sparse);
     ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(out);
     o2[0] = make_ulonglong2(s[0], s[1]);
     o2[1] = make_ulonglong2(s[2], s[3]);

@@ -211,8 +211,9 @@ MI_HD void mds(u64 (&s)[12], const u64 *__restrict__ rc_next)
 }
 
 // rc: 360 round constants (canonical); sp: tables of the optimised partial rounds (only read by MDS_SPARSE).
-// State in: any u64 encodings; out: canonical.
-template <int MDS>
+// State in: any u64 encodings; out: the first NCANON words canonical, the rest weakly reduced (a chained sponge
+// permutation needs none canonical, a tree node only its 4 digest words).
+template <int MDS, int NCANON = 12>
 MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables *__restrict__ sp = nullptr)
 {
     constexpr int FULL_MDS = (MDS == MDS_SPARSE) ? MDS_HALF32 : MDS;
@@ -243,7 +244,7 @@ MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables 
         mds<FULL_MDS>(s, r < 29 ? rc + (r + 1) * 12 : nullptr);
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+    for (int i = 0; i < NCANON; i++) s[i] = gl::canon(s[i]);
 }
 
 } // namespace pos

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi_stark.so")
+LIB_PATH = os.environ.get("MI_STARK_LIB") or os.path.join(HERE, "libmi_stark.so")   # override: A/B builds of the same library
 P = 0xFFFFFFFF00000001
 
 u64 = ctypes.c_uint64
