@@ -26,17 +26,19 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 7
 
 
 def valu_roofline(perms, leaf_ms):
-    """Issue-rate roofline of the Poseidon leaf kernel.  Static instruction counts per permutation come from the
-    gfx950 ISA of pos::permute<MDS_HALF32> (8 full rounds x 1715 + 22 partial rounds x 629 instructions, of which
-    11348 VALU instructions issue at 2 clk per wave64 and 14864 at 4 clk: DESIGN.md section 4); the two issue rates
-    are the best chip-wide rates measured by tools/ubench_int2.hip on this chip
-    (profiles/r01_ubench_int_issue_rates2.txt: 1047 G wave-instr/s for the 2-clk class, 592 G for the 4-clk class)."""
-    full_rate, half_rate = 8 * 830 + 22 * 214, 8 * 802 + 22 * 384   # VOP1/VOP2 (e32) class / VOP3 integer class, per permutation
-    t_min_per_wave_perm = full_rate / 1047e9 + half_rate / 592e9    # seconds of chip-wide issue time per wave-permutation
-    peak_perms = 64.0 / t_min_per_wave_perm
+    """Issue-rate roofline of the Poseidon leaf kernel.
+    Instructions per permutation: 24 685 VALU instructions per lane, MEASURED (rocprofv3 --pmc SQ_INSTS_VALU over the
+    launch / wave-permutations, profiles/r01_pmc_sq_leaf.txt).  Peak issue rates: measured on this chip by
+    tools/ubench_int2.hip (profiles/r01_ubench_int_issue_rates2.txt): 1047 G wave-instr/s for the 2-clk class
+    (v_add_u32, v_mov, v_cndmask ...) and 592 G for the 4-clk class (v_mad_u64_u32, shifts, carry adds,
+    v_lshl_add_u64); the kernel's static mix is 43 % / 57 %."""
+    instrs = 24685.0
+    blended_peak = 1.0 / (0.43 / 1047e9 + 0.57 / 592e9)         # wave-instructions per second, whole chip
+    peak_perms = blended_peak * 64.0 / instrs
     ach = perms / (leaf_ms * 1e-3) if leaf_ms > 0 else 0.0
     return {"kernel": "k_linear_hash_rows_lines", "bound": "valu-issue", "perms_per_launch": perms, "achieved": ach, "peak": peak_perms,
-            "unit": "permutations/s", "frac": ach / peak_perms, "instructions_per_permutation": full_rate + half_rate}
+            "unit": "permutations/s", "frac": ach / peak_perms, "valu_instructions_per_permutation": instrs,
+            "achieved_wave_instr_per_s": ach / 64.0 * instrs, "peak_wave_instr_per_s": blended_peak}
 
 
 def cpu_baseline(log_n, ncols):
