@@ -12,6 +12,8 @@
 #include "transcript.hpp"
 #include "polinomial.hpp"
 #include "friProve.hpp"
+#include "build_const_tree.hpp"
+#include <fstream>
 #include "../../oracle/gl_oracle.h"
 
 static int failures = 0;
@@ -179,6 +181,43 @@ int main()
     PoseidonGoldilocks::linear_hash(lh, cm1_n.data(), 18);
     glo_linear_hash(wlh, (const uint64_t *)cm1_n.data(), 18);
     EXPECT(same(lh, wlh, 4), "PoseidonGoldilocks::linear_hash == oracle");
+
+    // ---- bctree (tools/starkpil/bctree/build_const_tree.cpp:333-449): const pols -> consttree file + verkey,
+    //      then the file mapped back through MerkleTreeGL(Goldilocks::Element *tree) like starks.hpp:141-143,190
+    {
+        const uint64_t cb = 9, cbe = 10, cn = 1ULL << cb, cne = 1ULL << cbe, nPols = 7;
+        std::vector<Goldilocks::Element> cpols(cn * nPols);
+        for (uint64_t i = 0; i < cpols.size(); i++) cpols[i] = Goldilocks::fromU64(splitmix(9, i));
+        const char *dir = std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp";
+        const std::string base = std::string(dir) + "/mi_bctree_test", fconst = base + ".const", fstruct = base + ".starkstruct.json",
+                          ftree = base + ".consttree", fkey = base + ".verkey.json";
+        { std::ofstream f(fconst, std::ios::binary); f.write((const char *)cpols.data(), cpols.size() * 8); }
+        { std::ofstream f(fstruct); f << "{\n  \"nBits\": 9,\n  \"nBitsExt\": 10,\n  \"nQueries\": 8,\n  \"verificationHashType\": \"GL\"\n}\n"; }
+        buildConstTree(fconst, fstruct, ftree, fkey);
+        std::string blob = bctree_detail::slurp(ftree);
+        const uint64_t want_size = (2 + nPols * cne + (2 * cne - 1) * 4) * 8;
+        EXPECT(blob.size() == want_size, "consttree file size");
+        Goldilocks::Element *tree = (Goldilocks::Element *)blob.data();
+        std::vector<uint64_t> wext(cne * nPols), wnodes((2 * cne - 1) * 4);
+        glo_extend_pol(wext.data(), (const uint64_t *)cpols.data(), cne, cn, nPols);
+        glo_merkletree(wnodes.data(), wext.data(), nPols, cne);
+        EXPECT(blob.size() == want_size && tree[0].fe == nPols && tree[1].fe == cne && same(&tree[2], wext.data(), wext.size()) &&
+                   same(&tree[2 + nPols * cne], wnodes.data(), wnodes.size()),
+               "consttree contents == oracle (header, LDE'd pols, nodes)");
+        MerkleTreeGL ctree(tree); // file-backed constant tree, as treesGL[4] in starks.hpp:190
+        Goldilocks::Element croot[4];
+        ctree.getRoot(croot);
+        std::vector<Goldilocks::Element> cproof(nPols + ctree.MerkleProofSize() * HASH_SIZE);
+        ctree.getGroupProof(cproof.data(), 333);
+        EXPECT(ctree.width == nPols && ctree.height == cne && same(croot, &wnodes[wnodes.size() - 4], 4) &&
+                   glo_merkle_verify((const uint64_t *)croot, (const uint64_t *)cproof.data(), nPols, (const uint64_t *)&cproof[nPols], cbe, 333),
+               "MerkleTreeGL(tree*) over the consttree file: root and group proof");
+        const std::string key = bctree_detail::slurp(fkey);
+        EXPECT(key.find("\"constRoot\"") != std::string::npos && key.find(std::to_string(wnodes[wnodes.size() - 4])) != std::string::npos &&
+                   key.find(std::to_string(wnodes[wnodes.size() - 1])) != std::string::npos,
+               "verkey.json holds the constRoot");
+        std::remove(fconst.c_str()); std::remove(fstruct.c_str()); std::remove(ftree.c_str()); std::remove(fkey.c_str());
+    }
 
     delete treesGL[0];
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "ALL OK", failures);
