@@ -1,7 +1,7 @@
 // friProve.hpp -- FRIProve::prove with the reference's control flow (friProve.cpp:5-190) on device-resident
 // data: the FRI polynomial stays in HBM across steps (fold -> transpose -> step tree), only step roots, the
-// final polynomial and the query openings come back.  StarkInfo / FRIProof carry just the fields this path
-// reads (stark_info.hpp:21-35, friProof.hpp:9-236 minus the JSON writers).
+// final polynomial and the query openings come back.  StarkInfo carries just the fields this path reads
+// (stark_info.hpp:21-35); the proof container is friProof.hpp.
 #ifndef FRI_PROVE
 #define FRI_PROVE
 #include <vector>
@@ -9,55 +9,11 @@
 #include "polinomial.hpp"
 #include "merkleTreeGL.hpp"
 #include "ntt_goldilocks.hpp"
+#include "friProof.hpp"
 
 class StepStruct { public: uint64_t nBits; };
 class StarkStruct { public: uint64_t nBits = 0, nBitsExt = 0, nQueries = 0; std::vector<StepStruct> steps; };
 class StarkInfo { public: StarkStruct starkStruct; };
-
-class MerkleProof
-{
-public:
-    std::vector<std::vector<Goldilocks::Element>> v;
-    std::vector<std::vector<Goldilocks::Element>> mp;
-    MerkleProof(uint64_t nLinears, uint64_t elementsTree, Goldilocks::Element *pointer)
-        : v(nLinears, std::vector<Goldilocks::Element>(1, Goldilocks::zero())), mp(elementsTree, std::vector<Goldilocks::Element>(HASH_SIZE, Goldilocks::zero()))
-    {
-        for (uint64_t i = 0; i < nLinears; i++) v[i][0] = pointer[i];
-        for (uint64_t j = 0; j < elementsTree; j++) std::memcpy(&mp[j][0], &pointer[nLinears + j * HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
-    };
-};
-class ProofTree
-{
-public:
-    std::vector<Goldilocks::Element> root;
-    std::vector<std::vector<MerkleProof>> polQueries;
-    ProofTree() : root(HASH_SIZE){};
-    void setRoot(Goldilocks::Element *_root) { std::memcpy(&root[0], _root, HASH_SIZE * sizeof(Goldilocks::Element)); };
-};
-class Fri
-{
-public:
-    std::vector<std::vector<Goldilocks::Element>> pol;
-    std::vector<ProofTree> trees;
-    Fri(uint64_t polN, uint64_t dim, uint64_t numSteps) : pol(polN, std::vector<Goldilocks::Element>(dim, Goldilocks::zero())), trees(numSteps){};
-    void setPol(Goldilocks::Element *pPol)
-    {
-        for (uint64_t i = 0; i < pol.size(); i++) std::memcpy(&pol[i][0], &pPol[i * pol[i].size()], pol[i].size() * sizeof(Goldilocks::Element));
-    }
-};
-class Proofs
-{
-public:
-    Fri fri;
-    Proofs(StarkInfo &starkInfo)
-        : fri(1ULL << starkInfo.starkStruct.steps[starkInfo.starkStruct.steps.size() - 1].nBits, FIELD_EXTENSION, starkInfo.starkStruct.steps.size()){};
-};
-class FRIProof
-{
-public:
-    Proofs proofs;
-    FRIProof(StarkInfo &starkInfo) : proofs(starkInfo){};
-};
 
 class FRIProve
 {

@@ -13,6 +13,7 @@
 #include "polinomial.hpp"
 #include "friProve.hpp"
 #include "build_const_tree.hpp"
+#include "proof2zkinStark.hpp"
 #include <fstream>
 #include "../../oracle/gl_oracle.h"
 
@@ -115,7 +116,7 @@ int main()
     for (uint64_t i = 0; i < f_2ns.size(); i++) f_2ns[i] = Goldilocks::fromU64(splitmix(4, i));
     std::vector<uint64_t> opol((const uint64_t *)f_2ns.data(), (const uint64_t *)f_2ns.data() + f_2ns.size());
     Polinomial friPol(f_2ns.data(), NExtended, 3, 3, "friPol");
-    FRIProof fproof(starkInfo);
+    FRIProof fproof(1ULL << 3, FIELD_EXTENSION, starkInfo.starkStruct.steps.size(), 5, 3); // (polN, dim, numTrees, evalSize, nPublics)
     FRIProve::prove(fproof, treesGL, transcript, friPol, nBitsExt, starkInfo);
 
     // oracle mirror of FRIProve::prove
@@ -168,6 +169,23 @@ int main()
         for (auto &y : ys) if (si < 3) y %= (1ULL << starkInfo.starkStruct.steps[si + 1].nBits);
     }
     EXPECT(q_ok, "FRI query openings == oracle and verify against the roots");
+
+    // ---- proof.json / zkin.json writers (friProof.hpp:176-218, proof2zkinStark.cpp:8-82); checked by the python side
+    {
+        std::memcpy(&fproof.proofs.root1[0], root0, sizeof(root0));
+        std::vector<Goldilocks::Element> ev(5 * 3);
+        for (size_t i = 0; i < ev.size(); i++) ev[i] = Goldilocks::fromU64(1000 + i);
+        fproof.proofs.setEvals(ev.data());
+        for (int i = 0; i < 3; i++) fproof.publics[i] = publics[i];
+        const char *out = std::getenv("MI_FLOW_JSON_DIR");
+        if (out) {
+            std::ofstream(std::string(out) + "/proof.json") << fproof.proofs.proof2json();
+            std::ofstream(std::string(out) + "/zkin.json") << proof2zkinStark(fproof, true);
+        }
+        const std::string z = proof2zkinStark(fproof);
+        EXPECT(z.find("\"s3_root\"") != std::string::npos && z.find("\"s0_vals1\"") != std::string::npos && z.find("\"finalPol\"") != std::string::npos,
+               "proof2zkinStark emits the zkin keys");
+    }
 
     // ---- scalar API spot checks used by the reference (zhInv.cpp, starks.hpp:149-160)
     EXPECT(Goldilocks::toU64(Goldilocks::w(3)) == glo_w(3) && Goldilocks::toU64(Goldilocks::w(24)) == glo_w(24), "Goldilocks::w");

@@ -25,8 +25,30 @@ def test_shims_compile_against_the_c_abi():
 
 
 @pytest.mark.gpu
-def test_starkpil_flow_on_gpu():
+def test_starkpil_flow_on_gpu(tmp_path):
+    import json
+    import numpy as np
     build_exe()
-    r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, MI_FLOW_JSON_DIR=str(tmp_path))
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=600, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ALL OK" in r.stdout
+    # the zkin.json it wrote has the reference's layout (proof2zkinStark.cpp:8-82; golden files in tests/golden) and
+    # passes the same checks as the reference's golden proofs: every opened Merkle path climbs to its root
+    z = json.load(open(tmp_path / "zkin.json"))
+    steps = [13, 9, 6, 3]
+    assert set(z) == {"root1", "root2", "root3", "root4", "evals", "s1_root", "s1_vals", "s1_siblings", "s2_root", "s2_vals", "s2_siblings",
+                      "s3_root", "s3_vals", "s3_siblings", "s0_vals1", "s0_siblings1", "finalPol", "publics"}
+    U = lambda x: np.array(x, dtype=object).astype(np.uint64)
+    assert len(z["s0_vals1"]) == 11 and len(z["s0_vals1"][0]) == 37 and len(z["s0_siblings1"][0]) == 13 and len(z["finalPol"]) == 8
+    assert all(isinstance(v, str) for v in z["root1"])
+    # recover each query index from the step-0 path (as tests/golden/make_golden.py does) and check the chain
+    for q in range(11):
+        vals, sibs = U(z["s0_vals1"][q]), U(z["s0_siblings1"][q])
+        idx = [i for i in range(1 << 13) if glo.merkle_verify(U(z["root1"]), vals, sibs, i)]
+        assert len(idx) == 1
+        for s in (1, 2, 3):
+            assert glo.merkle_verify(U(z[f"s{s}_root"]), U(z[f"s{s}_vals"][q]), U(z[f"s{s}_siblings"][q]), idx[0] % (1 << steps[s]))
+    p = json.load(open(tmp_path / "proof.json"))
+    assert list(p) == ["root1", "root2", "root3", "root4", "evals", "fri"] and len(p["fri"]) == 5 and p["fri"][1]["root"] == z["s1_root"]
+    assert p["fri"][4] == z["finalPol"] and p["evals"][4] == ["1012", "1013", "1014"]
