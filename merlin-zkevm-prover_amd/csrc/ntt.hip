@@ -87,42 +87,54 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     const uint32_t c0 = (uint32_t)(lt % a.n_col_tiles) << a.tcp_log;
 
     if (tid < 256) w256[tid] = a.w256[tid];
-    for (uint32_t e = tid; e < (uint32_t)R * TJ; e += NTT_THREADS) {
-        const uint32_t k1 = e >> a.tj_log, tj = e & (TJ - 1);
-        const uint64_t beta = beta0 + tj;
-        const uint64_t ip = beta >> a.log_K, kappa = beta & (K - 1);
-        uint64_t ex = (ip * k1) << a.log_K; // exponent of w_n, < n
-        if (INV) ex = (n - ex) & (n - 1);
-        u64 t = 1;
-        if (ex) t = gl::mul(a.tw_hi[ex >> a.tw_lo_bits], a.tw_lo[ex & ((1ull << a.tw_lo_bits) - 1)]);
-        if (a.apply_scale) {
-            const uint64_t ro = (((ip << LOG_R) + k1) << a.log_K) + kappa;
-            t = gl::mul(t, gl::mul(a.sc_hi[ro >> a.sc_lo_bits], a.sc_lo[ro & ((1ull << a.sc_lo_bits) - 1)]));
+    auto fill_tw = [&]() {
+        for (uint32_t e = tid; e < (uint32_t)R * TJ; e += NTT_THREADS) {
+            const uint32_t k1 = e >> a.tj_log, tj = e & (TJ - 1);
+            const uint64_t beta = beta0 + tj;
+            const uint64_t ip = beta >> a.log_K, kappa = beta & (K - 1);
+            uint64_t ex = (ip * k1) << a.log_K; // exponent of w_n, < n
+            if (INV) ex = (n - ex) & (n - 1);
+            u64 t = 1;
+            if (ex) t = gl::mul(a.tw_hi[ex >> a.tw_lo_bits], a.tw_lo[ex & ((1ull << a.tw_lo_bits) - 1)]);
+            if (a.apply_scale) {
+                const uint64_t ro = (((ip << LOG_R) + k1) << a.log_K) + kappa;
+                t = gl::mul(t, gl::mul(a.sc_hi[ro >> a.sc_lo_bits], a.sc_lo[ro & ((1ull << a.sc_lo_bits) - 1)]));
+            }
+            tw[e] = t;
         }
-        tw[e] = t;
-    }
+    };
 
     // ---- load (any encoding; dft_reg accepts it)
     if (WIDE) { // lanes run along column PAIRS: 16 lanes cover a 256-byte row segment, 32 rows per sweep
+        constexpr int NW = (R * (B / 2) + NTT_THREADS - 1) / NTT_THREADS; // 16-byte loads per thread (8 at r = 256)
         const uint32_t bp = (tid & (B / 2 - 1)) * 2, tj = bp >> a.tcp_log, c = bp & (TCP - 1);
         const uint32_t col = c0 + c;
         const u64 *p = a.src + (beta0 + tj) * a.src_pitch + col;
-#pragma unroll 8
-        for (uint32_t i1 = tid / (B / 2); i1 < (uint32_t)R; i1 += NTT_THREADS / (B / 2)) {
+        ulonglong2 v[NW];
+        // all of the tile's loads are in flight before the twiddle table (dependent L2 loads + multiplies) is built
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
             const uint64_t row = (uint64_t)i1 * mK + beta0 + tj;
             const u64 *pr = p + (uint64_t)i1 * mK * a.src_pitch;
-            ulonglong2 v = make_ulonglong2(0, 0);
-            if (row < a.in_valid_rows) {
+            v[k] = make_ulonglong2(0, 0);
+            if (i1 < (uint32_t)R && row < a.in_valid_rows) {
                 if (col + 1 < a.ncols) {
                     const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
-                    v = make_ulonglong2(w.x, w.y);
+                    v[k] = make_ulonglong2(w.x, w.y);
                 } else if (col < a.ncols) {
-                    v.x = pr[0];
+                    v[k].x = pr[0];
                 }
             }
-            *reinterpret_cast<ulonglong2 *>(&tile[i1 * B + bp]) = v;
+        }
+        fill_tw();
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
+            if (i1 < (uint32_t)R) *reinterpret_cast<ulonglong2 *>(&tile[i1 * B + bp]) = v[k];
         }
     } else { // lanes run along the B batch elements, 16 rows per sweep
+        fill_tw();
         const uint32_t b = tid & (B - 1), tj = b >> a.tcp_log, c = b & (TCP - 1);
         const uint32_t col = c0 + c;
         const bool active = col < a.ncols;
