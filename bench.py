@@ -74,9 +74,10 @@ def main():
     ap.add_argument("--log-n", type=int, default=23, help="log2 of trace rows (BASELINE: 23)")
     ap.add_argument("--cols", type=int, default=665, help="committed columns (BASELINE: 665)")
     ap.add_argument("--workspace-gib", type=float, default=16.0)
-    ap.add_argument("--poseidon-variant", type=int, default=0)
+    ap.add_argument("--poseidon-variant", type=int, default=2)
     ap.add_argument("--cpu-log-n", type=int, default=16, help="log2 rows of the CPU-baseline sample")
     ap.add_argument("--ntt-log-b", type=int, default=5)
+    ap.add_argument("--lde-fuse", type=int, default=1, help="0 = separate last-INTT / first-NTT passes (A/B only)")
     ap.add_argument("--leaf-mode", type=int, default=1, help="1 = line-aligned leaf fetch (default), 0 = per-block loads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -102,6 +103,7 @@ def main():
     ctx = mi_stark.Context(local_rank, workspace_limit=int(args.workspace_gib * (1 << 30)))
     ctx.set_poseidon_variant(args.poseidon_variant)
     ctx.set_ntt_tile(args.ntt_log_b)
+    ctx.set_lde_fuse(args.lde_fuse)
     ctx.set_leaf_mode(args.leaf_mode)
     n, n_ext, ncols = 1 << args.log_n, 2 << args.log_n, args.cols
     plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=rank)

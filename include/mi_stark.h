@@ -151,13 +151,18 @@ void *mi_dev_alloc(mi_ctx *ctx, uint64_t bytes);
 int mi_dev_free(mi_ctx *ctx, void *p);
 int mi_copy_h2d(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
-/* Selects the Poseidon code path: 0 = naive rounds, MDS on 32-bit halves (v_mad_u64_u32); 1 = naive rounds, MDS on
- * 22-bit limbs (v_mad_u32_u24); 2 = optimised partial rounds (sparse matrices, tools/gen_poseidon_sparse.py).
+/* Selects the Poseidon code path: 2 (default) = full rounds with the MDS on 32-bit halves (v_mad_u64_u32) and the
+ * 22 partial rounds in the grouped optimised form (dot products with 64-bit constants, tools/gen_poseidon_sparse.py);
+ * 0 = naive rounds throughout, MDS on 32-bit halves; 1 = naive rounds, MDS on 22-bit limbs (v_mad_u32_u24).
  * All are bit-identical; exposed for benchmarking. */
 int mi_set_poseidon_variant(mi_ctx *ctx, int variant);
 /* NTT tile width in elements per row segment: log_b = 4 (128-byte segments, 4 workgroups per CU) or 5
  * (256-byte segments, 2 per CU).  Results are identical; exposed for benchmarking. */
 int mi_set_ntt_tile(mi_ctx *ctx, int log_b);
+/* extendPol: 1 (default) = the last INTT pass and the first pass of the extended NTT run as one kernel whenever
+ * their radices line up (the coefficients never reach HBM), 0 = always separate passes.  Results are identical;
+ * exposed for benchmarking and for testing both paths. */
+int mi_set_lde_fuse(mi_ctx *ctx, int fuse);
 /* Leaf sponge memory access: 1 (default) = every lane fetches whole aligned 128-byte lines into a register
  * ring, 0 = plain per-block loads.  Results are identical; exposed for benchmarking. */
 int mi_set_leaf_mode(mi_ctx *ctx, int line_aligned);

@@ -130,6 +130,13 @@ extern "C" int mi_set_leaf_mode(mi_ctx *c, int line_aligned)
     return MI_OK;
 }
 
+extern "C" int mi_set_lde_fuse(mi_ctx *c, int fuse)
+{
+    CTX_OK(c);
+    c->lde_fuse_mid = fuse != 0;
+    return MI_OK;
+}
+
 extern "C" int mi_set_ntt_tile(mi_ctx *c, int log_b)
 {
     CTX_OK(c);

@@ -50,7 +50,7 @@ struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int poseidon_variant = 0; // 0 = 32-bit halves / v_mad_u64_u32 (fewer instructions; all int multiplies issue at the same rate on gfx950)
+    int poseidon_variant = 2; // 2 = full rounds on 32-bit halves (v_mad_u64_u32) + grouped optimised partial rounds; 0 / 1 = naive rounds
     uint64_t workspace_limit = 16ULL << 30;
     u64 *workspace = nullptr;
     uint64_t workspace_bytes = 0;
@@ -61,6 +61,7 @@ struct mi_ctx {
     hipEvent_t ev_start[8] = {}, ev_stop[8] = {};
     int cu_count = 256;
     bool leaf_line_aligned = true; // leaf sponge fetches whole aligned 128-byte lines (k_linear_hash_rows_lines)
+    bool lde_fuse_mid = true; // extendPol: last INTT pass and first NTT pass in one kernel (k_lde_mid) when the splits line up
     uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
 };
 

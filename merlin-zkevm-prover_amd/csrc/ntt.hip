@@ -55,6 +55,74 @@ __device__ __forceinline__ u64 from_lane_xor1(u64 v)
     return ((u64)(u32)hi << 32) | (u32)lo;
 }
 
+// ---- tile-level building blocks shared by the plain pass and the fused LDE middle pass.
+// An r-point DFT over the rows of an LDS tile [r][B] is two in-register steps (LA + LB bits, LB <= 4):
+template <int LOG_R>
+struct TileRadix {
+    static constexpr int R = 1 << LOG_R;
+    static constexpr int LB = LOG_R >= 4 ? 4 : LOG_R; // second in-register step
+    static constexpr int LA = LOG_R - LB;             // first in-register step (0..4 bits)
+    static constexpr int RA = 1 << LA, RB = 1 << LB;
+};
+
+// step A: RA-point DFTs over the high bits, in place, then twiddle by w_r^(p' ka).  Caller syncs afterwards.
+template <int LOG_R, bool INV, int LOG_B>
+__device__ __forceinline__ void tile_step_a(u64 *tile, const u64 *w256, uint32_t tid)
+{
+    using T = TileRadix<LOG_R>;
+    constexpr int B = 1 << LOG_B, NTT_THREADS = 16 * B;
+    if (T::LA > 0) {
+        for (uint32_t item = tid; item < (uint32_t)T::RB * B; item += NTT_THREADS) {
+            const uint32_t b = item & (B - 1), pp = item >> LOG_B;
+            u64 x[T::RA];
+#pragma unroll
+            for (int i = 0; i < T::RA; i++) x[i] = tile[(i * T::RB + pp) * B + b];
+            nttm::dft_reg<T::LA, INV>(x);
+#pragma unroll
+            for (int ka = 1; ka < T::RA; ka++) {
+                uint32_t idx = (pp * ka) << (8 - LOG_R);
+                if (INV) idx = (256 - idx) & 255;
+                x[ka] = gl::mul_w(x[ka], w256[idx]);
+            }
+#pragma unroll
+            for (int ka = 0; ka < T::RA; ka++) tile[(ka * T::RB + pp) * B + b] = x[ka];
+        }
+    }
+}
+
+// step B for one work item (kap, b): RB-point DFT over the low bits; x[kb] is output k1 = kap + RA * kb
+template <int LOG_R, bool INV, int LOG_B>
+__device__ __forceinline__ void tile_step_b(const u64 *tile, uint32_t kap, uint32_t b, u64 (&x)[TileRadix<LOG_R>::RB])
+{
+    using T = TileRadix<LOG_R>;
+    constexpr int B = 1 << LOG_B;
+#pragma unroll
+    for (int i = 0; i < T::RB; i++) x[i] = tile[(kap * T::RB + i) * B + b];
+    nttm::dft_reg<T::LB, INV>(x);
+}
+
+// 16-byte stores of two adjacent columns: lanes b (even) and b+1 hold the same rows of two adjacent columns; they
+// swap halves (DPP) so that the even lane owns rows kb = 0,2,4.. and the odd lane rows 1,3,5.. of BOTH columns.
+// q_e points at (first output row of this item, first column of the pair); executed by every lane of the wave.
+template <int RB>
+__device__ __forceinline__ void store_pairs(u64 *q_e, uint64_t qstride, const u64 (&x)[RB], bool odd, bool pair_ok, bool lone_ok)
+{
+#pragma unroll
+    for (int j = 0; j < RB / 2; j++) {
+        const u64 give = odd ? x[2 * j] : x[2 * j + 1];
+        const u64 got = from_lane_xor1(give);
+        U64x2 w;
+        w.x = odd ? got : x[2 * j];
+        w.y = odd ? x[2 * j + 1] : got;
+        u64 *qr = q_e + (uint64_t)(2 * j + (odd ? 1 : 0)) * qstride;
+        if (pair_ok) *reinterpret_cast<U64x2 *>(qr) = w;
+        else if (lone_ok) { // last, unpaired column: the even lane writes both rows itself
+            q_e[(uint64_t)(2 * j) * qstride] = x[2 * j];
+            q_e[(uint64_t)(2 * j + 1) * qstride] = x[2 * j + 1];
+        }
+    }
+}
+
 // WIDE: every lane moves two adjacent columns (16 bytes) per access on both the load and the store side.  With
 // 8-byte accesses the pass is limited by the address/L1 path, not by HBM (measured on the movement alone:
 // 211 ms -> 173 ms for the loads).  Needs at least two columns per tile row (TCP >= 2); single-column
@@ -149,35 +217,15 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     }
     __syncthreads();
 
-    // ---- step A: RA-point DFTs over the high bits, in place, then twiddle by w_r^(p' ka)
-    if (LA > 0) {
-        for (uint32_t item = tid; item < (uint32_t)RB * B; item += NTT_THREADS) {
-            const uint32_t b = item & (B - 1), pp = item >> LOG_B;
-            u64 x[RA];
-#pragma unroll
-            for (int i = 0; i < RA; i++) x[i] = tile[(i * RB + pp) * B + b];
-            nttm::dft_reg<LA, INV>(x);
-#pragma unroll
-            for (int ka = 1; ka < RA; ka++) {
-                uint32_t idx = (pp * ka) << (8 - LOG_R);
-                if (INV) idx = (256 - idx) & 255;
-                x[ka] = gl::mul_w(x[ka], w256[idx]);
-            }
-#pragma unroll
-            for (int ka = 0; ka < RA; ka++) tile[(ka * RB + pp) * B + b] = x[ka];
-        }
-        __syncthreads();
-    }
-
-    // ---- step B: RB-point DFTs over the low bits, inter-pass twiddle / scale, store in natural order
+    // ---- step A (high bits, in place) and step B (low bits) + inter-pass twiddle / scale + store in natural order
+    tile_step_a<LOG_R, INV, LOG_B>(tile, w256, tid);
+    if (LA > 0) __syncthreads();
     for (uint32_t item = tid; item < (uint32_t)RA * B; item += NTT_THREADS) { // trip count is wave-uniform
         const uint32_t b = item & (B - 1), kap = item >> LOG_B;
         const uint32_t tj = b >> a.tcp_log, c = b & (TCP - 1);
         const uint32_t col = c0 + c;
         u64 x[RB];
-#pragma unroll
-        for (int i = 0; i < RB; i++) x[i] = tile[(kap * RB + i) * B + b];
-        nttm::dft_reg<LB, INV>(x);
+        tile_step_b<LOG_R, INV, LOG_B>(tile, kap, b, x);
         const uint64_t beta = beta0 + tj;
         const uint64_t ip = beta >> a.log_K, kappa = beta & (K - 1);
         // output row of k1 = kap + RA*kb is ((ip << LOG_R) + k1) * K + kappa: a constant stride in kb
@@ -187,31 +235,134 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
 #pragma unroll
         for (int kb = 0; kb < RB; kb++) x[kb] = gl::mul(x[kb], t[kb * tstride]);
         if (WIDE && RB >= 2) {
-            // lanes b (even) and b+1 hold the same rows of two adjacent columns: swap halves so that the even lane
-            // owns rows kb = 0,2,4.. and the odd lane rows 1,3,5.. of BOTH columns, then store 16 bytes per lane
             const bool odd = b & 1;
-            const uint32_t col_e = col & ~1u;                      // first column of the pair
-            const bool pair_ok = col_e + 1 < a.ncols;
+            const uint32_t col_e = col & ~1u; // first column of the pair
             u64 *q = a.dst + col_e + ((((ip << LOG_R) + kap) << a.log_K) + kappa) * a.dst_pitch;
-#pragma unroll
-            for (int j = 0; j < RB / 2; j++) {
-                const u64 give = odd ? x[2 * j] : x[2 * j + 1];
-                const u64 got = from_lane_xor1(give);              // executed by every lane (no divergence here)
-                U64x2 w;
-                w.x = odd ? got : x[2 * j];
-                w.y = odd ? x[2 * j + 1] : got;
-                u64 *qr = q + (uint64_t)(2 * j + (odd ? 1 : 0)) * qstride;
-                if (pair_ok) *reinterpret_cast<U64x2 *>(qr) = w;
-                else if (!odd && col < a.ncols) {                  // last, unpaired column: this lane writes both rows
-                    q[(uint64_t)(2 * j) * qstride] = x[2 * j];
-                    q[(uint64_t)(2 * j + 1) * qstride] = x[2 * j + 1];
-                }
-            }
+            store_pairs<RB>(q, qstride, x, odd, col_e + 1 < a.ncols, !odd && col < a.ncols);
         } else if (col < a.ncols) {
             u64 *q = a.dst + col + ((((ip << LOG_R) + kap) << a.log_K) + kappa) * a.dst_pitch;
 #pragma unroll
             for (int kb = 0; kb < RB; kb++) q[kb * qstride] = x[kb];
         }
+    }
+}
+
+// ---- fused middle pass of extendPol: the LAST pass of INTT_N (radix r1, with the shift^k / N scale) and the FIRST
+// pass of NTT_Next on the zero-padded coefficients (radix r2 = blowup * r1) work on the same data: the INTT tile
+// (kappa, column tile) produces coefficients k = k1 * K1 + kappa, k1 < r1, K1 = N / r1, and the NTT's first pass
+// reads rows i1 * (Next / r2) + beta = i1 * K1 + beta, i.e. with beta = kappa exactly those coefficients as its
+// rows i1 < r1 (rows r1.. are the zero padding).  Keeping them in LDS saves one write and one read of the
+// N x cols coefficient matrix (2 of the 17 pass-volumes) and a launch.
+struct LdeMid {
+    const u64 *src;
+    u64 *dst;
+    uint64_t src_pitch, dst_pitch;
+    uint32_t ncols, log_n1, log_n2;
+    uint32_t tj_log, tcp_log, n_col_tiles;
+    uint64_t n_tiles;
+    const u64 *sc_lo, *sc_hi; // shift^k / N over k < N
+    uint32_t sc_lo_bits;
+    const u64 *tw_lo, *tw_hi; // w_Next^e
+    uint32_t tw_lo_bits;
+    const u64 *w256;
+};
+
+template <int LOG_R1, int LOG_BLOW, int LOG_B>
+__global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
+{
+    constexpr int LOG_R2 = LOG_R1 + LOG_BLOW;
+    using T1 = TileRadix<LOG_R1>;
+    using T2 = TileRadix<LOG_R2>;
+    constexpr int B = 1 << LOG_B, NTT_THREADS = 16 * B, R1 = T1::R, R2 = T2::R;
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    u64 *tile = smem;           // [R2][B]
+    u64 *w256 = tile + R2 * B;  // [256]
+    u64 *tw1 = w256 + 256;      // [R1][TJ] scale of coefficient k1*K1 + kappa
+    u64 *tw2 = tw1 + ((size_t)R1 << a.tj_log); // [R2][TJ] w_Next^(kappa * k1')
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t TJ = 1u << a.tj_log, TCP = 1u << a.tcp_log;
+    const uint32_t log_K1 = a.log_n1 - LOG_R1;
+    const uint64_t K1 = 1ull << log_K1;
+    uint64_t lt = blockIdx.x;
+    if ((a.n_tiles & 7) == 0) lt = (lt & 7) * (a.n_tiles >> 3) + (lt >> 3);
+    const uint64_t kappa0 = (lt / a.n_col_tiles) << a.tj_log;
+    const uint32_t c0 = (uint32_t)(lt % a.n_col_tiles) << a.tcp_log;
+
+    if (tid < 256) w256[tid] = a.w256[tid];
+    // ---- R1 input rows i1 * K1 + kappa, two adjacent columns per lane
+    constexpr int NW = (R1 * (B / 2) + NTT_THREADS - 1) / NTT_THREADS;
+    const uint32_t bp = (tid & (B / 2 - 1)) * 2, ltj = bp >> a.tcp_log, lc = bp & (TCP - 1);
+    const uint32_t lcol = c0 + lc;
+    ulonglong2 v[NW];
+    {
+        const u64 *p = a.src + (kappa0 + ltj) * a.src_pitch + lcol;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
+            const u64 *pr = p + (uint64_t)i1 * K1 * a.src_pitch;
+            v[k] = make_ulonglong2(0, 0);
+            if (i1 < (uint32_t)R1) {
+                if (lcol + 1 < a.ncols) {
+                    const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
+                    v[k] = make_ulonglong2(w.x, w.y);
+                } else if (lcol < a.ncols) {
+                    v[k].x = pr[0];
+                }
+            }
+        }
+    }
+    for (uint32_t e = tid; e < (uint32_t)R1 * TJ; e += NTT_THREADS) { // scale of coefficient k = k1 * K1 + kappa
+        const uint64_t k = ((uint64_t)(e >> a.tj_log) << log_K1) + kappa0 + (e & (TJ - 1));
+        tw1[e] = gl::mul(a.sc_hi[k >> a.sc_lo_bits], a.sc_lo[k & ((1ull << a.sc_lo_bits) - 1)]);
+    }
+    for (uint32_t e = tid; e < (uint32_t)R2 * TJ; e += NTT_THREADS) { // w_Next^(kappa * k1')
+        const uint64_t ex = (kappa0 + (e & (TJ - 1))) * (uint64_t)(e >> a.tj_log); // < K1 * R2 = Next
+        tw2[e] = ex ? gl::mul(a.tw_hi[ex >> a.tw_lo_bits], a.tw_lo[ex & ((1ull << a.tw_lo_bits) - 1)]) : 1;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
+        if (i1 < (uint32_t)R1) *reinterpret_cast<ulonglong2 *>(&tile[i1 * B + bp]) = v[k];
+    }
+    __syncthreads();
+
+    // ---- INTT over the R1 rows; results (times scale) go back to rows k1 in natural order, rows R1.. are zeroed
+    tile_step_a<LOG_R1, true, LOG_B>(tile, w256, tid);
+    if (T1::LA > 0) __syncthreads();
+    {
+        const bool has_item = tid < (uint32_t)T1::RA * B; // RA1 * B <= 16 * B = threads: at most one item per thread
+        const uint32_t b = tid & (B - 1), kap = tid >> LOG_B, tj = b >> a.tcp_log;
+        u64 x[T1::RB];
+        if (has_item) {
+            tile_step_b<LOG_R1, true, LOG_B>(tile, kap, b, x);
+#pragma unroll
+            for (int kb = 0; kb < T1::RB; kb++) x[kb] = gl::mul_w(x[kb], tw1[((kap + T1::RA * kb) << a.tj_log) + tj]);
+        }
+        __syncthreads(); // every read of the INTT input rows is done
+        if (has_item) {
+#pragma unroll
+            for (int kb = 0; kb < T1::RB; kb++) tile[(kap + T1::RA * kb) * B + b] = x[kb];
+        }
+        for (uint32_t e = tid; e < (uint32_t)(R2 - R1) * B; e += NTT_THREADS) tile[R1 * B + e] = 0; // the zero padding
+    }
+    __syncthreads();
+
+    // ---- first pass of NTT_Next: rows kappa * R2 + k1' of the destination
+    tile_step_a<LOG_R2, false, LOG_B>(tile, w256, tid);
+    if (T2::LA > 0) __syncthreads();
+    for (uint32_t item = tid; item < (uint32_t)T2::RA * B; item += NTT_THREADS) {
+        const uint32_t b = item & (B - 1), kap = item >> LOG_B;
+        const uint32_t tj = b >> a.tcp_log, c = b & (TCP - 1);
+        const uint32_t col = c0 + c;
+        u64 x[T2::RB];
+        tile_step_b<LOG_R2, false, LOG_B>(tile, kap, b, x);
+#pragma unroll
+        for (int kb = 0; kb < T2::RB; kb++) x[kb] = gl::mul(x[kb], tw2[((kap + T2::RA * kb) << a.tj_log) + tj]);
+        const bool odd = b & 1;
+        const uint32_t col_e = col & ~1u;
+        u64 *q = a.dst + col_e + (((kappa0 + tj) << LOG_R2) + kap) * a.dst_pitch;
+        store_pairs<T2::RB>(q, (uint64_t)T2::RA * a.dst_pitch, x, odd, col_e + 1 < a.ncols, !odd && col < a.ncols);
     }
 }
 
@@ -335,14 +486,19 @@ struct Buf {
 };
 
 // Runs the passes of one length-n transform.  bufs[0] = source, bufs[i] = destination of pass i.
+// Only passes ps_begin <= ps < ps_end are launched (the fused LDE middle pass replaces one at either end).
 static int run_passes(mi_ctx *ctx, NttPlan *plan, const std::vector<Buf> &bufs, uint64_t ncols, bool inv,
-                      uint64_t in_valid_rows, const PowTable *scale)
+                      uint64_t in_valid_rows, const PowTable *scale, uint32_t ps_begin = 0, uint32_t ps_end = ~0u)
 {
     const uint32_t L = plan->log_n;
     const uint32_t P = (uint32_t)bufs.size() - 1;
     uint32_t log_K = 0;
     for (uint32_t ps = 0; ps < P; ps++) {
         const uint32_t log_r = L / P + (ps < L % P ? 1 : 0);
+        if (ps < ps_begin || ps >= ps_end) {
+            log_K += log_r;
+            continue;
+        }
         NttPass a = {};
         a.src = bufs[ps].p;
         a.src_pitch = bufs[ps].pitch;
@@ -368,6 +524,65 @@ static int run_passes(mi_ctx *ctx, NttPlan *plan, const std::vector<Buf> &bufs, 
 }
 
 static uint32_t num_passes(uint32_t L) { return L == 0 ? 0 : (L + 7) / 8; }
+static uint32_t pass_log_r(uint32_t L, uint32_t P, uint32_t ps) { return L / P + (ps < L % P ? 1 : 0); }
+
+template <int LOG_R1, int LOG_BLOW>
+static int launch_lde_mid_t(mi_ctx *ctx, const LdeMid &a, size_t lds)
+{
+    auto k = k_lde_mid<LOG_R1, LOG_BLOW, 5>;
+    if (lds > 48 * 1024) MI_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)a.n_tiles), dim3(512), lds, ctx->stream, a);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// The fused middle pass exists for tile rows of 32 elements holding at least one column pair, radix 16..128 on the
+// INTT side and blowup 2 or 4, when the two transforms' pass splits line up (r2 = blowup * r1).
+static bool lde_mid_applies(const mi_ctx *ctx, uint32_t L1, uint32_t L2, uint64_t ncols)
+{
+    if (!ctx->lde_fuse_mid || ctx->ntt_log_b != 5 || ncols < 2 || L1 == 0 || L2 <= L1 || L2 - L1 > 2) return false;
+    const uint32_t P1 = num_passes(L1), P2 = num_passes(L2);
+    const uint32_t r1 = pass_log_r(L1, P1, P1 - 1), r2 = pass_log_r(L2, P2, 0);
+    return r1 >= 4 && r2 == r1 + (L2 - L1) && r2 <= 8;
+}
+
+static int launch_lde_mid(mi_ctx *ctx, NttPlan *p1, NttPlan *p2, const Buf &src, const Buf &dst, uint64_t ncols)
+{
+    const uint32_t L1 = p1->log_n, L2 = p2->log_n, P1 = num_passes(L1);
+    const uint32_t log_r1 = pass_log_r(L1, P1, P1 - 1), log_blow = L2 - L1;
+    const uint64_t K1 = 1ull << (L1 - log_r1);
+    LdeMid a = {};
+    a.src = src.p;
+    a.src_pitch = src.pitch;
+    a.dst = dst.p;
+    a.dst_pitch = dst.pitch;
+    a.ncols = (uint32_t)ncols;
+    a.log_n1 = L1;
+    a.log_n2 = L2;
+    uint32_t tcp_log = 0;
+    while ((1u << tcp_log) < a.ncols && tcp_log < 5) tcp_log++;
+    uint32_t tj_log = 5 - tcp_log;
+    while ((1ull << tj_log) > K1) tj_log--;
+    a.tcp_log = tcp_log;
+    a.tj_log = tj_log;
+    a.n_col_tiles = (a.ncols + (1u << tcp_log) - 1) >> tcp_log;
+    a.n_tiles = (K1 >> tj_log) * a.n_col_tiles;
+    MI_REQUIRE(a.n_tiles < (1ull << 31), "LDE grid too large");
+    a.sc_lo = p1->lde_scale.lo;
+    a.sc_hi = p1->lde_scale.hi;
+    a.sc_lo_bits = p1->lde_scale.lo_bits;
+    a.tw_lo = p2->tw.lo;
+    a.tw_hi = p2->tw.hi;
+    a.tw_lo_bits = p2->tw.lo_bits;
+    a.w256 = ctx->w256;
+    const uint32_t log_r2 = log_r1 + log_blow;
+    const size_t lds = (((size_t)(1u << log_r2) << 5) + 256 + ((size_t)(1u << log_r1) << tj_log) + ((size_t)(1u << log_r2) << tj_log)) * 8;
+#define MID(R1, BL) if (log_r1 == R1 && log_blow == BL) return launch_lde_mid_t<R1, BL>(ctx, a, lds);
+    MID(4, 1) MID(5, 1) MID(6, 1) MID(7, 1) MID(4, 2) MID(5, 2) MID(6, 2)
+#undef MID
+    mi_set_error("no fused LDE pass for this radix");
+    return MI_ERR_INVALID;
+}
 
 __global__ __launch_bounds__(256) void k_copy_canon(u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch,
                                                     uint64_t nrows, uint32_t ncols)
@@ -447,8 +662,9 @@ int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_
     if (L2) MI_TRY(mi_get_plan(ctx, L2, &p2));
     if (L2 == 0) return copy_canon(ctx, out, out_pitch, in, in_pitch, 1, ncols);
     const uint32_t P1 = num_passes(L1), P2 = num_passes(L2);
-    // scratch per column: coefficients (n) + one n_ext ping-pong buffer + INTT intermediate (n)
-    const uint64_t per_col = (2 * n + n_ext) * 8;
+    const bool fuse = lde_mid_applies(ctx, L1, L2, ncols);
+    // scratch per column: one n_ext ping-pong buffer + INTT intermediate (n) [+ coefficients (n) when not fused]
+    const uint64_t per_col = ((fuse ? 1 : 2) * n + n_ext) * 8;
     uint64_t chunk = ctx->workspace_limit / per_col;
     if (chunk == 0) chunk = 1;
     if (chunk >= 32) chunk &= ~31ull;
@@ -458,25 +674,29 @@ int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_
         const uint64_t cw = (ncols - c0 < chunk) ? ncols - c0 : chunk;
         const Buf S = {const_cast<u64 *>(in) + c0, in_pitch}, D = {out + c0, out_pitch};
         u64 *w = ctx->workspace;
-        const Buf C = {w, cw};                 // coefficients, n rows
-        const Buf T = {w + n * cw, cw};        // INTT intermediate, n rows
-        const Buf X = {w + 2 * n * cw, cw};    // n_ext-row ping-pong partner of D
-        const Buf Dlo = {D.p, D.pitch};        // first n rows of the output double as an INTT intermediate
-        // ---- INTT_n with the shift^k / n scale folded into its last pass: S -> ... -> C
-        if (L1 == 0) {
-            MI_TRY(copy_canon(ctx, C.p, C.pitch, S.p, S.pitch, 1, cw)); // n = 1: the coefficient is the value
-        } else {
-            std::vector<Buf> b1;
-            b1.push_back(S);
-            for (uint32_t i = 1; i < P1; i++) b1.push_back(((P1 - i) & 1) ? T : Dlo); // last intermediate is T
-            b1.push_back(C);
-            MI_TRY(run_passes(ctx, p1, b1, cw, true, n, &p1->lde_scale));
-        }
-        // ---- NTT_next of the zero-padded coefficients: C -> ... -> D
-        std::vector<Buf> b2;
+        const Buf T = {w, cw};                             // INTT intermediate, n rows
+        const Buf X = {w + n * cw, cw};                    // n_ext-row ping-pong partner of D
+        const Buf C = {w + n * cw + n_ext * cw, cw};       // coefficients, n rows (unfused path only)
+        const Buf Dlo = {D.p, D.pitch};                    // first n rows of the output double as an INTT intermediate
+        std::vector<Buf> b1, b2;
+        b1.push_back(S);
+        for (uint32_t i = 1; i < P1; i++) b1.push_back(((P1 - i) & 1) ? T : Dlo); // last intermediate is T
+        b1.push_back(C);
         b2.push_back(C);
         for (uint32_t i = 1; i < P2; i++) b2.push_back(((P2 - i) & 1) ? X : D); // last intermediate is X
         b2.push_back(D);
+        if (fuse) {
+            // INTT passes 0..P1-2, [last INTT pass + first NTT pass] b1[P1-1] -> b2[1], NTT passes 1..P2-1.
+            // b1[P1-1] is S or T and never overlaps b2[1] (X or D).
+            MI_TRY(run_passes(ctx, p1, b1, cw, true, n, nullptr, 0, P1 - 1));
+            MI_TRY(launch_lde_mid(ctx, p1, p2, b1[P1 - 1], b2[1], cw));
+            MI_TRY(run_passes(ctx, p2, b2, cw, false, n_ext, nullptr, 1, P2));
+            continue;
+        }
+        // ---- INTT_n with the shift^k / n scale folded into its last pass: S -> ... -> C
+        if (L1 == 0) MI_TRY(copy_canon(ctx, C.p, C.pitch, S.p, S.pitch, 1, cw)); // n = 1: the coefficient is the value
+        else MI_TRY(run_passes(ctx, p1, b1, cw, true, n, &p1->lde_scale));
+        // ---- NTT_next of the zero-padded coefficients: C -> ... -> D
         MI_TRY(run_passes(ctx, p2, b2, cw, false, n, nullptr));
     }
     return MI_OK;

@@ -121,8 +121,11 @@ __device__ __forceinline__ void ring_load_line(u64 (&win)[32], const u64 *line, 
     }
 }
 
+// Three waves per SIMD (<= 168 VGPRs) is worth more than keeping every ring register resident: with the grouped
+// partial rounds the kernel would otherwise take 194 VGPRs and drop to two waves (measured 750 ms vs 650 ms for
+// 2^24 x 665; the compiler moves ~15 ring words per lane to scratch across the permutation).
 template <int MDS>
-__global__ __launch_bounds__(256) void k_linear_hash_rows_lines(u64 *__restrict__ digests, const u64 *__restrict__ src,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_hash_rows_lines(u64 *__restrict__ digests, const u64 *__restrict__ src,
                                                                 uint64_t pitch, uint32_t ncols, uint64_t nrows)
 {
     const uint32_t lane = threadIdx.x & 63;

@@ -13,6 +13,7 @@
 // the multiplies; with a whole state per lane every VALU slot does useful work and no LDS / cross-lane
 // traffic is needed.  (MFMA: not applicable -- exact 64-bit modular accumulation, 12x12 only.)
 #pragma once
+#include <type_traits>
 #include "gl_math.h"
 #include "poseidon_constants.h"
 #include "poseidon_sparse_constants.h"
@@ -23,6 +24,15 @@ static constexpr int MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20}; /
 static constexpr int MD0 = 8;                                                   // == MI_POS_MDIAG[0]
 
 enum { MDS_HALF32 = 0, MDS_LIMB22 = 1, MDS_SPARSE = 2 };
+
+template <int I, int N, typename F>
+MI_HD void nttm_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        nttm_static_for<I + 1, N>(f);
+    }
+}
 
 MI_HD u64 sbox(u64 x)
 {
@@ -100,34 +110,47 @@ MI_HD void mds_limb22(u64 (&s)[12])
 }
 
 // ---- optimised partial rounds (variant MDS_SPARSE): tables derived and verified by tools/gen_poseidon_sparse.py.
-// A partial round becomes: S-box on s0, one 12-term dot product with 64-bit constants for the new s0 and eleven
-// "s_i += w_i * s0".  The dot product is accumulated WITHOUT carries: each constant is pre-split into 22/22/20-bit
-// limbs, so the six 64-bit accumulators (2 halves of s_j x 3 limbs) stay below 2^58 over 12 terms and a single
-// reduction closes the row.
+// The textbook optimised form makes a partial round "S-box on s0, one 12-term dot product with 64-bit constants for
+// the new s0, eleven s_i += w_i * s0".  On CDNA4 the eleven multiply-adds are the expensive part (a full 128-bit
+// reduction each, ~25 instructions), while a term of a dot product costs 6 v_mad_u64_u32 and nothing else: each
+// constant is pre-split into 22/22/20-bit limbs, so the six 64-bit accumulators (2 halves of the variable x 3 limbs)
+// stay below 2^59 over 23 terms and a single reduction (dot_close) closes the row.  The grouped form below therefore
+// rewrites the s_i updates of 11 consecutive rounds into dot products as well.
+// Tables of the grouped optimised partial rounds (tools/gen_poseidon_sparse.py, section 3), every 64-bit constant
+// pre-split into 22/22/20-bit limbs.  Two groups of 11 rounds share one code path.
+struct GroupTables {
+    u64 k[12];             // scalar added to element 0 after the S-box of round r (k of round 21 is 0; [11] pads)
+    u32 d[11][11][3];      // D[r][j]: coefficient of z_j (the group's starting s[1+j]) in round r's new element 0
+    u32 c[55][3];          // C[r (r-1)/2 + t]: coefficient of y_t (post-S-box element 0 of round t < r)
+    u32 w[11][11][3];      // W[i][t]: coefficient of y_t in the group's closing z_i
+    u32 pre[11][11][3];    // PRE[i][j]: closing z_i = PRE[i] . z (group 0) -- group 1 closes with z_i itself
+};
 struct SparseTables {
     u64 first_rc[12];
-    u64 k[22];            // k[21] unused (0)
-    u64 w[22][11];
-    u32 vhat_l[22][11][3];
-    u32 pre_l[11][11][3];
+    GroupTables g[2];
 };
+
+inline void split22(u32 (&l)[3], u64 v)
+{
+    l[0] = (u32)(v & 0x3FFFFF); l[1] = (u32)((v >> 22) & 0x3FFFFF); l[2] = (u32)(v >> 44);
+}
 
 inline void fill_sparse_tables(SparseTables &t)
 {
+    t = SparseTables{};
     for (int i = 0; i < 12; i++) t.first_rc[i] = MI_POS_FIRST_RC[i];
-    for (int r = 0; r < 22; r++) {
-        t.k[r] = r < 21 ? MI_POS_K[r] : 0;
-        for (int j = 0; j < 11; j++) {
-            t.w[r][j] = MI_POS_W[r * 11 + j];
-            const u64 v = MI_POS_VHAT[r * 11 + j];
-            t.vhat_l[r][j][0] = (u32)(v & 0x3FFFFF); t.vhat_l[r][j][1] = (u32)((v >> 22) & 0x3FFFFF); t.vhat_l[r][j][2] = (u32)(v >> 44);
+    for (int g = 0; g < 2; g++) {
+        GroupTables &T = t.g[g];
+        for (int r = 0; r < 11; r++) {
+            T.k[r] = (11 * g + r < 21) ? MI_POS_K[11 * g + r] : 0;
+            for (int j = 0; j < 11; j++) {
+                split22(T.d[r][j], MI_POS_GD[(g * 11 + r) * 11 + j]);
+                split22(T.w[j][r], MI_POS_W[(11 * g + r) * 11 + j]); // W[i = j][t = r] = w[11 g + t][i]
+                split22(T.pre[r][j], MI_POS_PRE[r * 11 + j]);
+            }
         }
+        for (int e = 0; e < 55; e++) split22(T.c[e], MI_POS_GC[g * 55 + e]);
     }
-    for (int i = 0; i < 11; i++)
-        for (int j = 0; j < 11; j++) {
-            const u64 v = MI_POS_PRE[i * 11 + j];
-            t.pre_l[i][j][0] = (u32)(v & 0x3FFFFF); t.pre_l[i][j][1] = (u32)((v >> 22) & 0x3FFFFF); t.pre_l[i][j][2] = (u32)(v >> 44);
-        }
 }
 
 struct DotAcc { u64 a[2][3]; };
@@ -142,56 +165,88 @@ MI_HD void dot_acc(DotAcc &d, u64 x, const u32 (&c)[3])
     }
 }
 
-// value = sum_{h,l} a[h][l] * 2^(32h + 22l), every a < 2^60  ->  weakly reduced
+// a 32-bit multiplier the compiler cannot see through: keeps "x * 2^k + acc" one v_mad_u64_u32 instead of a
+// 64-bit shift plus a 64-bit add
+MI_HD u32 opaque_u32(u32 k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(k));
+#endif
+    return k;
+}
+
+// value = sum_{h,l} a[h][l] * 2^(32h + 22l), every a < 2^58  ->  weakly reduced.
+// The twelve 32-bit words of the six accumulators are gathered by multiply-adds into the coefficients of
+// 2^0, 2^32, 2^64, 2^96 (U0..U3, no overflow: each stays below 2^60) and folded with 2^64 = 2^32 - 1, 2^96 = -1.
 MI_HD u64 dot_close(const DotAcc &d)
 {
-    typedef unsigned __int128 u128;
-    const u128 X = (u128)d.a[0][0] + ((u128)d.a[0][1] << 22) + ((u128)d.a[0][2] << 44); // < 2^105
-    const u128 Y = (u128)d.a[1][0] + ((u128)d.a[1][1] << 22) + ((u128)d.a[1][2] << 44);
-    const u64 ylo = (u64)Y, yhi = (u64)(Y >> 64);                                        // yhi < 2^41
-    // Y * 2^32 = (ylo mod 2^32) * 2^32 + (ylo >> 32) * 2^64 + yhi * 2^96  ==  ... + (ylo >> 32) * eps - yhi
-    const u128 T = (u128)(u64)X + (u128)(u64)(X >> 64) * GL_EPS + ((u128)(ylo & GL_EPS) << 32) + (u128)(ylo >> 32) * GL_EPS;
-    const u64 r = gl::reduce128_w((u64)T, (u64)(T >> 64));
-    return gl::sub_wc(r, yhi);
+    const u32 k22 = opaque_u32(1u << 22), k12 = opaque_u32(1u << 12);
+    const u64 A00 = d.a[0][0], A01 = d.a[0][1], A02 = d.a[0][2], A10 = d.a[1][0], A11 = d.a[1][1], A12 = d.a[1][2];
+    // bit positions: A00 0, A01 22, A02 44, A10 32, A11 54, A12 76; a word w of A at position q sits at q (+32 for the high word)
+    const u64 U0 = (u64)(u32)A01 * k22 + A00;                       // 2^0 : A00 (whole) + lo(A01) 2^22
+    u64 U1 = (u64)(u32)(A01 >> 32) * k22 + A10;                     // 2^32: A10 (whole) + hi(A01) 2^22 + lo(A02) 2^12 + lo(A11) 2^22
+    U1 = (u64)(u32)A02 * k12 + U1;
+    U1 = (u64)(u32)A11 * k22 + U1;
+    u64 U2 = (u64)(u32)(A02 >> 32) * k12;                           // 2^64: hi(A02) 2^12 + hi(A11) 2^22 + lo(A12) 2^12
+    U2 = (u64)(u32)(A11 >> 32) * k22 + U2;
+    U2 = (u64)(u32)A12 * k12 + U2;
+    const u64 U3 = (u64)(u32)(A12 >> 32) * k12;                     // 2^96: hi(A12) 2^12   (< 2^38)
+    const u64 lo = U0 + (U1 << 32);
+    const u64 W2 = U2 + (U1 >> 32) + (lo < U0 ? 1 : 0);             // coefficient of 2^64, < 2^50
+    const u32 hl = (u32)W2;
+    const u64 HH = (W2 >> 32) + U3;                                 // coefficient of 2^96, < 2^39
+    u64 t0 = lo - HH;
+    if (gl::rare(lo < HH)) { // needs lo < 2^39
+        MI_KEEP_BRANCH();
+        t0 = lo < HH ? t0 - GL_EPS : t0;
+    }
+    const u64 t1 = (u64)hl * 0xFFFFFFFFu;
+    const u64 r = t0 + t1;
+    return r < t1 ? r + GL_EPS : r;
 }
 
-// s_i + w * s0 (all 64-bit, any encodings) -> weakly reduced
-MI_HD u64 axpy_w(u64 si, u64 w, u64 s0)
-{
-    u64 lo, hi;
-    gl::mul64x64(w, s0, lo, hi);
-    const u64 l2 = lo + si;
-    hi += l2 < lo ? 1 : 0; // (2^64-1)^2 + 2^64 - 1 < 2^128: no overflow of hi
-    return gl::reduce128_w(l2, hi);
-}
-
+// The 22 partial rounds, grouped (see the generator): per round one S-box and ONE dot product (11 terms over the
+// group's starting z = s[1:], r terms over the earlier y_t); per group eleven closing dot products.  No
+// "s_i += w * s0" with its own 128-bit reduction is ever materialised.
 MI_HD void partial_rounds_sparse(u64 (&s)[12], const SparseTables &t)
 {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add_wc(s[i], t.first_rc[i]);
-    { // s[1:] = PRE * s[1:]
-        u64 o[11];
 #pragma unroll 1
+    for (int g = 0; g < 2; g++) {
+        const GroupTables &T = t.g[g];
+        u64 y[11];
+        u64 s0 = s[0];
+        nttm_static_for<0, 11>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            y[r] = gl::add_wc(sbox(s0), T.k[r]);
+            DotAcc d = {};
+            d.a[0][0] = (u64)(u32)y[r] * MI_POS_M00;
+            d.a[1][0] = (u64)(u32)(y[r] >> 32) * MI_POS_M00;
+#pragma unroll
+            for (int j = 0; j < 11; j++) dot_acc(d, s[1 + j], T.d[r][j]);
+#pragma unroll
+            for (int tt = 0; tt < r; tt++) dot_acc(d, y[tt], T.c[r * (r - 1) / 2 + tt]);
+            s0 = dot_close(d);
+        });
+        u64 z[11];
+#pragma unroll
         for (int i = 0; i < 11; i++) {
             DotAcc d = {};
+            if (g == 0) {
 #pragma unroll
-            for (int j = 0; j < 11; j++) dot_acc(d, s[1 + j], t.pre_l[i][j]);
-            o[i] = dot_close(d);
+                for (int j = 0; j < 11; j++) dot_acc(d, s[1 + j], T.pre[i][j]);
+            } else {
+                d.a[0][0] = (u32)s[1 + i];
+                d.a[1][0] = s[1 + i] >> 32;
+            }
+#pragma unroll
+            for (int tt = 0; tt < 11; tt++) dot_acc(d, y[tt], T.w[i][tt]);
+            z[i] = dot_close(d);
         }
 #pragma unroll
-        for (int i = 0; i < 11; i++) s[1 + i] = o[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        u64 s0 = gl::add_wc(sbox(s[0]), t.k[r]);
-        DotAcc d = {};
-        d.a[0][0] = (u64)(u32)s0 * MI_POS_M00;
-        d.a[1][0] = (u64)(u32)(s0 >> 32) * MI_POS_M00;
-#pragma unroll
-        for (int j = 0; j < 11; j++) dot_acc(d, s[1 + j], t.vhat_l[r][j]);
-#pragma unroll
-        for (int i = 0; i < 11; i++) s[1 + i] = axpy_w(s[1 + i], t.w[r][i], s0);
-        s[0] = dot_close(d);
+        for (int i = 0; i < 11; i++) s[1 + i] = z[i];
+        s[0] = s0;
     }
 }
 

@@ -53,7 +53,7 @@ EXPORTS = [
     "mi_fri_fold_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
-    "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
+    "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16",
 ]
@@ -122,6 +122,9 @@ class Context:
 
     def set_leaf_mode(self, line_aligned):
         _check(lib().mi_set_leaf_mode(self.h, ctypes.c_int(int(line_aligned))))
+
+    def set_lde_fuse(self, fuse):
+        _check(lib().mi_set_lde_fuse(self.h, ctypes.c_int(int(fuse))))
 
     def set_ntt_tile(self, log_b):
         _check(lib().mi_set_ntt_tile(self.h, ctypes.c_int(log_b)))

@@ -243,17 +243,28 @@ def test_config2_roundtrip_2pow23(ctx):
     assert np.array_equal(ctx.to_host(y), x)
 
 
-LDE_CASES = [(1, 2, 3), (2, 4, 1), (4, 8, 5), (16, 32, 37), (256, 512, 3), (256, 1024, 6), (512, 1024, 70), (1024, 2048, 1),
-             (1 << 12, 1 << 13, 33), (1 << 15, 1 << 16, 6), (1 << 16, 1 << 17, 2), (8, 8, 4)]
+# sizes where the fused middle pass (last INTT pass + first NTT pass in one kernel) applies -- radix r1 -> r2:
+# 16->32 .. 128->256 single pass, (5,4)->(5,5), (6,6)->(7,6), (7,7)->(8,7), (8,7)->(8,8), blowup 4: 64->256,
+# (5,4)->(6,5), (7,6)->(8,7) -- and where it does not (n < 16, one column, 256->(5,4), (8,8)->(6,6,5), n_ext = n).
+LDE_CASES = [(1, 2, 3), (2, 4, 1), (4, 8, 5), (16, 32, 37), (32, 64, 2), (64, 128, 9), (128, 256, 33), (64, 256, 5),
+             (256, 512, 3), (256, 1024, 6), (512, 1024, 70), (512, 2048, 35), (1024, 2048, 1), (1024, 2048, 4),
+             (1 << 12, 1 << 13, 33), (1 << 13, 1 << 15, 3), (1 << 14, 1 << 15, 7), (1 << 15, 1 << 16, 6),
+             (1 << 16, 1 << 17, 2), (8, 8, 4)]
 
 
 @pytest.mark.parametrize("n,n_ext,ncols", LDE_CASES)
 def test_lde_matches_oracle(ctx, n, n_ext, ncols):
     rng = np.random.default_rng(n + n_ext + ncols)
     x = glo.rand_fe(rng, (n, ncols))
-    out = ctx.empty(n_ext * ncols)
-    ctx.lde(out, ctx.to_device(x), n_ext, n, ncols)
-    assert np.array_equal(ctx.to_host(out).reshape(n_ext, ncols), glo.extend_pol(x, n_ext, n, ncols))
+    want = glo.extend_pol(x, n_ext, n, ncols)
+    try:
+        for fuse in (1, 0):
+            ctx.set_lde_fuse(fuse)
+            out = ctx.empty(n_ext * ncols)
+            ctx.lde(out, ctx.to_device(x), n_ext, n, ncols)
+            assert np.array_equal(ctx.to_host(out).reshape(n_ext, ncols), want), fuse
+    finally:
+        ctx.set_lde_fuse(1)
 
 
 def test_lde_column_chunks_and_pitches(ctx):

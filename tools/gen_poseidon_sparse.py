@@ -107,6 +107,41 @@ for t in range(50):
     assert perm_naive(st) == perm_fast(st), t
 assert [hex(x) for x in perm_fast([0] * 12)[:2]] == ["0x3c18a9786cb0b359", "0xc4055e3364a246c3"]
 
+# ---- (3) grouped form: the 22 partial rounds in two groups of 11.  Inside a group the eleven "s[1+i] += w*s0"
+# updates are not materialised; with z = s[1:] at the group start and y_t = the post-S-box element 0 of round t,
+#     s0_{r+1} = M00 y_r + vhat[r] . z + sum_{t<r} (vhat[r] . w[t]) y_t ,   z_end = z + sum_t w[t] y_t
+# so every multiplication by a 64-bit constant sits in a dot product that is reduced once.  Group 0 also absorbs
+# PRE: its z is PRE * u, so vhat[r] . z = (vhat[r] PRE) . u and z_end = PRE u + sum_t w[t] y_t.
+G = 11
+def dot(a, b): return sum(x * y for x, y in zip(a, b)) % P
+GD, GC = [], []
+for g in range(2):
+    rows = range(g * G, g * G + G)
+    GD.append([vhat[r] if g else [dot(vhat[r], [PRE[i][j] for i in range(11)]) for j in range(11)] for r in rows])
+    GC.append([dot(vhat[r], w[t]) for r in rows for t in range(g * G, r)])      # packed: r' (r' - 1) / 2 + t'
+def perm_grouped(s):
+    s = s[:]
+    for r in range(4):
+        s = matvec(M, [sbox((a + b) % P) for a, b in zip(s, RC[12 * r:12 * r + 12])])
+    s = [(a + b) % P for a, b in zip(s, first_rc)]
+    s0, z = s[0], s[1:]
+    for g in range(2):
+        y = []
+        for rr in range(G):
+            r = g * G + rr
+            yr = (sbox(s0) + (k[r] if r < RP - 1 else 0)) % P
+            s0 = (M00 * yr + dot(GD[g][rr], z) + sum(GC[g][rr * (rr - 1) // 2 + t] * y[t] for t in range(rr))) % P
+            y.append(yr)
+        base = [dot(PRE[i], z) for i in range(11)] if g == 0 else z
+        z = [(base[i] + sum(w[g * G + t][i] * y[t] for t in range(G))) % P for i in range(11)]
+    s = [s0] + z
+    for r in range(26, 30):
+        s = matvec(M, [sbox((a + b) % P) for a, b in zip(s, RC[12 * r:12 * r + 12])])
+    return s
+for t in range(50):
+    st = [rnd.randrange(P) for _ in range(12)] if t else [0] * 12
+    assert perm_naive(st) == perm_grouped(st), t
+
 def arr(name, vals, per_line=4):
     s = f"static const uint64_t {name}[{len(vals)}] = {{\n"
     for i in range(0, len(vals), per_line):
@@ -124,5 +159,8 @@ with open(out, "w") as f:
     f.write("/* scalar added to element 0 after the S-box of partial rounds 0..20 */\n" + arr("MI_POS_K", k))
     f.write("/* VHAT[r][j], 22x11 */\n" + arr("MI_POS_VHAT", [x for row in vhat for x in row]))
     f.write("/* W[r][i], 22x11 */\n" + arr("MI_POS_W", [x for row in w for x in row]))
+    f.write("/* grouped form (two groups of 11 partial rounds): GD[g][r][j] = vhat[11g+r] (times PRE for g = 0), 2x11x11 */\n"
+            + arr("MI_POS_GD", [x for g in GD for row in g for x in row]))
+    f.write("/* GC[g][r (r-1)/2 + t] = vhat[11g+r] . w[11g+t], t < r, 2x55 */\n" + arr("MI_POS_GC", [x for g in GC for x in g]))
     f.write("#endif\n")
 print("ok: verified 50 states; wrote", out, "max vhat bits", max(x.bit_length() for row in vhat for x in row))
