@@ -41,6 +41,16 @@ MI_HD bool rare(bool c)
 #define MI_KEEP_BRANCH() do { } while (0)
 #endif
 
+// a 32-bit value the compiler cannot see through (stays in an SGPR): keeps "x * k + acc" one v_mad_u64_u32 where it
+// would otherwise strength-reduce the multiplication into shifts, zero-extending moves and 64-bit adds
+MI_HD u32 opaque_u32(u32 k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(k));
+#endif
+    return k;
+}
+
 MI_HD u64 canon_sel(u64 a) { return a >= GL_P ? a - GL_P : a; } // select form (no branch)
 
 MI_HD u64 canon(u64 a)
@@ -86,16 +96,19 @@ MI_HD u64 sub_wc(u64 a, u64 b)
 MI_HD u64 neg_w(u64 a) { return GL_P - canon(a); }
 
 // 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
+// (the overflow builtin makes the borrow test a compare against the difference: one 64-bit compare, no
+// zero-extended copy of hh)
 MI_HD u64 reduce128_w(u64 lo, u64 hi)
 {
-    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u64 t0 = lo - hh;
-    if (rare(lo < hh)) { // borrowed 2^64 = p + eps (needs lo < 2^32: ~never)
+    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 t0;
+    const bool borrow = __builtin_usubll_overflow(lo, (u64)hh, &t0);
+    if (rare(borrow)) { // borrowed 2^64 = p + eps (needs lo < 2^32: ~never)
         MI_KEEP_BRANCH();
-        t0 = lo < hh ? t0 - GL_EPS : t0;
+        t0 = borrow ? t0 - GL_EPS : t0;
     }
-    u64 t1 = ((u64)hl << 32) - hl; // hl * (2^32 - 1)
-    u64 r = t0 + t1;
+    const u64 t1 = ((u64)hl << 32) - hl; // hl * (2^32 - 1)
+    const u64 r = t0 + t1;
     return r < t1 ? r + GL_EPS : r;
 }
 

@@ -91,43 +91,38 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
 
 // ---- line-aligned variant of the leaf sponge (default).
 // HBM is fetched in 128-byte lines, but a row of 665 elements starts at an arbitrary 8-byte offset inside its
-// first line, so a lane reading "its next 64 bytes" touches most lines twice, one permutation (~100 us) apart;
+// first line, so a lane reading "its next 64 bytes" touches most lines twice, one permutation (~40 us) apart;
 // with 32768 such half-consumed lines per XCD (= the whole 4 MiB L2) a third of them are fetched again
-// (measured: 1.36x the algorithmic bytes).  Here every lane fetches whole ALIGNED lines (8 x dwordx4) into a
-// two-line register ring and takes its 8-element blocks out of the ring, so each line crosses the fabric once.
-// Static register indexing needs the row's offset inside its line to be wave-uniform: wave (q, j) takes the rows
-// r = 1024 q + 16 lane + j, whose offsets (r * pitch + base) mod 16 depend on j only.
-template <int IDX>
-__device__ __forceinline__ void ring_take(u64 (&s)[12], const u64 (&win)[32])
-{
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = win[(IDX + i) & 31];
-}
+// (measured: 1.36x the algorithmic bytes).  Here every lane fetches whole ALIGNED lines (8 x dwordx4), one
+// permutation ahead of their use, and parks them in a per-lane ring in LDS from which the 8-element blocks are
+// taken, so each line crosses the fabric once and the prefetched data costs no registers while the permutation runs
+// (only the line in flight does: 32 VGPRs).  Ring occupancy: a line is requested when fewer than 8 unconsumed
+// elements would remain, and lands (16 more) before the next take: at most 7 + 16 = 23 elements, hence 24 slots.
+// 24 slots x 256 threads x 8 B = 48 KiB per workgroup -> three workgroups (three waves per SIMD) per CU.
+// All stream positions are wave-uniform (scalar control flow, LDS addresses = lane offset + scalar): wave (q, j)
+// takes the rows r = 1024 q + 16 lane + j, whose offsets (r * pitch + base) mod 16 depend on j only.
+static constexpr uint32_t LEAF_RING = 24;
 
-template <int SLOT>
-__device__ __forceinline__ void ring_load_line(u64 (&win)[32], const u64 *line, const u64 *lo, const u64 *hi)
+__device__ __forceinline__ void line_fetch(ulonglong2 (&v)[8], const u64 *line, const u64 *lo, const u64 *hi)
 {
     if (line >= lo && line + 16 <= hi) { // whole line inside the matrix: 8 aligned 16-byte loads
         const ulonglong2 *l2 = reinterpret_cast<const ulonglong2 *>(line);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const ulonglong2 v = l2[i];
-            win[SLOT * 16 + 2 * i] = v.x;
-            win[SLOT * 16 + 2 * i + 1] = v.y;
-        }
+        for (int i = 0; i < 8; i++) v[i] = l2[i];
     } else { // first / last line of the matrix: never read outside [lo, hi)
 #pragma unroll
-        for (int i = 0; i < 16; i++) win[SLOT * 16 + i] = (line + i >= lo && line + i < hi) ? line[i] : 0;
+        for (int i = 0; i < 8; i++) {
+            v[i].x = (line + 2 * i >= lo && line + 2 * i < hi) ? line[2 * i] : 0;
+            v[i].y = (line + 2 * i + 1 >= lo && line + 2 * i + 1 < hi) ? line[2 * i + 1] : 0;
+        }
     }
 }
 
-// Three waves per SIMD (<= 168 VGPRs) is worth more than keeping every ring register resident: with the grouped
-// partial rounds the kernel would otherwise take 194 VGPRs and drop to two waves (measured 750 ms vs 650 ms for
-// 2^24 x 665; the compiler moves ~15 ring words per lane to scratch across the permutation).
 template <int MDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_hash_rows_lines(u64 *__restrict__ digests, const u64 *__restrict__ src,
-                                                                uint64_t pitch, uint32_t ncols, uint64_t nrows)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_hash_rows_lines(
+    u64 *__restrict__ digests, const u64 *__restrict__ src, uint64_t pitch, uint32_t ncols, uint64_t nrows)
 {
+    __shared__ u64 ring[LEAF_RING * 256]; // [slot][thread]
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t row = (gw >> 4) * 1024 + (uint64_t)lane * 16 + (gw & 15);
@@ -136,33 +131,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const u64 *p = src + (active ? row : (gw & 15)) * pitch; // idle lanes shadow a valid row of the same residue class
     // offset of the row inside its 128-byte line, in elements: identical in every lane of the wave
     const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((uintptr_t)p >> 3) & 15));
-    const u64 *lp = p - o;
-    u64 win[32], s[12];
-    ring_load_line<0>(win, lp, lo, hi);
-    if (o + ncols > 16) ring_load_line<1>(win, lp + 16, lo, hi);
+    const u64 *lp = p - o;         // the row's line stream: element e of the stream is lp[e], the row is [o, end)
+    const uint32_t end = o + ncols;
+    u64 *my = ring + threadIdx.x;
+    uint32_t fetched = 0, f24 = 0; // the ring holds stream elements [pos, fetched); f24 = fetched mod 24
+    ulonglong2 v[8];
+    u64 s[12];
+    auto land = [&]() { // the line in v becomes stream elements [fetched, fetched + 16)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t a = f24 + 2 * i, b = f24 + 2 * i + 1;
+            a = a >= LEAF_RING ? a - LEAF_RING : a;
+            b = b >= LEAF_RING ? b - LEAF_RING : b;
+            my[a * 256] = v[i].x;
+            my[b * 256] = v[i].y;
+        }
+        fetched += 16;
+        f24 = f24 + 16 >= LEAF_RING ? f24 + 16 - LEAF_RING : f24 + 16;
+    };
+    line_fetch(v, lp, lo, hi);
+    land();
+    if (o > 8 && end > 16) { // the first block already crosses into the second line (occupancy 32 - o <= 23)
+        line_fetch(v, lp + 16, lo, hi);
+        land();
+    }
+    bool inflight = false;
+    uint32_t p24 = o; // pos mod 24
 #pragma unroll
     for (int i = 0; i < 4; i++) s[8 + i] = 0;
-    const uint32_t end = o + ncols; // one past the last stream position of the row
     for (uint32_t pos = o; pos < end; pos += 8) {
-        switch (pos & 31) {
-#define RT(I) case I: ring_take<I>(s, win); break;
-            RT(0) RT(1) RT(2) RT(3) RT(4) RT(5) RT(6) RT(7) RT(8) RT(9) RT(10) RT(11) RT(12) RT(13) RT(14) RT(15)
-            RT(16) RT(17) RT(18) RT(19) RT(20) RT(21) RT(22) RT(23) RT(24) RT(25) RT(26) RT(27) RT(28) RT(29) RT(30) RT(31)
-#undef RT
+        if (inflight) {
+            land();
+            inflight = false;
         }
-        if (end - pos < 8) { // last, partial block: zero pad (wave-uniform)
 #pragma unroll
-            for (uint32_t i = 1; i < 8; i++)
-                if (i >= end - pos) s[i] = 0;
+        for (uint32_t i = 0; i < 8; i++) { // take the block; past the end of the row: zero padding
+            uint32_t a = p24 + i;
+            a = a >= LEAF_RING ? a - LEAF_RING : a;
+            s[i] = (pos + i < end) ? my[a * 256] : 0;
         }
-        // a line is fully consumed once the stream crosses a multiple of 16: refill its slot with the line after next
-        const uint32_t consumed = pos + 8;
-        if ((consumed >> 4) != (pos >> 4)) {
-            const uint32_t dead = (consumed >> 4) - 1;
-            if ((dead + 2) * 16 < end) {
-                if (dead & 1) ring_load_line<1>(win, lp + (uint64_t)(dead + 2) * 16, lo, hi);
-                else ring_load_line<0>(win, lp + (uint64_t)(dead + 2) * 16, lo, hi);
-            }
+        p24 = p24 + 8 >= LEAF_RING ? p24 + 8 - LEAF_RING : p24 + 8;
+        // fewer than 8 unconsumed elements left and the row goes on: request the next line now, it lands after the
+        // permutation
+        if ((int32_t)(fetched - pos - 8) < 8 && fetched < end) {
+            line_fetch(v, lp + fetched, lo, hi);
+            inflight = true;
         }
         pos::permute<MDS, 0>(s, c_rc, &c_sparse);
         if (pos + 8 < end) {

@@ -50,6 +50,10 @@ MI_HD void mds_half32(u64 (&s)[12], const u64 *__restrict__ rc_next = nullptr)
 {
     u32 lo[12], hi[12];
     u64 rcn[12];
+    bool ovf[12];
+    // the entries 2 and 16 would otherwise become "zero-extend to a register pair (2 moves), shift-add": keep them
+    // multiply-adds like the other ten
+    const u32 m2 = gl::opaque_u32(2), m16 = gl::opaque_u32(16);
 #pragma unroll
     for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); rcn[i] = rc_next ? rc_next[i] : 0; }
 #pragma unroll
@@ -57,16 +61,27 @@ MI_HD void mds_half32(u64 (&s)[12], const u64 *__restrict__ rc_next = nullptr)
         u64 al = (u64)(u32)rcn[x], ah = rcn[x] >> 32;
 #pragma unroll
         for (int y = 0; y < 12; y++) {
-            const u32 m = (u32)(MC[(y - x + 12) % 12] + ((x == 0 && y == 0) ? MD0 : 0));
+            const u32 mc = (u32)(MC[(y - x + 12) % 12] + ((x == 0 && y == 0) ? MD0 : 0));
+            const u32 m = mc == 2 ? m2 : mc == 16 ? m16 : mc;
             al += (u64)lo[y] * m;
             ah += (u64)hi[y] * m;
         }
         // value = al + ah*2^32 = al + (ah_lo << 32) + ah_hi * 2^64 ;  2^64 = 2^32 - 1
-        u64 ahh = ah >> 32;                          // < 2^10
-        u64 r = al + ((ahh << 32) - ahh);            // < 2^43, no wrap
-        u64 b = ah << 32;
-        u64 t = r + b;
-        s[x] = t < b ? t + GL_EPS : t; // (a wave-uniform branch here splits the block and un-hoists the constant loads)
+        const u32 ahl = (u32)ah, ahh = (u32)(ah >> 32);   // ahh < 2^10
+        const u64 r = (u64)ahh * 0xFFFFFFFFu + al;        // < 2^43: one multiply-add, no wrap
+        const u32 thi = (u32)(r >> 32) + ahl;             // adding ah_lo * 2^32 touches the high word only
+        ovf[x] = thi < ahl;                               // wraps 2^64 with probability ~2^-21 per value
+        s[x] = ((u64)thi << 32) | (u32)r;
+    }
+    // one wave-uniform check for all twelve rows, after every multiply-add has been issued (a branch per row splits
+    // the block and un-hoists the constant loads)
+    bool any = false;
+#pragma unroll
+    for (int x = 0; x < 12; x++) any |= ovf[x];
+    if (gl::rare(any)) {
+        MI_KEEP_BRANCH();
+#pragma unroll
+        for (int x = 0; x < 12; x++) s[x] = ovf[x] ? s[x] + GL_EPS : s[x]; // wrapped value < 2^43: no second wrap
     }
 }
 
@@ -165,22 +180,12 @@ MI_HD void dot_acc(DotAcc &d, u64 x, const u32 (&c)[3])
     }
 }
 
-// a 32-bit multiplier the compiler cannot see through: keeps "x * 2^k + acc" one v_mad_u64_u32 instead of a
-// 64-bit shift plus a 64-bit add
-MI_HD u32 opaque_u32(u32 k)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+s"(k));
-#endif
-    return k;
-}
-
 // value = sum_{h,l} a[h][l] * 2^(32h + 22l), every a < 2^58  ->  weakly reduced.
 // The twelve 32-bit words of the six accumulators are gathered by multiply-adds into the coefficients of
 // 2^0, 2^32, 2^64, 2^96 (U0..U3, no overflow: each stays below 2^60) and folded with 2^64 = 2^32 - 1, 2^96 = -1.
 MI_HD u64 dot_close(const DotAcc &d)
 {
-    const u32 k22 = opaque_u32(1u << 22), k12 = opaque_u32(1u << 12);
+    const u32 k22 = gl::opaque_u32(1u << 22), k12 = gl::opaque_u32(1u << 12);
     const u64 A00 = d.a[0][0], A01 = d.a[0][1], A02 = d.a[0][2], A10 = d.a[1][0], A11 = d.a[1][1], A12 = d.a[1][2];
     // bit positions: A00 0, A01 22, A02 44, A10 32, A11 54, A12 76; a word w of A at position q sits at q (+32 for the high word)
     const u64 U0 = (u64)(u32)A01 * k22 + A00;                       // 2^0 : A00 (whole) + lo(A01) 2^22
