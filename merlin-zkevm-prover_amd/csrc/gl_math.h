@@ -66,7 +66,7 @@ MI_HD u64 canon(u64 a)
 MI_HD u64 add_wc(u64 a, u64 b)
 {
     u64 s = a + b;
-    return s < a ? s + GL_EPS : s; // wrapped: true sum < 2^64 + p, so s < p and s + eps cannot wrap again
+    return s + (s < a ? GL_EPS : 0); // wrapped: true sum < 2^64 + p, so s < p and s + eps cannot wrap again
 }
 
 // both canonical -> canonical
@@ -90,26 +90,28 @@ MI_HD u64 neg(u64 a) { return a ? GL_P - a : 0; }
 MI_HD u64 sub_wc(u64 a, u64 b)
 {
     u64 d = a - b;
-    return a < b ? d - GL_EPS : d; // borrowed: d >= 2^64 - p + 1 > eps, so d - eps cannot borrow again
+    return d - (a < b ? GL_EPS : 0); // borrowed: d >= 2^64 - p + 1 > eps, so d - eps cannot borrow again
 }
 // any u64 -> weakly reduced -a
 MI_HD u64 neg_w(u64 a) { return GL_P - canon(a); }
 
 // 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
-// (the overflow builtin makes the borrow test a compare against the difference: one 64-bit compare, no
-// zero-extended copy of hh)
+// Spelled with the 32-bit borrow chain so that the rare-borrow branch tests the borrow flag itself (no 64-bit
+// compare, no zero-extended copy of hh), and with the wrap correction as "+ (wrapped ? eps : 0)" (one select).
 MI_HD u64 reduce128_w(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u64 t0;
-    const bool borrow = __builtin_usubll_overflow(lo, (u64)hh, &t0);
-    if (rare(borrow)) { // borrowed 2^64 = p + eps (needs lo < 2^32: ~never)
+    u32 b1, b2;
+    const u32 d0 = __builtin_subc((u32)lo, hh, 0u, &b1);
+    const u32 d1 = __builtin_subc((u32)(lo >> 32), 0u, b1, &b2);
+    u64 t0 = ((u64)d1 << 32) | d0;
+    if (rare(b2 != 0)) { // borrowed 2^64 = p + eps (needs lo < 2^32: ~never)
         MI_KEEP_BRANCH();
-        t0 = borrow ? t0 - GL_EPS : t0;
+        t0 = b2 ? t0 - GL_EPS : t0;
     }
     const u64 t1 = ((u64)hl << 32) - hl; // hl * (2^32 - 1)
     const u64 r = t0 + t1;
-    return r < t1 ? r + GL_EPS : r;
+    return r + ((r < t1) ? GL_EPS : 0);
 }
 
 MI_HD void mul64x64(u64 a, u64 b, u64 &lo, u64 &hi)

@@ -42,11 +42,11 @@ MI_HD u64 mul_pow2(u64 x)
         if (E <= 20) { // t1 < 2^(32+E): the wrap has probability ~2^(E-32) per value
             if (gl::rare(r < t1)) {
                 MI_KEEP_BRANCH();
-                r = r < t1 ? r + GL_EPS : r;
+                r = r + (r < t1 ? GL_EPS : 0);
             }
             return r;
         }
-        return r < t1 ? r + GL_EPS : r;
+        return r + (r < t1 ? GL_EPS : 0);
     } else {
         return gl::reduce128_w(x << E, x >> (64 - E));
     }

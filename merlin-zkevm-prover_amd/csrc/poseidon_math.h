@@ -207,7 +207,7 @@ MI_HD u64 dot_close(const DotAcc &d)
     }
     const u64 t1 = (u64)hl * 0xFFFFFFFFu;
     const u64 r = t0 + t1;
-    return r < t1 ? r + GL_EPS : r;
+    return r + (r < t1 ? GL_EPS : 0);
 }
 
 // The 22 partial rounds, grouped (see the generator): per round one S-box and ONE dot product (11 terms over the
