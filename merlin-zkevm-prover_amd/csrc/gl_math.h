@@ -96,22 +96,31 @@ MI_HD u64 sub_wc(u64 a, u64 b)
 MI_HD u64 neg_w(u64 a) { return GL_P - canon(a); }
 
 // 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
-// Spelled with the 32-bit borrow chain so that the rare-borrow branch tests the borrow flag itself (no 64-bit
-// compare, no zero-extended copy of hh), and with the wrap correction as "+ (wrapped ? eps : 0)" (one select).
+// "lo + hl * (2^32-1)" is ONE v_mad_u64_u32 whose carry-out drives the wrap correction; the compiler will not use
+// that carry (it splits the multiply-add to re-derive it with a 64-bit compare), hence the two-instruction asm.
+// The subtraction of hh is spelled as the 32-bit borrow chain so that the rare-borrow branch tests the flag itself.
 MI_HD u64 reduce128_w(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u64 r1;
+    u32 e; // wrapped ? 2^32 - 1 : 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    // VALU write of VCC -> VALU read as a select mask: two wait states on gfx950
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=v"(r1), "=v"(e) : "v"(hl), "v"(lo) : "vcc");
+#else
+    r1 = (u64)hl * 0xFFFFFFFFu + lo;
+    e = r1 < lo ? 0xFFFFFFFFu : 0;
+#endif
+    const u64 r2 = r1 + e; // the wrapped sum is < hl * (2^32-1) <= (2^32-1)^2: adding eps cannot wrap again
     u32 b1, b2;
-    const u32 d0 = __builtin_subc((u32)lo, hh, 0u, &b1);
-    const u32 d1 = __builtin_subc((u32)(lo >> 32), 0u, b1, &b2);
-    u64 t0 = ((u64)d1 << 32) | d0;
-    if (rare(b2 != 0)) { // borrowed 2^64 = p + eps (needs lo < 2^32: ~never)
+    const u32 d0 = __builtin_subc((u32)r2, hh, 0u, &b1);
+    const u32 d1 = __builtin_subc((u32)(r2 >> 32), 0u, b1, &b2);
+    u64 t = ((u64)d1 << 32) | d0;
+    if (rare(b2 != 0)) { // borrowed 2^64 = p + eps (needs r2 < 2^32: ~never)
         MI_KEEP_BRANCH();
-        t0 = b2 ? t0 - GL_EPS : t0;
+        t = b2 ? t - GL_EPS : t; // t >= 2^64 - 2^32 + 1 > eps: no second borrow
     }
-    const u64 t1 = ((u64)hl << 32) - hl; // hl * (2^32 - 1)
-    const u64 r = t0 + t1;
-    return r + ((r < t1) ? GL_EPS : 0);
+    return t;
 }
 
 MI_HD void mul64x64(u64 a, u64 b, u64 &lo, u64 &hi)
