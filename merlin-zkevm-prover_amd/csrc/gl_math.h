@@ -95,23 +95,29 @@ MI_HD u64 sub_wc(u64 a, u64 b)
 // any u64 -> weakly reduced -a
 MI_HD u64 neg_w(u64 a) { return GL_P - canon(a); }
 
-// 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
-// "lo + hl * (2^32-1)" is ONE v_mad_u64_u32 whose carry-out drives the wrap correction; the compiler will not use
-// that carry (it splits the multiply-add to re-derive it with a 64-bit compare), hence the two-instruction asm.
-// The subtraction of hh is spelled as the 32-bit borrow chain so that the rare-borrow branch tests the flag itself.
-MI_HD u64 reduce128_w(u64 lo, u64 hi)
+// lo + h * (2^32 - 1)  ->  weakly reduced; any lo, any 32-bit h.
+// ONE v_mad_u64_u32 whose carry-out drives the wrap correction; the compiler will not use that carry (it splits the
+// multiply-add to re-derive it with a 64-bit compare), hence the two-instruction asm.
+MI_HD u64 add_mul_eps(u64 lo, u32 h)
 {
-    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u64 r1;
     u32 e; // wrapped ? 2^32 - 1 : 0
 #if defined(__HIP_DEVICE_COMPILE__)
     // VALU write of VCC -> VALU read as a select mask: two wait states on gfx950
-    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=v"(r1), "=v"(e) : "v"(hl), "v"(lo) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=v"(r1), "=v"(e) : "v"(h), "v"(lo) : "vcc");
 #else
-    r1 = (u64)hl * 0xFFFFFFFFu + lo;
+    r1 = (u64)h * 0xFFFFFFFFu + lo;
     e = r1 < lo ? 0xFFFFFFFFu : 0;
 #endif
-    const u64 r2 = r1 + e; // the wrapped sum is < hl * (2^32-1) <= (2^32-1)^2: adding eps cannot wrap again
+    return r1 + e; // the wrapped sum is < h * (2^32-1) <= (2^32-1)^2: adding eps cannot wrap again
+}
+
+// 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
+// The subtraction of hh is spelled as the 32-bit borrow chain so that the rare-borrow branch tests the flag itself.
+MI_HD u64 reduce128_w(u64 lo, u64 hi)
+{
+    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    const u64 r2 = add_mul_eps(lo, hl);
     u32 b1, b2;
     const u32 d0 = __builtin_subc((u32)r2, hh, 0u, &b1);
     const u32 d1 = __builtin_subc((u32)(r2 >> 32), 0u, b1, &b2);

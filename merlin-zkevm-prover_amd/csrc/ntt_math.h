@@ -36,17 +36,8 @@ MI_HD u64 mul_pow2(u64 x)
     } else if constexpr (E >= 64) {
         return mul_pow2<E - 48>(mul_pow2<48>(x));
     } else if constexpr (E < 32) {
-        const u64 lo = x << E, hi = x >> (64 - E); // hi < 2^31: hi * 2^64 = hi * (2^32 - 1)
-        const u64 t1 = (hi << 32) - hi;
-        u64 r = lo + t1;
-        if (E <= 20) { // t1 < 2^(32+E): the wrap has probability ~2^(E-32) per value
-            if (gl::rare(r < t1)) {
-                MI_KEEP_BRANCH();
-                r = r + (r < t1 ? GL_EPS : 0);
-            }
-            return r;
-        }
-        return r + (r < t1 ? GL_EPS : 0);
+        // x * 2^E = lo + hi * 2^64 with hi < 2^31, and 2^64 = 2^32 - 1
+        return gl::add_mul_eps(x << E, (u32)(x >> (64 - E)));
     } else {
         return gl::reduce128_w(x << E, x >> (64 - E));
     }
