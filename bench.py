@@ -44,11 +44,12 @@ def valu_roofline(perms, leaf_ms):
 def cpu_baseline(log_n, ncols):
     """CPU oracle ("port", OpenMP) on a bounded sample of the same workload: LDE + Merkle tree of a
     2^log_n x ncols trace.  tests/glo.py is the oracle binding; it is used here only as the timed baseline."""
-    # threads = this process's CPU share (the GPU box gives 16 cores per GPU), set before libgomp starts
+    # threads = this process's CPU share (the GPU box gives 16 cores per GPU).  libgomp is already loaded (torch), so
+    # the environment variable would come too late: set the count through the oracle itself.
     share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(share, 16))))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import glo
+    glo.lib().glo_set_num_threads(max(1, min(share, 16)))
     n, n_ext = 1 << log_n, 2 << log_n
     trace = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
     glo.lib()

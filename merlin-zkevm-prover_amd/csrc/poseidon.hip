@@ -91,40 +91,58 @@ __global__ __launch_bounds__(256) void k_linear_hash_rows(u64 *__restrict__ dige
 
 // ---- line-aligned variant of the leaf sponge (default).
 // HBM is fetched in 128-byte lines, but a row of 665 elements starts at an arbitrary 8-byte offset inside its
-// first line, so a lane reading "its next 64 bytes" touches most lines twice, one permutation (~40 us) apart;
+// first line, so a lane reading "its next 64 bytes" touches most lines twice, one permutation (~35 us) apart;
 // with 32768 such half-consumed lines per XCD (= the whole 4 MiB L2) a third of them are fetched again
-// (measured: 1.36x the algorithmic bytes).  Here every lane fetches whole ALIGNED lines (8 x dwordx4), one
-// permutation ahead of their use, and parks them in a per-lane ring in LDS from which the 8-element blocks are
-// taken, so each line crosses the fabric once and the prefetched data costs no registers while the permutation runs
-// (only the line in flight does: 32 VGPRs).  Ring occupancy: a line is requested when fewer than 8 unconsumed
-// elements would remain, and lands (16 more) before the next take: at most 7 + 16 = 23 elements, hence 24 slots.
-// 24 slots x 256 threads x 8 B = 48 KiB per workgroup -> three workgroups (three waves per SIMD) per CU.
+// (measured: 1.36x the algorithmic bytes).  Here every lane fetches whole ALIGNED lines, one permutation ahead of
+// their use, straight into a per-lane ring in LDS (global_load_lds_dwordx4: the data never passes through VGPRs,
+// which the permutation needs all of), and takes its 8-element blocks out of the ring: each line crosses the
+// fabric once.  Ring occupancy: a line is requested when fewer than 8 unconsumed elements would remain and lands
+// (16 more) before the next take: at most 7 + 16 = 23 elements, hence 24 slots = 12 sixteen-byte pairs.
+// 12 pairs x 256 threads x 16 B = 48 KiB per workgroup -> three workgroups (three waves per SIMD) per CU.
 // All stream positions are wave-uniform (scalar control flow, LDS addresses = lane offset + scalar): wave (q, j)
 // takes the rows r = 1024 q + 16 lane + j, whose offsets (r * pitch + base) mod 16 depend on j only.
 static constexpr uint32_t LEAF_RING = 24;
 
-__device__ __forceinline__ void line_fetch(ulonglong2 (&v)[8], const u64 *line, const u64 *lo, const u64 *hi)
+// Requests the aligned 16-element line at `line` for every lane; it lands in ring pairs (f24 / 2 + i) mod 12, i < 8.
+// wave_ring: this wave's 64 consecutive entries of pair 0 (wave-uniform).  Lines that stick out of the matrix (the
+// very first / last line) are read element-wise and stored through registers instead: never read outside [lo, hi).
+__device__ __forceinline__ void line_fetch(ulonglong2 *wave_ring, uint32_t lane, uint32_t f24, const u64 *line, const u64 *lo,
+                                           const u64 *hi)
 {
-    if (line >= lo && line + 16 <= hi) { // whole line inside the matrix: 8 aligned 16-byte loads
-        const ulonglong2 *l2 = reinterpret_cast<const ulonglong2 *>(line);
+    const bool inside = line >= lo && line + 16 <= hi;
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = l2[i];
-    } else { // first / last line of the matrix: never read outside [lo, hi)
+        for (uint32_t i = 0; i < 8; i++) {
+            uint32_t pr = (f24 >> 1) + i;
+            pr = pr >= LEAF_RING / 2 ? pr - LEAF_RING / 2 : pr;
+            // LDS destination = M0 base (wave-uniform) + lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(line + 2 * i),
+                                             (__attribute__((address_space(3))) void *)(wave_ring + pr * 256), 16, 0, 0);
+        }
+    } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            v[i].x = (line + 2 * i >= lo && line + 2 * i < hi) ? line[2 * i] : 0;
-            v[i].y = (line + 2 * i + 1 >= lo && line + 2 * i + 1 < hi) ? line[2 * i + 1] : 0;
+        for (uint32_t i = 0; i < 8; i++) {
+            uint32_t pr = (f24 >> 1) + i;
+            pr = pr >= LEAF_RING / 2 ? pr - LEAF_RING / 2 : pr;
+            ulonglong2 v;
+            v.x = (line + 2 * i >= lo && line + 2 * i < hi) ? line[2 * i] : 0;
+            v.y = (line + 2 * i + 1 >= lo && line + 2 * i + 1 < hi) ? line[2 * i + 1] : 0;
+            wave_ring[pr * 256 + lane] = v;
         }
     }
 }
+
+// every requested line has landed in LDS (LDS-direct loads are counted by vmcnt) and is visible to the reads below
+__device__ __forceinline__ void lines_landed() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 template <int MDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_hash_rows_lines(
     u64 *__restrict__ digests, const u64 *__restrict__ src, uint64_t pitch, uint32_t ncols, uint64_t nrows)
 {
-    __shared__ u64 ring[LEAF_RING * 256]; // [slot][thread]
+    __shared__ ulonglong2 ring[(LEAF_RING / 2) * 256]; // [pair][thread]
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t gw = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
     const uint64_t row = (gw >> 4) * 1024 + (uint64_t)lane * 16 + (gw & 15);
     const bool active = row < nrows;
     const u64 *lo = src, *hi = src + (nrows - 1) * pitch + ncols;
@@ -133,51 +151,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((uintptr_t)p >> 3) & 15));
     const u64 *lp = p - o;         // the row's line stream: element e of the stream is lp[e], the row is [o, end)
     const uint32_t end = o + ncols;
-    u64 *my = ring + threadIdx.x;
+    ulonglong2 *wave_ring = ring + wave * 64;
+    const u64 *my = reinterpret_cast<const u64 *>(wave_ring + lane); // element in slot a: my[(a >> 1) * 512 + (a & 1)]
     uint32_t fetched = 0, f24 = 0; // the ring holds stream elements [pos, fetched); f24 = fetched mod 24
-    ulonglong2 v[8];
     u64 s[12];
-    auto land = [&]() { // the line in v becomes stream elements [fetched, fetched + 16)
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint32_t a = f24 + 2 * i, b = f24 + 2 * i + 1;
-            a = a >= LEAF_RING ? a - LEAF_RING : a;
-            b = b >= LEAF_RING ? b - LEAF_RING : b;
-            my[a * 256] = v[i].x;
-            my[b * 256] = v[i].y;
-        }
+    auto fetch_next = [&]() { // request stream elements [fetched, fetched + 16)
+        line_fetch(wave_ring, lane, f24, lp + fetched, lo, hi);
         fetched += 16;
         f24 = f24 + 16 >= LEAF_RING ? f24 + 16 - LEAF_RING : f24 + 16;
     };
-    line_fetch(v, lp, lo, hi);
-    land();
-    if (o > 8 && end > 16) { // the first block already crosses into the second line (occupancy 32 - o <= 23)
-        line_fetch(v, lp + 16, lo, hi);
-        land();
-    }
-    bool inflight = false;
+    fetch_next();
+    if (o > 8 && end > 16) fetch_next(); // the first block already crosses into the second line (occupancy 32 - o <= 23)
     uint32_t p24 = o; // pos mod 24
 #pragma unroll
     for (int i = 0; i < 4; i++) s[8 + i] = 0;
     for (uint32_t pos = o; pos < end; pos += 8) {
-        if (inflight) {
-            land();
-            inflight = false;
-        }
+        lines_landed();
 #pragma unroll
         for (uint32_t i = 0; i < 8; i++) { // take the block; past the end of the row: zero padding
             uint32_t a = p24 + i;
             a = a >= LEAF_RING ? a - LEAF_RING : a;
-            s[i] = (pos + i < end) ? my[a * 256] : 0;
+            s[i] = (pos + i < end) ? my[(a >> 1) * 512 + (a & 1)] : 0;
         }
         p24 = p24 + 8 >= LEAF_RING ? p24 + 8 - LEAF_RING : p24 + 8;
-        // fewer than 8 unconsumed elements left and the row goes on: request the next line now, it lands after the
-        // permutation
-        if ((int32_t)(fetched - pos - 8) < 8 && fetched < end) {
-            line_fetch(v, lp + fetched, lo, hi);
-            inflight = true;
-        }
-        pos::permute<MDS, 0>(s, c_rc, &c_sparse);
+        // fewer than 8 unconsumed elements left and the row goes on: request the next line during this permutation (it
+        // lands before the next take).  The request is issued from inside the permutation, ahead of its last four
+        // rounds: ~10 us of arithmetic follow, enough to hide the HBM latency.
+        const bool want = (int32_t)(fetched - pos - 8) < 8 && fetched < end;
+        pos::permute<MDS, 0>(s, c_rc, &c_sparse, [&]() {
+            if (want) fetch_next();
+        });
         if (pos + 8 < end) {
 #pragma unroll
             for (int i = 0; i < 4; i++) s[8 + i] = s[i];

@@ -275,8 +275,14 @@ MI_HD void mds(u64 (&s)[12], const u64 *__restrict__ rc_next)
 // rc: 360 round constants (canonical); sp: tables of the optimised partial rounds (only read by MDS_SPARSE).
 // State in: any u64 encodings; out: the first NCANON words canonical, the rest weakly reduced (a chained sponge
 // permutation needs none canonical, a tree node only its 4 digest words).
-template <int MDS, int NCANON = 12>
-MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables *__restrict__ sp = nullptr)
+// before_last_rounds: called once, after the partial rounds and before the closing four full rounds -- the point of
+// lowest register pressure with still ~a quarter of the permutation to run.  The leaf sponge issues its next line
+// fetch there, so the registers the data lands in are not live across the (register-hungry) partial rounds.
+struct NoHook { MI_HD void operator()() const {} };
+
+template <int MDS, int NCANON = 12, typename Hook = NoHook>
+MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables *__restrict__ sp = nullptr,
+                   Hook before_last_rounds = Hook())
 {
     constexpr int FULL_MDS = (MDS == MDS_SPARSE) ? MDS_HALF32 : MDS;
     // round r: s <- M * S(s + rc_r).  The "+ rc_{r+1}" of the next round rides in the MDS of round r.
@@ -299,6 +305,7 @@ MI_HD void permute(u64 (&s)[12], const u64 *__restrict__ rc, const SparseTables 
             mds<FULL_MDS>(s, rc + (r + 1) * 12);
         }
     }
+    before_last_rounds();
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll

@@ -15,6 +15,15 @@
 typedef unsigned __int128 u128;
 #define P GLO_P
 
+void glo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int glo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -103,6 +103,7 @@ void glo_zhinv(uint64_t *out, unsigned nbits, unsigned nbits_ext);
 /* LEv: out[k] = xis^k (ext), k < n   (starks.cpp:305-323) */
 void glo_geom_seq3(uint64_t *out, uint64_t n, const uint64_t ratio[3]);
 
+void glo_set_num_threads(int n); /* OpenMP threads used by the parallel loops (0 = leave as is) */
 int glo_num_threads(void);
 
 #ifdef __cplusplus
