@@ -25,20 +25,24 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T full-rate lane-ops/s
 
 
-def valu_roofline(perms, leaf_ms):
-    """Issue-rate roofline of the Poseidon leaf kernel.
-    Instructions per permutation: 24 685 VALU instructions per lane, MEASURED (rocprofv3 --pmc SQ_INSTS_VALU over the
-    launch / wave-permutations, profiles/r01_pmc_sq_leaf.txt).  Peak issue rates: measured on this chip by
-    tools/ubench_int2.hip (profiles/r01_ubench_int_issue_rates2.txt): 1047 G wave-instr/s for the 2-clk class
-    (v_add_u32, v_mov, v_cndmask ...) and 592 G for the 4-clk class (v_mad_u64_u32, shifts, carry adds,
-    v_lshl_add_u64); the kernel's static mix is 43 % / 57 %."""
-    instrs = 24685.0
-    blended_peak = 1.0 / (0.43 / 1047e9 + 0.57 / 592e9)         # wave-instructions per second, whole chip
+def valu_roofline(perms, leaf_ms, pmc):
+    """Issue-rate roofline of the Poseidon leaf kernel (the kernel is VALU-bound, not HBM-bound).
+    Instructions per permutation: MEASURED (rocprofv3 --pmc SQ_INSTS_VALU over the launch / wave-permutations,
+    profiles/r01_pmc_traffic.json).  Peak issue rates: measured on this chip by tools/ubench_int2.hip
+    (profiles/r01_ubench_int_issue_rates2.txt) for the two issue classes (2-clk: v_mov, v_cndmask, 32-bit adds ...;
+    4-clk: v_mad_u64_u32, v_lshl_add_u64, carry adds, shifts); the kernel's loop-weighted static mix comes from
+    tools/valu_mix.py.  peak = 1 / (f2 / R2 + f4 / R4) wave-instructions per second for the whole chip."""
+    instrs = float(pmc["valu_instructions_per_permutation"])
+    f2, f4 = pmc["issue_mix"]["frac_2clk"], pmc["issue_mix"]["frac_4clk"]
+    r2, r4 = pmc["issue_rates_wave_instr_per_s"]["2clk"], pmc["issue_rates_wave_instr_per_s"]["4clk"]
+    blended_peak = 1.0 / (f2 / r2 + f4 / r4)
     peak_perms = blended_peak * 64.0 / instrs
     ach = perms / (leaf_ms * 1e-3) if leaf_ms > 0 else 0.0
     return {"kernel": "k_linear_hash_rows_lines", "bound": "valu-issue", "perms_per_launch": perms, "achieved": ach, "peak": peak_perms,
             "unit": "permutations/s", "frac": ach / peak_perms, "valu_instructions_per_permutation": instrs,
-            "achieved_wave_instr_per_s": ach / 64.0 * instrs, "peak_wave_instr_per_s": blended_peak}
+            "issue_mix": {"frac_2clk": f2, "frac_4clk": f4},
+            "achieved_wave_instr_per_s": ach / 64.0 * instrs, "peak_wave_instr_per_s": blended_peak,
+            "source": "profiles/r01_pmc_traffic.json (SQ_INSTS_VALU), tools/valu_mix.py, tools/ubench_int2.hip"}
 
 
 def cpu_baseline(log_n, ncols):
@@ -193,9 +197,8 @@ def main():
             "roofline": {"kernel": "k_linear_hash_rows_lines" if args.leaf_mode else "k_linear_hash_rows", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": leaf_bytes, "avg_launch_ms": leaf_ms,
-                         "note": "VALU-bound kernel (~3e4 integer ops per 64 B absorbed): see valu + DESIGN.md"},
-            "valu": valu_roofline(perms, leaf_ms),
-            "roofline_lde": {"kernel": "k_ntt_pass (9 launches per column chunk)", "bound": "hbm",
+                         "note": "VALU-bound kernel (~1.7e4 integer instructions per 64 B absorbed): see valu + DESIGN.md"},
+            "roofline_lde": {"kernel": "k_ntt_pass x4 + k_lde_mid per 64-column chunk", "bound": "hbm",
                              "achieved": lde_bytes / (lde_ms * 1e-3) / 1e9 if lde_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "algorithmic_bytes": lde_bytes, "avg_ms": lde_ms},
             "phase_ms": {"STARK_STEP_1_LDE": lde_ms, "STARK_STEP_1_MERKLETREE_leaves": leaf_ms, "STARK_STEP_1_MERKLETREE_levels": t_lvls / K},
@@ -204,10 +207,12 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (they cannot run inside the
         # timed process); the committed summary of the same command is read back here when the workload matches
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if world == 1 and args.log_n == 23 and ncols == 665 and args.leaf_mode == 1 and os.path.exists(pmc_path):
+        if (world == 1 and args.log_n == 23 and ncols == 665 and args.leaf_mode == 1 and args.poseidon_variant == 2
+                and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))["kernels"]["k_linear_hash_rows_lines"]
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 x2 read correction)"
+            out["valu"] = valu_roofline(perms, leaf_ms, pmc)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols)
         else:
