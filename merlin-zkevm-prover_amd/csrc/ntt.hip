@@ -34,6 +34,7 @@ struct NttPass {
     uint32_t ncols;
     uint32_t log_n, log_K;
     uint32_t apply_scale;
+    uint32_t unit_tw; // last pass of an unscaled transform: every inter-pass twiddle is 1, outputs are only canonicalised
     uint32_t tj_log, tcp_log; // TJ = beta rows per tile, TCP = padded columns per tile, TJ*TCP = 32
     uint32_t n_col_tiles;
     uint64_t n_tiles;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
 
     if (tid < 256) w256[tid] = a.w256[tid];
     auto fill_tw = [&]() {
+        if (a.unit_tw) return;
         for (uint32_t e = tid; e < (uint32_t)R * TJ; e += NTT_THREADS) {
             const uint32_t k1 = e >> a.tj_log, tj = e & (TJ - 1);
             const uint64_t beta = beta0 + tj;
@@ -232,8 +234,13 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
         const uint64_t qstride = ((uint64_t)RA << a.log_K) * a.dst_pitch;
         const u64 *t = tw + ((kap << a.tj_log) + tj);
         const uint32_t tstride = (uint32_t)RA << a.tj_log;
+        if (a.unit_tw) {
 #pragma unroll
-        for (int kb = 0; kb < RB; kb++) x[kb] = gl::mul(x[kb], t[kb * tstride]);
+            for (int kb = 0; kb < RB; kb++) x[kb] = gl::canon(x[kb]);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) x[kb] = gl::mul(x[kb], t[kb * tstride]);
+        }
         if (WIDE && RB >= 2) {
             const bool odd = b & 1;
             const uint32_t col_e = col & ~1u; // first column of the pair
@@ -512,6 +519,7 @@ static int run_passes(mi_ctx *ctx, NttPlan *plan, const std::vector<Buf> &bufs, 
         a.tw_hi = plan->tw.hi;
         a.tw_lo_bits = plan->tw.lo_bits;
         a.apply_scale = (ps == P - 1 && scale) ? 1 : 0;
+        a.unit_tw = (ps == P - 1 && !scale) ? 1 : 0; // ip = 0 in every tile of the last pass: exponent 0
         if (a.apply_scale) {
             a.sc_lo = scale->lo;
             a.sc_hi = scale->hi;
