@@ -108,6 +108,8 @@ __device__ __forceinline__ void tile_step_b(const u64 *tile, uint32_t kap, uint3
 template <int RB>
 __device__ __forceinline__ void store_pairs(u64 *q_e, uint64_t qstride, const u64 (&x)[RB], bool odd, bool pair_ok, bool lone_ok)
 {
+    u64 *qr = q_e + (odd ? qstride : 0); // this lane's rows: kb = 2 j + odd
+    const uint64_t step = 2 * qstride;
 #pragma unroll
     for (int j = 0; j < RB / 2; j++) {
         const u64 give = odd ? x[2 * j] : x[2 * j + 1];
@@ -115,12 +117,12 @@ __device__ __forceinline__ void store_pairs(u64 *q_e, uint64_t qstride, const u6
         U64x2 w;
         w.x = odd ? got : x[2 * j];
         w.y = odd ? x[2 * j + 1] : got;
-        u64 *qr = q_e + (uint64_t)(2 * j + (odd ? 1 : 0)) * qstride;
         if (pair_ok) *reinterpret_cast<U64x2 *>(qr) = w;
         else if (lone_ok) { // last, unpaired column: the even lane writes both rows itself
-            q_e[(uint64_t)(2 * j) * qstride] = x[2 * j];
-            q_e[(uint64_t)(2 * j + 1) * qstride] = x[2 * j + 1];
+            qr[0] = x[2 * j];
+            qr[qstride] = x[2 * j + 1];
         }
+        qr += step;
     }
 }
 
@@ -182,18 +184,31 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
         const u64 *p = a.src + (beta0 + tj) * a.src_pitch + col;
         ulonglong2 v[NW];
         // all of the tile's loads are in flight before the twiddle table (dependent L2 loads + multiplies) is built
+        constexpr bool FULL_SWEEPS = (R * (B / 2)) % NTT_THREADS == 0; // every thread owns NW rows
+        const bool plain = FULL_SWEEPS && a.in_valid_rows >= n && __builtin_amdgcn_ballot_w64(col + 1 >= a.ncols) == 0;
+        if (plain) { // interior tile (wave-uniform): no guards, the row pointer advances by a constant stride
+            const u64 *pr = p + (uint64_t)(tid / (B / 2)) * mK * a.src_pitch;
+            const uint64_t rstride = (uint64_t)(NTT_THREADS / (B / 2)) * mK * a.src_pitch;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
-            const uint64_t row = (uint64_t)i1 * mK + beta0 + tj;
-            const u64 *pr = p + (uint64_t)i1 * mK * a.src_pitch;
-            v[k] = make_ulonglong2(0, 0);
-            if (i1 < (uint32_t)R && row < a.in_valid_rows) {
-                if (col + 1 < a.ncols) {
-                    const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
-                    v[k] = make_ulonglong2(w.x, w.y);
-                } else if (col < a.ncols) {
-                    v[k].x = pr[0];
+            for (int k = 0; k < NW; k++) {
+                const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
+                v[k] = make_ulonglong2(w.x, w.y);
+                pr += rstride;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
+                const uint64_t row = (uint64_t)i1 * mK + beta0 + tj;
+                const u64 *pr = p + (uint64_t)i1 * mK * a.src_pitch;
+                v[k] = make_ulonglong2(0, 0);
+                if (i1 < (uint32_t)R && row < a.in_valid_rows) {
+                    if (col + 1 < a.ncols) {
+                        const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
+                        v[k] = make_ulonglong2(w.x, w.y);
+                    } else if (col < a.ncols) {
+                        v[k].x = pr[0];
+                    }
                 }
             }
         }
@@ -304,17 +319,29 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
     ulonglong2 v[NW];
     {
         const u64 *p = a.src + (kappa0 + ltj) * a.src_pitch + lcol;
+        constexpr bool FULL_SWEEPS = (R1 * (B / 2)) % NTT_THREADS == 0; // every thread owns NW rows
+        if (FULL_SWEEPS && __builtin_amdgcn_ballot_w64(lcol + 1 >= a.ncols) == 0) { // interior tile (wave-uniform)
+            const u64 *pr = p + (uint64_t)(tid / (B / 2)) * K1 * a.src_pitch;
+            const uint64_t rstride = (uint64_t)(NTT_THREADS / (B / 2)) * K1 * a.src_pitch;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
-            const u64 *pr = p + (uint64_t)i1 * K1 * a.src_pitch;
-            v[k] = make_ulonglong2(0, 0);
-            if (i1 < (uint32_t)R1) {
-                if (lcol + 1 < a.ncols) {
-                    const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
-                    v[k] = make_ulonglong2(w.x, w.y);
-                } else if (lcol < a.ncols) {
-                    v[k].x = pr[0];
+            for (int k = 0; k < NW; k++) {
+                const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
+                v[k] = make_ulonglong2(w.x, w.y);
+                pr += rstride;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const uint32_t i1 = tid / (B / 2) + k * (NTT_THREADS / (B / 2));
+                const u64 *pr = p + (uint64_t)i1 * K1 * a.src_pitch;
+                v[k] = make_ulonglong2(0, 0);
+                if (i1 < (uint32_t)R1) {
+                    if (lcol + 1 < a.ncols) {
+                        const U64x2 w = *reinterpret_cast<const U64x2 *>(pr);
+                        v[k] = make_ulonglong2(w.x, w.y);
+                    } else if (lcol < a.ncols) {
+                        v[k].x = pr[0];
+                    }
                 }
             }
         }
