@@ -76,6 +76,24 @@ def test_linear_hash_rows_all_widths(ctx, variant):
     ctx.set_poseidon_variant(0)
 
 
+def test_linear_hash_rows_line_ring_corner_cases(ctx):
+    """The leaf kernel streams whole aligned 128-byte lines through a 24-slot LDS ring: exercise every in-line start
+    offset (matrix base not line-aligned, odd pitches), rows on both sides of a 1024-row wave group, row counts that
+    leave idle lanes, and rows short enough that the stream ends inside the first or second line."""
+    rng = np.random.default_rng(1234)
+    for (h, w, pitch, off) in [(1, 5, 5, 0), (1, 5, 5, 1), (3, 7, 9, 5), (17, 8, 8, 3), (33, 9, 9, 15), (1030, 13, 14, 7),
+                               (1100, 16, 17, 2), (70, 23, 23, 9), (70, 24, 29, 11), (2050, 31, 31, 13), (40, 33, 35, 6),
+                               (130, 47, 47, 1), (20, 100, 101, 4), (18, 665, 665, 3), (5, 666, 667, 14)]:
+        buf = glo.rand_fe(rng, off + h * pitch)
+        d = ctx.to_device(buf)
+        out = ctx.empty(h * 4)
+        ctx.linear_hash_rows(out, d, w, h, pitch=pitch, src_off=off)
+        got = ctx.to_host(out).reshape(h, 4)
+        rows = buf[off:].reshape(h, pitch)
+        for r in list(range(min(h, 40))) + list(range(max(0, h - 40), h)):
+            assert np.array_equal(got[r], glo.linear_hash(np.ascontiguousarray(rows[r, :w]))), (h, w, pitch, off, r)
+
+
 @pytest.mark.parametrize("h,w", [(1, 5), (2, 3), (4, 1), (8, 9), (64, 18), (512, 21), (1024, 6), (2048, 39), (4096, 4), (1 << 13, 12)])
 def test_merkle_tree_matches_oracle(ctx, h, w):
     rng = np.random.default_rng(h + w)
