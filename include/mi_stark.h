@@ -163,8 +163,9 @@ int mi_set_ntt_tile(mi_ctx *ctx, int log_b);
  * their radices line up (the coefficients never reach HBM), 0 = always separate passes.  Results are identical;
  * exposed for benchmarking and for testing both paths. */
 int mi_set_lde_fuse(mi_ctx *ctx, int fuse);
-/* Leaf sponge memory access: 1 (default) = every lane fetches whole aligned 128-byte lines into a register
- * ring, 0 = plain per-block loads.  Results are identical; exposed for benchmarking. */
+/* Leaf sponge memory access: 1 (default) = every lane fetches whole aligned 128-byte lines straight into a
+ * per-lane ring in LDS (global_load_lds), 0 = plain per-block loads.  Results are identical; exposed for
+ * benchmarking. */
 int mi_set_leaf_mode(mi_ctx *ctx, int line_aligned);
 
 /* Timing hooks used by bench.py: HIP events recorded on the context's stream. */
