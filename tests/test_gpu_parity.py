@@ -263,11 +263,11 @@ def test_config2_roundtrip_2pow23(ctx):
 
 # sizes where the fused middle pass (last INTT pass + first NTT pass in one kernel) applies -- radix r1 -> r2:
 # 16->32 .. 128->256 single pass, (5,4)->(5,5), (6,6)->(7,6), (7,7)->(8,7), (8,7)->(8,8), blowup 4: 64->256,
-# (5,4)->(6,5), (7,6)->(8,7) -- and where it does not (n < 16, one column, 256->(5,4), (8,8)->(6,6,5), n_ext = n).
+# (5,4)->(6,5), (7,6)->(8,7), three-pass splits (6,6,5)->(6,6,6), (6,6,6)->(7,6,6), (6,6,5)->(7,6,6) -- and where it does not (n < 16, one column, 256->(5,4), (8,8)->(6,6,5), n_ext = n).
 LDE_CASES = [(1, 2, 3), (2, 4, 1), (4, 8, 5), (16, 32, 37), (32, 64, 2), (64, 128, 9), (128, 256, 33), (64, 256, 5),
              (256, 512, 3), (256, 1024, 6), (512, 1024, 70), (512, 2048, 35), (1024, 2048, 1), (1024, 2048, 4),
              (1 << 12, 1 << 13, 33), (1 << 13, 1 << 15, 3), (1 << 14, 1 << 15, 7), (1 << 15, 1 << 16, 6),
-             (1 << 16, 1 << 17, 2), (8, 8, 4)]
+             (1 << 16, 1 << 17, 2), (1 << 17, 1 << 18, 5), (1 << 18, 1 << 19, 3), (1 << 17, 1 << 19, 2), (8, 8, 4)]
 
 
 @pytest.mark.parametrize("n,n_ext,ncols", LDE_CASES)
@@ -303,6 +303,28 @@ def test_lde_column_chunks_and_pitches(ctx):
     assert np.array_equal(small.to_host(o2).reshape(1 << 11, 70), glo.ntt(x, 1 << 11, 70))
     assert np.array_equal(small.lde_host(x[:256, :5], 512, 256, 5), glo.extend_pol(np.ascontiguousarray(x[:256, :5]), 512, 256, 5))
     small.close()
+
+
+def test_config3_shape_at_2pow18_rows_bit_exact():
+    """BASELINE configs[2] with fewer rows: 2^18 x 665 trace -> LDE to 2^19 -> Poseidon Merkle tree, the whole result
+    compared with the oracle (Merkle root = a checksum of all 2^19 x 665 extended values, plus sampled rows).  A small
+    workspace forces the production column chunking (21 chunks of 32 columns + a ragged one)."""
+    import mi_stark
+    c = mi_stark.Context(0, workspace_limit=256 << 20)
+    n, n_ext, ncols = 1 << 18, 1 << 19, 665
+    trace = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
+    d_ext = c.empty(n_ext * ncols)
+    c.lde(d_ext, c.to_device(trace), n_ext, n, ncols)
+    nodes = c.empty((2 * n_ext - 1) * 4)
+    c.merkle_build(nodes, d_ext, ncols, n_ext)
+    want_ext = glo.extend_pol(trace, n_ext, n, ncols)
+    got_ext = c.to_host(d_ext).reshape(n_ext, ncols)
+    for r in (0, 1, 2, n - 1, n, n_ext - 1, 12345, 400001):
+        assert np.array_equal(got_ext[r], want_ext[r]), r
+    assert np.array_equal(got_ext, want_ext)
+    want_nodes = glo.merkletree(want_ext, ncols, n_ext)
+    assert np.array_equal(c.to_host(nodes)[-4:], want_nodes[-4:])
+    c.close()
 
 
 def test_lde_merkle_large_properties(ctx):
