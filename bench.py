@@ -21,6 +21,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "merlin-zkevm-prover_amd"))
 
+# Merkle root of the default workload (2^23 x 665, seed 0x5EED0003) as computed by the single-GPU path; every
+# N > 1 run must reproduce it (the sharded path is bit-identical by construction).
+ROOT_2P23_X665 = [1687745183620725494, 6203522448509826964, 3423305870569619816, 5297016707118823433]
+
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T full-rate lane-ops/s
 
@@ -85,7 +89,16 @@ def main():
     ap.add_argument("--lde-fuse", type=int, default=1, help="0 = separate last-INTT / first-NTT passes (A/B only)")
     ap.add_argument("--leaf-mode", type=int, default=1, help="1 = line-aligned leaf fetch (default), 0 = per-block loads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: run the N > 1 code path (chunked LDE, RCCL all-to-all, repack, root all-gather) on a "
+                         "one-rank communicator, to rehearse it and to price its overhead on a single GPU")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner on
+    # communicator creation), so keep a private handle on the real stdout and point fd 1 at stderr for everything else.
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import torch
     import mi_stark
@@ -99,9 +112,10 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -118,12 +132,16 @@ def main():
     ctx.fill_synthetic_2d(trace, n, plan.my_cols, ncols, plan.col0, 0x5EED0003)
     bufs = {"ext": ctx.empty(max(n_ext * plan.max_cols, plan.rows_per_rank * ncols)),
             "nodes": ctx.empty((2 * plan.rows_per_rank - 1) * 4)}
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         bufs["recv"] = ctx.empty(plan.rows_per_rank * ncols)
         bufs["roots"] = ctx.empty((2 * world - 1) * 4)
 
     class Ops:
-        lde = staticmethod(lambda out, inp, ne, nn, c: ctx.lde(out, inp, ne, nn, c))
+        @staticmethod
+        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+
         copy_2d = staticmethod(ctx.copy_2d)
         merkle_levels = staticmethod(ctx.merkle_levels)
 
@@ -139,12 +157,16 @@ def main():
 
     t_lde = t_leaf = t_lvls = 0.0
 
+    LDE_SLOT0 = 3   # one HIP-event timer per pipeline chunk (world > 1: up to shard.PIPE_DEPTH LDE calls per step)
+
     class OpsTimed(Ops):
         @staticmethod
-        def lde(out, inp, ne, nn, c):
-            ctx.timer_start(0)
-            ctx.lde(out, inp, ne, nn, c)
-            ctx.timer_stop(0)
+        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+            ctx.timer_start(LDE_SLOT0 + chunk)
+            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+            ctx.timer_stop(LDE_SLOT0 + chunk)
+
+    lde_calls = [k for k in range(plan.n_chunks) if plan.chunk_width(rank, k)] if exchange else [0]
 
     def barrier():
         if dist is not None:
@@ -153,15 +175,15 @@ def main():
 
     root = None
     for _ in range(args.warmup):
-        root = lde_merkle_sharded(plan, Ops, dist, trace, bufs)
+        root = lde_merkle_sharded(plan, Ops, dist, trace, bufs, always_exchange=exchange)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        root = lde_merkle_sharded(plan, OpsTimed, dist, trace, bufs)
+        root = lde_merkle_sharded(plan, OpsTimed, dist, trace, bufs, always_exchange=exchange)
         # HIP-event readings need the stop events complete; reading them after the loop would only see the
         # last step, so accumulate per step (the sync this implies is inside the timed region on purpose:
         # it costs microseconds against a ~1 s step and keeps per-kernel times honest)
-        t_lde += ctx.timer_ms(0)
+        t_lde += sum(ctx.timer_ms(LDE_SLOT0 + k) for k in lde_calls)
         t_leaf += ctx.timer_ms(1)
         t_lvls += ctx.timer_ms(2)
     barrier()
@@ -194,6 +216,7 @@ def main():
                        "rows": n, "cols": ncols, "rows_ext": n_ext, "parallelism": "col-shard LDE -> all-to-all -> row-shard Merkle x%d" % world,
                        "poseidon_variant": args.poseidon_variant},
             "root": root_host,
+            "root_matches_single_gpu_run": (root_host == ROOT_2P23_X665) if (args.log_n == 23 and ncols == 665) else None,
             "roofline": {"kernel": "k_linear_hash_rows_lines" if args.leaf_mode else "k_linear_hash_rows", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": leaf_bytes, "avg_launch_ms": leaf_ms,
@@ -217,7 +240,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -489,12 +489,15 @@ def test_sharded_path_emulated_on_one_gpu(ctx, world):
     """The multi-GPU orchestration (shard.py) with the REAL device ops, all ranks emulated one after the other on
     this GPU and the all-to-all / all-gather done by tensor copies: the root must equal the single-GPU root."""
     import torch
-    from shard import ShardPlan, phase_lde, phase_merkle_local, phase_top
-    n, ncols = 1 << 10, 37
+    from shard import ShardPlan, phase_lde_chunk, phase_merkle_local, phase_top
+    n, ncols = 1 << 10, 37 if world == 2 else 150
     n_ext = 2 * n
 
     class Ops:
-        lde = staticmethod(lambda out, inp, ne, nn, c: ctx.lde(out, inp, ne, nn, c))
+        @staticmethod
+        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+
         copy_2d = staticmethod(ctx.copy_2d)
         merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
         merkle_levels = staticmethod(ctx.merkle_levels)
@@ -515,19 +518,64 @@ def test_sharded_path_emulated_on_one_gpu(ctx, world):
         ctx.fill_synthetic_2d(trace, n, p.my_cols, ncols, p.col0, 0x5EED0003)     # column shard of the same trace
         b = {"ext": ctx.empty(max(n_ext * p.max_cols, p.rows_per_rank * ncols)), "nodes": ctx.empty((2 * p.rows_per_rank - 1) * 4),
              "recv": ctx.empty(p.rows_per_rank * ncols), "roots": ctx.empty((2 * world - 1) * 4)}
-        phase_lde(p, Ops, trace, b)
+        for k in range(p.n_chunks):
+            phase_lde_chunk(p, Ops, trace, b, k)
         bufs.append(b)
     torch.cuda.synchronize()
-    for dst in plans:                                                                # all-to-all by copies
-        off = 0
-        for src in plans:
-            cnt = dst.rows_per_rank * src.my_cols
-            start = dst.rank * dst.rows_per_rank * src.my_cols
-            bufs[dst.rank]["recv"][off:off + cnt] = bufs[src.rank]["ext"][start:start + cnt]
-            off += cnt
+    for dst in plans:                                                                # the chunked all-to-alls, by copies
+        for k in range(dst.n_chunks):
+            for src in plans:
+                s_off, s_cnt = src.send_block(k, dst.rank)
+                r_off, r_cnt = dst.recv_slab(k, src.rank)
+                assert s_cnt == r_cnt
+                bufs[dst.rank]["recv"][r_off:r_off + r_cnt] = bufs[src.rank]["ext"][s_off:s_off + s_cnt]
     roots = [phase_merkle_local(p, Ops, bufs[p.rank]).clone() for p in plans]
     for p in plans:                                                                  # all-gather by copies
         for r in range(world):
             bufs[p.rank]["roots"][4 * r:4 * r + 4] = roots[r]
         got = phase_top(p, Ops, bufs[p.rank])
         assert np.array_equal(ctx.to_host(got), want_root), p.rank
+
+
+def test_pipelined_exchange_on_a_one_rank_rccl_group(ctx):
+    """The N>1 code path (chunked LDE -> async all_to_all_single -> repack -> subtree -> all_gather -> top levels)
+    through REAL RCCL calls, on a communicator of one rank: the exchange degenerates to self-copies, but the
+    collective API use, the split sizes, the stream ordering between the library's kernels and the collectives and
+    the buffer layouts are the ones bench.py runs with at N = 2/4/8."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from shard import ShardPlan, lde_merkle_sharded
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, ncols = 1 << 12, 150
+        n_ext = 2 * n
+        plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=1, rank=0)
+        assert plan.n_chunks == 3                      # 64 + 64 + 22 columns
+        trace = ctx.empty(n * ncols)
+        ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, 0x5EED0003)
+        bufs = {"ext": ctx.empty(n_ext * ncols), "nodes": ctx.empty((2 * n_ext - 1) * 4), "recv": ctx.empty(n_ext * ncols),
+                "roots": ctx.empty(4)}
+
+        class Ops:
+            @staticmethod
+            def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+                ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+
+            copy_2d = staticmethod(ctx.copy_2d)
+            merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
+            merkle_levels = staticmethod(ctx.merkle_levels)
+
+        for _ in range(2):                              # twice: buffers are reused across steps like in bench.py
+            root = lde_merkle_sharded(plan, Ops, dist, trace, bufs, always_exchange=True)
+            torch.cuda.synchronize()
+        want = glo.merkletree(glo.extend_pol(ctx.to_host(trace).reshape(n, ncols), n_ext, n, ncols), ncols, n_ext)
+        assert np.array_equal(ctx.to_host(root), want[-4:])
+        assert np.array_equal(ctx.to_host(bufs["nodes"]), want)
+    finally:
+        dist.destroy_process_group()

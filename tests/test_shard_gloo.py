@@ -20,7 +20,39 @@ def test_column_partition():
         assert parts[0][0] == 0 and sum(x[1] for x in parts) == nc
         assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
     p = ShardPlan(n=8, n_ext=16, ncols=7, world=2, rank=1)
-    assert p.send_splits == [8 * 3, 8 * 3] and p.recv_splits == [8 * 4, 8 * 3] and (p.col0, p.my_cols) == (4, 3)
+    assert (p.col0, p.my_cols) == (4, 3) and p.chunks == [[4], [3]] and p.n_chunks == 1
+    assert p.send_block(0, 0) == (0, 8 * 3) and p.send_block(0, 1) == (8 * 3, 8 * 3)
+    assert p.recv_slab(0, 0) == (0, 8 * 4) and p.recv_slab(0, 1) == (8 * 4, 8 * 3)
+
+
+def test_pipeline_chunks_and_exchange_layout():
+    """Every rank derives the same number of pipeline chunks; the send blocks tile bufs['ext'] and the receive slabs
+    tile bufs['recv'] without gaps or overlaps; a rank with fewer chunks takes part with an empty block."""
+    from shard import pipeline_chunks
+    assert pipeline_chunks(84, 84) == [32, 32, 20] and pipeline_chunks(83, 84) == [32, 32, 19]
+    assert pipeline_chunks(333, 333) == [96, 96, 96, 45] and pipeline_chunks(33, 33) == [32, 1] and pipeline_chunks(32, 33) == [32]
+    for (ncols, world) in ((665, 8), (665, 2), (65, 2), (13, 4), (128, 8), (5, 4)):
+        plans = [ShardPlan(n=64, n_ext=128, ncols=ncols, world=world, rank=r) for r in range(world)]
+        assert len({p.n_chunks for p in plans}) == 1 and plans[0].n_chunks <= 4
+        for p in plans:
+            assert sum(p.chunks[p.rank]) == p.my_cols
+            sent = sorted(p.send_block(k, peer) for k in range(p.n_chunks) for peer in range(world))
+            pos = 0
+            for off, cnt in sent:
+                if cnt:
+                    assert off == pos
+                    pos += cnt
+            assert pos == p.n_ext * p.my_cols
+            got = sorted(p.recv_slab(k, peer) for k in range(p.n_chunks) for peer in range(world))
+            pos = 0
+            for off, cnt in got:
+                if cnt:
+                    assert off == pos
+                    pos += cnt
+            assert pos == p.rows_per_rank * ncols
+            for k in range(p.n_chunks):   # what I send to a peer is what that peer expects from me
+                for peer in plans:
+                    assert p.send_block(k, peer.rank)[1] == peer.recv_slab(k, p.rank)[1]
 
 
 class OracleOps:
@@ -31,9 +63,14 @@ class OracleOps:
         return t.numpy().view(np.uint64)
 
     @staticmethod
-    def lde(out, inp, n_ext, n, ncols):
-        o = glo.extend_pol(OracleOps._np(inp)[:n * ncols].reshape(n, ncols), n_ext, n, ncols)
-        OracleOps._np(out)[:n_ext * ncols] = o.reshape(-1)
+    def lde(out, inp, n_ext, n, ncols, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+        out_pitch, in_pitch = out_pitch or ncols, in_pitch or ncols
+        src = OracleOps._np(inp)[in_off:in_off + (n - 1) * in_pitch + ncols]
+        cols = np.stack([src[r * in_pitch:r * in_pitch + ncols] for r in range(n)])
+        o = glo.extend_pol(np.ascontiguousarray(cols), n_ext, n, ncols)
+        dst = OracleOps._np(out)
+        for r in range(n_ext):
+            dst[out_off + r * out_pitch:out_off + r * out_pitch + ncols] = o[r]
 
     @staticmethod
     def copy_2d(dst, src, nrows, ncols, dst_pitch, src_pitch, dst_off=0, src_off=0):
@@ -59,6 +96,9 @@ class OracleOps:
 
 
 def _worker(rank, world, port, n, ncols, q):
+    import shard
+    if ncols == 70:
+        shard.MAX_MSG_BYTES = 8 * 100      # many message rounds per chunk (the production cap is 256 MiB)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -84,7 +124,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,ncols", [(2, 7), (4, 13)])
+@pytest.mark.parametrize("world,ncols", [(2, 7), (4, 13), (2, 70), (2, 65)])
 def test_sharded_path_reproduces_single_process_tree(world, ncols):
     n = 64
     full = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
