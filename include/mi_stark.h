@@ -83,6 +83,17 @@ int mi_poseidon_permute_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *in, uint
 /* digests[r*4..] = linear_hash(row r)  (device) */
 int mi_linear_hash_rows_dev(mi_ctx *ctx, uint64_t *digests, const uint64_t *src, uint64_t pitch,
                             uint64_t ncols, uint64_t nrows);
+/* Streaming form of the same sponge, for rows whose columns arrive in pieces (the row-sharded multi-GPU path
+ * receives one column window per peer and per pipeline round and never repacks them): absorbs, for every row r,
+ * the columns of nwindows column windows in order -- window i holds widths[i] consecutive columns, row r at
+ * bases[i] + r * pitches[i] (device pointers; the three arrays themselves are host arrays of nwindows entries,
+ * nwindows <= 16) -- into the running capacity kept in digests[r*4..].  first != 0: start from the zero capacity
+ * (the row's first columns); final != 0: these are the row's last columns, only then may the last window's width
+ * be other than a multiple of 8.  After the final call digests[r*4..] = linear_hash(row r) provided the row has
+ * more than 4 columns in total (linear_hash copies shorter rows instead of hashing them: use the entry point
+ * above for those). */
+int mi_linear_hash_absorb_dev(mi_ctx *ctx, uint64_t *digests, uint32_t nwindows, const uint64_t *const *bases,
+                              const uint64_t *pitches, const uint64_t *widths, uint64_t nrows, int first, int final);
 /* nodes: (2*nrows-1)*4 u64, leaves first then each level appended, root = last 4
  * (merkleTreeGL.hpp:61-68).  nrows must be a power of two. */
 int mi_merkle_build_dev(mi_ctx *ctx, uint64_t *nodes, const uint64_t *src, uint64_t pitch,

@@ -254,6 +254,16 @@ extern "C" int mi_linear_hash_rows_dev(mi_ctx *c, uint64_t *digests, const uint6
     return launch_linear_hash_rows(c, (u64 *)digests, (const u64 *)src, pitch, ncols, nrows);
 }
 
+extern "C" int mi_linear_hash_absorb_dev(mi_ctx *c, uint64_t *digests, uint32_t nwindows, const uint64_t *const *bases,
+                                         const uint64_t *pitches, const uint64_t *widths, uint64_t nrows, int first, int final)
+{
+    CTX_OK(c);
+    MI_REQUIRE(nrows == 0 || nwindows == 0 || (digests && bases && pitches && widths), "null buffer");
+    for (uint32_t i = 0; i < nwindows && nrows; i++) MI_REQUIRE(bases[i] || widths[i] == 0, "null column window");
+    return launch_linear_hash_absorb(c, (u64 *)digests, nwindows, (const u64 *const *)bases, pitches, widths, nrows, first != 0,
+                                     final != 0);
+}
+
 extern "C" int mi_poseidon_linear_hash(mi_ctx *c, uint64_t out[4], const uint64_t *in, uint64_t size)
 {
     CTX_OK(c);

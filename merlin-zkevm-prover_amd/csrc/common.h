@@ -33,6 +33,17 @@ void mi_set_error(const char *fmt, ...);
         if (s_ != MI_OK) return s_; \
     } while (0)
 
+// Column windows ("slabs") of the rows a leaf-hash launch absorbs, in order: window i holds `width[i]` consecutive
+// columns of every row, row r at base[i] + r * pitch[i] (kernel argument, so a plain aggregate).
+#define MI_MAX_SLABS 16
+struct LeafSlabs {
+    const u64 *base[MI_MAX_SLABS];
+    uint64_t pitch[MI_MAX_SLABS];
+    uint32_t width[MI_MAX_SLABS];
+    uint32_t nslabs;
+    uint32_t carry_in; // 1: the sponge capacity starts from digests[row] (earlier columns were absorbed by an earlier launch)
+};
+
 // Two-level power table: g^e = hi[e >> lo_bits] * lo[e & mask]   (lo[j] = s0 * g^j, hi[j] = g^(j << lo_bits))
 struct PowTable {
     u64 *lo = nullptr, *hi = nullptr;
@@ -80,6 +91,8 @@ static inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 // ---- internal launchers (defined in the .hip files)
 int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count);
 int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows);
+int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const u64 *const *bases, const uint64_t *pitches,
+                              const uint64_t *widths, uint64_t nrows, bool first, bool final);
 int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves);
 int launch_group_proofs(mi_ctx *ctx, u64 *proofs, const u64 *nodes, const u64 *src, uint64_t pitch, uint64_t height,
                         uint64_t width, const u64 *idx_dev, uint64_t nq);

@@ -135,9 +135,14 @@ __device__ __forceinline__ void line_fetch(ulonglong2 *wave_ring, uint32_t lane,
 // every requested line has landed in LDS (LDS-direct loads are counted by vmcnt) and is visible to the reads below
 __device__ __forceinline__ void lines_landed() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
+// The columns of a row may come from several "slabs" (column windows stored as separate row-major matrices: the
+// row-sharded multi-GPU path receives one slab per peer and never repacks them), absorbed in order; a plain matrix
+// is one slab.  carry_in: the sponge capacity starts from digests[row] -- an earlier call absorbed the columns
+// before these -- instead of zero.  Only the last slab may have a width that is not a multiple of 8 (zero padding
+// exists at the end of a row only).
 template <int MDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_hash_rows_lines(
-    u64 *__restrict__ digests, const u64 *__restrict__ src, uint64_t pitch, uint32_t ncols, uint64_t nrows)
+    u64 *__restrict__ digests, const LeafSlabs sl, uint64_t nrows)
 {
     __shared__ ulonglong2 ring[(LEAF_RING / 2) * 256]; // [pair][thread]
     const uint32_t lane = threadIdx.x & 63;
@@ -145,51 +150,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
     const uint64_t row = (gw >> 4) * 1024 + (uint64_t)lane * 16 + (gw & 15);
     const bool active = row < nrows;
-    const u64 *lo = src, *hi = src + (nrows - 1) * pitch + ncols;
-    const u64 *p = src + (active ? row : (gw & 15)) * pitch; // idle lanes shadow a valid row of the same residue class
-    // offset of the row inside its 128-byte line, in elements: identical in every lane of the wave
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((uintptr_t)p >> 3) & 15));
-    const u64 *lp = p - o;         // the row's line stream: element e of the stream is lp[e], the row is [o, end)
-    const uint32_t end = o + ncols;
+    const uint64_t srow = active ? row : (gw & 15); // idle lanes shadow a valid row of the same residue class
     ulonglong2 *wave_ring = ring + wave * 64;
     const u64 *my = reinterpret_cast<const u64 *>(wave_ring + lane); // element in slot a: my[(a >> 1) * 512 + (a & 1)]
-    uint32_t fetched = 0, f24 = 0; // the ring holds stream elements [pos, fetched); f24 = fetched mod 24
     u64 s[12];
-    auto fetch_next = [&]() { // request stream elements [fetched, fetched + 16)
-        line_fetch(wave_ring, lane, f24, lp + fetched, lo, hi);
-        fetched += 16;
-        f24 = f24 + 16 >= LEAF_RING ? f24 + 16 - LEAF_RING : f24 + 16;
-    };
-    fetch_next();
-    if (o > 8 && end > 16) fetch_next(); // the first block already crosses into the second line (occupancy 32 - o <= 23)
-    uint32_t p24 = o; // pos mod 24
+    if (sl.carry_in) {
+        const ulonglong2 *c2 = reinterpret_cast<const ulonglong2 *>(digests + srow * 4);
+        const ulonglong2 c0 = c2[0], c1 = c2[1];
+        s[8] = c0.x, s[9] = c0.y, s[10] = c1.x, s[11] = c1.y;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; i++) s[8 + i] = 0;
-    for (uint32_t pos = o; pos < end; pos += 8) {
-        lines_landed();
+        for (int i = 0; i < 4; i++) s[8 + i] = 0;
+    }
+    for (uint32_t si = 0; si < sl.nslabs; si++) {
+        const u64 *src = sl.base[si];
+        const uint64_t pitch = sl.pitch[si];
+        const uint32_t ncols = sl.width[si];
+        const u64 *lo = src, *hi = src + (nrows - 1) * pitch + ncols;
+        const u64 *p = src + srow * pitch;
+        // offset of the row inside its 128-byte line, in elements: identical in every lane of the wave
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(((uintptr_t)p >> 3) & 15));
+        const u64 *lp = p - o;     // the row's line stream: element e of the stream is lp[e], the row is [o, end)
+        const uint32_t end = o + ncols;
+        uint32_t fetched = 0, f24 = 0; // the ring holds stream elements [pos, fetched); f24 = fetched mod 24
+        auto fetch_next = [&]() {      // request stream elements [fetched, fetched + 16)
+            line_fetch(wave_ring, lane, f24, lp + fetched, lo, hi);
+            fetched += 16;
+            f24 = f24 + 16 >= LEAF_RING ? f24 + 16 - LEAF_RING : f24 + 16;
+        };
+        fetch_next();
+        if (o > 8 && end > 16) fetch_next(); // the first block already crosses into the second line (occupancy 32 - o <= 23)
+        uint32_t p24 = o; // pos mod 24
+        for (uint32_t pos = o; pos < end; pos += 8) {
+            lines_landed();
 #pragma unroll
-        for (uint32_t i = 0; i < 8; i++) { // take the block; past the end of the row: zero padding
-            uint32_t a = p24 + i;
-            a = a >= LEAF_RING ? a - LEAF_RING : a;
-            s[i] = (pos + i < end) ? my[(a >> 1) * 512 + (a & 1)] : 0;
-        }
-        p24 = p24 + 8 >= LEAF_RING ? p24 + 8 - LEAF_RING : p24 + 8;
-        // fewer than 8 unconsumed elements left and the row goes on: request the next line during this permutation (it
-        // lands before the next take).  The request is issued from inside the permutation, ahead of its last four
-        // rounds: ~10 us of arithmetic follow, enough to hide the HBM latency.
-        const bool want = (int32_t)(fetched - pos - 8) < 8 && fetched < end;
-        pos::permute<MDS, 0>(s, c_rc, &c_sparse, [&]() {
-            if (want) fetch_next();
-        });
-        if (pos + 8 < end) {
+            for (uint32_t i = 0; i < 8; i++) { // take the block; past the end of the row: zero padding
+                uint32_t a = p24 + i;
+                a = a >= LEAF_RING ? a - LEAF_RING : a;
+                s[i] = (pos + i < end) ? my[(a >> 1) * 512 + (a & 1)] : 0;
+            }
+            p24 = p24 + 8 >= LEAF_RING ? p24 + 8 - LEAF_RING : p24 + 8;
+            // fewer than 8 unconsumed elements left and the row goes on: request the next line during this permutation
+            // (it lands before the next take).  The request is issued from inside the permutation, ahead of its last
+            // four rounds: ~10 us of arithmetic follow, enough to hide the HBM latency.
+            const bool want = (int32_t)(fetched - pos - 8) < 8 && fetched < end;
+            pos::permute<MDS, 0>(s, c_rc, &c_sparse, [&]() {
+                if (want) fetch_next();
+            });
 #pragma unroll
-            for (int i = 0; i < 4; i++) s[8 + i] = s[i];
+            for (int i = 0; i < 4; i++) s[8 + i] = s[i]; // capacity of the next block = this digest
         }
     }
     if (active) {
         ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(digests + row * 4);
-        o2[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
-        o2[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
+        o2[0] = make_ulonglong2(gl::canon(s[8]), gl::canon(s[9]));
+        o2[1] = make_ulonglong2(gl::canon(s[10]), gl::canon(s[11]));
     }
 }
 
@@ -267,24 +282,60 @@ int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count)
     });
 }
 
+static int launch_leaf_slabs(mi_ctx *ctx, u64 *digests, const LeafSlabs &sl, uint64_t nrows)
+{
+    const uint64_t waves = ((nrows + 1023) / 1024) * 16;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    return by_variant(ctx, [&](auto v) {
+        hipLaunchKernelGGL((k_linear_hash_rows_lines<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, digests, sl, nrows);
+    });
+}
+
 int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows)
 {
     if (nrows == 0) return MI_OK;
     MI_REQUIRE(ncols < (1ull << 30), "ncols too large");
     MI_REQUIRE(nrows < (1ull << 39), "nrows too large");
     if (ncols > 4 && ctx->leaf_line_aligned) {
-        const uint64_t waves = ((nrows + 1023) / 1024) * 16;
-        const unsigned grid = (unsigned)((waves + 3) / 4);
-        return by_variant(ctx, [&](auto v) {
-            hipLaunchKernelGGL((k_linear_hash_rows_lines<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, digests, src,
-                               pitch, (uint32_t)ncols, nrows);
-        });
+        LeafSlabs sl = {};
+        sl.base[0] = src;
+        sl.pitch[0] = pitch;
+        sl.width[0] = (uint32_t)ncols;
+        sl.nslabs = 1;
+        return launch_leaf_slabs(ctx, digests, sl, nrows);
     }
     const unsigned grid = (unsigned)((nrows + 255) / 256);
     return by_variant(ctx, [&](auto v) {
         hipLaunchKernelGGL((k_linear_hash_rows<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, digests, src, pitch,
                            (uint32_t)ncols, nrows);
     });
+}
+
+// Streaming form of the leaf sponge: absorbs the next columns of every row, given as nslabs column windows, into
+// the running capacity kept in digests[row].  first: the capacity starts at zero; final: these are the row's last
+// columns (only then may the last window's width be other than a multiple of 8).
+int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const u64 *const *bases, const uint64_t *pitches,
+                              const uint64_t *widths, uint64_t nrows, bool first, bool final)
+{
+    if (nrows == 0 || nslabs == 0) return MI_OK;
+    MI_REQUIRE(nslabs <= MI_MAX_SLABS, "too many column windows in one call");
+    MI_REQUIRE(nrows < (1ull << 39), "nrows too large");
+    LeafSlabs sl = {};
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < nslabs; i++) {
+        if (widths[i] == 0) continue; // an empty window contributes nothing
+        MI_REQUIRE(widths[i] < (1ull << 30) && pitches[i] >= widths[i], "bad column window");
+        sl.base[k] = bases[i];
+        sl.pitch[k] = pitches[i];
+        sl.width[k] = (uint32_t)widths[i];
+        k++;
+    }
+    if (k == 0) return MI_OK;
+    for (uint32_t i = 0; i + 1 < k; i++) MI_REQUIRE(sl.width[i] % 8 == 0, "only a row's last column window may have a width that is not a multiple of 8");
+    MI_REQUIRE(final || sl.width[k - 1] % 8 == 0, "a window that is not the row's last must have a width that is a multiple of 8");
+    sl.nslabs = k;
+    sl.carry_in = first ? 0 : 1;
+    return launch_leaf_slabs(ctx, digests, sl, nrows);
 }
 
 int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)

@@ -48,7 +48,7 @@ EXPORTS = [
     "mi_last_error", "mi_version", "mi_device_count",
     "mi_ntt_dev", "mi_lde_dev", "mi_ntt", "mi_lde",
     "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
-    "mi_linear_hash_rows_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
+    "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
     "mi_merkle_group_proofs_dev",
     "mi_fri_fold_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
@@ -144,6 +144,15 @@ class Context:
 
     def linear_hash_rows(self, digests, src, ncols, nrows, pitch=None, src_off=0):
         _check(lib().mi_linear_hash_rows_dev(self.h, _dp(digests), _dp(src, src_off), u64(pitch or ncols), u64(ncols), u64(nrows)))
+
+    def linear_hash_absorb(self, digests, windows, nrows, first, final):
+        """windows: [(tensor, element_offset, width, pitch)] column windows absorbed in order (see mi_stark.h)."""
+        k = len(windows)
+        bases = (ctypes.c_void_p * k)(*[t.data_ptr() + 8 * off for (t, off, w, p) in windows])
+        pitches = (ctypes.c_uint64 * k)(*[p for (t, off, w, p) in windows])
+        widths = (ctypes.c_uint64 * k)(*[w for (t, off, w, p) in windows])
+        _check(lib().mi_linear_hash_absorb_dev(self.h, _dp(digests), ctypes.c_uint32(k), bases, pitches, widths, u64(nrows),
+                                               ctypes.c_int(int(first)), ctypes.c_int(int(final))))
 
     def merkle_build(self, nodes, src, ncols, nrows, pitch=None, src_off=0):
         _check(lib().mi_merkle_build_dev(self.h, _dp(nodes), _dp(src, src_off), u64(pitch or ncols), u64(ncols), u64(nrows)))

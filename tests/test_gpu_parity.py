@@ -94,6 +94,34 @@ def test_linear_hash_rows_line_ring_corner_cases(ctx):
             assert np.array_equal(got[r], glo.linear_hash(np.ascontiguousarray(rows[r, :w]))), (h, w, pitch, off, r)
 
 
+def test_linear_hash_absorb_column_windows(ctx):
+    """Streaming leaf sponge: the columns of a row arrive as separate column windows (own pitch, own base), over
+    several calls; the result must equal linear_hash of the concatenated row."""
+    import mi_stark
+    rng = np.random.default_rng(4321)
+    for (h, widths_per_call) in [(70, [[32, 32, 32], [32, 25]]), (1100, [[8], [16, 8], [3]]), (33, [[64, 32, 19]]),
+                                 (5, [[40], [40], [40], [7]]), (2050, [[32, 32], [32, 20]]), (17, [[8, 0, 8], [0], [16, 1]])]:
+        cols = [glo.rand_fe(rng, (h, w + 2)) for call in widths_per_call for w in call]     # each window: pitch = w + 2
+        flat = [w for call in widths_per_call for w in call]
+        row_cat = np.concatenate([c[:, :w] for c, w in zip(cols, flat)], axis=1)
+        dev = [ctx.to_device(np.concatenate([np.zeros(3, dtype=np.uint64), c.reshape(-1)])) for c in cols]   # base offset 3
+        dig = ctx.zeros(h * 4)
+        i = 0
+        for ci, call in enumerate(widths_per_call):
+            wins = [(dev[i + j], 3, w, w + 2) for j, w in enumerate(call)]
+            ctx.linear_hash_absorb(dig, wins, h, first=(ci == 0), final=(ci == len(widths_per_call) - 1))
+            i += len(call)
+        got = ctx.to_host(dig).reshape(h, 4)
+        for r in list(range(min(h, 30))) + list(range(max(0, h - 30), h)):
+            assert np.array_equal(got[r], glo.linear_hash(np.ascontiguousarray(row_cat[r]))), (h, widths_per_call, r)
+    with pytest.raises(mi_stark.MiStarkError):     # a window that is not the row's last must be a multiple of 8 wide
+        d = ctx.zeros(8 * 12)
+        ctx.linear_hash_absorb(ctx.zeros(8 * 4), [(d, 0, 12, 12)], 8, first=True, final=False)
+    with pytest.raises(mi_stark.MiStarkError):
+        d = ctx.zeros(8 * 20)
+        ctx.linear_hash_absorb(ctx.zeros(8 * 4), [(d, 0, 12, 12), (d, 0, 8, 8)], 8, first=True, final=True)
+
+
 @pytest.mark.parametrize("h,w", [(1, 5), (2, 3), (4, 1), (8, 9), (64, 18), (512, 21), (1024, 6), (2048, 39), (4096, 4), (1 << 13, 12)])
 def test_merkle_tree_matches_oracle(ctx, h, w):
     rng = np.random.default_rng(h + w)
