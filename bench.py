@@ -6,9 +6,10 @@ Workload (BASELINE.json configs[2], the configuration the metric "field-elements
 in HBM -> LDE to 2^24 rows (blow-up 2) -> Poseidon Merkle tree of the extended trace.  One "step" = one full
 pass over that trace.  value = trace field elements (rows x cols of the INPUT) per second, whole job.
 
-N > 1 (one process per GPU, torch.distributed over RCCL): committed columns are sharded for the LDE, one
-all-to-all turns column shards into row shards, each GPU hashes its rows, subtree roots are all-gathered
-(merlin-zkevm-prover_amd/shard.py).  Total work is fixed -> "scaling": "strong".
+N > 1 (one process per GPU, torch.distributed over RCCL): 32-column tiles of the trace are dealt round-robin to the
+ranks; each round a rank extends one tile, ships every peer its rows of it (batched isend/irecv) and absorbs the
+previous round's columns of its own rows into the leaf sponges, so exchange and arithmetic overlap; subtree roots
+are all-gathered (merlin-zkevm-prover_amd/shard.py).  Total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus "roofline" and "cpu_baseline".
 """
@@ -23,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "merlin-zkevm-prover_amd"))
 
 # Merkle root of the default workload (2^23 x 665, seed 0x5EED0003) as computed by the single-GPU path; every
 # N > 1 run must reproduce it (the sharded path is bit-identical by construction).
-ROOT_2P23_X665 = [1687745183620725494, 6203522448509826964, 3423305870569619816, 5297016707118823433]
+ROOT_2P23_X665 = [17877856175459861405, 3297257765296605804, 13052643778398375791, 11912701812281293778]
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T full-rate lane-ops/s
@@ -128,21 +129,33 @@ def main():
     plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=rank)
 
     # ---- device-resident buffers (HBM layout: DESIGN.md "Data layout")
-    trace = ctx.empty(n * plan.my_cols)
-    ctx.fill_synthetic_2d(trace, n, plan.my_cols, ncols, plan.col0, 0x5EED0003)
-    bufs = {"ext": ctx.empty(max(n_ext * plan.max_cols, plan.rows_per_rank * ncols)),
-            "nodes": ctx.empty((2 * plan.rows_per_rank - 1) * 4)}
     exchange = world > 1 or args.force_exchange
     if exchange:
-        bufs["recv"] = ctx.empty(plan.rows_per_rank * ncols)
-        bufs["roots"] = ctx.empty((2 * world - 1) * 4)
+        # my tiles of the synthetic trace (tile t = columns [32 t, 32 t + 32), dealt round-robin), packed side by side
+        trace = ctx.empty(n * max(plan.my_cols, 1))
+        for k, t in enumerate(plan.my_tiles):
+            c0, w = plan.tile_cols(t)
+            ctx.fill_synthetic_2d(trace, n, w, ncols, c0, 0x5EED0003, out_pitch=plan.my_cols, out_off=plan.local_col(k))
+        bufs = {"ext": ctx.empty(plan.ext_elems()), "recv": ctx.empty(plan.recv_elems()),
+                "nodes": ctx.empty((2 * plan.rows_per_rank - 1) * 4), "roots": ctx.empty((2 * world - 1) * 4)}
+    else:
+        trace = ctx.empty(n * ncols)
+        ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, 0x5EED0003)
+        bufs = {"ext": ctx.empty(n_ext * ncols), "nodes": ctx.empty((2 * n_ext - 1) * 4)}
+
+    # HIP-event timer slots: 0..2 the three phases of the single-GPU path; 8+k / 36+k the LDE / absorb of pipeline round k
+    LDE_SLOT0, ABSORB_SLOT0 = 8, 36
+    assert plan.n_rounds <= 28
 
     class Ops:
         @staticmethod
         def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
             ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
 
-        copy_2d = staticmethod(ctx.copy_2d)
+        @staticmethod
+        def absorb(digests, windows, nrows, first, final, chunk=0):
+            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
+
         merkle_levels = staticmethod(ctx.merkle_levels)
 
         @staticmethod
@@ -155,18 +168,33 @@ def main():
             ctx.merkle_levels(nodes, rows)
             ctx.timer_stop(2)
 
-    t_lde = t_leaf = t_lvls = 0.0
-
-    LDE_SLOT0 = 3   # one HIP-event timer per pipeline chunk (world > 1: up to shard.PIPE_DEPTH LDE calls per step)
-
     class OpsTimed(Ops):
         @staticmethod
         def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
-            ctx.timer_start(LDE_SLOT0 + chunk)
+            slot = LDE_SLOT0 + chunk if exchange else 0
+            ctx.timer_start(slot)
             ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
-            ctx.timer_stop(LDE_SLOT0 + chunk)
+            ctx.timer_stop(slot)
 
-    lde_calls = [k for k in range(plan.n_chunks) if plan.chunk_width(rank, k)] if exchange else [0]
+        @staticmethod
+        def absorb(digests, windows, nrows, first, final, chunk=0):
+            ctx.timer_start(ABSORB_SLOT0 + chunk)
+            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
+            ctx.timer_stop(ABSORB_SLOT0 + chunk)
+
+        @staticmethod
+        def merkle_levels(nodes, nleaves):
+            if nleaves == plan.rows_per_rank:        # my subtree (the top levels over the G roots are not timed apart)
+                ctx.timer_start(2)
+                ctx.merkle_levels(nodes, nleaves)
+                ctx.timer_stop(2)
+            else:
+                ctx.merkle_levels(nodes, nleaves)
+
+    lde_rounds = [k for k in range(plan.n_rounds) if plan.width(k, rank)] if exchange else []
+    absorb_rounds = list(range(plan.n_rounds)) if exchange else []
+
+    t_lde = t_leaf = t_lvls = 0.0
 
     def barrier():
         if dist is not None:
@@ -183,8 +211,12 @@ def main():
         # HIP-event readings need the stop events complete; reading them after the loop would only see the
         # last step, so accumulate per step (the sync this implies is inside the timed region on purpose:
         # it costs microseconds against a ~1 s step and keeps per-kernel times honest)
-        t_lde += sum(ctx.timer_ms(LDE_SLOT0 + k) for k in lde_calls)
-        t_leaf += ctx.timer_ms(1)
+        if exchange:
+            t_lde += sum(ctx.timer_ms(LDE_SLOT0 + k) for k in lde_rounds)
+            t_leaf += sum(ctx.timer_ms(ABSORB_SLOT0 + k) for k in absorb_rounds)
+        else:
+            t_lde += ctx.timer_ms(0)
+            t_leaf += ctx.timer_ms(1)
         t_lvls += ctx.timer_ms(2)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -203,7 +235,8 @@ def main():
         leaf_bytes = 8.0 * rows_local * ncols + 32.0 * rows_local
         leaf_ms = t_leaf / K
         perms = rows_local * ((ncols + 7) // 8 if ncols > 4 else 0)
-        lde_bytes = 8.0 * n * plan.my_cols + 8.0 * n_ext * plan.my_cols
+        my_cols = plan.my_cols if exchange else ncols
+        lde_bytes = 8.0 * n * my_cols + 8.0 * n_ext * my_cols
         lde_ms = t_lde / K
         achieved = leaf_bytes / (leaf_ms * 1e-3) / 1e9 if leaf_ms > 0 else 0.0
         out = {
@@ -213,7 +246,7 @@ def main():
             "vs_baseline": None, "dtype": "u64 (Goldilocks mod 2^64-2^32+1, 32-bit integer VALU)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 2^%d-row x %d-col trace -> LDE blow-up 2 -> Poseidon Merkle tree"
                                    % (args.log_n, ncols),
-                       "rows": n, "cols": ncols, "rows_ext": n_ext, "parallelism": "col-shard LDE -> all-to-all -> row-shard Merkle x%d" % world,
+                       "rows": n, "cols": ncols, "rows_ext": n_ext, "parallelism": "tile-cyclic column-shard LDE -> pipelined point-to-point exchange -> row-shard streaming Merkle x%d" % world,
                        "poseidon_variant": args.poseidon_variant},
             "root": root_host,
             "root_matches_single_gpu_run": (root_host == ROOT_2P23_X665) if (args.log_n == 23 and ncols == 665) else None,

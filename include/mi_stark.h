@@ -154,8 +154,7 @@ int mi_fill_synthetic_dev(mi_ctx *ctx, uint64_t *out, uint64_t count, uint64_t s
  * (r, col0 + c) of a matrix with global_cols columns, so any column partition reproduces one trace. */
 int mi_fill_synthetic_2d_dev(mi_ctx *ctx, uint64_t *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols,
                              uint64_t global_cols, uint64_t col0, uint64_t seed);
-/* dst[r*dst_pitch + c] = canonical(src[r*src_pitch + c]): repacks the column slabs received in the
- * multi-GPU columns->rows exchange into row-major rows. */
+/* dst[r*dst_pitch + c] = canonical(src[r*src_pitch + c]): strided 2-D copy (column windows <-> row-major rows). */
 int mi_copy_2d_dev(mi_ctx *ctx, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch,
                    uint64_t nrows, uint64_t ncols);
 void *mi_dev_alloc(mi_ctx *ctx, uint64_t bytes);

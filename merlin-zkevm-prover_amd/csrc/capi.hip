@@ -57,7 +57,7 @@ extern "C" int mi_ctx_create(mi_ctx **out, int device)
     c->stream = nullptr; // the device's default stream until the caller hands one over
     c->own_stream = false;
     MI_HIP_CHECK(hipMalloc((void **)&c->small, 4096));
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
         MI_HIP_CHECK(hipEventCreate(&c->ev_start[i]));
         MI_HIP_CHECK(hipEventCreate(&c->ev_stop[i]));
     }
@@ -73,7 +73,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->workspace) (void)hipFree(c->workspace);
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
     }
@@ -476,7 +476,7 @@ extern "C" int mi_copy_d2h(mi_ctx *c, void *dst, const void *src, uint64_t bytes
 extern "C" int mi_timer_start(mi_ctx *c, int slot)
 {
     CTX_OK(c);
-    MI_REQUIRE(slot >= 0 && slot < 8, "timer slot out of range");
+    MI_REQUIRE(slot >= 0 && slot < mi_ctx::N_TIMERS, "timer slot out of range");
     MI_HIP_CHECK(hipEventRecord(c->ev_start[slot], c->stream));
     return MI_OK;
 }
@@ -484,7 +484,7 @@ extern "C" int mi_timer_start(mi_ctx *c, int slot)
 extern "C" int mi_timer_stop(mi_ctx *c, int slot)
 {
     CTX_OK(c);
-    MI_REQUIRE(slot >= 0 && slot < 8, "timer slot out of range");
+    MI_REQUIRE(slot >= 0 && slot < mi_ctx::N_TIMERS, "timer slot out of range");
     MI_HIP_CHECK(hipEventRecord(c->ev_stop[slot], c->stream));
     return MI_OK;
 }
@@ -492,7 +492,7 @@ extern "C" int mi_timer_stop(mi_ctx *c, int slot)
 extern "C" int mi_timer_elapsed_ms(mi_ctx *c, int slot, float *ms)
 {
     CTX_OK(c);
-    MI_REQUIRE(slot >= 0 && slot < 8 && ms, "bad timer arguments");
+    MI_REQUIRE(slot >= 0 && slot < mi_ctx::N_TIMERS && ms, "bad timer arguments");
     MI_HIP_CHECK(hipEventSynchronize(c->ev_stop[slot]));
     MI_HIP_CHECK(hipEventElapsedTime(ms, c->ev_start[slot], c->ev_stop[slot]));
     return MI_OK;

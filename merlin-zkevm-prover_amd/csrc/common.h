@@ -33,6 +33,18 @@ void mi_set_error(const char *fmt, ...);
         if (s_ != MI_OK) return s_; \
     } while (0)
 
+// Blocks of 256 threads for an element-wise kernel over `total` elements.  A launch may not have 2^32 or more threads
+// in one grid dimension (HIP truncates the global size: a 5.6e9-element fill silently covered 1.3e9 elements), so the
+// grid is capped and the kernels below loop with stride gridDim.x * 256.
+static inline unsigned mi_grid_256(uint64_t total)
+{
+    const uint64_t blocks = (total + 255) / 256;
+    return (unsigned)(blocks < (1ull << 22) ? blocks : (1ull << 22));
+}
+
+// one thread per element, no loop in the kernel: the element count must leave the grid below 2^32 threads
+#define MI_REQUIRE_1D_GRID(total) MI_REQUIRE((uint64_t)(total) < (1ull << 32) - 1024, "too many elements for one launch")
+
 // Column windows ("slabs") of the rows a leaf-hash launch absorbs, in order: window i holds `width[i]` consecutive
 // columns of every row, row r at base[i] + r * pitch[i] (kernel argument, so a plain aggregate).
 #define MI_MAX_SLABS 16
@@ -69,7 +81,8 @@ struct mi_ctx {
     u64 *small = nullptr; // 4 KiB device scratch for host-pointer single hashes
     std::map<uint32_t, NttPlan> plans;
     std::vector<void *> owned; // tables to free
-    hipEvent_t ev_start[8] = {}, ev_stop[8] = {};
+    static constexpr int N_TIMERS = 64;
+    hipEvent_t ev_start[N_TIMERS] = {}, ev_stop[N_TIMERS] = {};
     int cu_count = 256;
     bool leaf_line_aligned = true; // leaf sponge fetches whole aligned 128-byte lines (k_linear_hash_rows_lines)
     bool lde_fuse_mid = true; // extendPol: last INTT pass and first NTT pass in one kernel (k_lde_mid) when the splits line up

@@ -150,6 +150,7 @@ int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n
     MI_REQUIRE(qdeg >= 1 && (uint64_t)qdeg * n <= n_ext, "qdeg * n must not exceed n_ext");
     const u64 shift_in = gl::pow(gl::inv(49), n);
     const uint64_t tot = n_ext * qdeg;
+    MI_REQUIRE_1D_GRID(tot);
     hipLaunchKernelGGL(k_q_split, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, qq2, qq1, n, n_ext,
                        (uint32_t)qdeg, shift_in);
     MI_HIP_CHECK(hipGetLastError());
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void k_batch_inverse3(u64 *res, const u64 *src
 int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n)
 {
     if (!n) return MI_OK;
+    MI_REQUIRE_1D_GRID(n);
     hipLaunchKernelGGL(k_batch_inverse3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, res, src, n);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256) void k_geom_seq(u64 *out, uint64_t n, u64 star
 int launch_geom_seq(mi_ctx *ctx, u64 *out, uint64_t n, u64 start, u64 ratio)
 {
     if (!n) return MI_OK;
+    MI_REQUIRE_1D_GRID(n);
     hipLaunchKernelGGL(k_geom_seq, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, n, gl::canon(start),
                        gl::canon(ratio));
     MI_HIP_CHECK(hipGetLastError());
@@ -285,6 +288,7 @@ int launch_geom_seq3(mi_ctx *ctx, u64 *out, uint64_t n, const u64 ratio[3])
 {
     if (!n) return MI_OK;
     const E3 r = {{gl::canon(ratio[0]), gl::canon(ratio[1]), gl::canon(ratio[2])}};
+    MI_REQUIRE_1D_GRID(n);
     hipLaunchKernelGGL(k_geom_seq3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, n, r);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -305,6 +309,7 @@ int launch_x_div_x_sub(mi_ctx *ctx, u64 *out, const u64 *x, uint64_t n, const u6
 {
     if (!n) return MI_OK;
     const E3 e = {{gl::canon(xi[0]), gl::canon(xi[1]), gl::canon(xi[2])}};
+    MI_REQUIRE_1D_GRID(n);
     hipLaunchKernelGGL(k_x_div_x_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, x, n, e);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(256) void k_zhinv(u64 *out, uint64_t cnt, u64 sn, u
 
 int launch_zhinv(mi_ctx *ctx, u64 *out, uint64_t cnt, u64 sn, u64 w)
 {
+    MI_REQUIRE_1D_GRID(cnt);
     hipLaunchKernelGGL(k_zhinv, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, out, cnt, sn, w);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -325,20 +331,20 @@ int launch_zhinv(mi_ctx *ctx, u64 *out, uint64_t cnt, u64 sn, u64 w)
 
 __global__ __launch_bounds__(256) void k_fill_synthetic(u64 *out, uint64_t count, u64 seed)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL; // splitmix64
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z ^= z >> 31;
-    out[i] = gl::canon(z);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL; // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        out[i] = gl::canon(z);
+    }
 }
 
 int launch_fill_synthetic(mi_ctx *ctx, u64 *out, uint64_t count, u64 seed)
 {
     if (!count) return MI_OK;
     MI_REQUIRE(count < (1ull << 39), "count too large");
-    hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, out, count, seed);
+    hipLaunchKernelGGL(k_fill_synthetic, dim3(mi_grid_256(count)), dim3(256), 0, ctx->stream, out, count, seed);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
@@ -346,14 +352,14 @@ int launch_fill_synthetic(mi_ctx *ctx, u64 *out, uint64_t count, u64 seed)
 __global__ __launch_bounds__(256) void k_fill_synthetic_2d(u64 *out, uint64_t out_pitch, uint64_t nrows, uint32_t ncols,
                                                            uint64_t global_cols, uint64_t col0, u64 seed)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nrows * ncols) return;
-    const uint64_t r = i / ncols, c = i % ncols;
-    u64 z = seed + (r * global_cols + col0 + c + 1) * 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z ^= z >> 31;
-    out[r * out_pitch + c] = gl::canon(z);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nrows * ncols; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / ncols, c = i % ncols;
+        u64 z = seed + (r * global_cols + col0 + c + 1) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        out[r * out_pitch + c] = gl::canon(z);
+    }
 }
 
 int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols, uint64_t global_cols,
@@ -362,7 +368,7 @@ int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t
     const uint64_t tot = nrows * ncols;
     if (!tot) return MI_OK;
     MI_REQUIRE(tot < (1ull << 39) && ncols < (1ull << 31), "matrix too large");
-    hipLaunchKernelGGL(k_fill_synthetic_2d, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, out, out_pitch, nrows,
+    hipLaunchKernelGGL(k_fill_synthetic_2d, dim3(mi_grid_256(tot)), dim3(256), 0, ctx->stream, out, out_pitch, nrows,
                        (uint32_t)ncols, global_cols, col0, seed);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;

@@ -497,7 +497,7 @@ static int launch_pass(mi_ctx *ctx, NttPass &a, uint32_t log_r, bool inv)
     a.tj_log = tj_log;
     a.n_col_tiles = (a.ncols + (1u << tcp_log) - 1) >> tcp_log;
     a.n_tiles = (mK >> tj_log) * a.n_col_tiles;
-    MI_REQUIRE(a.n_tiles < (1ull << 31), "NTT grid too large");
+    MI_REQUIRE(a.n_tiles < (1ull << 22), "NTT grid too large"); // 512 threads each: the grid must stay below 2^32 threads
     a.w256 = ctx->w256;
     const size_t lds = (((size_t)(1u << log_r) << log_b) + 256 + ((size_t)(1u << log_r) << tj_log)) * 8;
     switch (log_r) {
@@ -602,7 +602,7 @@ static int launch_lde_mid(mi_ctx *ctx, NttPlan *p1, NttPlan *p2, const Buf &src,
     a.tj_log = tj_log;
     a.n_col_tiles = (a.ncols + (1u << tcp_log) - 1) >> tcp_log;
     a.n_tiles = (K1 >> tj_log) * a.n_col_tiles;
-    MI_REQUIRE(a.n_tiles < (1ull << 31), "LDE grid too large");
+    MI_REQUIRE(a.n_tiles < (1ull << 22), "LDE grid too large"); // 512 threads each: the grid must stay below 2^32 threads
     a.sc_lo = p1->lde_scale.lo;
     a.sc_hi = p1->lde_scale.hi;
     a.sc_lo_bits = p1->lde_scale.lo_bits;
@@ -622,10 +622,10 @@ static int launch_lde_mid(mi_ctx *ctx, NttPlan *p1, NttPlan *p2, const Buf &src,
 __global__ __launch_bounds__(256) void k_copy_canon(u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch,
                                                     uint64_t nrows, uint32_t ncols)
 {
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nrows * ncols) return;
-    uint64_t r = i / ncols, c = i % ncols;
-    dst[r * dst_pitch + c] = gl::canon(src[r * src_pitch + c]);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nrows * ncols; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / ncols, c = i % ncols;
+        dst[r * dst_pitch + c] = gl::canon(src[r * src_pitch + c]);
+    }
 }
 
 int launch_copy_2d(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols);
@@ -634,7 +634,7 @@ static int copy_canon(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src,
 {
     const uint64_t tot = nrows * ncols;
     if (!tot) return MI_OK;
-    hipLaunchKernelGGL(k_copy_canon, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dst, dst_pitch, src,
+    hipLaunchKernelGGL(k_copy_canon, dim3(mi_grid_256(tot)), dim3(256), 0, ctx->stream, dst, dst_pitch, src,
                        src_pitch, nrows, (uint32_t)ncols);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;

@@ -276,6 +276,7 @@ static int by_variant(mi_ctx *ctx, F f)
 int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count)
 {
     if (count == 0) return MI_OK;
+    MI_REQUIRE_1D_GRID(count);
     const unsigned grid = (unsigned)((count + 255) / 256);
     return by_variant(ctx, [&](auto v) {
         hipLaunchKernelGGL((k_permute<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, out, in, count);
@@ -295,7 +296,7 @@ int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t 
 {
     if (nrows == 0) return MI_OK;
     MI_REQUIRE(ncols < (1ull << 30), "ncols too large");
-    MI_REQUIRE(nrows < (1ull << 39), "nrows too large");
+    MI_REQUIRE_1D_GRID(nrows + 1024);
     if (ncols > 4 && ctx->leaf_line_aligned) {
         LeafSlabs sl = {};
         sl.base[0] = src;
@@ -319,7 +320,7 @@ int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const 
 {
     if (nrows == 0 || nslabs == 0) return MI_OK;
     MI_REQUIRE(nslabs <= MI_MAX_SLABS, "too many column windows in one call");
-    MI_REQUIRE(nrows < (1ull << 39), "nrows too large");
+    MI_REQUIRE_1D_GRID(nrows + 1024);
     LeafSlabs sl = {};
     uint32_t k = 0;
     for (uint32_t i = 0; i < nslabs; i++) {
@@ -341,6 +342,7 @@ int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const 
 int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)
 {
     MI_REQUIRE(is_pow2(nleaves), "number of leaves must be a power of two");
+    MI_REQUIRE_1D_GRID(nleaves);
     u64 *level = nodes;
     uint64_t n = nleaves;
     while (n > 512) {

@@ -247,8 +247,8 @@ class Context:
     def fill_synthetic(self, out, count, seed, off=0):
         _check(lib().mi_fill_synthetic_dev(self.h, _dp(out, off), u64(count), u64(seed)))
 
-    def fill_synthetic_2d(self, out, nrows, ncols, global_cols, col0, seed, out_pitch=None):
-        _check(lib().mi_fill_synthetic_2d_dev(self.h, _dp(out), u64(out_pitch or ncols), u64(nrows), u64(ncols),
+    def fill_synthetic_2d(self, out, nrows, ncols, global_cols, col0, seed, out_pitch=None, out_off=0):
+        _check(lib().mi_fill_synthetic_2d_dev(self.h, _dp(out, out_off), u64(out_pitch or ncols), u64(nrows), u64(ncols),
                                               u64(global_cols), u64(col0), u64(seed)))
 
     def copy_2d(self, dst, src, nrows, ncols, dst_pitch, src_pitch, dst_off=0, src_off=0):

@@ -2,51 +2,33 @@
 
 One process per GPU.  The path has exactly one real exchange step:
 
-  1. LDE is independent per column      -> rank g extends a contiguous COLUMN range of the trace;
+  1. LDE is independent per column      -> a rank extends COLUMNS of the trace;
   2. a Merkle leaf is a sponge over a whole row (linear_hash chains across all columns)
-     -> leaves need ROWS, so the extended columns are redistributed all-to-all: rank g sends peer p the
-     block rows[p] x cols[g]; with point-to-point xGMI every GPU talks to its 7 peers at once (batched
-     isend/irecv, messages of at most 256 MiB).  Steps 1 and 2 are pipelined over up to four column chunks
-     per rank: the exchange of chunk k (async, on the communicator's own stream) runs while chunk k+1 is
-     being extended;
+     -> leaves need ROWS, so the extended columns are redistributed all-to-all: a rank sends peer p the
+     rows[p] of its columns; with point-to-point xGMI every GPU talks to its 7 peers at once (batched
+     isend/irecv, messages of at most 256 MiB);
   3. rank p hashes its rows and builds the subtree over them (2^k rows -> the subtree root is one node
      of level log2(n_ext/G) of the global tree);
   4. the G subtree roots (4 u64 each) are all-gathered and every rank hashes the top log2(G) levels,
      giving the same root as a single-GPU build.
+
+Steps 1-3 are one pipeline.  Columns are dealt to the ranks in TILES of 32 (the NTT tile width), round-robin:
+tile t belongs to rank t mod G.  In round k every rank extends its k-th tile, ships it, and the G tiles of the
+round -- columns [32 G k, 32 G (k+1)), a contiguous piece of every row -- arrive at each rank as G column windows.
+Because the sponge absorbs a row's columns in order, round k's windows can be absorbed as soon as they are
+there (mi_linear_hash_absorb_dev keeps the running capacity in the digest buffer): the exchange of round k
+runs on the communicator's stream beside the LDE of round k+1 and the absorption of round k-1, and the windows
+are hashed where they land -- nothing is repacked.  The slower of "a rank's arithmetic" and "a rank's link
+traffic", not their sum, bounds a step.
 
 The compute steps are injected (`ops`), so the same orchestration runs on RCCL with the HIP library
 (bench.py) and on gloo with CPU tensors in tests/test_shard_gloo.py.
 """
 import os
 from dataclasses import dataclass
-from typing import List
 
-
-def column_partition(ncols: int, world: int) -> List[tuple]:
-    """Contiguous column ranges, sizes differing by at most one: [(col0, width)] per rank."""
-    base, rem = divmod(ncols, world)
-    out, c = [], 0
-    for g in range(world):
-        w = base + (1 if g < rem else 0)
-        out.append((c, w))
-        c += w
-    return out
-
-
-PIPE_TILE = 32      # columns per NTT tile: pipeline chunks are whole tiles
-PIPE_DEPTH = 4      # at most this many LDE -> all-to-all pipeline stages per rank
-
-
-def pipeline_chunks(width: int, max_width: int) -> List[int]:
-    """Column chunks in which a rank extends and ships its columns, so that the all-to-all of chunk k runs while
-    chunk k+1 is being extended.  The chunk width is derived from the WIDEST rank (every rank computes the same
-    value), a multiple of the NTT tile width, giving at most PIPE_DEPTH chunks; the last chunk takes the remainder."""
-    tiles = -(-max_width // PIPE_TILE)
-    cw = PIPE_TILE * -(-tiles // PIPE_DEPTH)
-    out = [cw] * (width // cw)
-    if width % cw:
-        out.append(width % cw)
-    return out
+# cap of one point-to-point message (see phase_exchange)
+MAX_MSG_BYTES = int(os.environ.get("MI_SHARD_MAX_MSG_BYTES", 256 << 20))
 
 
 @dataclass
@@ -56,118 +38,142 @@ class ShardPlan:
     ncols: int      # total committed columns
     world: int
     rank: int
+    tile: int = 32  # columns per tile (a multiple of 8: the sponge absorbs whole 8-column blocks per window)
 
     def __post_init__(self):
         assert self.world >= 1 and (self.world & (self.world - 1)) == 0, "world size must be a power of two"
-        assert self.n_ext % self.world == 0
-        self.cols = column_partition(self.ncols, self.world)
-        self.col0, self.my_cols = self.cols[self.rank]
+        assert self.n_ext % self.world == 0 and self.tile % 8 == 0
+        self.n_tiles = -(-self.ncols // self.tile)
+        self.n_rounds = -(-self.n_tiles // self.world)          # same on every rank
         self.rows_per_rank = self.n_ext // self.world
         self.row0 = self.rank * self.rows_per_rank
-        self.chunks = [pipeline_chunks(w, self.max_cols) for (_, w) in self.cols]   # per rank
-        self.n_chunks = max(len(c) for c in self.chunks)                            # collectives per step (same on every rank)
+        self.my_tiles = list(range(self.rank, self.n_tiles, self.world))
+        self.my_cols = sum(self.tile_width(t) for t in self.my_tiles)
+
+    # ---- tiles
+    def tile_width(self, t: int) -> int:
+        return max(0, min(self.tile, self.ncols - t * self.tile)) if 0 <= t < self.n_tiles else 0
+
+    def round_tile(self, k: int, rank: int) -> int:
+        """Global index of the tile `rank` extends in round k (may be >= n_tiles: that rank sits the round out)."""
+        return k * self.world + rank
+
+    def width(self, k: int, rank: int) -> int:
+        return self.tile_width(self.round_tile(k, rank))
+
+    def tile_cols(self, t: int):
+        """(first global column, width) of tile t."""
+        return t * self.tile, self.tile_width(t)
 
     @property
-    def max_cols(self):
-        return max(w for (_, w) in self.cols)
+    def max_cols(self) -> int:
+        """Columns of the rank with the most tiles (rank 0)."""
+        return sum(self.tile_width(t) for t in range(0, self.n_tiles, self.world))
 
-    def chunk_width(self, rank: int, k: int) -> int:
-        c = self.chunks[rank]
-        return c[k] if k < len(c) else 0      # a rank with fewer chunks takes part with an empty block
+    # ---- buffer layouts (element offsets)
+    # trace shard : [n x my_cols], my k-th tile at local column k * tile (only the globally last tile is narrower,
+    #               and it is the last tile of its owner)
+    # bufs['ext'] : my extended tiles back to back, tile k as [n_ext x w] with pitch w, at n_ext * k * tile
+    # bufs['recv']: window (k, p) = peer p's tile of round k restricted to my rows, [rows_per_rank x w] with pitch w,
+    #               at rows_per_rank * (first global column of that tile); my own slot stays unused (my rows of my
+    #               tile are read in place from bufs['ext'])
+    def local_col(self, k: int) -> int:
+        return k * self.tile
 
-    def chunk_col(self, rank: int, k: int) -> int:
-        """First column (inside the rank's own range) of its chunk k."""
-        return sum(self.chunks[rank][:k])
-
-    # ---- layouts of the two exchange buffers (element offsets)
-    def ext_chunk_base(self, k: int) -> int:
-        """bufs['ext'] holds this rank's extended chunks back to back, chunk k as [n_ext x cw_k] with pitch cw_k."""
-        return self.n_ext * self.chunk_col(self.rank, k)
+    def ext_base(self, k: int) -> int:
+        return self.n_ext * k * self.tile
 
     def send_block(self, k: int, peer: int):
-        """(offset, count) in bufs['ext'] of what goes to `peer` from chunk k: its rows of my chunk."""
-        cw = self.chunk_width(self.rank, k)
-        return self.ext_chunk_base(k) + peer * self.rows_per_rank * cw, self.rows_per_rank * cw
+        """(offset, count) in bufs['ext'] of peer's rows of my round-k tile."""
+        w = self.width(k, self.rank)
+        return self.ext_base(k) + peer * self.rows_per_rank * w, self.rows_per_rank * w
 
-    def recv_chunk_base(self, k: int) -> int:
-        return self.rows_per_rank * sum(self.chunk_width(p, kk) for kk in range(k) for p in range(self.world))
+    def recv_window(self, k: int, peer: int):
+        """(offset, count) in bufs['recv'] of the window that arrives from `peer` in round k."""
+        return self.rows_per_rank * self.round_tile(k, peer) * self.tile, self.rows_per_rank * self.width(k, peer)
 
-    def recv_slab(self, k: int, peer: int):
-        """(offset, count) in bufs['recv'] of the slab [rows_per_rank x cw] that arrives from `peer` for chunk k."""
-        off = self.recv_chunk_base(k) + self.rows_per_rank * sum(self.chunk_width(p, k) for p in range(peer))
-        return off, self.rows_per_rank * self.chunk_width(peer, k)
+    def windows(self, k: int):
+        """Round k's column windows of MY rows in column order: [(buffer name, offset, width, pitch)]."""
+        out = []
+        for p in range(self.world):
+            w = self.width(k, p)
+            if not w:
+                continue
+            if p == self.rank:
+                out.append(("ext", self.ext_base(k) + self.row0 * w, w, w))
+            else:
+                out.append(("recv", self.recv_window(k, p)[0], w, w))
+        return out
 
+    def ext_elems(self) -> int:
+        return self.n_ext * max(self.max_cols, 1)
 
-def phase_lde_chunk(plan: ShardPlan, ops, trace_shard, bufs, k: int):
-    """Step 1 for pipeline chunk k: extend my columns [chunk_col, +cw) into bufs['ext'] (contiguous, pitch cw)."""
-    cw = plan.chunk_width(plan.rank, k)
-    if cw:
-        ops.lde(bufs["ext"], trace_shard, plan.n_ext, plan.n, cw, out_pitch=cw, in_pitch=plan.my_cols,
-                out_off=plan.ext_chunk_base(k), in_off=plan.chunk_col(plan.rank, k), chunk=k)
-
-
-MAX_MSG_BYTES = int(os.environ.get("MI_SHARD_MAX_MSG_BYTES", 256 << 20))   # cap of one point-to-point message (see phase_exchange_chunk)
+    def recv_elems(self) -> int:
+        return self.rows_per_rank * self.n_tiles * self.tile
 
 
 def exchange_messages(plan: ShardPlan, k: int):
-    """The point-to-point messages of pipeline chunk k as (peer, send_off, send_cnt, recv_off, recv_cnt) element
-    ranges of bufs['ext'] / bufs['recv'], grouped into rounds; every rank derives the same number of rounds.
-    A peer's block [rows_per_rank x cw] is cut by rows into pieces of at most MAX_MSG_BYTES."""
+    """The point-to-point messages of round k as message rounds of (peer, send_off, send_cnt, recv_off, recv_cnt)
+    element ranges of bufs['ext'] / bufs['recv']; every rank derives the same number of message rounds.  A peer's
+    block [rows_per_rank x w] is cut by rows into pieces of at most MAX_MSG_BYTES."""
     p = plan
-    max_cw = max(p.chunk_width(peer, k) for peer in range(p.world))
-    rows_per_msg = max(1, (MAX_MSG_BYTES // 8) // max(max_cw, 1))
-    rounds = []
+    rows_per_msg = max(1, (MAX_MSG_BYTES // 8) // p.tile)
+    out = []
+    w_me = p.width(k, p.rank)
     for r0 in range(0, p.rows_per_rank, rows_per_msg):
         r1 = min(p.rows_per_rank, r0 + rows_per_msg)
         msgs = []
-        cw_me = p.chunk_width(p.rank, k)
         for peer in range(p.world):
-            cw_peer = p.chunk_width(peer, k)
-            s_off = p.send_block(k, peer)[0] + r0 * cw_me
-            r_off = p.recv_slab(k, peer)[0] + r0 * cw_peer
-            msgs.append((peer, s_off, (r1 - r0) * cw_me, r_off, (r1 - r0) * cw_peer))
-        rounds.append(msgs)
-    return rounds
-
-
-def phase_exchange_chunk(plan: ShardPlan, dist, bufs, k: int):
-    """Step 2 for pipeline chunk k: columns -> rows.  Returns the async work handles; the transfers are ordered after
-    the chunk's LDE on the current stream and run beside the next chunk's LDE.
-
-    Point-to-point sends/receives in batches (one NCCL group per round: every GPU talks to all its peers at once over
-    its xGMI links), not all_to_all_single, for two reasons measured on this stack (RCCL 2.26): a send-to-self of
-    more than 1 GiB delivers only its first half, and message sizes should not depend on the world size.  So the
-    block a rank keeps is a plain device copy, and every message is at most MAX_MSG_BYTES."""
-    p = plan
-    works = []
-    for msgs in exchange_messages(p, k):
-        ops = []
-        for (peer, s_off, s_cnt, r_off, r_cnt) in msgs:
             if peer == p.rank:
-                if s_cnt:
-                    bufs["recv"][r_off:r_off + r_cnt].copy_(bufs["ext"][s_off:s_off + s_cnt])
                 continue
+            w_peer = p.width(k, peer)
+            msgs.append((peer, p.send_block(k, peer)[0] + r0 * w_me, (r1 - r0) * w_me,
+                         p.recv_window(k, peer)[0] + r0 * w_peer, (r1 - r0) * w_peer))
+        out.append(msgs)
+    return out
+
+
+def phase_lde(plan: ShardPlan, ops, trace_shard, bufs, k: int):
+    """Round k, step 1: extend my k-th tile into bufs['ext'] (contiguous, pitch = its width)."""
+    w = plan.width(k, plan.rank)
+    if w:
+        ops.lde(bufs["ext"], trace_shard, plan.n_ext, plan.n, w, out_pitch=w, in_pitch=plan.my_cols,
+                out_off=plan.ext_base(k), in_off=plan.local_col(k), chunk=k)
+
+
+def phase_exchange(plan: ShardPlan, dist, bufs, k: int):
+    """Round k, step 2: every rank sends each peer that peer's rows of its tile.  Returns the async work handles; the
+    transfers are ordered after the tile's LDE on the current stream.
+
+    Point-to-point sends/receives in batches (one NCCL group per message round: every GPU talks to all its peers at
+    once over its xGMI links), not all_to_all_single: measured on this stack (RCCL 2.26) a send-to-self of more than
+    1 GiB delivers only its first half, and message sizes should not depend on the world size.  The rows a rank keeps
+    are not moved at all, and every message is at most MAX_MSG_BYTES."""
+    works = []
+    for msgs in exchange_messages(plan, k):
+        p2p = []
+        for (peer, s_off, s_cnt, r_off, r_cnt) in msgs:
             if s_cnt:
-                ops.append(dist.P2POp(dist.isend, bufs["ext"][s_off:s_off + s_cnt], peer))
+                p2p.append(dist.P2POp(dist.isend, bufs["ext"][s_off:s_off + s_cnt], peer))
             if r_cnt:
-                ops.append(dist.P2POp(dist.irecv, bufs["recv"][r_off:r_off + r_cnt], peer))
-        if ops:
-            works.extend(dist.batch_isend_irecv(ops))
+                p2p.append(dist.P2POp(dist.irecv, bufs["recv"][r_off:r_off + r_cnt], peer))
+        if p2p:
+            works.extend(dist.batch_isend_irecv(p2p))
     return works
 
 
-def phase_merkle_local(plan: ShardPlan, ops, bufs):
-    """Step 3: repack the slabs into row-major rows (reusing bufs['ext']) and build my subtree.  Returns my root."""
-    p = plan
-    rows, recv = bufs["ext"], bufs["recv"]
-    for k in range(p.n_chunks):
-        for peer, (c0, _) in enumerate(p.cols):
-            cw = p.chunk_width(peer, k)
-            if cw:
-                ops.copy_2d(rows, recv, p.rows_per_rank, cw, dst_pitch=p.ncols, src_pitch=cw,
-                            dst_off=c0 + p.chunk_col(peer, k), src_off=p.recv_slab(k, peer)[0])
-    ops.merkle_build(bufs["nodes"], rows, p.ncols, p.rows_per_rank)
-    return bufs["nodes"][(2 * p.rows_per_rank - 2) * 4:(2 * p.rows_per_rank - 1) * 4]
+def phase_absorb(plan: ShardPlan, ops, bufs, k: int):
+    """Round k, step 3: absorb the round's columns [tile * G * k, ...) of my rows into the running leaf digests
+    (level 0 of my subtree in bufs['nodes'])."""
+    wins = [(bufs[name], off, w, pitch) for (name, off, w, pitch) in plan.windows(k)]
+    if wins:
+        ops.absorb(bufs["nodes"], wins, plan.rows_per_rank, first=(k == 0), final=(k == plan.n_rounds - 1), chunk=k)
+
+
+def phase_subtree(plan: ShardPlan, ops, bufs):
+    """Levels above my leaves.  Returns my subtree root (a view)."""
+    ops.merkle_levels(bufs["nodes"], plan.rows_per_rank)
+    return bufs["nodes"][(2 * plan.rows_per_rank - 2) * 4:(2 * plan.rows_per_rank - 1) * 4]
 
 
 def phase_top(plan: ShardPlan, ops, bufs):
@@ -177,22 +183,31 @@ def phase_top(plan: ShardPlan, ops, bufs):
 
 
 def lde_merkle_sharded(plan: ShardPlan, ops, dist, trace_shard, bufs, always_exchange=False):
-    """Runs steps 1-4.  always_exchange: take the pipelined exchange path even for world == 1 (a one-rank
-    communicator; used to exercise the collective calls on a single GPU).  `ops` provides lde / copy_2d / merkle_build / merkle_levels on the device the tensors live
-    on; `dist` is torch.distributed (or None when world == 1).
-    bufs: dict with 'ext' (max(n_ext*max_cols, rows_per_rank*ncols)), 'recv' (rows_per_rank*ncols),
+    """Runs steps 1-4.  `ops` provides lde / absorb / merkle_build / merkle_levels on the device the tensors live on;
+    `dist` is torch.distributed (or None when world == 1).  always_exchange: take the pipelined path even for
+    world == 1 (then there are no peers and every window is read in place; used to rehearse the path on one GPU).
+    bufs: 'ext' (plan.ext_elems(); world 1 without always_exchange: n_ext * ncols), 'recv' (plan.recv_elems()),
     'nodes' ((2*rows_per_rank-1)*4), 'roots' ((2*world-1)*4).  Returns the tensor holding the global root (4 u64)."""
     p = plan
+    assert p.ncols > 4, "linear_hash copies rows of at most 4 elements instead of hashing them: nothing to shard"
     if p.world == 1 and not always_exchange:
-        ops.lde(bufs["ext"], trace_shard, p.n_ext, p.n, p.my_cols)
+        ops.lde(bufs["ext"], trace_shard, p.n_ext, p.n, p.ncols)
         ops.merkle_build(bufs["nodes"], bufs["ext"], p.ncols, p.n_ext)
         return bufs["nodes"][(2 * p.n_ext - 2) * 4:(2 * p.n_ext - 1) * 4]
-    works = []
-    for k in range(p.n_chunks):       # LDE of chunk k+1 overlaps the exchange of chunk k
-        phase_lde_chunk(p, ops, trace_shard, bufs, k)
-        works.extend(phase_exchange_chunk(p, dist, bufs, k))
-    for w in works:
+    pending = None
+    for k in range(p.n_rounds):
+        phase_lde(p, ops, trace_shard, bufs, k)
+        works = phase_exchange(p, dist, bufs, k) if p.world > 1 else []
+        if pending is not None:          # round k-1 has arrived (its transfers ran beside this round's LDE)
+            for w in pending[1]:
+                w.wait()
+            phase_absorb(p, ops, bufs, pending[0])
+        pending = (k, works)
+    for w in pending[1]:
         w.wait()
-    my_root = phase_merkle_local(p, ops, bufs)
+    phase_absorb(p, ops, bufs, pending[0])
+    my_root = phase_subtree(p, ops, bufs)
+    if p.world == 1:
+        return my_root
     dist.all_gather_into_tensor(bufs["roots"][:p.world * 4], my_root.contiguous())
     return phase_top(p, ops, bufs)

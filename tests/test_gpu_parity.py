@@ -512,24 +512,32 @@ def test_genproof_shaped_flow_small():
     assert out["config"]["fri_steps_bits"] == [13, 8, 3]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_path_emulated_on_one_gpu(ctx, world):
-    """The multi-GPU orchestration (shard.py) with the REAL device ops, all ranks emulated one after the other on
-    this GPU and the all-to-all / all-gather done by tensor copies: the root must equal the single-GPU root."""
-    import torch
-    from shard import ShardPlan, phase_lde_chunk, phase_merkle_local, phase_top
-    n, ncols = 1 << 10, 37 if world == 2 else 150
-    n_ext = 2 * n
-
+def _device_ops(ctx):
     class Ops:
         @staticmethod
         def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
             ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
 
-        copy_2d = staticmethod(ctx.copy_2d)
+        @staticmethod
+        def absorb(digests, windows, nrows, first, final, chunk=0):
+            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
+
         merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
         merkle_levels = staticmethod(ctx.merkle_levels)
 
+    return Ops
+
+
+@pytest.mark.parametrize("world,ncols,tile", [(2, 37, 8), (4, 150, 32), (8, 665, 32), (4, 70, 8)])
+def test_sharded_path_emulated_on_one_gpu(ctx, world, ncols, tile):
+    """The multi-GPU orchestration (shard.py) with the REAL device ops, all ranks emulated one after the other on
+    this GPU and the point-to-point exchange / all-gather done by tensor copies following the plan's message list:
+    the root must equal the single-GPU root, and every rank's leaf digests its slice of level 0."""
+    import torch
+    from shard import ShardPlan, exchange_messages, phase_lde, phase_absorb, phase_subtree, phase_top
+    n = 1 << 10
+    n_ext = 2 * n
+    Ops = _device_ops(ctx)
     # single-GPU reference
     full = ctx.empty(n * ncols)
     ctx.fill_synthetic_2d(full, n, ncols, ncols, 0, 0x5EED0003)
@@ -537,39 +545,48 @@ def test_sharded_path_emulated_on_one_gpu(ctx, world):
     ctx.lde(ext1, full, n_ext, n, ncols)
     ctx.merkle_build(nodes1, ext1, ncols, n_ext)
     want_root = ctx.to_host(nodes1[-4:])
-    assert np.array_equal(ctx.to_host(nodes1), glo.merkletree(glo.extend_pol(ctx.to_host(full).reshape(n, ncols), n_ext, n, ncols), ncols, n_ext))
+    want_leaves = ctx.to_host(nodes1[:n_ext * 4])
     # emulated ranks
-    plans = [ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=r) for r in range(world)]
-    bufs = []
+    plans = [ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=r, tile=tile) for r in range(world)]
+    bufs, traces = [], []
     for p in plans:
-        trace = ctx.empty(n * p.my_cols)
-        ctx.fill_synthetic_2d(trace, n, p.my_cols, ncols, p.col0, 0x5EED0003)     # column shard of the same trace
-        b = {"ext": ctx.empty(max(n_ext * p.max_cols, p.rows_per_rank * ncols)), "nodes": ctx.empty((2 * p.rows_per_rank - 1) * 4),
-             "recv": ctx.empty(p.rows_per_rank * ncols), "roots": ctx.empty((2 * world - 1) * 4)}
-        for k in range(p.n_chunks):
-            phase_lde_chunk(p, Ops, trace, b, k)
-        bufs.append(b)
-    torch.cuda.synchronize()
-    for dst in plans:                                                                # the chunked all-to-alls, by copies
-        for k in range(dst.n_chunks):
-            for src in plans:
-                s_off, s_cnt = src.send_block(k, dst.rank)
-                r_off, r_cnt = dst.recv_slab(k, src.rank)
-                assert s_cnt == r_cnt
-                bufs[dst.rank]["recv"][r_off:r_off + r_cnt] = bufs[src.rank]["ext"][s_off:s_off + s_cnt]
-    roots = [phase_merkle_local(p, Ops, bufs[p.rank]).clone() for p in plans]
-    for p in plans:                                                                  # all-gather by copies
+        trace = ctx.empty(n * max(p.my_cols, 1))
+        for k, t in enumerate(p.my_tiles):                                            # my tiles of the same trace
+            c0, w = p.tile_cols(t)
+            ctx.fill_synthetic_2d(trace, n, w, ncols, c0, 0x5EED0003, out_pitch=p.my_cols, out_off=p.local_col(k))
+        traces.append(trace)
+        bufs.append({"ext": ctx.empty(p.ext_elems()), "nodes": ctx.empty((2 * p.rows_per_rank - 1) * 4),
+                     "recv": ctx.zeros(p.recv_elems()), "roots": ctx.empty((2 * world - 1) * 4)})
+    for k in range(plans[0].n_rounds):
+        for p in plans:
+            phase_lde(p, Ops, traces[p.rank], bufs[p.rank], k)
+        torch.cuda.synchronize()
+        for p in plans:                                                                # the round's messages, by copies
+            for msgs in exchange_messages(p, k):
+                for (peer, s_off, s_cnt, r_off, r_cnt) in msgs:
+                    # what p sends to peer lands where peer expects p's window
+                    pr_off, pr_cnt = None, None
+                    for pm in exchange_messages(plans[peer], k)[exchange_messages(p, k).index(msgs)]:
+                        if pm[0] == p.rank:
+                            pr_off, pr_cnt = pm[3], pm[4]
+                    assert pr_cnt == s_cnt
+                    bufs[peer]["recv"][pr_off:pr_off + pr_cnt] = bufs[p.rank]["ext"][s_off:s_off + s_cnt]
+        for p in plans:
+            phase_absorb(p, Ops, bufs[p.rank], k)
+    roots = [phase_subtree(p, Ops, bufs[p.rank]).clone() for p in plans]
+    for p in plans:                                                                    # all-gather by copies
+        assert np.array_equal(ctx.to_host(bufs[p.rank]["nodes"][:p.rows_per_rank * 4]),
+                              want_leaves[p.row0 * 4:(p.row0 + p.rows_per_rank) * 4]), p.rank
         for r in range(world):
             bufs[p.rank]["roots"][4 * r:4 * r + 4] = roots[r]
         got = phase_top(p, Ops, bufs[p.rank])
         assert np.array_equal(ctx.to_host(got), want_root), p.rank
 
 
-def test_pipelined_exchange_on_a_one_rank_rccl_group(ctx):
-    """The N>1 code path (chunked LDE -> async all_to_all_single -> repack -> subtree -> all_gather -> top levels)
-    through REAL RCCL calls, on a communicator of one rank: the exchange degenerates to self-copies, but the
-    collective API use, the split sizes, the stream ordering between the library's kernels and the collectives and
-    the buffer layouts are the ones bench.py runs with at N = 2/4/8."""
+def test_pipelined_path_with_real_rccl_calls_on_one_rank(ctx):
+    """lde_merkle_sharded itself on a one-rank RCCL communicator: no peers, so every window is read in place, but
+    the all_gather and the stream ordering between the library's kernels and the collective are the real ones;
+    run twice because bench.py reuses the buffers across steps."""
     import socket
     import torch
     import torch.distributed as dist
@@ -584,26 +601,20 @@ def test_pipelined_exchange_on_a_one_rank_rccl_group(ctx):
         n, ncols = 1 << 12, 150
         n_ext = 2 * n
         plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=1, rank=0)
-        assert plan.n_chunks == 3                      # 64 + 64 + 22 columns
+        assert plan.n_rounds == 5                       # 4 x 32 + 22 columns
         trace = ctx.empty(n * ncols)
         ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, 0x5EED0003)
-        bufs = {"ext": ctx.empty(n_ext * ncols), "nodes": ctx.empty((2 * n_ext - 1) * 4), "recv": ctx.empty(n_ext * ncols),
+        bufs = {"ext": ctx.empty(plan.ext_elems()), "nodes": ctx.empty((2 * n_ext - 1) * 4), "recv": ctx.empty(plan.recv_elems()),
                 "roots": ctx.empty(4)}
-
-        class Ops:
-            @staticmethod
-            def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
-                ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
-
-            copy_2d = staticmethod(ctx.copy_2d)
-            merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
-            merkle_levels = staticmethod(ctx.merkle_levels)
-
-        for _ in range(2):                              # twice: buffers are reused across steps like in bench.py
-            root = lde_merkle_sharded(plan, Ops, dist, trace, bufs, always_exchange=True)
+        for _ in range(2):
+            root = lde_merkle_sharded(plan, _device_ops(ctx), dist, trace, bufs, always_exchange=True)
             torch.cuda.synchronize()
         want = glo.merkletree(glo.extend_pol(ctx.to_host(trace).reshape(n, ncols), n_ext, n, ncols), ncols, n_ext)
         assert np.array_equal(ctx.to_host(root), want[-4:])
         assert np.array_equal(ctx.to_host(bufs["nodes"]), want)
+        t = torch.arange(8, dtype=torch.int64, device="cuda")        # and one real collective on the same stream
+        o = torch.zeros(8, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(o, t)
+        assert torch.equal(o, t)
     finally:
         dist.destroy_process_group()

@@ -9,50 +9,35 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import glo
-from shard import ShardPlan, column_partition, lde_merkle_sharded
+from shard import ShardPlan, lde_merkle_sharded
 
 
-def test_column_partition():
-    assert column_partition(665, 8) == [(0, 84), (84, 83), (167, 83), (250, 83), (333, 83), (416, 83), (499, 83), (582, 83)]
-    assert column_partition(6, 4) == [(0, 2), (2, 2), (4, 1), (5, 1)]
-    for nc, w in ((665, 1), (665, 2), (128, 8), (3, 2)):
-        parts = column_partition(nc, w)
-        assert parts[0][0] == 0 and sum(x[1] for x in parts) == nc
-        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
-    p = ShardPlan(n=8, n_ext=16, ncols=7, world=2, rank=1)
-    assert (p.col0, p.my_cols) == (4, 3) and p.chunks == [[4], [3]] and p.n_chunks == 1
-    assert p.send_block(0, 0) == (0, 8 * 3) and p.send_block(0, 1) == (8 * 3, 8 * 3)
-    assert p.recv_slab(0, 0) == (0, 8 * 4) and p.recv_slab(0, 1) == (8 * 4, 8 * 3)
-
-
-def test_pipeline_chunks_and_exchange_layout():
-    """Every rank derives the same number of pipeline chunks; the send blocks tile bufs['ext'] and the receive slabs
-    tile bufs['recv'] without gaps or overlaps; a rank with fewer chunks takes part with an empty block."""
-    from shard import pipeline_chunks
-    assert pipeline_chunks(84, 84) == [32, 32, 20] and pipeline_chunks(83, 84) == [32, 32, 19]
-    assert pipeline_chunks(333, 333) == [96, 96, 96, 45] and pipeline_chunks(33, 33) == [32, 1] and pipeline_chunks(32, 33) == [32]
-    for (ncols, world) in ((665, 8), (665, 2), (65, 2), (13, 4), (128, 8), (5, 4)):
-        plans = [ShardPlan(n=64, n_ext=128, ncols=ncols, world=world, rank=r) for r in range(world)]
-        assert len({p.n_chunks for p in plans}) == 1 and plans[0].n_chunks <= 4
-        for p in plans:
-            assert sum(p.chunks[p.rank]) == p.my_cols
-            sent = sorted(p.send_block(k, peer) for k in range(p.n_chunks) for peer in range(world))
-            pos = 0
-            for off, cnt in sent:
-                if cnt:
-                    assert off == pos
-                    pos += cnt
-            assert pos == p.n_ext * p.my_cols
-            got = sorted(p.recv_slab(k, peer) for k in range(p.n_chunks) for peer in range(world))
-            pos = 0
-            for off, cnt in got:
-                if cnt:
-                    assert off == pos
-                    pos += cnt
-            assert pos == p.rows_per_rank * ncols
-            for k in range(p.n_chunks):   # what I send to a peer is what that peer expects from me
+def test_tile_dealing_and_buffer_layouts():
+    """Tiles are dealt round-robin; every rank derives the same number of rounds; what a rank sends a peer is what
+    that peer expects; a round's windows are consecutive columns of the row, in order; the receive windows do not
+    overlap."""
+    p = ShardPlan(n=1 << 23, n_ext=1 << 24, ncols=665, world=8, rank=4)
+    assert p.n_tiles == 21 and p.n_rounds == 3 and p.my_tiles == [4, 12, 20] and p.my_cols == 32 + 32 + 25
+    assert [p.width(2, r) for r in range(8)] == [32, 32, 32, 32, 25, 0, 0, 0] and p.max_cols == 96
+    assert ShardPlan(n=8, n_ext=16, ncols=7, world=2, rank=1, tile=8).my_cols == 0        # fewer tiles than ranks
+    for (ncols, world, tile) in ((665, 8, 32), (665, 2, 32), (70, 2, 8), (13, 4, 8), (128, 8, 32), (5, 4, 8), (64, 2, 8)):
+        plans = [ShardPlan(n=64, n_ext=128, ncols=ncols, world=world, rank=r, tile=tile) for r in range(world)]
+        assert len({q.n_rounds for q in plans}) == 1 and sum(q.my_cols for q in plans) == ncols
+        for q in plans:
+            col = 0
+            seen = []
+            for k in range(q.n_rounds):
+                for (name, off, w, pitch) in q.windows(k):
+                    assert pitch == w and w > 0
+                    seen.append((name, off, off + q.rows_per_rank * w if name == "recv" else None))
+                    col += w
+                assert col == min(ncols, tile * world * (k + 1))          # a contiguous prefix of the row after every round
                 for peer in plans:
-                    assert p.send_block(k, peer.rank)[1] == peer.recv_slab(k, p.rank)[1]
+                    if peer.rank != q.rank:
+                        assert q.send_block(k, peer.rank)[1] == peer.recv_window(k, q.rank)[1]
+                        assert q.send_block(k, peer.rank)[0] + q.send_block(k, peer.rank)[1] <= q.ext_elems()
+            recv = sorted((a, b) for (nm, a, b) in seen if nm == "recv")
+            assert all(recv[i][1] <= recv[i + 1][0] for i in range(len(recv) - 1)) and (not recv or recv[-1][1] <= q.recv_elems())
 
 
 class OracleOps:
@@ -65,18 +50,29 @@ class OracleOps:
     @staticmethod
     def lde(out, inp, n_ext, n, ncols, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
         out_pitch, in_pitch = out_pitch or ncols, in_pitch or ncols
-        src = OracleOps._np(inp)[in_off:in_off + (n - 1) * in_pitch + ncols]
-        cols = np.stack([src[r * in_pitch:r * in_pitch + ncols] for r in range(n)])
+        src = OracleOps._np(inp)
+        cols = np.stack([src[in_off + r * in_pitch:in_off + r * in_pitch + ncols] for r in range(n)])
         o = glo.extend_pol(np.ascontiguousarray(cols), n_ext, n, ncols)
         dst = OracleOps._np(out)
         for r in range(n_ext):
             dst[out_off + r * out_pitch:out_off + r * out_pitch + ncols] = o[r]
 
     @staticmethod
-    def copy_2d(dst, src, nrows, ncols, dst_pitch, src_pitch, dst_off=0, src_off=0):
-        d, s = OracleOps._np(dst), OracleOps._np(src)
+    def absorb(digests, windows, nrows, first, final, chunk=0):
+        """The streaming sponge of mi_linear_hash_absorb_dev, restated with the oracle's permutation."""
+        d = OracleOps._np(digests)
         for r in range(nrows):
-            d[dst_off + r * dst_pitch:dst_off + r * dst_pitch + ncols] = s[src_off + r * src_pitch:src_off + r * src_pitch + ncols]
+            cap = np.zeros(4, dtype=np.uint64) if first else d[r * 4:r * 4 + 4].copy()
+            for wi, (t, off, w, pitch) in enumerate(windows):
+                v = OracleOps._np(t)[off + r * pitch:off + r * pitch + w]
+                assert w % 8 == 0 or (final and wi == len(windows) - 1)
+                for c in range(0, w, 8):
+                    st = np.zeros(12, dtype=np.uint64)
+                    blk = v[c:c + 8]
+                    st[:len(blk)] = blk
+                    st[8:] = cap
+                    cap = glo.perm(st)[:4]
+            d[r * 4:r * 4 + 4] = cap
 
     @staticmethod
     def merkle_build(nodes, src, ncols, nrows):
@@ -98,18 +94,19 @@ class OracleOps:
 def _worker(rank, world, port, n, ncols, q):
     import shard
     if ncols == 70:
-        shard.MAX_MSG_BYTES = 8 * 100      # many message rounds per chunk (the production cap is 256 MiB)
+        shard.MAX_MSG_BYTES = 8 * 100      # many message rounds per tile (the production cap is 256 MiB)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_ext = 2 * n
-    plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=rank)
+    plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=rank, tile=8)
     full = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
-    shard = np.ascontiguousarray(full[:, plan.col0:plan.col0 + plan.my_cols])
-    trace = torch.from_numpy(shard.view(np.int64).reshape(-1).copy())
-    z = lambda k: torch.zeros(k, dtype=torch.int64)
-    bufs = {"ext": z(max(n_ext * plan.max_cols, plan.rows_per_rank * ncols)), "nodes": z((2 * plan.rows_per_rank - 1) * 4),
-            "recv": z(plan.rows_per_rank * ncols), "roots": z((2 * world - 1) * 4)}
+    shard_cols = [full[:, c0:c0 + w] for (c0, w) in (plan.tile_cols(t) for t in plan.my_tiles)]
+    shard_np = np.ascontiguousarray(np.concatenate(shard_cols, axis=1)) if shard_cols else np.zeros((n, 0), dtype=np.uint64)
+    trace = torch.from_numpy(shard_np.view(np.int64).reshape(-1).copy())
+    z = lambda k: torch.zeros(max(k, 1), dtype=torch.int64)
+    bufs = {"ext": z(plan.ext_elems()), "nodes": z((2 * plan.rows_per_rank - 1) * 4), "recv": z(plan.recv_elems()),
+            "roots": z((2 * world - 1) * 4)}
     root = lde_merkle_sharded(plan, OracleOps, dist, trace, bufs)
     q.put((rank, root.numpy().view(np.uint64).copy(), bufs["nodes"].numpy().view(np.uint64)[:plan.rows_per_rank * 4].copy()))
     dist.barrier()
@@ -124,7 +121,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,ncols", [(2, 7), (4, 13), (2, 70), (2, 65)])
+@pytest.mark.parametrize("world,ncols", [(2, 7), (4, 13), (2, 70), (4, 65), (2, 64)])
 def test_sharded_path_reproduces_single_process_tree(world, ncols):
     n = 64
     full = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
@@ -144,6 +141,19 @@ def test_sharded_path_reproduces_single_process_tree(world, ncols):
     for rank, root, leaves in res:
         assert np.array_equal(root, nodes[-4:]), rank                       # every rank ends with the global root
         assert np.array_equal(leaves, nodes[rank * rows * 4:(rank + 1) * rows * 4])   # and owns its slice of level 0
+
+
+def test_world_one_pipelined_path_without_peers():
+    """always_exchange at world 1: every window is read in place, nothing is sent; same root as the plain build."""
+    n, ncols = 32, 21
+    full = glo.splitmix64(0x5EED0003, n * ncols)
+    plan = ShardPlan(n=n, n_ext=2 * n, ncols=ncols, world=1, rank=0, tile=8)
+    z = lambda k: torch.zeros(k, dtype=torch.int64)
+    bufs = {"ext": z(plan.ext_elems()), "recv": z(plan.recv_elems()), "nodes": z((4 * n - 1) * 4), "roots": z(4)}
+    root = lde_merkle_sharded(plan, OracleOps, None, torch.from_numpy(full.view(np.int64).copy()), bufs, always_exchange=True)
+    want = glo.merkletree(glo.extend_pol(full.reshape(n, ncols), 2 * n, n, ncols), ncols, 2 * n)
+    assert np.array_equal(root.numpy().view(np.uint64), want[-4:])
+    assert np.array_equal(bufs["nodes"].numpy().view(np.uint64), want)
 
 
 def test_world_one_is_plain_merkle_build():
