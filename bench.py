@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=23, help="log2 of trace rows (BASELINE: 23)")
     ap.add_argument("--cols", type=int, default=665, help="committed columns (BASELINE: 665)")
-    ap.add_argument("--workspace-gib", type=float, default=16.0)
+    ap.add_argument("--workspace-gib", type=float, default=32.0)
     ap.add_argument("--poseidon-variant", type=int, default=2)
     ap.add_argument("--cpu-log-n", type=int, default=16, help="log2 rows of the CPU-baseline sample")
     ap.add_argument("--ntt-log-b", type=int, default=5)

@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--widths", type=int, nargs=3, default=[665, 128, 371])
     ap.add_argument("--n-evals", type=int, default=512)
     ap.add_argument("--n-queries", type=int, default=128)
-    ap.add_argument("--workspace-gib", type=float, default=16.0)
+    ap.add_argument("--workspace-gib", type=float, default=32.0)
     ap.add_argument("--check-queries", type=int, default=4)
     args = ap.parse_args()
 

@@ -53,7 +53,7 @@ void mi_ctx_destroy(mi_ctx *ctx);
  * value) is the device's default stream. */
 int mi_ctx_set_stream(mi_ctx *ctx, void *hip_stream);
 int mi_ctx_sync(mi_ctx *ctx);
-/* Scratch HBM the library may allocate lazily for NTT/LDE ping-pong buffers (default 16 GiB,
+/* Scratch HBM the library may allocate lazily for NTT/LDE ping-pong buffers (default 32 GiB,
  * clamped to what the problem needs).  Wide LDEs are processed in column chunks that fit it. */
 int mi_ctx_set_workspace_limit(mi_ctx *ctx, uint64_t bytes);
 const char *mi_last_error(void);

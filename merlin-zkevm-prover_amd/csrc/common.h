@@ -74,7 +74,7 @@ struct mi_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int poseidon_variant = 2; // 2 = full rounds on 32-bit halves (v_mad_u64_u32) + grouped optimised partial rounds; 0 / 1 = naive rounds
-    uint64_t workspace_limit = 16ULL << 30;
+    uint64_t workspace_limit = 32ULL << 30;
     u64 *workspace = nullptr;
     uint64_t workspace_bytes = 0;
     u64 *w256 = nullptr; // w_256^j, j < 256

@@ -698,28 +698,40 @@ int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_
     if (L2 == 0) return copy_canon(ctx, out, out_pitch, in, in_pitch, 1, ncols);
     const uint32_t P1 = num_passes(L1), P2 = num_passes(L2);
     const bool fuse = lde_mid_applies(ctx, L1, L2, ncols);
-    // scratch per column: one n_ext ping-pong buffer + INTT intermediate (n) [+ coefficients (n) when not fused]
+    // scratch per column: one n_ext ping-pong buffer + INTT intermediate (n) [+ coefficients (n) when not fused].
+    // The caller's output doubles as the other ping-pong buffer -- unless it is a window of a wider matrix (row pitch
+    // 5320 B for the 665-column trace: every 256-byte row segment straddles three 128-byte lines) and the workspace
+    // has room for a second, compact n_ext buffer Y without narrowing the column chunks below two tiles: then only the
+    // first read and the last write touch the strided matrices.
     const uint64_t per_col = ((fuse ? 1 : 2) * n + n_ext) * 8;
-    uint64_t chunk = ctx->workspace_limit / per_col;
-    if (chunk == 0) chunk = 1;
-    if (chunk >= 32) chunk &= ~31ull;
-    if (chunk > ncols) chunk = ncols;
-    MI_TRY(mi_ensure_workspace(ctx, chunk * per_col));
+    auto chunk_for = [&](uint64_t pc) {
+        uint64_t c = ctx->workspace_limit / pc;
+        if (c == 0) c = 1;
+        if (c >= 32) c &= ~31ull;
+        return c > ncols ? ncols : c;
+    };
+    uint64_t chunk = chunk_for(per_col);
+    const uint64_t chunk_y = chunk_for(per_col + n_ext * 8);
+    const bool use_y = out_pitch > chunk_y && chunk_y >= (ncols < 64 ? ncols : 64); // a chunk is a window narrower than the pitch
+    if (use_y) chunk = chunk_y;
+    MI_TRY(mi_ensure_workspace(ctx, chunk * (per_col + (use_y ? n_ext * 8 : 0))));
     for (uint64_t c0 = 0; c0 < ncols; c0 += chunk) {
         const uint64_t cw = (ncols - c0 < chunk) ? ncols - c0 : chunk;
-        const Buf S = {const_cast<u64 *>(in) + c0, in_pitch}, D = {out + c0, out_pitch};
+        const Buf S = {const_cast<u64 *>(in) + c0, in_pitch}, Dout = {out + c0, out_pitch};
         u64 *w = ctx->workspace;
         const Buf T = {w, cw};                             // INTT intermediate, n rows
-        const Buf X = {w + n * cw, cw};                    // n_ext-row ping-pong partner of D
+        const Buf X = {w + n * cw, cw};                    // n_ext-row ping-pong buffer
         const Buf C = {w + n * cw + n_ext * cw, cw};       // coefficients, n rows (unfused path only)
-        const Buf Dlo = {D.p, D.pitch};                    // first n rows of the output double as an INTT intermediate
+        const Buf Y = {C.p + (fuse ? 0 : n * cw), cw};     // second n_ext-row ping-pong buffer (use_y)
+        const Buf D = use_y ? Y : Dout;                    // ping-pong partner of X: Y, or the output itself
+        const Buf Dlo = {D.p, D.pitch};                    // its first n rows double as an INTT intermediate
         std::vector<Buf> b1, b2;
         b1.push_back(S);
         for (uint32_t i = 1; i < P1; i++) b1.push_back(((P1 - i) & 1) ? T : Dlo); // last intermediate is T
         b1.push_back(C);
         b2.push_back(C);
         for (uint32_t i = 1; i < P2; i++) b2.push_back(((P2 - i) & 1) ? X : D); // last intermediate is X
-        b2.push_back(D);
+        b2.push_back(Dout);
         if (fuse) {
             // INTT passes 0..P1-2, [last INTT pass + first NTT pass] b1[P1-1] -> b2[1], NTT passes 1..P2-1.
             // b1[P1-1] is S or T and never overlaps b2[1] (X or D).

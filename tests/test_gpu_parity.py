@@ -331,6 +331,17 @@ def test_lde_column_chunks_and_pitches(ctx):
     assert np.array_equal(small.to_host(o2).reshape(1 << 11, 70), glo.ntt(x, 1 << 11, 70))
     assert np.array_equal(small.lde_host(x[:256, :5], 512, 256, 5), glo.extend_pol(np.ascontiguousarray(x[:256, :5]), 512, 256, 5))
     small.close()
+    # 3 MiB: chunks of 64 columns AND room for a second compact ping-pong buffer, so that the strided output is only
+    # written by the last pass (the configuration the full-size run takes with the default 32 GiB)
+    mid = mi_stark.Context(0, workspace_limit=3 << 20)
+    for (n, n_ext, ncols, in_pitch, out_pitch) in ((1 << 10, 1 << 11, 200, 203, 201), (1 << 9, 1 << 11, 150, 150, 150)):
+        src = glo.rand_fe(rng, (n, in_pitch))
+        out = mid.zeros(n_ext * out_pitch)
+        mid.lde(out, mid.to_device(src), n_ext, n, ncols, out_pitch=out_pitch, in_pitch=in_pitch)
+        got = mid.to_host(out).reshape(n_ext, out_pitch)
+        assert np.array_equal(got[:, :ncols], glo.extend_pol(np.ascontiguousarray(src[:, :ncols]), n_ext, n, ncols))
+        assert not got[:, ncols:].any()
+    mid.close()
 
 
 def test_config3_shape_at_2pow18_rows_bit_exact():
