@@ -629,3 +629,32 @@ def test_pipelined_path_with_real_rccl_calls_on_one_rank(ctx):
         assert torch.equal(o, t)
     finally:
         dist.destroy_process_group()
+
+
+def test_element_wise_kernels_beyond_2pow32_elements(ctx):
+    """A HIP launch of 2^32 or more threads is truncated silently; the element-wise kernels (synthetic fills, 2-D
+    copy) must cover buffers larger than that -- the BASELINE trace has 5.6e9 elements.  Checks the tail, which a
+    truncated launch leaves untouched."""
+    import torch
+    nrows, ncols = 1 << 22, 1030
+    count = nrows * ncols                                      # 4.32e9 > 2^32
+    buf = ctx.zeros(count)
+    ctx.fill_synthetic(buf, count, 0x5EED0003)
+    want = glo.splitmix64(0x5EED0003, 64)                      # elements 0..63
+    assert np.array_equal(ctx.to_host(buf[:64]), want)
+    idx = np.arange(count - 64, count, dtype=np.uint64) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        z = np.uint64(0x5EED0003) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    tail = np.where(z >= np.uint64(glo.P), z - np.uint64(glo.P), z)
+    assert np.array_equal(ctx.to_host(buf[count - 64:]), tail)
+    # 2-D fill of the same stream in two column windows, then a strided copy: both > 2^32 elements
+    a = ctx.zeros(nrows * ncols)
+    ctx.fill_synthetic_2d(a, nrows, ncols, ncols, 0, 0x5EED0003)
+    assert torch.equal(a, buf[:nrows * ncols])                # the 2-D fill of all columns is the flat stream
+    del buf
+    b = ctx.zeros(nrows * ncols)
+    ctx.copy_2d(b, a, nrows, ncols, dst_pitch=ncols, src_pitch=ncols)
+    assert torch.equal(a, b)
