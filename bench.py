@@ -91,8 +91,8 @@ def main():
     ap.add_argument("--leaf-mode", type=int, default=1, help="1 = line-aligned leaf fetch (default), 0 = per-block loads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="N = 1 only: run the N > 1 code path (chunked LDE, RCCL all-to-all, repack, root all-gather) on a "
-                         "one-rank communicator, to rehearse it and to price its overhead on a single GPU")
+                    help="N = 1 only: run the N > 1 code path (tile-by-tile LDE, streaming leaf absorption, subtree) on a one-rank "
+                         "communicator, to rehearse it at full size on a single GPU")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner on
