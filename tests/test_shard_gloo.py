@@ -121,7 +121,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,ncols", [(2, 7), (4, 13), (2, 70), (4, 65), (2, 64)])
+@pytest.mark.parametrize("world,ncols", [(2, 7), (4, 13), (2, 70), (4, 65), (2, 64), (8, 100)])
 def test_sharded_path_reproduces_single_process_tree(world, ncols):
     n = 64
     full = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
