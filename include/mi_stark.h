@@ -191,6 +191,11 @@ uint64_t mi_dbg_host_mul(uint64_t a, uint64_t b);
 void mi_dbg_host_e3_mul(uint64_t out[3], const uint64_t a[3], const uint64_t b[3]);
 void mi_dbg_host_e3_inv(uint64_t out[3], const uint64_t a[3]);
 void mi_dbg_host_dft16(uint64_t x[16], int log_size, int inverse);
+/* The DEVICE build of the field arithmetic (it differs from the host build: inline asm, wave-uniform branches), element
+ * by element over device arrays a, b of n entries (any u64 encodings): out[0..n) = a*b, out[n..2n) = a+b,
+ * out[2n..3n) = a-b, out[3n..4n) = -a (as a * 2^96 through the 32-bit-shift twiddle form), out[4n..5n) = a * 2^40
+ * (the wide-shift twiddle form); all canonical. */
+int mi_dbg_field_ops_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
 
 #ifdef __cplusplus
 }

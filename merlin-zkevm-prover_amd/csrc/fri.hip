@@ -374,6 +374,31 @@ int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t
     return MI_OK;
 }
 
+// test hook: out[i] = a[i] * b[i] and out[n + i] = a[i] + b[i] - b[i]^2 ... through the DEVICE arithmetic (the device
+// build of gl_math.h differs from the host build: inline asm, wave-uniform branches)
+__global__ __launch_bounds__(256) void k_dbg_field_ops(u64 *out, const u64 *a, const u64 *b, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 x = a[i], y = b[i];
+    out[i] = gl::mul(x, y);                                                   // any u64 encodings in, canonical out
+    out[n + i] = gl::canon(gl::add_wc(x, gl::canon(y)));                      // x + y
+    out[2 * n + i] = gl::canon(gl::sub_wc(x, gl::canon(y)));                  // x - y
+    out[3 * n + i] = gl::canon(nttm::mul_pow2<12>(nttm::mul_pow2<84>(x)));    // x * 2^96 = -x : both shift forms
+    out[4 * n + i] = gl::canon(nttm::mul_pow2<40>(x));                        // 128-bit shift form
+}
+
+extern "C" int mi_dbg_field_ops_dev(mi_ctx *c, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n)
+{
+    if (!c) return MI_ERR_INVALID;
+    if (!n) return MI_OK;
+    MI_REQUIRE_1D_GRID(n);
+    hipLaunchKernelGGL(k_dbg_field_ops, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (u64 *)out, (const u64 *)a,
+                       (const u64 *)b, n);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
 extern "C" uint64_t mi_dbg_host_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 extern "C" void mi_dbg_host_e3_mul(uint64_t out[3], const uint64_t a[3], const uint64_t b[3])
 {

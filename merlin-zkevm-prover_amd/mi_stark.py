@@ -54,7 +54,7 @@ EXPORTS = [
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
-    "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
+    "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16",
 ]
 
@@ -254,6 +254,9 @@ class Context:
     def copy_2d(self, dst, src, nrows, ncols, dst_pitch, src_pitch, dst_off=0, src_off=0):
         _check(lib().mi_copy_2d_dev(self.h, _dp(dst, dst_off), u64(dst_pitch), _dp(src, src_off), u64(src_pitch),
                                     u64(nrows), u64(ncols)))
+
+    def dbg_field_ops(self, out, a, b, n):
+        _check(lib().mi_dbg_field_ops_dev(self.h, _dp(out), _dp(a), _dp(b), u64(n)))
 
     # ---- timers (HIP events on the context's stream)
     def timer_start(self, slot=0):

@@ -23,6 +23,35 @@ def dev_roundtrip(ctx, a):
     return ctx.to_host(ctx.to_device(a))
 
 
+# ------------------------------------------------------------------ field arithmetic (device build)
+def test_device_field_arithmetic_on_adversarial_operands(ctx):
+    """mul / add / sub / shift-twiddles exactly as the kernels compute them (inline-asm multiply-add with carry-out,
+    borrow-chain reduction, wave-uniform rare branches), against Python integers: every pair of a set of boundary
+    values (0, 1, 2^32 +- 1, p - 1, p, p + 1, 2^64 - 1, powers of two and their complements), plus random pairs."""
+    special = [0, 1, 2, 0xFFFFFFFE, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, P - 2, P - 1, P, P + 1, P + 2, (1 << 64) - 2, (1 << 64) - 1,
+               0xFFFFFFFF00000000, 0x00000000FFFFFFFF, 0x8000000000000000, 0x7FFFFFFFFFFFFFFF, 0xFFFFFFFEFFFFFFFF]
+    special += [1 << k for k in range(0, 64, 3)] + [P - (1 << k) for k in range(0, 64, 5)] + [((1 << 64) - (1 << k)) for k in range(1, 64, 7)]
+    special = sorted(set(v % (1 << 64) for v in special))
+    rng = np.random.default_rng(99)
+    a = np.array([x for x in special for _ in special], dtype=np.uint64)
+    b = np.array([y for _ in special for y in special], dtype=np.uint64)
+    ra = rng.integers(0, 1 << 64, size=200000, dtype=np.uint64)
+    rb = rng.integers(0, 1 << 64, size=200000, dtype=np.uint64)
+    rb[:50000] = ra[:50000]                                    # squares
+    ra[50000:60000] &= np.uint64(0xFFFFFFFF)                   # small operands: products with empty high words
+    a, b = np.concatenate([a, ra]), np.concatenate([b, rb])
+    n = a.size
+    out = ctx.empty(5 * n)
+    ctx.dbg_field_ops(out, ctx.to_device(a), ctx.to_device(b), n)
+    got = ctx.to_host(out).reshape(5, n)
+    ai, bi = [int(v) for v in a], [int(v) for v in b]
+    want = np.array([[x * y % P for x, y in zip(ai, bi)], [(x + y) % P for x, y in zip(ai, bi)], [(x - y) % P for x, y in zip(ai, bi)],
+                     [(-x) % P for x in ai], [(x << 40) % P for x in ai]], dtype=np.uint64)
+    for k, name in enumerate(("mul", "add", "sub", "neg via 2^96", "shift 40")):
+        bad = np.nonzero(got[k] != want[k])[0]
+        assert bad.size == 0, (name, hex(ai[bad[0]]), hex(bi[bad[0]]), hex(int(got[k][bad[0]])), hex(int(want[k][bad[0]])))
+
+
 # ------------------------------------------------------------------ Poseidon
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_permute_matches_oracle(ctx, variant):
