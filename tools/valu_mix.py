@@ -31,14 +31,16 @@ TWO_CLK = ("v_mov_b32", "v_cndmask_b32", "v_add_u32", "v_sub_u32", "v_and_b32", 
 
 def main():
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    name = "_Z24k_linear_hash_rows_linesILi%dEEvPyPKymjm" % variant
+    prefix = "_Z24k_linear_hash_rows_linesILi%dEE" % variant
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "pos.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-S",
                                "--cuda-device-only", os.path.join(CSRC, "poseidon.hip"), "-o", asm],
                               stderr=subprocess.DEVNULL)
         txt = open(asm).read()
-    i = txt.index("\n" + name + ":")
+    m = re.search(r"\n(" + re.escape(prefix) + r"\w*):", txt)
+    name = m.group(1)
+    i = m.start()
     j = txt.index("s_endpgm", i)
     instrs, labels = [], {}
     for l in txt[i:j].split("\n"):
@@ -70,9 +72,11 @@ def main():
         n = b - a
         inner = [(x, y) for (x, y) in loops if x >= a and y <= b and (x, y) != (a, b)]
         if n > 4000:
-            trip = 1.0      # the sponge loop: one pass per permutation
+            trip = 1.0      # the sponge / column-window loops: one pass per permutation
         elif inner:
-            trip = 2.0      # the two groups of 11 partial rounds
+            # the two groups of 11 partial rounds contain the short closing loop; any other backward branch around a
+            # loop is block placement, not iteration
+            trip = 2.0 if any(y - x < 400 for (x, y) in inner) else 1.0
         elif n > 1000:
             trip = 4.0      # four full rounds
         else:
