@@ -67,7 +67,9 @@ struct TileRadix {
 };
 
 // step A: RA-point DFTs over the high bits, in place, then twiddle by w_r^(p' ka).  Caller syncs afterwards.
-template <int LOG_R, bool INV, int LOG_B>
+// NZ: only the first NZ of the RA inputs of a DFT can be non-zero (zero-padded first pass of the extended NTT): the
+// others are neither read nor computed with -- the unrolled butterflies fold the constants away.
+template <int LOG_R, bool INV, int LOG_B, int NZ = (1 << (LOG_R - (LOG_R >= 4 ? 4 : LOG_R)))>
 __device__ __forceinline__ void tile_step_a(u64 *tile, const u64 *w256, uint32_t tid)
 {
     using T = TileRadix<LOG_R>;
@@ -77,7 +79,7 @@ __device__ __forceinline__ void tile_step_a(u64 *tile, const u64 *w256, uint32_t
             const uint32_t b = item & (B - 1), pp = item >> LOG_B;
             u64 x[T::RA];
 #pragma unroll
-            for (int i = 0; i < T::RA; i++) x[i] = tile[(i * T::RB + pp) * B + b];
+            for (int i = 0; i < T::RA; i++) x[i] = i < NZ ? tile[(i * T::RB + pp) * B + b] : 0;
             nttm::dft_reg<T::LA, INV>(x);
 #pragma unroll
             for (int ka = 1; ka < T::RA; ka++) {
@@ -296,6 +298,9 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
     using T1 = TileRadix<LOG_R1>;
     using T2 = TileRadix<LOG_R2>;
     constexpr int B = 1 << LOG_B, NTT_THREADS = 16 * B, R1 = T1::R, R2 = T2::R;
+    // rows i >= R1 of the NTT tile are the zero padding; step A reads rows ia * RB + pp, so with RA >= blowup exactly the
+    // inputs ia >= RA / blowup of every DFT are zero
+    constexpr bool PAD_KNOWN = (T2::RA >> LOG_BLOW) >= 1;
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     u64 *tile = smem;           // [R2][B]
     u64 *w256 = tile + R2 * B;  // [256]
@@ -378,12 +383,14 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
 #pragma unroll
             for (int kb = 0; kb < T1::RB; kb++) tile[(kap + T1::RA * kb) * B + b] = x[kb];
         }
-        for (uint32_t e = tid; e < (uint32_t)(R2 - R1) * B; e += NTT_THREADS) tile[R1 * B + e] = 0; // the zero padding
+        // the zero padding: rows R1.. are never read when step A knows they are zero
+        if (!PAD_KNOWN)
+            for (uint32_t e = tid; e < (uint32_t)(R2 - R1) * B; e += NTT_THREADS) tile[R1 * B + e] = 0;
     }
     __syncthreads();
 
     // ---- first pass of NTT_Next: rows kappa * R2 + k1' of the destination
-    tile_step_a<LOG_R2, false, LOG_B>(tile, w256, tid);
+    tile_step_a<LOG_R2, false, LOG_B, PAD_KNOWN ? (T2::RA >> LOG_BLOW) : T2::RA>(tile, w256, tid);
     if (T2::LA > 0) __syncthreads();
     for (uint32_t item = tid; item < (uint32_t)T2::RA * B; item += NTT_THREADS) {
         const uint32_t b = item & (B - 1), kap = item >> LOG_B;
