@@ -3,10 +3,11 @@
 //
 // Spec followed: src/sm/poseidon_g/poseidon_g_executor.cpp:174-205 (naive round form: add RC, S-box on
 // all lanes in rounds 0-3/26-29 else lane 0, state = M*state) with M = circ(MCIRC) + diag(MDIAG)
-// (poseidon_g_executor.hpp:37-50).  The upstream library uses the algebraically equal "optimised partial
-// round" form; on CDNA4 the naive form is the cheaper one: its MDS constants are < 2^6, so the
-// mat-vec needs no 64x64 multiplies at all (see mds_limb22), whereas the optimised form trades it for
-// 23 full 64-bit modular multiplies per partial round.
+// (poseidon_g_executor.hpp:37-50).  Full rounds are computed in that form: the MDS constants are < 2^6, so the
+// mat-vec needs no 64x64 multiplies (mds_half32).  The 22 partial rounds are computed in an algebraically equal
+// "grouped" form derived from the textbook optimised partial rounds (partial_rounds_sparse, tables generated and
+// verified against the naive form by tools/gen_poseidon_sparse.py); the naive partial rounds stay available as
+// variants 0 / 1 and all variants are bit-identical.
 //
 // Why one state per lane and not a wave-cooperative round with the state spread over 12 lanes: 22 of
 // the 30 rounds apply the S-box to lane 0 only, which would idle 11 of 12 cooperating lanes for ~2/3 of
