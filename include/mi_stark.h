@@ -196,6 +196,11 @@ void mi_dbg_host_dft16(uint64_t x[16], int log_size, int inverse);
  * out[2n..3n) = a-b, out[3n..4n) = -a (as a * 2^96 through the 32-bit-shift twiddle form), out[4n..5n) = a * 2^40
  * (the wide-shift twiddle form); all canonical. */
 int mi_dbg_field_ops_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
+/* Verification hook: out[r] = (accumulate ? out[r] : 0) + sum_c coef[c] * src[r*pitch + c] mod p for r < nrows (device
+ * pointers; coef: ncols canonical values; accumulate lets a matrix stored as several column windows be summed).  The LDE is linear, so the full-size checks compare the oracle's extension of this one column
+ * of the trace with the same combination of the extended trace: a checksum over every column at every row. */
+int mi_dbg_lincomb_cols_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *src, uint64_t pitch, uint64_t nrows,
+                            uint64_t ncols, const uint64_t *coef, int accumulate);
 
 #ifdef __cplusplus
 }

@@ -27,13 +27,33 @@ extern "C" int mi_device_count(void)
     return n;
 }
 
-#define CTX_OK(ctx)                                   \
-    do {                                              \
-        if (!(ctx)) {                                 \
-            mi_set_error("%s: null context", __func__); \
-            return MI_ERR_INVALID;                    \
-        }                                             \
-    } while (0)
+// every entry point: reject a null context, take the context lock, make its device current
+#define CTX_OK(ctx)                                                   \
+    if (!(ctx)) {                                                     \
+        mi_set_error("%s: null context", __func__);                   \
+        return MI_ERR_INVALID;                                        \
+    }                                                                 \
+    std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);       \
+    MI_HIP_CHECK(hipSetDevice((ctx)->device))
+
+extern "C" void mi_ctx_destroy(mi_ctx *c);
+
+static int ctx_init(mi_ctx *c, int device)
+{
+    if (device >= 0) MI_HIP_CHECK(hipSetDevice(device));
+    MI_HIP_CHECK(hipGetDevice(&c->device));
+    hipDeviceProp_t prop;
+    MI_HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
+    c->cu_count = prop.multiProcessorCount;
+    c->stream = nullptr; // the device's default stream until the caller hands one over
+    c->own_stream = false;
+    MI_HIP_CHECK(hipMalloc((void **)&c->small, 4096));
+    for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
+        MI_HIP_CHECK(hipEventCreate(&c->ev_start[i]));
+        MI_HIP_CHECK(hipEventCreate(&c->ev_stop[i]));
+    }
+    return MI_OK;
+}
 
 extern "C" int mi_ctx_create(mi_ctx **out, int device)
 {
@@ -49,17 +69,10 @@ extern "C" int mi_ctx_create(mi_ctx **out, int device)
         return MI_ERR_INVALID;
     }
     mi_ctx *c = new mi_ctx();
-    if (device >= 0) MI_HIP_CHECK(hipSetDevice(device));
-    MI_HIP_CHECK(hipGetDevice(&c->device));
-    hipDeviceProp_t prop;
-    MI_HIP_CHECK(hipGetDeviceProperties(&prop, c->device));
-    c->cu_count = prop.multiProcessorCount;
-    c->stream = nullptr; // the device's default stream until the caller hands one over
-    c->own_stream = false;
-    MI_HIP_CHECK(hipMalloc((void **)&c->small, 4096));
-    for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
-        MI_HIP_CHECK(hipEventCreate(&c->ev_start[i]));
-        MI_HIP_CHECK(hipEventCreate(&c->ev_stop[i]));
+    const int st = ctx_init(c, device);
+    if (st != MI_OK) { // nothing half-built survives a failed create
+        mi_ctx_destroy(c);
+        return st;
     }
     *out = c;
     return MI_OK;
@@ -68,6 +81,7 @@ extern "C" int mi_ctx_create(mi_ctx **out, int device)
 extern "C" void mi_ctx_destroy(mi_ctx *c)
 {
     if (!c) return;
+    (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
     if (c->workspace) (void)hipFree(c->workspace);
@@ -438,6 +452,8 @@ extern "C" int mi_copy_2d_dev(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, cons
 extern "C" void *mi_dev_alloc(mi_ctx *c, uint64_t bytes)
 {
     if (!c) return nullptr;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
     if (e != hipSuccess) {

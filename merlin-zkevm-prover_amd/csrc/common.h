@@ -5,6 +5,7 @@
 #include <string>
 #include <map>
 #include <vector>
+#include <mutex>
 #include "../../include/mi_stark.h"
 #include "gl_math.h"
 
@@ -87,6 +88,11 @@ struct mi_ctx {
     bool leaf_line_aligned = true; // leaf sponge fetches whole aligned 128-byte lines (k_linear_hash_rows_lines)
     bool lde_fuse_mid = true; // extendPol: last INTT pass and first NTT pass in one kernel (k_lde_mid) when the splits line up
     uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
+    bool poseidon_constants_uploaded = false; // c_rc / c_sparse on this context's device
+    // Entry points serialise on the context (scratch, plans, workspace and timers are shared state) and make
+    // ctx->device current first, so one context may be called from several host threads like the reference's
+    // static Poseidon / NTT methods; recursive because host-pointer wrappers call other entry points.
+    std::recursive_mutex mu;
 };
 
 int mi_ensure_workspace(mi_ctx *ctx, uint64_t bytes);

@@ -61,6 +61,7 @@ int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, u
     MI_REQUIRE(lnx <= 6, "FRI reduction of more than 6 bits per step is not supported");
     const uint64_t pol2n = 1ull << cur_bits;
     if (lnx == 0) { // friProve.cpp:82-85 (step 0 is a copy)
+        MI_REQUIRE_1D_GRID(pol2n * 3);
         hipLaunchKernelGGL(k_copy_canon_flat, dim3((unsigned)((pol2n * 3 + 255) / 256)), dim3(256), 0, ctx->stream, out, pol,
                            pol2n * 3);
         MI_HIP_CHECK(hipGetLastError());
@@ -395,6 +396,40 @@ extern "C" int mi_dbg_field_ops_dev(mi_ctx *c, uint64_t *out, const uint64_t *a,
     MI_REQUIRE_1D_GRID(n);
     hipLaunchKernelGGL(k_dbg_field_ops, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (u64 *)out, (const u64 *)a,
                        (const u64 *)b, n);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// verification hook: out[r] = (accumulate ? out[r] : 0) + sum_c coef[c] * src[r][c] mod p -- one column that depends on EVERY column of the matrix.
+// The LDE is linear, so LDE(lincomb(trace)) == lincomb(LDE(trace)) ties all columns at all rows of a full-size
+// extension to one single-column transform the CPU oracle can redo.  One wave per row, lanes strided over the columns.
+__global__ __launch_bounds__(256) void k_dbg_lincomb_cols(u64 *__restrict__ out, const u64 *__restrict__ src, uint64_t pitch,
+                                                          uint64_t nrows, uint32_t ncols, const u64 *__restrict__ coef,
+                                                          int accumulate)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < nrows; r += (uint64_t)gridDim.x * 4) {
+        const u64 *p = src + r * pitch;
+        u64 acc = 0;
+        for (uint32_t c = lane; c < ncols; c += 64) acc = gl::add(acc, gl::mul(coef[c], p[c]));
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const u32 lo = (u32)__shfl_xor((int)(u32)acc, m, 64), hi = (u32)__shfl_xor((int)(u32)(acc >> 32), m, 64);
+            acc = gl::add(acc, ((u64)hi << 32) | lo);
+        }
+        if (lane == 0) out[r] = accumulate ? gl::add(gl::canon(out[r]), acc) : acc;
+    }
+}
+
+extern "C" int mi_dbg_lincomb_cols_dev(mi_ctx *c, uint64_t *out, const uint64_t *src, uint64_t pitch, uint64_t nrows,
+                                       uint64_t ncols, const uint64_t *coef, int accumulate)
+{
+    if (!c) return MI_ERR_INVALID;
+    if (!nrows) return MI_OK;
+    MI_REQUIRE(out && src && coef && ncols < (1ull << 31) && pitch >= ncols, "bad arguments");
+    const uint64_t blocks = (nrows + 3) / 4;
+    hipLaunchKernelGGL(k_dbg_lincomb_cols, dim3((unsigned)(blocks < (1u << 20) ? blocks : (1u << 20))), dim3(256), 0, c->stream,
+                       (u64 *)out, (const u64 *)src, pitch, nrows, (uint32_t)ncols, (const u64 *)coef, accumulate);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

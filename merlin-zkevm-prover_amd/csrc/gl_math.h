@@ -87,6 +87,11 @@ MI_HD u64 sub(u64 a, u64 b)
 MI_HD u64 neg(u64 a) { return a ? GL_P - a : 0; }
 
 // a any u64, b canonical (< p)  ->  weakly reduced a - b
+// As compiled: v_sub_co, v_subb_co, v_cmp_lt_u64, 2 x v_cndmask, v_lshl_add_u64 (20 issue clocks).  The compare
+// re-derives the chain's own borrow, but every way of using that borrow directly was tried in r02 and is no cheaper:
+// __builtin_usubll_overflow is canonicalised back into sub + compare; an inline-asm chain must either finish with a
+// second 32-bit carry chain (2 x 4 clk instead of one v_lshl_add_u64) or hand two selected words back to the compiler,
+// which then forms the 64-bit addend with extra moves (measured: +8 % instructions in k_ntt_pass).
 MI_HD u64 sub_wc(u64 a, u64 b)
 {
     u64 d = a - b;
@@ -114,10 +119,27 @@ MI_HD u64 add_mul_eps(u64 lo, u32 h)
 
 // 128-bit (hi:lo) -> weakly reduced u64.   x = lo + hl*2^64 + hh*2^96 = lo + hl*(2^32-1) - hh
 // The subtraction of hh is spelled as the 32-bit borrow chain so that the rare-borrow branch tests the flag itself.
+#ifndef MI_REDUCE_SUBB_ASM
+#define MI_REDUCE_SUBB_ASM 0
+#endif
 MI_HD u64 reduce128_w(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     const u64 r2 = add_mul_eps(lo, hl);
+#if defined(__HIP_DEVICE_COMPILE__) && MI_REDUCE_SUBB_ASM
+    // r2 - hh as the two-instruction borrow chain (the compiler materialises the first borrow with a select and then
+    // subtracts it: v_sub_co, v_cndmask, v_sub_co); the final borrow mask goes to an SGPR pair for the rare-case branch
+    u32 d0, d1;
+    u64 m;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\ts_nop 1\n\tv_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\ts_nop 1\n\ts_mov_b64 %2, vcc"
+        : "=&v"(d0), "=&v"(d1), "=s"(m) : "v"((u32)r2), "v"((u32)(r2 >> 32)), "v"(hh) : "vcc");
+    u64 t = ((u64)d1 << 32) | d0;
+    if (m != 0) { // wave-uniform: some lane borrowed 2^64 = p + eps (needs r2 < 2^32: ~never)
+        MI_KEEP_BRANCH();
+        t = ((m >> __lane_id()) & 1) ? t - GL_EPS : t;
+    }
+    return t;
+#else
     u32 b1, b2;
     const u32 d0 = __builtin_subc((u32)r2, hh, 0u, &b1);
     const u32 d1 = __builtin_subc((u32)(r2 >> 32), 0u, b1, &b2);
@@ -127,6 +149,7 @@ MI_HD u64 reduce128_w(u64 lo, u64 hi)
         t = b2 ? t - GL_EPS : t; // t >= 2^64 - 2^32 + 1 > eps: no second borrow
     }
     return t;
+#endif
 }
 
 MI_HD void mul64x64(u64 a, u64 b, u64 &lo, u64 &hi)

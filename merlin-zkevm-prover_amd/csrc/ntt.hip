@@ -35,7 +35,8 @@ struct NttPass {
     uint32_t log_n, log_K;
     uint32_t apply_scale;
     uint32_t unit_tw; // last pass of an unscaled transform: every inter-pass twiddle is 1, outputs are only canonicalised
-    uint32_t tj_log, tcp_log; // TJ = beta rows per tile, TCP = padded columns per tile, TJ*TCP = 32
+    uint32_t tj_log, tcp_log; // TJ = beta rows per tile, TCP = padded columns per tile; TJ*TCP = B, or less when the
+                              // transform has fewer than B/TCP beta rows: the surplus lanes of a tile row then own nothing
     uint32_t n_col_tiles;
     uint64_t n_tiles;
     const u64 *tw_lo, *tw_hi;
@@ -44,6 +45,9 @@ struct NttPass {
     uint32_t sc_lo_bits;
     const u64 *w256;
 };
+
+// column index of a lane that owns no element: fails every `col < ncols` / `col + 1 < ncols` guard
+static constexpr uint32_t NO_COL = 0xFFFFFFF0u;
 
 // 16 bytes that are only 8-byte aligned (row pitch 665 is odd): gfx950 serves them with one dwordx4 access
 struct __attribute__((packed, aligned(8))) U64x2 { u64 x, y; };
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     if (WIDE) { // lanes run along column PAIRS: 16 lanes cover a 256-byte row segment, 32 rows per sweep
         constexpr int NW = (R * (B / 2) + NTT_THREADS - 1) / NTT_THREADS; // 16-byte loads per thread (8 at r = 256)
         const uint32_t bp = (tid & (B / 2 - 1)) * 2, tj = bp >> a.tcp_log, c = bp & (TCP - 1);
-        const uint32_t col = c0 + c;
+        const uint32_t col = tj < TJ ? c0 + c : NO_COL; // TJ * TCP < B (few beta rows): the surplus lanes own nothing
         const u64 *p = a.src + (beta0 + tj) * a.src_pitch + col;
         ulonglong2 v[NW];
         // all of the tile's loads are in flight before the twiddle table (dependent L2 loads + multiplies) is built
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     } else { // lanes run along the B batch elements, 16 rows per sweep
         fill_tw();
         const uint32_t b = tid & (B - 1), tj = b >> a.tcp_log, c = b & (TCP - 1);
-        const uint32_t col = c0 + c;
+        const uint32_t col = tj < TJ ? c0 + c : NO_COL;
         const bool active = col < a.ncols;
         const u64 *p = a.src + (beta0 + tj) * a.src_pitch + col;
 #pragma unroll 8
@@ -241,8 +245,9 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     if (LA > 0) __syncthreads();
     for (uint32_t item = tid; item < (uint32_t)RA * B; item += NTT_THREADS) { // trip count is wave-uniform
         const uint32_t b = item & (B - 1), kap = item >> LOG_B;
-        const uint32_t tj = b >> a.tcp_log, c = b & (TCP - 1);
-        const uint32_t col = c0 + c;
+        const uint32_t tj_raw = b >> a.tcp_log, c = b & (TCP - 1);
+        const uint32_t tj = tj_raw < TJ ? tj_raw : 0; // surplus lanes (see the load) compute on zeros and store nothing
+        const uint32_t col = tj_raw < TJ ? c0 + c : NO_COL;
         u64 x[RB];
         tile_step_b<LOG_R, INV, LOG_B>(tile, kap, b, x);
         const uint64_t beta = beta0 + tj;
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
     // ---- R1 input rows i1 * K1 + kappa, two adjacent columns per lane
     constexpr int NW = (R1 * (B / 2) + NTT_THREADS - 1) / NTT_THREADS;
     const uint32_t bp = (tid & (B / 2 - 1)) * 2, ltj = bp >> a.tcp_log, lc = bp & (TCP - 1);
-    const uint32_t lcol = c0 + lc;
+    const uint32_t lcol = ltj < TJ ? c0 + lc : NO_COL; // TJ * TCP < B (few kappa rows): the surplus lanes own nothing
     ulonglong2 v[NW];
     {
         const u64 *p = a.src + (kappa0 + ltj) * a.src_pitch + lcol;
@@ -371,7 +376,8 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
     if (T1::LA > 0) __syncthreads();
     {
         const bool has_item = tid < (uint32_t)T1::RA * B; // RA1 * B <= 16 * B = threads: at most one item per thread
-        const uint32_t b = tid & (B - 1), kap = tid >> LOG_B, tj = b >> a.tcp_log;
+        const uint32_t b = tid & (B - 1), kap = tid >> LOG_B, tj_raw = b >> a.tcp_log;
+        const uint32_t tj = tj_raw < TJ ? tj_raw : 0;
         u64 x[T1::RB];
         if (has_item) {
             tile_step_b<LOG_R1, true, LOG_B>(tile, kap, b, x);
@@ -394,8 +400,9 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
     if (T2::LA > 0) __syncthreads();
     for (uint32_t item = tid; item < (uint32_t)T2::RA * B; item += NTT_THREADS) {
         const uint32_t b = item & (B - 1), kap = item >> LOG_B;
-        const uint32_t tj = b >> a.tcp_log, c = b & (TCP - 1);
-        const uint32_t col = c0 + c;
+        const uint32_t tj_raw = b >> a.tcp_log, c = b & (TCP - 1);
+        const uint32_t tj = tj_raw < TJ ? tj_raw : 0;
+        const uint32_t col = tj_raw < TJ ? c0 + c : NO_COL;
         u64 x[T2::RB];
         tile_step_b<LOG_R2, false, LOG_B>(tile, kap, b, x);
 #pragma unroll
@@ -417,6 +424,7 @@ __global__ __launch_bounds__(256) void k_fill_pow(u64 *out, uint64_t count, u64 
 
 int launch_fill_pow(mi_ctx *ctx, u64 *out, uint64_t count, u64 s0, u64 g, uint64_t stride_exp)
 {
+    MI_REQUIRE_1D_GRID(count);
     hipLaunchKernelGGL(k_fill_pow, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, out, count, s0, g,
                        stride_exp);
     MI_HIP_CHECK(hipGetLastError());
@@ -568,6 +576,18 @@ static int run_passes(mi_ctx *ctx, NttPlan *plan, const std::vector<Buf> &bufs, 
 static uint32_t num_passes(uint32_t L) { return L == 0 ? 0 : (L + 7) / 8; }
 static uint32_t pass_log_r(uint32_t L, uint32_t P, uint32_t ps) { return L / P + (ps < L % P ? 1 : 0); }
 
+// Widest column chunk whose passes stay inside the launch limit (n_tiles < 2^22 workgroups): a pass over a chunk of
+// at least one full tile width has TJ = 1, i.e. (n >> log_r) row tiles per column tile; the smallest radix of the split
+// gives the most.  0: even a single column tile exceeds the limit (n > 2^29).
+static uint64_t grid_chunk_cap(uint32_t L, uint32_t log_b)
+{
+    if (L == 0) return ~0ull;
+    const uint32_t P = num_passes(L), min_r = L / P;
+    const uint64_t row_tiles = 1ull << (L - min_r);
+    const uint64_t col_tiles = ((1ull << 22) - 1) / row_tiles;
+    return col_tiles << log_b;
+}
+
 template <int LOG_R1, int LOG_BLOW>
 static int launch_lde_mid_t(mi_ctx *ctx, const LdeMid &a, size_t lds)
 {
@@ -674,8 +694,10 @@ int launch_ntt(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64
         if (fit == 0) fit = 1;
         if (fit >= 32) fit &= ~31ull;
         if (fit < chunk) chunk = fit;
-        MI_TRY(mi_ensure_workspace(ctx, (chunk < ncols ? chunk : ncols) * per_col));
     }
+    const uint64_t cap = grid_chunk_cap(L, ctx->ntt_log_b);
+    if (cap && cap < chunk) chunk = cap; // cap == 0: launch_pass reports "NTT grid too large"
+    if (P > 1) MI_TRY(mi_ensure_workspace(ctx, chunk * 2 * n * 8));
     for (uint64_t c0 = 0; c0 < ncols; c0 += chunk) {
         const uint64_t cw = (ncols - c0 < chunk) ? ncols - c0 : chunk;
         const Buf S = {const_cast<u64 *>(src) + c0, src_pitch}, D = {dst + c0, dst_pitch};
@@ -715,6 +737,8 @@ int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_
         uint64_t c = ctx->workspace_limit / pc;
         if (c == 0) c = 1;
         if (c >= 32) c &= ~31ull;
+        const uint64_t cap = grid_chunk_cap(L2, ctx->ntt_log_b);
+        if (cap && cap < c) c = cap;
         return c > ncols ? ncols : c;
     };
     uint64_t chunk = chunk_for(per_col);

@@ -4,25 +4,30 @@
 // merkleTreeGL.cpp:37-44 and transcript.cpp:23,46, and MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35).
 //
 // Mapping: ONE ROW (one sponge) PER LANE.  A leaf of the 665-column trace is 84 chained permutations, so
-// the kernel is VALU-bound by three orders of magnitude (~3e4 integer ops per 64 B absorbed): each lane
-// streams its own row with plain 8-byte loads, prefetching the next 64-byte block while the current
-// permutation runs; neighbouring half-lines are picked up from L2 by the next absorb.  Tree levels read
-// two sibling digests (64 B contiguous per lane, fully coalesced) and write 32 B.
+// the kernel is VALU-bound by three orders of magnitude (~1.7e4 integer instructions per 64 B absorbed).
+// Default leaf kernel (k_linear_hash_rows_lines): every lane pulls whole aligned 128-byte lines of its row,
+// one permutation ahead of their use, straight into a per-lane ring in LDS (global_load_lds_dwordx4) so that
+// each line crosses the fabric once; k_linear_hash_rows (plain 8-byte loads of the next blocks) is kept for
+// rows of at most 4 columns and for A/B runs (mi_set_leaf_mode 0).  Tree levels read two sibling digests
+// (64 B contiguous per lane, fully coalesced) and write 32 B.
 #include "common.h"
 #include "poseidon_math.h"
 
 __constant__ u64 c_rc[360];
 __constant__ pos::SparseTables c_sparse;
 
+// __constant__ symbols exist once per device; every context uploads them to ITS device the first time it hashes
+// (entry points make ctx->device current before they get here).
 static int upload_rc_once(mi_ctx *ctx)
 {
-    static int done_for_device = -1;
-    if (done_for_device == ctx->device) return MI_OK;
+    if (ctx->poseidon_constants_uploaded) return MI_OK;
     MI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), MI_POS_RC, sizeof(MI_POS_RC)));
-    static pos::SparseTables host_tables;
-    pos::fill_sparse_tables(host_tables);
-    MI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_sparse), &host_tables, sizeof(host_tables)));
-    done_for_device = ctx->device;
+    pos::SparseTables *host_tables = new pos::SparseTables();
+    pos::fill_sparse_tables(*host_tables);
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_sparse), host_tables, sizeof(*host_tables));
+    delete host_tables;
+    MI_HIP_CHECK(e);
+    ctx->poseidon_constants_uploaded = true;
     return MI_OK;
 }
 
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
     const uint64_t row = (gw >> 4) * 1024 + (uint64_t)lane * 16 + (gw & 15);
     const bool active = row < nrows;
-    const uint64_t srow = active ? row : (gw & 15); // idle lanes shadow a valid row of the same residue class
+    // idle lanes shadow a valid row (of the same residue class when there is one: then their line requests coincide
+    // with an active lane's; every load of a shadow is bounds-checked like any other)
+    const uint64_t srow = active ? row : ((gw & 15) < nrows ? (gw & 15) : 0);
     ulonglong2 *wave_ring = ring + wave * 64;
     const u64 *my = reinterpret_cast<const u64 *>(wave_ring + lane); // element in slot a: my[(a >> 1) * 512 + (a & 1)]
     u64 s[12];
@@ -331,7 +338,10 @@ int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const 
         sl.width[k] = (uint32_t)widths[i];
         k++;
     }
-    if (k == 0) return MI_OK;
+    if (k == 0) { // nothing to absorb; a first call still has to leave the zero capacity behind for the next one
+        if (first) MI_HIP_CHECK(hipMemsetAsync(digests, 0, nrows * 32, ctx->stream));
+        return MI_OK;
+    }
     for (uint32_t i = 0; i + 1 < k; i++) MI_REQUIRE(sl.width[i] % 8 == 0, "only a row's last column window may have a width that is not a multiple of 8");
     MI_REQUIRE(final || sl.width[k - 1] % 8 == 0, "a window that is not the row's last must have a width that is a multiple of 8");
     sl.nslabs = k;

@@ -55,7 +55,7 @@ EXPORTS = [
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
-    "mi_dbg_host_dft16",
+    "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
 ]
 
 
@@ -257,6 +257,10 @@ class Context:
 
     def dbg_field_ops(self, out, a, b, n):
         _check(lib().mi_dbg_field_ops_dev(self.h, _dp(out), _dp(a), _dp(b), u64(n)))
+
+    def dbg_lincomb_cols(self, out, src, nrows, ncols, coef, pitch=None, src_off=0, coef_off=0, accumulate=False):
+        _check(lib().mi_dbg_lincomb_cols_dev(self.h, _dp(out), _dp(src, src_off), u64(pitch or ncols), u64(nrows), u64(ncols),
+                                             _dp(coef, coef_off), ctypes.c_int(int(accumulate))))
 
     # ---- timers (HIP events on the context's stream)
     def timer_start(self, slot=0):

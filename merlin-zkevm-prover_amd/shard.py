@@ -12,9 +12,10 @@ One process per GPU.  The path has exactly one real exchange step:
   4. the G subtree roots (4 u64 each) are all-gathered and every rank hashes the top log2(G) levels,
      giving the same root as a single-GPU build.
 
-Steps 1-3 are one pipeline.  Columns are dealt to the ranks in TILES of 32 (the NTT tile width), round-robin:
-tile t belongs to rank t mod G.  In round k every rank extends its k-th tile, ships it, and the G tiles of the
-round -- columns [32 G k, 32 G (k+1)), a contiguous piece of every row -- arrive at each rank as G column windows.
+Steps 1-3 are one pipeline.  Columns are dealt to the ranks in TILES of at most 32 (the NTT tile width), in rounds:
+in round k every rank extends one tile of w_k columns (rank p the p-th of the round), ships it, and the G tiles of the
+round -- a contiguous piece of every row -- arrive at each rank as G column windows.  Every rank gets the same number
+of columns up to rounding to 8 (665 over 8 ranks: rounds of 32, 32 and 24 columns).
 Because the sponge absorbs a row's columns in order, round k's windows can be absorbed as soon as they are
 there (mi_linear_hash_absorb_dev keeps the running capacity in the digest buffer): the exchange of round k
 runs on the communicator's stream beside the LDE of round k+1 and the absorption of round k-1, and the windows
@@ -38,50 +39,57 @@ class ShardPlan:
     ncols: int      # total committed columns
     world: int
     rank: int
-    tile: int = 32  # columns per tile (a multiple of 8: the sponge absorbs whole 8-column blocks per window)
+    tile: int = 32  # widest tile (columns a rank extends per round); a multiple of 8: the sponge absorbs whole 8-column blocks
 
     def __post_init__(self):
         assert self.world >= 1 and (self.world & (self.world - 1)) == 0, "world size must be a power of two"
         assert self.n_ext % self.world == 0 and self.tile % 8 == 0
-        self.n_tiles = -(-self.ncols // self.tile)
-        self.n_rounds = -(-self.n_tiles // self.world)          # same on every rank
+        # Balanced dealing.  Every rank gets (up to) `per_rank` columns, the smallest multiple of 8 that covers ncols / world;
+        # they are dealt in rounds: in round k every rank extends ONE tile of round_w[k] columns, rank p the columns
+        # [round_c0[k] + p * w, + w) -- so a round is a contiguous piece of every row, in rank order.  All rounds use the
+        # full tile width except the last, which takes the remainder: 665 columns over 8 ranks = 88 per rank = rounds
+        # of 32, 32 and 24 columns (ranks 0..5 end with 88 columns, rank 6 with 73, rank 7 with 64), where dealing fixed
+        # 32-column tiles round-robin left ranks with 96 and 64.  Only the globally last non-empty tile may be narrower
+        # than its round (it is in the last round, so zero padding stays at the end of the row).
+        self.per_rank = -(-self.ncols // (8 * self.world)) * 8
+        self.round_w = [self.tile] * (self.per_rank // self.tile) + ([self.per_rank % self.tile] if self.per_rank % self.tile else [])
+        self.n_rounds = len(self.round_w)                       # same on every rank
+        self.round_c0 = [self.world * sum(self.round_w[:k]) for k in range(self.n_rounds)]
+        self.local_c0 = [sum(self.round_w[:k]) for k in range(self.n_rounds)]
         self.rows_per_rank = self.n_ext // self.world
         self.row0 = self.rank * self.rows_per_rank
-        self.my_tiles = list(range(self.rank, self.n_tiles, self.world))
-        self.my_cols = sum(self.tile_width(t) for t in self.my_tiles)
+        self.my_cols = sum(self.width(k, self.rank) for k in range(self.n_rounds))
 
     # ---- tiles
-    def tile_width(self, t: int) -> int:
-        return max(0, min(self.tile, self.ncols - t * self.tile)) if 0 <= t < self.n_tiles else 0
-
-    def round_tile(self, k: int, rank: int) -> int:
-        """Global index of the tile `rank` extends in round k (may be >= n_tiles: that rank sits the round out)."""
-        return k * self.world + rank
+    def round_cols(self, k: int, rank: int):
+        """(first global column, width) of the tile `rank` extends in round k; width 0: that rank sits the round out."""
+        c0 = self.round_c0[k] + rank * self.round_w[k]
+        return c0, max(0, min(self.round_w[k], self.ncols - c0))
 
     def width(self, k: int, rank: int) -> int:
-        return self.tile_width(self.round_tile(k, rank))
+        return self.round_cols(k, rank)[1]
 
-    def tile_cols(self, t: int):
-        """(first global column, width) of tile t."""
-        return t * self.tile, self.tile_width(t)
+    def my_tile_cols(self):
+        """[(first global column, width)] of my tiles, in round order (empty tiles left out)."""
+        return [self.round_cols(k, self.rank) for k in range(self.n_rounds) if self.width(k, self.rank)]
 
     @property
     def max_cols(self) -> int:
-        """Columns of the rank with the most tiles (rank 0)."""
-        return sum(self.tile_width(t) for t in range(0, self.n_tiles, self.world))
+        """Columns of the rank with the most (rank 0)."""
+        return sum(self.width(k, 0) for k in range(self.n_rounds))
 
     # ---- buffer layouts (element offsets)
-    # trace shard : [n x my_cols], my k-th tile at local column k * tile (only the globally last tile is narrower,
-    #               and it is the last tile of its owner)
-    # bufs['ext'] : my extended tiles back to back, tile k as [n_ext x w] with pitch w, at n_ext * k * tile
+    # trace shard : [n x my_cols], my round-k tile at local column local_c0[k] (only the globally last tile is narrower
+    #               than its round, and it is the last tile of its owner)
+    # bufs['ext'] : my extended tiles back to back, round k's as [n_ext x w] with pitch w, at n_ext * local_c0[k]
     # bufs['recv']: window (k, p) = peer p's tile of round k restricted to my rows, [rows_per_rank x w] with pitch w,
     #               at rows_per_rank * (first global column of that tile); my own slot stays unused (my rows of my
     #               tile are read in place from bufs['ext'])
     def local_col(self, k: int) -> int:
-        return k * self.tile
+        return self.local_c0[k]
 
     def ext_base(self, k: int) -> int:
-        return self.n_ext * k * self.tile
+        return self.n_ext * self.local_c0[k]
 
     def send_block(self, k: int, peer: int):
         """(offset, count) in bufs['ext'] of peer's rows of my round-k tile."""
@@ -90,7 +98,8 @@ class ShardPlan:
 
     def recv_window(self, k: int, peer: int):
         """(offset, count) in bufs['recv'] of the window that arrives from `peer` in round k."""
-        return self.rows_per_rank * self.round_tile(k, peer) * self.tile, self.rows_per_rank * self.width(k, peer)
+        c0, w = self.round_cols(k, peer)
+        return self.rows_per_rank * c0, self.rows_per_rank * w
 
     def windows(self, k: int):
         """Round k's column windows of MY rows in column order: [(buffer name, offset, width, pitch)]."""
@@ -105,11 +114,16 @@ class ShardPlan:
                 out.append(("recv", self.recv_window(k, p)[0], w, w))
         return out
 
+    def row_windows(self):
+        """All column windows of MY rows, in column order (the row-sharded extended trace as the leaf sponge and the
+        query openings read it)."""
+        return [w for k in range(self.n_rounds) for w in self.windows(k)]
+
     def ext_elems(self) -> int:
-        return self.n_ext * max(self.max_cols, 1)
+        return self.n_ext * self.per_rank
 
     def recv_elems(self) -> int:
-        return self.rows_per_rank * self.n_tiles * self.tile
+        return self.rows_per_rank * self.world * self.per_rank if self.world > 1 else 0   # no peers: nothing arrives
 
 
 def exchange_messages(plan: ShardPlan, k: int):
@@ -117,7 +131,7 @@ def exchange_messages(plan: ShardPlan, k: int):
     element ranges of bufs['ext'] / bufs['recv']; every rank derives the same number of message rounds.  A peer's
     block [rows_per_rank x w] is cut by rows into pieces of at most MAX_MSG_BYTES."""
     p = plan
-    rows_per_msg = max(1, (MAX_MSG_BYTES // 8) // p.tile)
+    rows_per_msg = max(1, (MAX_MSG_BYTES // 8) // p.round_w[k])
     out = []
     w_me = p.width(k, p.rank)
     for r0 in range(0, p.rows_per_rank, rows_per_msg):

@@ -9,29 +9,29 @@ u64 = ctypes.c_uint64
 _p64 = ctypes.POINTER(u64)
 
 
-def build():
-    so = os.path.join(ROOT, "oracle", "libgl_oracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("gl_oracle.c", "gl_oracle.h", "poseidon_constants.h")]
+def build(flavour=""):
+    so = os.path.join(ROOT, "oracle", "libgl_oracle%s.so" % ("_" + flavour if flavour else ""))
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("gl_oracle.c", "gl_oracle.h", "poseidon_constants.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return so
 
 
-_L = None
+_L = {}
 
 
-def lib():
-    global _L
-    if _L is None:
-        L = ctypes.CDLL(build())
+def lib(flavour=""):
+    """flavour "": the checker build; "avx2": the same source built -O3 -mavx2 (bench.py's cpu_baseline leg only)."""
+    if flavour not in _L:
+        L = ctypes.CDLL(build(flavour))
         for f in ("glo_canon", "glo_add", "glo_sub", "glo_mul", "glo_pow", "glo_inv", "glo_w", "glo_shift",
                   "glo_transcript_get_fields1"):
             getattr(L, f).restype = u64
         L.glo_add.argtypes = L.glo_sub.argtypes = L.glo_mul.argtypes = L.glo_pow.argtypes = [u64, u64]
         L.glo_inv.argtypes = L.glo_canon.argtypes = [u64]
         L.glo_w.argtypes = [ctypes.c_uint]
-        _L = L
-    return _L
+        _L[flavour] = L
+    return _L[flavour]
 
 
 def ptr(a):
@@ -74,10 +74,10 @@ def linear_hash(vals):
     return out
 
 
-def merkletree(src, ncols, nrows):
+def merkletree(src, ncols, nrows, flavour=""):
     src = A(src)
     nodes = np.zeros((2 * nrows - 1) * 4, dtype=np.uint64)
-    lib().glo_merkletree(ptr(nodes), ptr(src), u64(ncols), u64(nrows))
+    lib(flavour).glo_merkletree(ptr(nodes), ptr(src), u64(ncols), u64(nrows))
     return nodes
 
 
@@ -101,10 +101,10 @@ def ntt(src, n, ncols, inverse=False):
     return dst.reshape(n, ncols)
 
 
-def extend_pol(src, n_ext, n, ncols):
+def extend_pol(src, n_ext, n, ncols, flavour=""):
     src = A(src)
     out = np.zeros(n_ext * ncols, dtype=np.uint64)
-    lib().glo_extend_pol(ptr(out), ptr(src), u64(n_ext), u64(n), u64(ncols))
+    lib(flavour).glo_extend_pol(ptr(out), ptr(src), u64(n_ext), u64(n), u64(ncols))
     return out.reshape(n_ext, ncols)
 
 

@@ -1,0 +1,143 @@
+"""BASELINE config 3 AT FULL SIZE against the CPU oracle: the 2^23 x 665 -> 2^24 LDE + Poseidon Merkle tree the bench times
+(default 32 GiB workspace: production pass split 8,8,7 | 8,8,8, the fused middle pass at log_K = 16, the 2^12 x 2^12
+two-level twiddle tables, 96-column chunks with the second ping-pong buffer, offsets beyond 2^33 elements), the tile-by-tile
+path the N > 1 ranks run, and the stage 2-4 widths.  tests/verify_full.py says what is compared and why it pins
+every value: whole columns, a random combination of all columns at all rows, sampled leaves, every tree level."""
+import numpy as np
+import pytest
+
+import glo
+from verify_full import verify_lde_merkle, pull_row
+
+pytestmark = pytest.mark.gpu
+
+LOG_N, NCOLS, SEED = 23, 665, 0x5EED0003
+# regression constant, as in bench.py: what the oracle-verified run below produces
+ROOT_2P23_X665 = [17877856175459861405, 3297257765296605804, 13052643778398375791, 11912701812281293778]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import mi_stark
+    c = mi_stark.Context(0)          # default workspace limit (32 GiB), default kernels: what bench.py runs
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def state():
+    return {}
+
+
+def _free(*tensors):
+    import torch
+    for t in tensors:
+        del t
+    torch.cuda.empty_cache()
+
+
+def test_verification_harness_on_a_small_case_and_that_it_catches_a_wrong_value(ctx):
+    """verify_lde_merkle itself: passes on a correct 2^12 x 70 result (plain and as column windows), and a single wrong
+    value anywhere in the extension -- in a column that is not sampled, at a row that is not sampled -- fails the
+    all-columns combination check."""
+    n, n_ext, ncols = 1 << 12, 1 << 13, 70
+    trace = ctx.empty(n * ncols)
+    ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, 77)
+    ext, nodes = ctx.empty(n_ext * ncols), ctx.empty((2 * n_ext - 1) * 4)
+    ctx.lde(ext, trace, n_ext, n, ncols)
+    ctx.merkle_build(nodes, ext, ncols, n_ext)
+    s = verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(ext, 0, ncols, ncols)], nodes, n, n_ext, ncols, cols=[0, 1, 31, 32, 69], n_rows=16)
+    assert s["tree_levels_match_oracle"] and s["all_columns_all_rows_lincomb"]
+    want = glo.merkletree(glo.extend_pol(ctx.to_host(trace).reshape(n, ncols), n_ext, n, ncols), ncols, n_ext)
+    assert s["root"] == [int(v) for v in want[-4:]]
+    # the same matrix as two column windows (40 + 30 columns) in separate buffers
+    a, b = ctx.empty(n_ext * 40), ctx.empty(n_ext * 30 + 5)
+    ctx.copy_2d(a, ext, n_ext, 40, 40, ncols)
+    ctx.copy_2d(b, ext, n_ext, 30, 30, ncols, dst_off=5, src_off=40)
+    verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(a, 0, 40, 40), (b, 5, 30, 30)], nodes, n, n_ext, ncols, cols=[0, 39, 40, 69], n_rows=16)
+    bad = ext.clone()
+    bad[5000 * ncols + 17] += 1
+    with pytest.raises(AssertionError, match="combination"):
+        verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(bad, 0, ncols, ncols)], None, n, n_ext, ncols, cols=[0, 69])
+    nodes2 = nodes.clone()
+    nodes2[(n_ext + 100) * 4] ^= 1                                        # a corrupted level-1 node
+    with pytest.raises(AssertionError, match="tree levels"):
+        verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(ext, 0, ncols, ncols)], nodes2, n, n_ext, ncols, cols=[0], n_rows=8)
+
+
+def test_config3_full_size_single_gpu_path_vs_oracle(ctx, state):
+    import torch
+    n, n_ext = 1 << LOG_N, 2 << LOG_N
+    trace = ctx.empty(n * NCOLS)
+    ctx.fill_synthetic_2d(trace, n, NCOLS, NCOLS, 0, SEED)
+    assert np.array_equal(ctx.to_host(trace[:4096]), glo.splitmix64(SEED, 4096))          # the fill is the oracle's stream
+    assert np.array_equal(pull_row(ctx, [(trace, 0, NCOLS, NCOLS)], n - 1)[-8:], ctx.to_host(trace[n * NCOLS - 8:]))
+    ext = ctx.empty(n_ext * NCOLS)
+    nodes = ctx.empty((2 * n_ext - 1) * 4)
+    ctx.lde(ext, trace, n_ext, n, NCOLS)
+    ctx.merkle_build(nodes, ext, NCOLS, n_ext)
+    torch.cuda.synchronize()
+    s = verify_lde_merkle(ctx, [(trace, 0, NCOLS, NCOLS)], [(ext, 0, NCOLS, NCOLS)], nodes, n, n_ext, NCOLS)
+    assert s["tree_levels_match_oracle"] and s["all_columns_all_rows_lincomb"] and s["leaf_rows_checked"] >= 64
+    assert s["root"] == ROOT_2P23_X665, "oracle-verified root differs from the regression constant in bench.py"
+    state["leaf_digests"] = ctx.to_host(nodes[:4 * n_ext]).copy()
+    state["root"] = s["root"]
+    _free(trace, ext, nodes)
+
+
+def test_config3_full_size_tile_by_tile_path_vs_oracle(ctx, state):
+    """The path every rank of an N > 1 run takes (tile-by-tile LDE into tile-major windows, streaming leaf absorption,
+    subtree), rehearsed with world = 1 at full size: extension verified against the oracle, leaf digests and root equal to
+    the single-GPU path's."""
+    import torch
+    from shard import ShardPlan, lde_merkle_sharded
+    n, n_ext = 1 << LOG_N, 2 << LOG_N
+    plan = ShardPlan(n=n, n_ext=n_ext, ncols=NCOLS, world=1, rank=0)
+    assert plan.n_rounds == 21
+    trace = ctx.empty(n * NCOLS)
+    ctx.fill_synthetic_2d(trace, n, NCOLS, NCOLS, 0, SEED)
+    bufs = {"ext": ctx.empty(plan.ext_elems()), "recv": ctx.empty(plan.recv_elems()), "nodes": ctx.empty((2 * n_ext - 1) * 4),
+            "roots": ctx.empty(4)}
+
+    class Ops:
+        @staticmethod
+        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+
+        @staticmethod
+        def absorb(digests, windows, nrows, first, final, chunk=0):
+            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
+
+        merkle_levels = staticmethod(ctx.merkle_levels)
+
+    root = lde_merkle_sharded(plan, Ops, None, trace, bufs, always_exchange=True)
+    torch.cuda.synchronize()
+    ext_windows = [(bufs[name], off, w, pitch) for (name, off, w, pitch) in plan.row_windows()]
+    assert sum(w for (_, _, w, _) in ext_windows) == NCOLS
+    # columns at tile edges of THIS layout; the tree above the digests was verified in the test before, so equality of the
+    # level-0 digests and of the root with that run closes the loop without a second 30-second oracle tree
+    s = verify_lde_merkle(ctx, [(trace, 0, NCOLS, NCOLS)], ext_windows, bufs["nodes"], n, n_ext, NCOLS,
+                          cols=[0, 31, 32, 63, 639, 640, 664], n_rows=24, check_tree=False)
+    assert s["all_columns_all_rows_lincomb"]
+    if "leaf_digests" in state:
+        assert np.array_equal(ctx.to_host(bufs["nodes"][:4 * n_ext]), state["leaf_digests"])
+    assert [int(v) for v in ctx.to_host(root)] == ROOT_2P23_X665
+    _free(trace, bufs)
+
+
+@pytest.mark.parametrize("ncols", [6, 128])
+def test_stage_widths_full_size_lde_and_tree_vs_oracle(ctx, ncols):
+    """The other committed widths of the zkEVM STARK at 2^23 -> 2^24 rows (cm2_2ns: 128 columns, cm4_2ns: 6)."""
+    import torch
+    n, n_ext = 1 << LOG_N, 2 << LOG_N
+    trace = ctx.empty(n * ncols)
+    ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, SEED + ncols)
+    ext = ctx.empty(n_ext * ncols)
+    nodes = ctx.empty((2 * n_ext - 1) * 4)
+    ctx.lde(ext, trace, n_ext, n, ncols)
+    ctx.merkle_build(nodes, ext, ncols, n_ext)
+    torch.cuda.synchronize()
+    s = verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(ext, 0, ncols, ncols)], nodes, n, n_ext, ncols,
+                          cols=[0, 1, 2, 31, 32, 95, 96, ncols - 2, ncols - 1], n_rows=32, check_tree=(ncols == 128))
+    assert s["all_columns_all_rows_lincomb"]
+    _free(trace, ext, nodes)

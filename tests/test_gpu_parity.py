@@ -233,6 +233,70 @@ def test_ntt_matches_oracle(ctx, n, ncols):
         assert np.array_equal(ctx.to_host(out).reshape(n, ncols), glo.ntt(x, n, ncols, inverse=inverse)), inverse
 
 
+@pytest.mark.parametrize("n,ncols", [(2, 1), (8, 1), (16, 3), (128, 2), (256, 1), (512, 1), (512, 3), (1024, 2), (1 << 13, 1)])
+def test_small_transforms_stay_inside_their_buffers(ctx, n, ncols):
+    """Transforms with fewer beta rows than a tile has lanes for (TJ * TCP < tile width): the surplus lanes must neither
+    load nor store.  dst is followed by a canary region 40x its size (the overrun reached 32x), src sits at the very end of
+    its allocation, and the transform runs out of place and in place, forward and inverse, with both tile widths."""
+    rng = np.random.default_rng(n * 7 + ncols)
+    x = glo.rand_fe(rng, (n, ncols))
+    canary = np.uint64(0xC0FFEE0DDBA11AD5)
+    try:
+        for log_b in (5, 4):
+            ctx.set_ntt_tile(log_b)
+            for inverse in (False, True):
+                want = glo.ntt(x, n, ncols, inverse=inverse).reshape(-1)
+                buf = np.full(n * ncols * 41, canary, dtype=np.uint64)
+                d = ctx.to_device(buf)
+                ctx.ntt(d, ctx.to_device(x), n, ncols, inverse=inverse)
+                got = ctx.to_host(d)
+                assert np.array_equal(got[:n * ncols], want), (log_b, inverse)
+                assert np.all(got[n * ncols:] == canary), (log_b, inverse, int(np.nonzero(got[n * ncols:] != canary)[0][0]))
+                buf[:n * ncols] = x.reshape(-1)
+                d = ctx.to_device(buf)
+                ctx.ntt(d, d, n, ncols, inverse=inverse)                      # in place
+                got = ctx.to_host(d)
+                assert np.array_equal(got[:n * ncols], want), (log_b, inverse, "in place")
+                assert np.all(got[n * ncols:] == canary), (log_b, inverse, "in place")
+    finally:
+        ctx.set_ntt_tile(5)
+
+
+@pytest.mark.parametrize("n,n_ext,ncols", [(16, 32, 2), (32, 64, 2), (32, 128, 3), (64, 128, 1), (128, 256, 5), (256, 512, 2), (2, 4, 1)])
+def test_small_ldes_stay_inside_their_buffers(ctx, n, n_ext, ncols):
+    """Same for extendPol, fused middle pass on and off: nothing is written past row n_ext of the output."""
+    rng = np.random.default_rng(n + 3 * n_ext + ncols)
+    x = glo.rand_fe(rng, (n, ncols))
+    want = glo.extend_pol(x, n_ext, n, ncols).reshape(-1)
+    canary = np.uint64(0xC0FFEE0DDBA11AD5)
+    try:
+        for fuse in (1, 0):
+            ctx.set_lde_fuse(fuse)
+            d = ctx.to_device(np.full(n_ext * ncols * 41, canary, dtype=np.uint64))
+            ctx.lde(d, ctx.to_device(x), n_ext, n, ncols)
+            got = ctx.to_host(d)
+            assert np.array_equal(got[:n_ext * ncols], want), fuse
+            assert np.all(got[n_ext * ncols:] == canary), (fuse, int(np.nonzero(got[n_ext * ncols:] != canary)[0][0]))
+    finally:
+        ctx.set_lde_fuse(1)
+
+
+def test_absorb_first_call_without_windows_leaves_zero_capacity(ctx):
+    """A first absorb whose windows are all empty must still initialise the running capacity, and a kernel with fewer
+    than 16 rows and a carried-in capacity must not read digests of rows that do not exist."""
+    rng = np.random.default_rng(4242)
+    h, w = 5, 24
+    src = glo.rand_fe(rng, (h, w))
+    d = ctx.to_device(src)
+    dig = ctx.to_device(np.full(h * 4, 0xDEADBEEF, dtype=np.uint64))
+    ctx.linear_hash_absorb(dig, [(d, 0, 0, w)], h, True, False)          # nothing to absorb yet
+    ctx.linear_hash_absorb(dig, [(d, 0, 16, w)], h, False, False)
+    ctx.linear_hash_absorb(dig, [(d, 16, 8, w)], h, False, True)
+    got = ctx.to_host(dig).reshape(h, 4)
+    for r in range(h):
+        assert np.array_equal(got[r], glo.linear_hash(src[r])), r
+
+
 def test_ntt_and_lde_with_16_wide_tiles(ctx):
     """The NTT tile width is a tuning knob (128-byte or 256-byte row segments); results must not depend on it."""
     ctx.set_ntt_tile(4)
@@ -591,8 +655,7 @@ def test_sharded_path_emulated_on_one_gpu(ctx, world, ncols, tile):
     bufs, traces = [], []
     for p in plans:
         trace = ctx.empty(n * max(p.my_cols, 1))
-        for k, t in enumerate(p.my_tiles):                                            # my tiles of the same trace
-            c0, w = p.tile_cols(t)
+        for k, (c0, w) in enumerate(p.my_tile_cols()):                                # my tiles of the same trace
             ctx.fill_synthetic_2d(trace, n, w, ncols, c0, 0x5EED0003, out_pitch=p.my_cols, out_off=p.local_col(k))
         traces.append(trace)
         bufs.append({"ext": ctx.empty(p.ext_elems()), "nodes": ctx.empty((2 * p.rows_per_rank - 1) * 4),

@@ -13,31 +13,44 @@ from shard import ShardPlan, lde_merkle_sharded
 
 
 def test_tile_dealing_and_buffer_layouts():
-    """Tiles are dealt round-robin; every rank derives the same number of rounds; what a rank sends a peer is what
-    that peer expects; a round's windows are consecutive columns of the row, in order; the receive windows do not
-    overlap."""
-    p = ShardPlan(n=1 << 23, n_ext=1 << 24, ncols=665, world=8, rank=4)
-    assert p.n_tiles == 21 and p.n_rounds == 3 and p.my_tiles == [4, 12, 20] and p.my_cols == 32 + 32 + 25
-    assert [p.width(2, r) for r in range(8)] == [32, 32, 32, 32, 25, 0, 0, 0] and p.max_cols == 96
-    assert ShardPlan(n=8, n_ext=16, ncols=7, world=2, rank=1, tile=8).my_cols == 0        # fewer tiles than ranks
-    for (ncols, world, tile) in ((665, 8, 32), (665, 2, 32), (70, 2, 8), (13, 4, 8), (128, 8, 32), (5, 4, 8), (64, 2, 8)):
+    """Columns are dealt in rounds of equal-width tiles, balanced up to rounding to 8; every rank derives the same number
+    of rounds; what a rank sends a peer is what that peer expects; a round's windows are consecutive columns of the row,
+    in order; the receive windows do not overlap."""
+    p = ShardPlan(n=1 << 23, n_ext=1 << 24, ncols=665, world=8, rank=6)
+    assert p.per_rank == 88 and p.round_w == [32, 32, 24] and p.n_rounds == 3
+    assert [ShardPlan(n=1 << 23, n_ext=1 << 24, ncols=665, world=8, rank=r).my_cols for r in range(8)] == [88] * 6 + [73, 64]
+    assert [p.width(2, r) for r in range(8)] == [24] * 6 + [9, 0] and p.max_cols == 88 and p.my_tile_cols() == [(192, 32), (448, 32), (656, 9)]
+    assert ShardPlan(n=1 << 23, n_ext=1 << 24, ncols=665, world=1, rank=0).round_w == [32] * 21        # one GPU: 20 x 32 + 25
+    assert ShardPlan(n=1 << 23, n_ext=1 << 24, ncols=665, world=2, rank=1).round_w == [32] * 10 + [16]
+    assert ShardPlan(n=8, n_ext=16, ncols=7, world=2, rank=1, tile=8).my_cols == 0        # fewer columns than one tile
+    for (ncols, world, tile) in ((665, 8, 32), (665, 4, 32), (665, 2, 32), (70, 2, 8), (13, 4, 8), (128, 8, 32), (5, 4, 8), (64, 2, 8),
+                                 (100, 8, 8), (371, 8, 32), (6, 2, 32)):
         plans = [ShardPlan(n=64, n_ext=128, ncols=ncols, world=world, rank=r, tile=tile) for r in range(world)]
         assert len({q.n_rounds for q in plans}) == 1 and sum(q.my_cols for q in plans) == ncols
+        assert max(q.my_cols for q in plans) == plans[0].max_cols <= -(-ncols // (8 * world)) * 8     # balanced
         for q in plans:
             col = 0
             seen = []
             for k in range(q.n_rounds):
-                for (name, off, w, pitch) in q.windows(k):
+                wins = q.windows(k)
+                for i, (name, off, w, pitch) in enumerate(wins):
                     assert pitch == w and w > 0
+                    assert w % 8 == 0 or (k == q.n_rounds - 1 and i == len(wins) - 1)   # zero padding only at the row's end
                     seen.append((name, off, off + q.rows_per_rank * w if name == "recv" else None))
                     col += w
-                assert col == min(ncols, tile * world * (k + 1))          # a contiguous prefix of the row after every round
+                assert col == min(ncols, world * sum(q.round_w[:k + 1]))     # a contiguous prefix of the row after every round
                 for peer in plans:
                     if peer.rank != q.rank:
                         assert q.send_block(k, peer.rank)[1] == peer.recv_window(k, q.rank)[1]
                         assert q.send_block(k, peer.rank)[0] + q.send_block(k, peer.rank)[1] <= q.ext_elems()
+            assert col == ncols and [w for (_, _, w, _) in q.row_windows()] == [w for k in range(q.n_rounds) for (_, _, w, _) in q.windows(k)]
             recv = sorted((a, b) for (nm, a, b) in seen if nm == "recv")
             assert all(recv[i][1] <= recv[i + 1][0] for i in range(len(recv) - 1)) and (not recv or recv[-1][1] <= q.recv_elems())
+            loc = 0
+            for k in range(q.n_rounds):                                       # my tiles sit side by side in my trace shard
+                if q.width(k, q.rank):
+                    assert q.local_col(k) == loc
+                    loc += q.width(k, q.rank)
 
 
 class OracleOps:
@@ -101,7 +114,7 @@ def _worker(rank, world, port, n, ncols, q):
     n_ext = 2 * n
     plan = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=world, rank=rank, tile=8)
     full = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
-    shard_cols = [full[:, c0:c0 + w] for (c0, w) in (plan.tile_cols(t) for t in plan.my_tiles)]
+    shard_cols = [full[:, c0:c0 + w] for (c0, w) in plan.my_tile_cols()]
     shard_np = np.ascontiguousarray(np.concatenate(shard_cols, axis=1)) if shard_cols else np.zeros((n, 0), dtype=np.uint64)
     trace = torch.from_numpy(shard_np.view(np.int64).reshape(-1).copy())
     z = lambda k: torch.zeros(max(k, 1), dtype=torch.int64)
