@@ -20,6 +20,12 @@ typedef unsigned int u32;
 static constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
 static constexpr u64 GL_EPS = 0xFFFFFFFFULL; // 2^64 mod p = 2^32 - 1
 
+// How a carry flag becomes a 32-bit correction word in the hand-written sequences (A/B switch, see tools/ubench_field.hip):
+// 0: carry in VCC + v_cndmask_b32 (VOP2); 1: carry in an SGPR pair + v_cndmask_b32_e64; 2: -carry by v_subb_co_u32
+#ifndef MI_MASK_FORM
+#define MI_MASK_FORM 0
+#endif
+
 namespace gl {
 
 // true in at least one lane of the wave?  A correction that is needed with probability ~2^-32 per value (x >= p,
@@ -65,8 +71,16 @@ MI_HD u64 canon(u64 a)
 // a any u64, b canonical (< p)  ->  weakly reduced a + b
 MI_HD u64 add_wc(u64 a, u64 b)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && MI_MASK_FORM == 1
+    u64 s, m;
+    u32 e;
+    asm("v_lshl_add_u64 %0, %3, 0, %4\n\tv_cmp_lt_u64_e64 %2, %0, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, %2"
+        : "=&v"(s), "=v"(e), "=&s"(m) : "v"(a), "v"(b));
+    return s + e;
+#else
     u64 s = a + b;
     return s + (s < a ? GL_EPS : 0); // wrapped: true sum < 2^64 + p, so s < p and s + eps cannot wrap again
+#endif
 }
 
 // both canonical -> canonical
@@ -108,8 +122,16 @@ MI_HD u64 add_mul_eps(u64 lo, u32 h)
     u64 r1;
     u32 e; // wrapped ? 2^32 - 1 : 0
 #if defined(__HIP_DEVICE_COMPILE__)
-    // VALU write of VCC -> VALU read as a select mask: two wait states on gfx950
+    // VALU write of a carry mask -> VALU read of it as a select mask / carry-in: two wait states on gfx950
+#if MI_MASK_FORM == 1
+    u64 m;
+    asm("v_mad_u64_u32 %0, %2, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, %2" : "=v"(r1), "=v"(e), "=&s"(m) : "v"(h), "v"(lo));
+#elif MI_MASK_FORM == 2
+    u64 m;
+    asm("v_mad_u64_u32 %0, vcc, %3, -1, %4\n\ts_nop 1\n\tv_subb_co_u32_e64 %1, %2, 0, 0, vcc" : "=v"(r1), "=v"(e), "=&s"(m) : "v"(h), "v"(lo) : "vcc");
+#else
     asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=v"(r1), "=v"(e) : "v"(h), "v"(lo) : "vcc");
+#endif
 #else
     r1 = (u64)h * 0xFFFFFFFFu + lo;
     e = r1 < lo ? 0xFFFFFFFFu : 0;

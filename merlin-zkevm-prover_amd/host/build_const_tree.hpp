@@ -24,20 +24,41 @@ inline std::string slurp(const std::string &path)
     ss << f.rdbuf();
     return ss.str();
 }
-// minimal field extraction from the flat starkstruct JSON ({"nBits": 23, "nBitsExt": 24, "verificationHashType": "GL", ...})
+// Value of a TOP-LEVEL key of the starkstruct JSON object ({"nBits": 23, "nBitsExt": 24, "verificationHashType": "GL",
+// "steps": [{"nBits": 24}, ...]}): keys nested inside "steps" (or any other array / object) are skipped by tracking the
+// bracket depth, strings are skipped as strings.  Numbers and strings only -- all this tool reads.
 inline bool json_field(const std::string &js, const std::string &key, std::string &out)
 {
-    size_t p = js.find("\"" + key + "\"");
-    if (p == std::string::npos) return false;
-    p = js.find(':', p);
-    if (p == std::string::npos) return false;
-    p++;
-    while (p < js.size() && (js[p] == ' ' || js[p] == '\n' || js[p] == '\t' || js[p] == '\r')) p++;
-    size_t e = p;
-    if (js[p] == '"') { e = js.find('"', p + 1); out = js.substr(p + 1, e - p - 1); return true; }
-    while (e < js.size() && js[e] != ',' && js[e] != '}' && js[e] != '\n' && js[e] != ' ') e++;
-    out = js.substr(p, e - p);
-    return true;
+    int depth = 0;
+    for (size_t p = 0; p < js.size(); p++) {
+        const char ch = js[p];
+        if (ch == '{' || ch == '[') { depth++; continue; }
+        if (ch == '}' || ch == ']') { depth--; continue; }
+        if (ch != '"') continue;
+        size_t e = p + 1;
+        while (e < js.size() && js[e] != '"') e += (js[e] == '\\') ? 2 : 1;
+        if (e >= js.size()) return false;
+        const std::string tok = js.substr(p + 1, e - p - 1);
+        size_t q = e + 1;
+        while (q < js.size() && (js[q] == ' ' || js[q] == '\n' || js[q] == '\t' || js[q] == '\r')) q++;
+        if (depth == 1 && q < js.size() && js[q] == ':' && tok == key) { // a key of the outermost object
+            q++;
+            while (q < js.size() && (js[q] == ' ' || js[q] == '\n' || js[q] == '\t' || js[q] == '\r')) q++;
+            if (q >= js.size()) return false;
+            if (js[q] == '"') {
+                size_t v = q + 1;
+                while (v < js.size() && js[v] != '"') v += (js[v] == '\\') ? 2 : 1;
+                out = js.substr(q + 1, v - q - 1);
+                return true;
+            }
+            size_t v = q;
+            while (v < js.size() && js[v] != ',' && js[v] != '}' && js[v] != '\n' && js[v] != ' ' && js[v] != '\r' && js[v] != '\t') v++;
+            out = js.substr(q, v - q);
+            return !out.empty();
+        }
+        p = e; // skip the string (a key at another depth, or a string value)
+    }
+    return false;
 }
 } // namespace bctree_detail
 
@@ -46,12 +67,15 @@ inline void buildConstTree(const std::string constFile, const std::string starkS
 {
     using namespace bctree_detail;
     const std::string js = slurp(starkStructFile);
-    std::string v, hashType = "GL";
+    std::string v, hashType;
     if (!json_field(js, "nBits", v)) { std::fprintf(stderr, "buildConstTree: nBits missing\n"); std::exit(-1); }
     const uint64_t nBits = std::stoull(v);
     if (!json_field(js, "nBitsExt", v)) { std::fprintf(stderr, "buildConstTree: nBitsExt missing\n"); std::exit(-1); }
     const uint64_t nBitsExt = std::stoull(v);
-    json_field(js, "verificationHashType", hashType);
+    if (!json_field(js, "verificationHashType", hashType)) { // the reference reads it unconditionally (build_const_tree.cpp:343)
+        std::fprintf(stderr, "buildConstTree: verificationHashType missing\n");
+        std::exit(-1);
+    }
     if (hashType != "GL") { // build_const_tree.cpp:404-443: BN128 trees belong to the recursiveF/SNARK side (out of scope)
         std::fprintf(stderr, "Invalid Hash Type: %s (only GL is built here)\n", hashType.c_str());
         std::exit(-1);

@@ -10,10 +10,7 @@
 #include "merkleTreeGL.hpp"
 #include "ntt_goldilocks.hpp"
 #include "friProof.hpp"
-
-class StepStruct { public: uint64_t nBits; };
-class StarkStruct { public: uint64_t nBits = 0, nBitsExt = 0, nQueries = 0; std::vector<StepStruct> steps; };
-class StarkInfo { public: StarkStruct starkStruct; };
+#include "stark_info.hpp"
 
 class FRIProve
 {
@@ -31,6 +28,7 @@ public:
         if (!d_pol || !d_next || !d_aux) mi::fail("FRIProve::prove (alloc)");
         mi::check(mi_copy_h2d(c, d_pol, friPol.address(), (3ULL << polBits) * 8), "FRIProve::prove (h2d)");
         std::vector<MerkleTreeGL *> treesFRIGL(steps.size(), nullptr);
+        std::vector<uint64_t *> owned_sources; // device leaves of the step trees, released after the query phase
         uint64_t pol2N = 0;
         for (uint64_t si = 0; si < steps.size(); si++) {
             const uint64_t curBits = steps[si].nBits;
@@ -53,13 +51,15 @@ public:
                 transcript.put(rootGL, HASH_SIZE);
                 fproof.proofs.fri.trees[si + 1].setRoot(rootGL);
                 treesFRIGL[si + 1] = t;
-                owned_sources().push_back(d_src);
+                owned_sources.push_back(d_src);
             } else { // friProve.cpp:128-134: the last polynomial goes into the transcript and the proof
                 std::vector<Goldilocks::Element> last(pol2N * 3);
                 mi::check(mi_copy_d2h(c, last.data(), d_next, pol2N * 3 * 8), "FRIProve::prove (final pol)");
                 for (uint64_t i = 0; i < pol2N; i++) transcript.put(&last[i * 3], FIELD_EXTENSION);
                 fproof.proofs.fri.setPol(last.data());
-                std::memcpy(friPol.address(), last.data(), pol2N * 3 * 8); // the reference leaves the folded pol in friPol
+                // the reference copies every step's folded polynomial over the head of friPol (friProve.cpp:136-140); a
+                // caller can only observe the final state, of which the head -- the last polynomial -- is reproduced
+                std::memcpy(friPol.address(), last.data(), pol2N * 3 * 8);
             }
             std::swap(d_pol, d_next);
             polBits = curBits;
@@ -100,16 +100,8 @@ public:
                 for (uint64_t i = 0; i < ys.size(); i++) ys[i] = ys[i] % (1ULL << steps[si + 1].nBits);
         }
         for (MerkleTreeGL *t : treesFRIGL) delete t;
-        for (uint64_t *p : owned_sources()) mi_dev_free(c, p);
-        owned_sources().clear();
+        for (uint64_t *p : owned_sources) mi_dev_free(c, p);
         mi_dev_free(c, d_pol); mi_dev_free(c, d_next); mi_dev_free(c, d_aux);
-    }
-
-private:
-    static std::vector<uint64_t *> &owned_sources()
-    {
-        static std::vector<uint64_t *> v;
-        return v;
     }
 };
 #endif

@@ -1,12 +1,20 @@
 // goldilocks_base_field.hpp -- same-named stand-in for the upstream header the reference includes
 // (polinomial.hpp:4, transcript.hpp:4, merkleTreeGL.hpp:4; API reconstructed in SURVEY.md App. B).
+// The standard headers below are the ones reference code relies on getting through this header (polinomial.hpp uses assert,
+// std::map, std::vector and the omp_* calls without including them.
 // Scalar host arithmetic only (the reference calls these on single elements: shiftIn, x tables, challenges);
 // every bulk loop of the hot path goes through libmi_stark.
 #ifndef GOLDILOCKS_BASE_FIELD
 #define GOLDILOCKS_BASE_FIELD
+#include <cassert>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <iostream>
+#include <map>
+#include <omp.h>
 #include <string>
+#include <vector>
 
 #define GOLDILOCKS_PRIME 0xFFFFFFFF00000001ULL
 

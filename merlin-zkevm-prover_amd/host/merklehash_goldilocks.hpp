@@ -3,7 +3,9 @@
 #ifndef MERKLEHASH_GOLDILOCKS
 #define MERKLEHASH_GOLDILOCKS
 #include "goldilocks_base_field.hpp"
+#ifndef HASH_SIZE
 #define HASH_SIZE 4
+#endif
 #define MERKLEHASHGOLDILOCKS_HEADER_SIZE 2
 #define MERKLEHASHGOLDILOCKS_ARITY 2
 

@@ -18,8 +18,11 @@ class NTT_Goldilocks
 public:
     NTT_Goldilocks(uint64_t maxDomainSize, uint32_t /*nThreads*/ = 0, int /*extension*/ = 1) : maxDomain(maxDomainSize) {}
     void NTT(Goldilocks::Element *dst, Goldilocks::Element *src, uint64_t size, uint64_t ncols = 1, Goldilocks::Element * /*buffer*/ = NULL,
-             uint64_t /*nphase*/ = 3, uint64_t /*nblock*/ = 1, bool inverse = false, bool /*extend*/ = false)
+             uint64_t /*nphase*/ = 3, uint64_t /*nblock*/ = 1, bool inverse = false, bool extend = false)
     {
+        // extend = true is the private mode extendPol uses between its two transforms upstream; no caller in src/starkpil
+        // passes it, and silently ignoring it would return a differently scaled result
+        if (extend) { std::fprintf(stderr, "NTT_Goldilocks::NTT: extend=true is not supported, call extendPol\n"); std::exit(-1); }
         mi::check(mi_ntt(mi::ctx(), (uint64_t *)dst, (const uint64_t *)src, size, ncols, inverse ? 1 : 0), "NTT_Goldilocks::NTT");
     }
     void INTT(Goldilocks::Element *dst, Goldilocks::Element *src, uint64_t size, uint64_t ncols = 1, Goldilocks::Element *buffer = NULL,

@@ -94,6 +94,10 @@ public:
     // polinomial.hpp:612-720 -- element-wise inverse of a dim-3, offset-3 polynomial, on the GPU; res may alias src
     static void batchInverse(Polinomial &res, Polinomial &src)
     {
+        if (src.dim() == 1) { // not on the path (the reference's own batchInverse asserts dim 3 through copyElement): host scalars
+            for (uint64_t i = 0; i < src.degree(); i++) res[i][0] = Goldilocks::inv(src[i][0]);
+            return;
+        }
         assert(src.dim() == 3 && src.offset() == 3 && res.offset() == 3);
         mi_ctx *c = mi::ctx();
         const uint64_t bytes = src.degree() * 3 * 8;

@@ -9,6 +9,9 @@
 #define SPONGE_WIDTH 12
 #define RATE 8
 #define CAPACITY 4
+#ifndef HASH_SIZE
+#define HASH_SIZE 4 // the reference's merkleTreeGL.hpp:63 gets it from this header (it includes no merklehash header)
+#endif
 
 class PoseidonGoldilocks
 {

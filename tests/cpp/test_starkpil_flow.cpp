@@ -210,7 +210,8 @@ int main()
         const std::string base = std::string(dir) + "/mi_bctree_test", fconst = base + ".const", fstruct = base + ".starkstruct.json",
                           ftree = base + ".consttree", fkey = base + ".verkey.json";
         { std::ofstream f(fconst, std::ios::binary); f.write((const char *)cpols.data(), cpols.size() * 8); }
-        { std::ofstream f(fstruct); f << "{\n  \"nBits\": 9,\n  \"nBitsExt\": 10,\n  \"nQueries\": 8,\n  \"verificationHashType\": \"GL\"\n}\n"; }
+        { std::ofstream f(fstruct); // "steps" first: its nested nBits must not be taken for the top-level key
+          f << "{\n  \"steps\": [ {\"nBits\": 10}, {\"nBits\": 5} ],\n  \"nBits\": 9,\n  \"nBitsExt\": 10,\n  \"nQueries\": 8,\n  \"verificationHashType\": \"GL\"\n}\n"; }
         buildConstTree(fconst, fstruct, ftree, fkey);
         std::string blob = bctree_detail::slurp(ftree);
         const uint64_t want_size = (2 + nPols * cne + (2 * cne - 1) * 4) * 8;

@@ -24,6 +24,18 @@ def test_shims_compile_against_the_c_abi():
     assert os.path.exists(EXE)
 
 
+def test_starkstruct_json_top_level_keys_only(tmp_path):
+    """host/build_const_tree.hpp reads nBits / nBitsExt / verificationHashType of the OUTER object even when "steps" (with
+    its own nBits entries) comes first; CPU only, nothing of libmi_stark is called."""
+    exe = str(tmp_path / "test_host_json")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "test_host_json.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-lmi_stark", "-Wl,-rpath," + os.path.join(ROOT, "merlin-zkevm-prover_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "json ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 @pytest.mark.gpu
 def test_starkpil_flow_on_gpu(tmp_path):
     import json

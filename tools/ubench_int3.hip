@@ -49,6 +49,11 @@
 #define I_NOT(r) "v_not_b32_e32 " #r ", " #r
 #define I_LSHLADD64(r) "v_lshl_add_u64 " #r ", " #r ", 0, %11"
 #define I_MULHI(r) "v_mul_hi_u32 " #r ", " #r ", %8"
+// realistic pairs: the mask is written by the VALU instruction right before the select (hazard wait states spelled out)
+#define I_PAIR_VCC(r) "v_cmp_lt_u32_e32 vcc, " #r ", %8\n s_nop 1\n v_cndmask_b32_e32 " #r ", " #r ", %9, vcc"
+#define I_PAIR_SGPR(r) "v_cmp_lt_u32_e64 s[20:21], " #r ", %8\n s_nop 1\n v_cndmask_b32_e64 " #r ", " #r ", %9, s[20:21]"
+#define I_PAIR_VCC_E64(r) "v_cmp_lt_u32_e32 vcc, " #r ", %8\n s_nop 1\n v_cndmask_b32_e64 " #r ", 0, -1, vcc"
+#define I_CNDMASK_VCC_E64(r) "v_cndmask_b32_e64 " #r ", " #r ", %8, vcc"
 
 KERNEL(k_add, I_ADD_E32, uint32_t) KERNEL(k_sub, I_SUB_E32, uint32_t) KERNEL(k_cmp64, I_CMP_LT_U64, uint64_t) KERNEL(k_cmp64s, I_CMP_LT_U64_S, uint64_t)
 KERNEL(k_cmp32, I_CMP_LT_U32, uint32_t) KERNEL(k_cnd_vcc, I_CNDMASK_VCC, uint32_t) KERNEL(k_cnd_s, I_CNDMASK_S, uint32_t) KERNEL(k_cnd_c, I_CNDMASK_C, uint32_t)
@@ -57,6 +62,7 @@ KERNEL(k_lshr64, I_LSHR64, uint64_t) KERNEL(k_lshl64, I_LSHL64, uint64_t) KERNEL
 KERNEL(k_dot2, I_DOT2, uint32_t) KERNEL(k_pkmad16, I_PKMAD16, uint32_t) KERNEL(k_pkmul16, I_PKMUL16, uint32_t) KERNEL(k_mad64, I_MAD64_NOCARRY, uint64_t)
 KERNEL(k_madi64, I_MADI64, uint64_t) KERNEL(k_alignbit, I_ALIGNBIT, uint32_t) KERNEL(k_and, I_AND_E32, uint32_t) KERNEL(k_not, I_NOT, uint32_t)
 KERNEL(k_lshladd64, I_LSHLADD64, uint64_t) KERNEL(k_mulhi, I_MULHI, uint32_t)
+KERNEL(k_pair_vcc, I_PAIR_VCC, uint32_t) KERNEL(k_pair_sgpr, I_PAIR_SGPR, uint32_t) KERNEL(k_pair_vcc64, I_PAIR_VCC_E64, uint32_t) KERNEL(k_cnd_vcc64, I_CNDMASK_VCC_E64, uint32_t)
 
 template <typename K>
 static int run(const char *name, K kern, uint32_t *d, unsigned long long *dclk, int cus, int waves_per_simd)
@@ -73,7 +79,7 @@ static int run(const char *name, K kern, uint32_t *d, unsigned long long *dclk, 
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     const double wave_insts = (double)blocks * 4 * ITER * 16;
     const double per_s = wave_insts / (ms * 1e-3);
-    printf("%-22s w/SIMD=%d %8.3f ms %8.1f G winst/s  -> %.2f clk/wave-instr/SIMD @2.4GHz\n", name, waves_per_simd, ms, per_s / 1e9,
+    printf("%-28s w/SIMD=%d %8.3f ms %8.1f G winst/s  -> %.2f clk/wave-instr/SIMD @2.4GHz\n", name, waves_per_simd, ms, per_s / 1e9,
            1024.0 * 2.4e9 / per_s * (cus / 256.0));
     return 0;
 }
@@ -89,7 +95,9 @@ int main()
         run("v_not_b32", k_not, d, dclk, cus, w);
         run("v_cmp_lt_u64 vcc", k_cmp64, d, dclk, cus, w); run("v_cmp_lt_u64 sgpr", k_cmp64s, d, dclk, cus, w); run("v_cmp_lt_u32 vcc", k_cmp32, d, dclk, cus, w);
         run("v_cndmask vcc(quiet)", k_cnd_vcc, d, dclk, cus, w); run("v_cndmask sgpr", k_cnd_s, d, dclk, cus, w);
-        run("v_cndmask 0,-1,sgpr", k_cnd_c, d, dclk, cus, w);
+        run("v_cndmask 0,-1,sgpr", k_cnd_c, d, dclk, cus, w); run("v_cndmask_e64 vcc(quiet)", k_cnd_vcc64, d, dclk, cus, w);
+        run("PAIR cmp->vcc,cndmask e32", k_pair_vcc, d, dclk, cus, w); run("PAIR cmp->sgpr,cndmask e64", k_pair_sgpr, d, dclk, cus, w);
+        run("PAIR cmp->vcc,cndmask e64", k_pair_vcc64, d, dclk, cus, w);
         run("v_sub_co_u32", k_subco, d, dclk, cus, w); run("v_subb_co_u32", k_subb, d, dclk, cus, w); run("v_subbrev_co_u32", k_subbrev, d, dclk, cus, w);
         run("v_mov_b64", k_mov64, d, dclk, cus, w); run("v_lshrrev_b64", k_lshr64, d, dclk, cus, w); run("v_lshlrev_b64", k_lshl64, d, dclk, cus, w);
         run("v_lshl_add_u64", k_lshladd64, d, dclk, cus, w);

@@ -5,11 +5,15 @@ Compiles merlin-zkevm-prover_amd/csrc/poseidon.hip to gfx950 assembly (device on
 k_linear_hash_rows_lines<variant>, weights every instruction by the trip counts of the loops around it (full rounds
 4, grouped partial rounds 2 x closing loop 11, one pass of the sponge loop = one permutation), leaves out the
 rare-fix blocks (the few instructions behind an "s_cbranch_vccz" that the common path jumps over), and sorts the
-VALU opcodes into the two issue classes measured on this chip by tools/ubench_int2.hip
-(profiles/r01_ubench_int_issue_rates2.txt):
+VALU opcodes into the two issue classes measured on this chip by tools/ubench_int2.hip and tools/ubench_int3.hip
+(profiles/r01_ubench_int_issue_rates*.txt, profiles/r02_ubench_int3_issue_rates.txt):
 
-  2-clk class (1047 G wave-instr/s): v_mov, v_cndmask, v_add/sub_u32, v_and/or/xor, 32-bit compares
-  4-clk class ( 592 G wave-instr/s): v_mad_u64_u32, v_lshl_add_u64, carry adds/subs, shifts, 64-bit compares, multiplies
+  2-clk class (~930 G wave-instr/s measured, 1229 G at a nominal 2.4 GHz): v_mov_b32, v_add_u32, v_sub_u32, v_and / v_or /
+      v_xor / v_not (plain 32-bit VOP1 / VOP2 ALU ops)
+  4-clk class (~565 G wave-instr/s measured,  614 G nominal): everything else the kernels use -- v_mad_u64_u32,
+      v_lshl_add_u64, carry adds / subs, every compare (32- and 64-bit), v_cndmask (4.4 clk with an SGPR or VCC mask;
+      r01's 23-clk figure was the VOP2 form selecting into its own source with a never-written VCC), shifts, v_mov_b64,
+      v_add3, v_and_or, v_bfe, v_perm, v_alignbit, DPP moves, multiplies, dot and packed ops
 
 Prints a JSON object: VALU instructions per permutation (static estimate; the PMC count SQ_INSTS_VALU is the
 measured one) and the class fractions that bench.py's issue roofline uses.
@@ -24,9 +28,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "merlin-zkevm-prover_amd", "csrc")
-TWO_CLK = ("v_mov_b32", "v_cndmask_b32", "v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_and_or_b32",
-           "v_cmp_eq_u32", "v_cmp_ne_u32", "v_cmp_lt_u32", "v_cmp_gt_u32", "v_cmp_le_u32", "v_cmp_ge_u32", "v_mov_b64",
-           "v_accvgpr", "v_readfirstlane_b32", "v_writelane_b32", "v_readlane_b32", "v_add3_u32", "v_bfe_u32", "v_perm_b32")
+TWO_CLK = ("v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32")
 
 
 def main():
@@ -95,7 +97,7 @@ def main():
             continue
         base = re.sub(r"_e(32|64)$", "", op)
         ops[base] += weight[k]
-        cls["2clk" if base.startswith(TWO_CLK) else "4clk"] += weight[k]
+        cls["2clk" if (base in TWO_CLK and "dpp" not in instrs[k]) else "4clk"] += weight[k]
     total = cls["2clk"] + cls["4clk"]
     print(json.dumps({
         "kernel": name, "loops": [{"instrs": b - a, "trip": tr} for (a, b), tr in trips],
