@@ -2,17 +2,20 @@
 """bench_genproof.py -- BASELINE config 4 substitute: a Starks::genProof-shaped pass over a SYNTHETIC trace.
 
 The real `genBatchProof` needs config/zkevm/* artefacts that are not in the reference tree ("hard
-parts"), and its constraint evaluators (chelpers) are out of scope for this round, so this driver runs every
-device-side phase of `Starks::genProof` (starks.cpp:9-403) on synthetic data of the zkEVM shape, in the
-reference's order and with its host/device synchronisation points (transcript challenges):
+parts"), so this driver runs every device-side phase of `Starks::genProof` (starks.cpp:9-403) on synthetic data of the
+zkEVM shape, in the reference's order and with its host/device synchronisation points (transcript challenges):
 
   step 1-3  extendPol + merkelize of the 665 / 128 / 371-column sections          (starks.cpp:52-59,133-140,214-221)
-  step 4    INTT of q (3 cols) -> split/shift -> NTT (6 cols) -> merkelize         (starks.cpp:261-292)
+  step 4    step42ns constraint evaluation (the chelpers interpreter, mi_chelpers_run_dev) over the extended sections
+            -> q_2ns -> INTT of q (3 cols) -> split/shift -> NTT (6 cols) -> merkelize   (starks.cpp:237-292)
   step 5    LEv / LpEv series + INTT, evmap, xDivXSubXi / xDivXSubWXi             (starks.cpp:305-365)
   FRI       fold steps, per-step trees, query openings                            (friProve.cpp:5-190)
 
-The stage-2/3 witness columns, q_2ns and f_2ns that chelpers would produce are replaced by synthetic fills
-(their cost is NOT included).  Prints one JSON line: wall time of the device phases, per-phase milliseconds
+The step42ns PROGRAM is synthetic too -- the reference's generated tables are reference source and do not travel --
+but of the real one's size and shape: as many field operations per row (17 986 after copy forwarding), every opcode,
+reading the three committed sections at their zkEVM widths and a 360-column constant section, at the real program's LDS
+footprint (96 words per row: mi_set_chelpers_min_words).  The stage-2/3 witness columns and f_2ns that the other chelpers
+steps would produce are still synthetic fills (their cost is NOT included).  Prints one JSON line: wall time of the device phases, per-phase milliseconds
 named after the reference's timers, and a few size-independent checks (Merkle paths verify against the roots,
 FRI fold relation holds on the opened groups).
 """
@@ -89,6 +92,8 @@ def main():
     ap.add_argument("--n-queries", type=int, default=128)
     ap.add_argument("--workspace-gib", type=float, default=32.0)
     ap.add_argument("--check-queries", type=int, default=4)
+    ap.add_argument("--n-const", type=int, default=360, help="constant polynomials read by the step42ns program")
+    ap.add_argument("--chelpers-field-ops", type=int, default=17986, help="field operations per row of the synthetic step42ns program")
     args = ap.parse_args()
 
     import torch
@@ -119,8 +124,12 @@ def main():
 
     # ---- buffers (device resident).  One trace buffer is reused for the three committed sections.
     trace = ctx.empty(N * max(w1, w2, w3))
-    ext = [ctx.empty(NE * w) for w in (w1, w2, w3)]
-    cm4 = ctx.empty(NE * qdim * qdeg)
+    # the extended sections are one polynomial area, as in the reference's memory map: the constraint program
+    # addresses every polynomial relative to one base
+    sec_off = [0, NE * w1, NE * (w1 + w2), NE * (w1 + w2 + w3)]
+    pols_area = ctx.empty(NE * (w1 + w2 + w3 + qdim * qdeg))
+    ext = [pols_area[sec_off[i]:sec_off[i] + NE * w] for i, w in enumerate((w1, w2, w3))]
+    cm4 = pols_area[sec_off[3]:sec_off[3] + NE * qdim * qdeg]
     trees = [ctx.empty((2 * NE - 1) * 4) for _ in range(4)]
     widths = [w1, w2, w3, qdim * qdeg]
     tr = Transcript(ctx)
@@ -138,8 +147,28 @@ def main():
         tr.get_field()
         tr.get_field()
     # ---- step 4
+    del trace                                                   # the committed sections are extended: 44.6 GB back
+    torch.cuda.empty_cache()
     q_2ns, qq1, qq2 = ctx.empty(NE * qdim), ctx.empty(NE * qdim), ctx.empty(NE * qdim * qdeg)
-    ctx.fill_synthetic(q_2ns, NE * qdim, 0x5EED0104)           # stands in for step42ns (chelpers)
+    # step42ns: a synthetic constraint program of the real one's size run by the interpreter over the extended sections
+    import chelpers_programs as cpg
+    prng = np.random.default_rng(42)
+    secs = [(sec_off[0], w1), (sec_off[1], w2), (sec_off[2], w3)]
+    per_pass = len(cpg.decode(*cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8, passes=4))[0]) / 4.0
+    c_ops, c_args = cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8,
+                                          passes=max(1, int(round(args.chelpers_field_ops / per_pass))))
+    prog = mi_stark.ChelpersProgram(ctx, c_ops, c_args)
+    ctx.set_chelpers_min_words(96)
+    const_2ns = ctx.empty(NE * args.n_const)
+    ctx.fill_synthetic(const_2ns, NE * args.n_const, 0x5EED0106)
+    x_2ns_c = ctx.empty(NE)
+    ctx.geom_seq(x_2ns_c, NE, 49, glo.lib().glo_w(nbits_ext))
+    zh = ctx.zhinv(nbits, nbits_ext)
+    c_chal, c_pub = glo.rand_fe(prng, 5 * 3), glo.rand_fe(prng, 8)
+    timed("STARK_STEP_4_CALCULATE_EXPS_2NS", lambda: prog.run(pols_area, const_2ns, args.n_const, c_chal, c_pub, x_2ns_c, 1, zh, q_2ns, 0, NE))
+    chelpers_stats = dict(prog.stats)
+    del const_2ns
+    torch.cuda.empty_cache()
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_INTT", lambda: ctx.ntt(qq1, q_2ns, NE, qdim, inverse=True))
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_MUL", lambda: ctx.q_split(qq2, qq1, N, NE, qdeg))
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_NTT", lambda: ctx.ntt(cm4, qq2, NE, qdim * qdeg))
@@ -241,6 +270,28 @@ def main():
 
     # ---- size-independent checks (oracle = checker only)
     checks = {}
+    # step42ns: sampled rows of q_2ns recomputed by the oracle's opcode-by-opcode interpreter from the device's polynomials
+    # ... the rows' operands are gathered to the host into a sparse copy of the polynomial area
+    ok = True
+    micro = cpg.decode(c_ops, c_args)[0]
+    rows_chk = [0, 1, NE // 2, NE - 1] + [int(v) for v in np.random.default_rng(7).integers(0, NE, 4)]
+    pa, ca = cpg.touched_addresses(micro, rows_chk, args.n_const)
+    import mmap
+    def sparse(n_elems):
+        return np.frombuffer(mmap.mmap(-1, n_elems * 8, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | getattr(mmap, "MAP_NORESERVE", 0x4000)), dtype=np.uint64)
+    h_pols, h_c, h_x, h_q = sparse(pols_area.numel()), sparse(NE * args.n_const), sparse(NE), sparse(NE * 3)
+    pidx = torch.tensor(sorted(pa), dtype=torch.int64, device=pols_area.device)
+    h_pols[np.array(sorted(pa))] = ctx.to_host(pols_area[pidx])
+    const_again = ctx.empty(NE * args.n_const)
+    ctx.fill_synthetic(const_again, NE * args.n_const, 0x5EED0106)
+    cidx = torch.tensor(sorted(ca), dtype=torch.int64, device=pols_area.device)
+    h_c[np.array(sorted(ca))] = ctx.to_host(const_again[cidx])
+    del const_again
+    h_x[rows_chk] = ctx.to_host(x_2ns_c[torch.tensor(rows_chk, device=pols_area.device)])
+    for r in rows_chk:
+        glo.chelpers_step42ns(c_ops, c_args, h_pols, h_c, args.n_const, c_chal, c_pub, h_x, 1, zh, h_q, r, 1)
+        ok &= bool(np.array_equal(h_q[3 * r:3 * r + 3], ctx.to_host(q_2ns[3 * r:3 * r + 3])))
+    checks["step42ns_rows_match_oracle"] = bool(ok)
     ok = True
     for t in range(4):
         root = ctx.to_host(trees[t][-4:])
@@ -289,11 +340,13 @@ def main():
     out = {
         "metric": "genproof_shaped_device_phases_wall_time", "value": wall, "unit": "s", "higher_is_better": False,
         "n_gpus": 1, "data": "synthetic", "dtype": "u64 (Goldilocks)",
-        "config": {"workload": "Starks::genProof-shaped pass (BASELINE config 4 substitute; chelpers outputs replaced by synthetic fills)",
+        "config": {"workload": "Starks::genProof-shaped pass (BASELINE config 4 substitute; step42ns by the chelpers interpreter on a synthetic program of the real size, other chelpers outputs replaced by synthetic fills)",
                    "rows": N, "rows_ext": NE, "committed_widths": [w1, w2, w3, qdim * qdeg], "n_evals": len(pols),
                    "fri_steps_bits": steps, "n_queries": args.n_queries},
         "field_elements_per_s_lde_merkle_fri": N * total_cols / sum(phases.values()) * 1e3,
         "phase_ms": phases, "device_phase_ms_total": sum(phases.values()), "checks": checks,
+        "chelpers_step42ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers_stats,
+                              "lds_words_per_row": 96, "rows": NE, "ms": phases.get("STARK_STEP_4_CALCULATE_EXPS_2NS")},
     }
     print(json.dumps(out))
     ctx.close()

@@ -147,6 +147,43 @@ int mi_x_div_x_sub_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *x, uint64_t n
 /* ZhInv table (zhInv.cpp:7-31), HOST output of 2^(nbits_ext-nbits) values */
 int mi_zhinv(mi_ctx *ctx, uint64_t *out, unsigned nbits, unsigned nbits_ext);
 
+/* ------------------------------------------------------------------ constraint evaluators ("chelpers")
+ * Replaces ZkevmSteps::step42ns_parser_first_avx / _avx512 (zkevm.chelpers.step42ns.parser.cpp:10-760; call site
+ * starks.cpp:237-248): the reference's generated PROGRAM -- the tables op42[NOPS_] / args42[NARGS_] of
+ * zkevm.chelpers.step42ns.parser.hpp, handed over as data -- is run once per row of the extended domain on the GPU, so that
+ * the extended polynomials never leave HBM for this step.  mi_chelpers_compile translates the tables once (host side:
+ * decode by the reference interpreter's opcode numbering, copy forwarding, Sethi-Ullman reschedule, temp re-allocation);
+ * a null ctx compiles for mi_dbg_host_chelpers_run only.  `step` names the opcode numbering of the tables. */
+#define MI_CHELPERS_STEP42NS 42
+typedef struct mi_chelpers_prog mi_chelpers_prog;
+typedef struct {
+    const uint64_t *pols;       /* device: params.pols, the base every polynomial offset of the program is relative to */
+    const uint64_t *const_pols; /* device: params.pConstPols2ns, element (col, row) at const_pols[col + row * n_const] */
+    uint64_t n_const;           /* pConstPols2ns->numPols() */
+    const uint64_t *challenges; /* HOST: params.challenges, n_challenges x 3 */
+    uint64_t n_challenges;
+    const uint64_t *publics;    /* HOST: params.publicInputs */
+    uint64_t n_publics;
+    const uint64_t *x;          /* device: params.x_2ns, element i at x[i * x_stride] (Polinomial offset()) */
+    uint64_t x_stride;
+    const uint64_t *zhinv;      /* HOST: the ZhInv table (mi_zhinv); zi.zhInv(i) = zhinv[i % n_zhinv] (zhInv.hpp:22-25) */
+    uint64_t n_zhinv;
+    uint64_t *q;                /* device: params.q_2ns, row i at q[3 i .. 3 i + 3) */
+} mi_chelpers_params;
+int mi_chelpers_compile(mi_ctx *ctx, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops,
+                        const uint64_t *args, uint64_t nargs);
+void mi_chelpers_free(mi_ctx *ctx, mi_chelpers_prog *prog);
+/* out[0..8) = opcodes in, field operations decoded, after copy forwarding, after dead-code removal (= instructions run per
+ * row), live 64-bit words per row as generated, after the reschedule, base temps allocated, extension temps allocated */
+int mi_chelpers_stats(const mi_chelpers_prog *prog, uint64_t out[8]);
+/* Benchmarking knob: allocate at least `words` 64-bit LDS words of temporaries per row whatever the program needs (0 = off),
+ * so that a synthetic program runs at the occupancy of a larger one (the zkEVM step42ns program needs 96: 3 workgroups
+ * per CU).  Results are unaffected. */
+int mi_set_chelpers_min_words(mi_ctx *ctx, uint64_t words);
+/* rows [row0, row0 + nrows) of the extended domain (the reference runs all NExtended rows: starks.cpp:240) */
+int mi_chelpers_run_dev(mi_ctx *ctx, const mi_chelpers_prog *prog, const mi_chelpers_params *params, uint64_t row0,
+                        uint64_t nrows);
+
 /* ------------------------------------------------------------------ utilities */
 /* Deterministic synthetic trace: out[i] = splitmix64(seed, i+1) reduced mod p. */
 int mi_fill_synthetic_dev(mi_ctx *ctx, uint64_t *out, uint64_t count, uint64_t seed);
@@ -196,6 +233,10 @@ void mi_dbg_host_dft16(uint64_t x[16], int log_size, int inverse);
  * out[2n..3n) = a-b, out[3n..4n) = -a (as a * 2^96 through the 32-bit-shift twiddle form), out[4n..5n) = a * 2^40
  * (the wide-shift twiddle form); all canonical. */
 int mi_dbg_field_ops_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
+/* The translated constraint-evaluator program run on the HOST CPU over host pointers (every pointer of `params` is a
+ * host pointer here) for the listed rows: same translator output, same instruction semantics as the kernel. */
+int mi_dbg_host_chelpers_run(const mi_chelpers_prog *prog, const mi_chelpers_params *params, const uint64_t *rows,
+                             uint64_t nrows);
 /* Verification hook: out[r] = (accumulate ? out[r] : 0) + sum_c coef[c] * src[r*pitch + c] mod p for r < nrows (device
  * pointers; coef: ncols canonical values; accumulate lets a matrix stored as several column windows be summed).  The LDE is linear, so the full-size checks compare the oracle's extension of this one column
  * of the trace with the same combination of the extended trace: a checksum over every column at every row. */

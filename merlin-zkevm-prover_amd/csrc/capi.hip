@@ -87,6 +87,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->workspace) (void)hipFree(c->workspace);
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
+    if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
     for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);

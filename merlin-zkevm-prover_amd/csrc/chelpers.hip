@@ -1,0 +1,633 @@
+// chelpers.hip -- the generated constraint evaluators ("chelpers") of Starks::genProof on the GPU.
+//
+// Reference: src/starkpil/zkevm/chelpers/zkevm.chelpers.step42ns.parser.{hpp,cpp}.  The reference ships, per STARK step,
+// a PROGRAM (two generated tables: op42[NOPS_] opcodes, args42[NARGS_] operands) and an INTERPRETER
+// (ZkevmSteps::step42ns_parser_first_avx, :10-760; its scalar twin step42ns_parser_first, :762-1441) that runs the
+// program once per row of the extended domain: ~12 000 opcodes = 19 198 field operations per row, 2^24 rows, reading
+// the committed / constant polynomials at the row (and at row + k mod N for the "prime" polynomials), the challenges,
+// public inputs, x_2ns and ZhInv, and writing q_2ns.  Starks::genProof calls it at starks.cpp:237-241.
+//
+// MI355X design (not a port of the AVX interpreter):
+//   * mi_chelpers_compile takes the reference's tables AS DATA and translates them once, on the host, into a uniform
+//     three-address code: {add | sub | mul | store-q} x {dst: base temp | ext temp | q} x two operand descriptors
+//     (temp, polynomial at row, polynomial at shifted row, constant polynomial, number, challenge, public, x, 1/Z_H).
+//     The 89 opcodes of the table are just the operand-kind combinations the generator happened to emit (five of them
+//     fusions of others); the role table below records, per opcode, what the reference interpreter does with each
+//     argument.
+//   * The generated program keeps ~975 base and ~170 extension temporaries live per row (11.8 KB) -- fine for a CPU
+//     stack, fatal for a GPU lane.  The translator therefore (1) forwards copies (a temp that only renames a polynomial
+//     element, a constant or another temp is replaced by its source), (2) puts the program in SSA form and RESCHEDULES
+//     it depth-first from the q store, evaluating the operand that needs more registers first (Sethi-Ullman): the
+//     expression is a long Horner chain over ~900 independently computable constraint values, which the generator
+//     computes up front and the reschedule consumes as they are produced, (3) drops dead code and (4) re-allocates
+//     temporaries by linear scan.  For the zkEVM step42ns program: 1 401 live words -> 89.
+//   * One row per lane, 64-lane workgroups, temporaries in LDS as [word][lane] (conflict-free 8-byte accesses, the word
+//     index is wave-uniform).  The instruction stream is wave-uniform: it is fetched through the scalar cache and
+//     every decode branch is scalar.  All arithmetic is the same gl:: code the other kernels use.
+//   * Polynomial reads are per-lane 8-byte gathers at a stride of one row (5 320 B for the 665-column section): each
+//     touches its own 64-byte sector.  Known cost (9x read amplification on the wide sections); the rows of a
+//     workgroup are consecutive, so the sectors are re-used while they stay in L2.
+//
+// Parity status: UNPINNED by reference data (no input / output pair for any chelpers step exists in the reference tree;
+// zkevm.starkinfo.json and the constant polynomials are absent).  The oracle (oracle/chelpers_oracle.c) restates the
+// reference interpreter opcode by opcode; tests compare this implementation with it on synthetic programs that use
+// every opcode, and -- where /root/reference is present -- on the reference's own program tables.
+#include "common.h"
+#include <algorithm>
+#include <array>
+#include <string.h>
+
+using gl::E3;
+
+namespace chp {
+
+enum Kind : uint32_t { K_NONE = 0, K_T1, K_T3, K_POL, K_POLS, K_NUM, K_CONST, K_CONSTS, K_CHAL, K_PUB, K_POL3, K_POL3S, K_X, K_ZHINV, K_Q };
+enum Cls : uint32_t { C_ADD = 0, C_SUB, C_MUL, C_COPY, C_STOREQ };
+
+static int kind_nargs(Kind k)
+{
+    switch (k) {
+    case K_T1: case K_T3: case K_NUM: case K_CONST: case K_CHAL: case K_PUB: return 1;
+    case K_POL: case K_POL3: return 2;   // offset, row stride
+    case K_CONSTS: return 3;             // column, row shift, modulus
+    case K_POLS: case K_POL3S: return 4; // offset, row shift, modulus, row stride
+    default: return 0;
+    }
+}
+static int kind_dim(Kind k) { return (k == K_T3 || k == K_CHAL || k == K_POL3 || k == K_POL3S || k == K_Q) ? 3 : 1; }
+
+// what one opcode of the reference interpreter does: dst kind, operation, the kinds of its two sources IN ARGUMENT ORDER
+// (argument 0 is always the destination temp; then the arguments of source a, then those of source b)
+struct Role { Cls cls; Kind dst, a, b; };
+
+// ---- step42ns (zkevm.chelpers.step42ns.parser.cpp): cases 0-83 of step42ns_parser_first_avx (:24-660) = cases 0-83 of the
+// scalar step42ns_parser_first (:781-1383); 84-88 are fusions (:661-748)
+static bool role_step42ns(uint64_t op, Role &r)
+{
+#define R(c, d, x, y) r = {c, d, x, y}; return true
+    switch (op) {
+    case 0: R(C_ADD, K_T1, K_T1, K_T1);        case 1: R(C_ADD, K_T1, K_T1, K_POL);        case 2: R(C_ADD, K_T1, K_T1, K_NUM);
+    case 3: R(C_ADD, K_T1, K_T1, K_CONST);     case 4: R(C_ADD, K_T1, K_POL, K_POL);       case 5: R(C_ADD, K_T1, K_POLS, K_POLS);
+    case 6: R(C_ADD, K_T1, K_POL, K_CONST);    case 7: R(C_ADD, K_T1, K_POL, K_NUM);       case 8: R(C_ADD, K_T1, K_CONST, K_CONST);
+    case 9: R(C_ADD, K_T1, K_CONSTS, K_CONSTS); case 10: R(C_ADD, K_T1, K_CONST, K_NUM);   case 11: R(C_ADD, K_T1, K_CONSTS, K_NUM);
+    case 12: R(C_ADD, K_T3, K_T1, K_T3);       case 13: R(C_ADD, K_T3, K_NUM, K_CHAL);     case 14: R(C_ADD, K_T3, K_T1, K_CHAL);
+    case 15: R(C_ADD, K_T3, K_POL, K_T3);      case 16: R(C_ADD, K_T3, K_POL, K_CHAL);     case 17: R(C_ADD, K_T3, K_T3, K_T3);
+    case 18: R(C_ADD, K_T3, K_T3, K_CHAL);     case 19: R(C_ADD, K_T3, K_POL3, K_T3);      case 20: R(C_ADD, K_T3, K_POL3, K_CHAL);
+    case 21: R(C_SUB, K_T1, K_T1, K_T1);       case 22: R(C_SUB, K_T1, K_T1, K_POL);       case 23: R(C_SUB, K_T1, K_T1, K_POLS);
+    case 24: R(C_SUB, K_T1, K_POL, K_T1);      case 25: R(C_SUB, K_T1, K_POLS, K_T1);      case 26: R(C_SUB, K_T1, K_T1, K_NUM);
+    case 27: R(C_SUB, K_T1, K_NUM, K_T1);      case 28: R(C_SUB, K_T1, K_POL, K_NUM);      case 29: R(C_SUB, K_T1, K_POLS, K_NUM);
+    case 30: R(C_SUB, K_T1, K_NUM, K_POL);     case 31: R(C_SUB, K_T1, K_NUM, K_POLS);     case 32: R(C_SUB, K_T1, K_NUM, K_CONST);
+    case 33: R(C_SUB, K_T1, K_NUM, K_CONSTS);  case 34: R(C_SUB, K_T1, K_POL, K_PUB);      case 35: R(C_SUB, K_T1, K_POLS, K_POL);
+    case 36: R(C_SUB, K_T1, K_POL, K_POLS);    case 37: R(C_SUB, K_T1, K_POL, K_POL);      case 38: R(C_SUB, K_T1, K_POLS, K_POLS);
+    case 39: R(C_SUB, K_T1, K_CONST, K_POL);   case 40: R(C_SUB, K_T1, K_T1, K_CONST);     case 41: R(C_SUB, K_T3, K_POL3, K_NUM);
+    case 42: R(C_SUB, K_T3, K_T3, K_T3);       case 43: R(C_SUB, K_T3, K_T3, K_CHAL);      case 44: R(C_SUB, K_T3, K_T3, K_POL3);
+    case 45: R(C_MUL, K_T1, K_T1, K_T1);       case 46: R(C_MUL, K_T1, K_NUM, K_T1);       case 47: R(C_MUL, K_T1, K_POL, K_T1);
+    case 48: R(C_MUL, K_T1, K_POLS, K_T1);     case 49: R(C_MUL, K_T1, K_T1, K_CONST);     case 50: R(C_MUL, K_T1, K_POL, K_POL);
+    case 51: R(C_MUL, K_T1, K_POL, K_POLS);    case 52: R(C_MUL, K_T1, K_POLS, K_POLS);    case 53: R(C_MUL, K_T1, K_NUM, K_POL);
+    case 54: R(C_MUL, K_T1, K_POL, K_CONST);   case 55: R(C_MUL, K_T1, K_POLS, K_CONST);   case 56: R(C_MUL, K_T1, K_T1, K_POL);
+    case 57: R(C_MUL, K_T1, K_T1, K_POLS);     case 58: R(C_MUL, K_T1, K_CONST, K_T1);     case 59: R(C_MUL, K_T3, K_T1, K_CHAL);
+    case 60: R(C_MUL, K_T3, K_CONST, K_T3);    case 61: R(C_MUL, K_T3, K_T1, K_T3);        case 62: R(C_MUL, K_T3, K_POL, K_CHAL);
+    case 63: R(C_MUL, K_T3, K_POLS, K_CHAL);   case 64: R(C_MUL, K_T3, K_POL, K_T3);       case 65: R(C_MUL, K_T3, K_POLS, K_T3);
+    case 66: R(C_MUL, K_T3, K_NUM, K_CHAL);    case 67: R(C_MUL, K_T3, K_X, K_CHAL);       case 68: R(C_MUL, K_T3, K_X, K_T3);
+    case 69: R(C_STOREQ, K_Q, K_T3, K_ZHINV);  // q_2ns[i] = zi.zhInv(i) * tmp3[arg0]: the only argument is the SOURCE
+    case 70: R(C_MUL, K_T3, K_CHAL, K_T3);     // mul33c(tmp3[a0], tmp3[a2], challenges[a1]): challenge index comes first
+    case 71: R(C_MUL, K_T3, K_T3, K_T3);       case 72: R(C_MUL, K_T3, K_POL3, K_POL3);    case 73: R(C_MUL, K_T3, K_POL3S, K_CHAL);
+    case 74: R(C_MUL, K_T3, K_POL3S, K_T3);    case 75: R(C_MUL, K_T3, K_POL3, K_T3);      case 76: R(C_MUL, K_T3, K_POL3, K_CHAL);
+    case 77: R(C_MUL, K_T3, K_POL3S, K_POL3);  case 78: R(C_COPY, K_T1, K_T1, K_NONE);     case 79: R(C_COPY, K_T1, K_POL, K_NONE);
+    case 80: R(C_COPY, K_T1, K_POLS, K_NONE);  case 81: R(C_COPY, K_T1, K_NUM, K_NONE);    case 82: R(C_COPY, K_T1, K_CONST, K_NONE);
+    case 83: R(C_COPY, K_T1, K_CONSTS, K_NONE);
+    }
+#undef R
+    return false;
+}
+static const std::vector<uint64_t> *fused_step42ns(uint64_t op)
+{
+    static const std::vector<uint64_t> f84 = {12, 70}, f85 = {0, 50}, f86 = {32, 47, 21, 32, 48}, f87 = {12, 70, 12, 70, 12, 70, 12, 70},
+                                       f88 = {21, 50, 21, 53, 0, 0, 50, 50, 0, 50, 21, 50};
+    switch (op) {
+    case 84: return &f84; case 85: return &f85; case 86: return &f86; case 87: return &f87; case 88: return &f88;
+    }
+    return nullptr;
+}
+
+// ---- device instruction (64 bytes, wave-uniform, fetched through the scalar cache)
+struct Opd { uint64_t off; uint32_t stride, shift; uint64_t mod; }; // meaning by kind, see load_operand
+struct DInstr {
+    uint32_t op;  // bits 0-3 class, 4-7 dst kind, 8-11 kind of a, 12-15 kind of b
+    uint32_t dst; // LDS word of the destination temp (ext temps take 3 consecutive words)
+    Opd a, b;
+    uint64_t pad;
+};
+static_assert(sizeof(DInstr) == 64, "instruction must be 64 bytes");
+
+struct RunArgs {
+    const u64 *pols, *cpols, *x, *zhinv, *chal, *pub;
+    u64 *q;
+    uint64_t n_const, x_stride, n_zhinv, row0, row_end;
+};
+
+// ---- host-side intermediate form
+struct HOpd { Kind k = K_NONE; uint64_t v[4] = {0, 0, 0, 0}; };
+struct MicroOp { Cls cls; Kind dst; uint64_t dst_slot; HOpd a, b; };
+
+} // namespace chp
+
+struct mi_chelpers_prog {
+    std::vector<chp::DInstr> host; // the translated program (kept for the host debug executor)
+    chp::DInstr *dev = nullptr;
+    uint64_t n_words = 0;          // LDS words per row
+    uint64_t stats[8] = {0};       // ops in, micro-ops, after copy forwarding, scheduled, live words before, after, t1 slots, t3 slots
+    uint64_t max_chal = 0, max_pub = 0;
+};
+
+namespace chp {
+
+// one operand at row r.  Memory is read through M so that the same code runs in the kernel (LDS temporaries) and in the
+// host debug executor (a plain array).
+template <typename Tmp>
+MI_HD void load_operand(uint32_t kind, const Opd &o, uint64_t r, const RunArgs &P, const Tmp &tmp, u64 (&v)[3])
+{
+    v[1] = v[2] = 0;
+    switch (kind) {
+    case K_T1: v[0] = tmp.get(o.off); break;
+    case K_T3: v[0] = tmp.get(o.off); v[1] = tmp.get(o.off + 1); v[2] = tmp.get(o.off + 2); break;
+    case K_NUM: v[0] = o.off; break; // canonicalised by the translator (Goldilocks::fromU64)
+    case K_POL: v[0] = gl::canon(P.pols[o.off + r * o.stride]); break;
+    case K_POL3: {
+        const u64 *p = P.pols + o.off + r * o.stride;
+        v[0] = gl::canon(p[0]); v[1] = gl::canon(p[1]); v[2] = gl::canon(p[2]);
+        break;
+    }
+    case K_POLS: case K_POL3S: {
+        // ((i + shift) % modulus): the modulus is the extended domain size in every generated program, a power of two
+        const uint64_t rs = (o.mod & (o.mod - 1)) == 0 ? ((r + o.shift) & (o.mod - 1)) : ((r + o.shift) % o.mod);
+        const u64 *p = P.pols + o.off + rs * o.stride;
+        v[0] = gl::canon(p[0]);
+        if (kind == K_POL3S) { v[1] = gl::canon(p[1]); v[2] = gl::canon(p[2]); }
+        break;
+    }
+    case K_CONST: v[0] = gl::canon(P.cpols[o.off + r * P.n_const]); break;
+    case K_CONSTS: {
+        const uint64_t rs = (o.mod & (o.mod - 1)) == 0 ? ((r + o.shift) & (o.mod - 1)) : ((r + o.shift) % o.mod);
+        v[0] = gl::canon(P.cpols[o.off + rs * P.n_const]);
+        break;
+    }
+    case K_CHAL: v[0] = P.chal[o.off * 3]; v[1] = P.chal[o.off * 3 + 1]; v[2] = P.chal[o.off * 3 + 2]; break;
+    case K_PUB: v[0] = P.pub[o.off]; break;
+    case K_X: v[0] = gl::canon(P.x[r * P.x_stride]); break;
+    case K_ZHINV: v[0] = P.zhinv[r % P.n_zhinv]; break;
+    default: v[0] = 0; break;
+    }
+}
+
+template <typename Tmp>
+MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P, Tmp &tmp)
+{
+    const uint32_t cls = I.op & 15, dk = (I.op >> 4) & 15, ak = (I.op >> 8) & 15, bk = (I.op >> 12) & 15;
+    u64 a[3], b[3], o[3];
+    load_operand(ak, I.a, r, P, tmp, a);
+    load_operand(bk, I.b, r, P, tmp, b);
+    const bool a3 = ak == K_T3 || ak == K_CHAL || ak == K_POL3 || ak == K_POL3S;
+    const bool b3 = bk == K_T3 || bk == K_CHAL || bk == K_POL3 || bk == K_POL3S;
+    switch (cls) {
+    case C_ADD: // a dimension-1 operand is (v, 0, 0): Goldilocks3::add13 / add31 / add1c3c
+        o[0] = gl::add(a[0], b[0]); o[1] = gl::add(a[1], b[1]); o[2] = gl::add(a[2], b[2]);
+        break;
+    case C_SUB: // Goldilocks3::sub31c / sub13c: component-wise on (v, 0, 0)
+        o[0] = gl::sub(a[0], b[0]); o[1] = gl::sub(a[1], b[1]); o[2] = gl::sub(a[2], b[2]);
+        break;
+    case C_MUL: case C_STOREQ:
+        if (a3 && b3) {
+            const E3 p = gl::e3_mul(E3{{a[0], a[1], a[2]}}, E3{{b[0], b[1], b[2]}});
+            o[0] = p.v[0]; o[1] = p.v[1]; o[2] = p.v[2];
+        } else if (a3) { // Goldilocks3::mul31 / mul13: scalar times extension element
+            o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[1], b[0]); o[2] = gl::mul(a[2], b[0]);
+        } else if (b3) {
+            o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[0], b[1]); o[2] = gl::mul(a[0], b[2]);
+        } else {
+            o[0] = gl::mul(a[0], b[0]); o[1] = o[2] = 0;
+        }
+        break;
+    default: // C_COPY
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+        break;
+    }
+    if (dk == K_T1) {
+        tmp.set(I.dst, o[0]);
+    } else if (dk == K_T3) {
+        tmp.set(I.dst, o[0]); tmp.set(I.dst + 1, o[1]); tmp.set(I.dst + 2, o[2]);
+    } else if (active) { // K_Q: (Goldilocks3::Element &)params.q_2ns[i * 3]
+        P.q[r * 3] = o[0]; P.q[r * 3 + 1] = o[1]; P.q[r * 3 + 2] = o[2];
+    }
+}
+
+struct LdsTmp { // [word][lane], 64 lanes
+    u64 *base;
+    uint32_t lane;
+    __device__ __forceinline__ u64 get(uint64_t w) const { return base[w * 64 + lane]; }
+    __device__ __forceinline__ void set(uint64_t w, u64 v) { base[w * 64 + lane] = v; }
+};
+struct HostTmp {
+    u64 *base;
+    u64 get(uint64_t w) const { return base[w]; }
+    void set(uint64_t w, u64 v) { base[w] = v; }
+};
+
+__global__ __launch_bounds__(64) void k_chelpers(const DInstr *__restrict__ prog, uint32_t n_instr, const RunArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t row = P.row0 + (uint64_t)blockIdx.x * 64 + lane;
+    const bool active = row < P.row_end;
+    const uint64_t r = active ? row : P.row0; // idle lanes shadow a valid row: every address they form is a valid one
+    LdsTmp tmp = {smem, lane};
+    // constant address space: wave-uniform loads of the instruction stream go through the scalar cache
+    const __attribute__((address_space(4))) DInstr *cp = (const __attribute__((address_space(4))) DInstr *)prog;
+    for (uint32_t pc = 0; pc < n_instr; pc++) {
+        DInstr I;
+        const __attribute__((address_space(4))) uint64_t *w = (const __attribute__((address_space(4))) uint64_t *)(cp + pc);
+        uint64_t raw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) raw[i] = w[i];
+        memcpy(&I, raw, sizeof(I));
+        exec_instr(I, r, active, P, tmp);
+    }
+}
+
+// ------------------------------------------------------------------ translator
+static int decode(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, std::vector<MicroOp> &out,
+                  uint64_t &max_chal, uint64_t &max_pub)
+{
+    MI_REQUIRE(step == MI_CHELPERS_STEP42NS, "only the step42ns opcode numbering is known to this build");
+    uint64_t ia = 0;
+    auto take = [&](Kind k, HOpd &o) -> bool {
+        o.k = k;
+        const int n = kind_nargs(k);
+        if (ia + n > nargs) return false;
+        for (int i = 0; i < n; i++) o.v[i] = args[ia + i];
+        ia += n;
+        if (k == K_NUM) o.v[0] = gl::canon(o.v[0]); // Goldilocks::fromU64
+        if (k == K_CHAL) max_chal = std::max(max_chal, o.v[0] + 1);
+        if (k == K_PUB) max_pub = std::max(max_pub, o.v[0] + 1);
+        return true;
+    };
+    auto one = [&](uint64_t op) -> int {
+        Role r;
+        if (!role_step42ns(op, r)) {
+            mi_set_error("mi_chelpers_compile: unknown opcode %llu", (unsigned long long)op);
+            return MI_ERR_INVALID;
+        }
+        MicroOp m;
+        m.cls = r.cls;
+        m.dst = r.dst;
+        m.dst_slot = 0;
+        bool ok = true;
+        if (r.cls != C_STOREQ) { // argument 0 = destination temp
+            ok = ia < nargs;
+            if (ok) m.dst_slot = args[ia++];
+        }
+        ok = ok && take(r.a, m.a);
+        if (ok && r.b != K_NONE && r.b != K_ZHINV) ok = take(r.b, m.b);
+        if (r.b == K_ZHINV) m.b.k = K_ZHINV;
+        if (!ok) {
+            mi_set_error("mi_chelpers_compile: argument table too short");
+            return MI_ERR_INVALID;
+        }
+        out.push_back(m);
+        return MI_OK;
+    };
+    for (uint64_t k = 0; k < nops; k++) {
+        if (const std::vector<uint64_t> *f = fused_step42ns(ops[k])) {
+            for (uint64_t sub : *f) MI_TRY(one(sub));
+        } else {
+            MI_TRY(one(ops[k]));
+        }
+    }
+    if (ia != nargs) { // the reference asserts i_args == NARGS_ after every row (parser.cpp:755)
+        mi_set_error("mi_chelpers_compile: program consumes %llu arguments, table holds %llu", (unsigned long long)ia, (unsigned long long)nargs);
+        return MI_ERR_INVALID;
+    }
+    return MI_OK;
+}
+
+static uint64_t live_words(const std::vector<MicroOp> &p)
+{
+    // peak of (live base temps + 3 * live ext temps) over the program as written
+    std::map<std::pair<int, uint64_t>, std::pair<uint64_t, uint64_t>> cur; // (kind, slot) -> (def position, last use)
+    std::vector<std::pair<uint64_t, int>> ev;
+    auto close = [&](std::pair<int, uint64_t> key) {
+        auto it = cur.find(key);
+        if (it == cur.end()) return;
+        const int w = key.first == K_T3 ? 3 : 1;
+        ev.push_back({it->second.first * 2 + 1, w});
+        ev.push_back({it->second.second * 2 + 2, -w});
+        cur.erase(it);
+    };
+    for (uint64_t pos = 0; pos < p.size(); pos++) {
+        for (const HOpd *o : {&p[pos].a, &p[pos].b})
+            if (o->k == K_T1 || o->k == K_T3) {
+                auto it = cur.find({o->k, o->v[0]});
+                if (it != cur.end()) it->second.second = pos;
+            }
+        if (p[pos].dst == K_T1 || p[pos].dst == K_T3) {
+            close({p[pos].dst, p[pos].dst_slot});
+            cur[{p[pos].dst, p[pos].dst_slot}] = {pos, pos};
+        }
+    }
+    while (!cur.empty()) close(cur.begin()->first);
+    std::sort(ev.begin(), ev.end());
+    int64_t c = 0, m = 0;
+    for (auto &e : ev) { c += e.second; m = std::max(m, c); }
+    return (uint64_t)m;
+}
+
+static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
+{
+    P->stats[1] = prog.size();
+    P->stats[4] = live_words(prog);
+    // ---- (1) copy forwarding: a base temp defined by a copy of something that is not a temp is an alias of it
+    {
+        std::map<uint64_t, HOpd> alias; // T1 slot -> source descriptor
+        std::vector<MicroOp> out;
+        out.reserve(prog.size());
+        for (MicroOp m : prog) {
+            for (HOpd *o : {&m.a, &m.b})
+                if (o->k == K_T1) {
+                    auto it = alias.find(o->v[0]);
+                    if (it != alias.end()) *o = it->second;
+                }
+            if (m.cls == C_COPY && m.dst == K_T1 && m.a.k != K_T1 && m.a.k != K_T3) {
+                alias[m.dst_slot] = m.a;
+                continue;
+            }
+            if (m.dst == K_T1) alias.erase(m.dst_slot);
+            out.push_back(m);
+        }
+        prog.swap(out);
+    }
+    P->stats[2] = prog.size();
+    // ---- (2) SSA: instruction i defines value i; sources become value ids
+    const size_t n = prog.size();
+    std::vector<std::array<int64_t, 2>> src(n, {-1, -1});
+    {
+        std::map<std::pair<int, uint64_t>, int64_t> cur;
+        for (size_t i = 0; i < n; i++) {
+            HOpd *os[2] = {&prog[i].a, &prog[i].b};
+            for (int s = 0; s < 2; s++)
+                if (os[s]->k == K_T1 || os[s]->k == K_T3) {
+                    auto it = cur.find({os[s]->k, os[s]->v[0]});
+                    if (it == cur.end()) {
+                        mi_set_error("mi_chelpers_compile: temporary read before it is written (instruction %zu)", i);
+                        return MI_ERR_INVALID;
+                    }
+                    src[i][s] = it->second;
+                }
+            if (prog[i].dst == K_T1 || prog[i].dst == K_T3) cur[{prog[i].dst, prog[i].dst_slot}] = (int64_t)i;
+        }
+    }
+    auto weight = [&](size_t i) { return prog[i].dst == K_T3 ? 3 : prog[i].dst == K_T1 ? 1 : 0; };
+    // ---- (3) Sethi-Ullman numbers (the DAG treated as a tree) and a depth-first order from the stores
+    std::vector<uint32_t> need(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        int64_t s0 = src[i][0], s1 = src[i][1];
+        if (s1 >= 0 && (s0 < 0 || need[s1] > need[s0])) std::swap(s0, s1); // s0 = the hungrier operand, evaluated first
+        uint32_t m = (uint32_t)weight(i), held = 0;
+        if (s0 >= 0) { m = std::max(m, need[s0]); held += weight(s0); }
+        if (s1 >= 0 && s1 != s0) { m = std::max(m, need[s1] + held); held += weight(s1); }
+        need[i] = std::max(m, held);
+    }
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    {
+        std::vector<uint8_t> done(n, 0);
+        std::vector<std::pair<size_t, int>> stack;
+        for (size_t root = 0; root < n; root++) {
+            if (prog[root].cls != C_STOREQ) continue; // only stores have effects: everything else is reached from them or dead
+            stack.push_back({root, 0});
+            while (!stack.empty()) {
+                auto [node, state] = stack.back();
+                stack.pop_back();
+                if (done[node]) continue;
+                if (state == 0) {
+                    stack.push_back({node, 1});
+                    int64_t s0 = src[node][0], s1 = src[node][1];
+                    if (s1 >= 0 && (s0 < 0 || need[s1] > need[s0])) std::swap(s0, s1);
+                    if (s1 >= 0 && !done[s1]) stack.push_back({(size_t)s1, 0}); // popped second
+                    if (s0 >= 0 && !done[s0]) stack.push_back({(size_t)s0, 0}); // popped first: the hungrier operand
+                } else {
+                    done[node] = 1;
+                    order.push_back((uint32_t)node);
+                }
+            }
+        }
+    }
+    P->stats[3] = order.size();
+    // ---- (4) linear-scan slot allocation over the new order; a destination may take over a source that dies here
+    std::vector<uint32_t> uses(n, 0);
+    for (uint32_t i : order)
+        for (int s = 0; s < 2; s++)
+            if (src[i][s] >= 0 && (s == 0 || src[i][1] != src[i][0])) uses[src[i][s]]++;
+    std::vector<uint64_t> word(n, 0);
+    std::vector<uint64_t> free1, free3;
+    uint64_t n1 = 0, n3 = 0;
+    // base temps live in words [0, n1), ext temps in 3-word groups after them: the split is fixed up after the scan
+    std::vector<std::pair<uint32_t, uint64_t>> t3_fix; // (instruction, ext slot)
+    std::vector<uint64_t> slot(n, 0);
+    uint64_t live = 0, peak = 0;
+    for (uint32_t i : order) {
+        for (int s = 0; s < 2; s++) {
+            const int64_t v = src[i][s];
+            if (v < 0 || (s == 1 && v == src[i][0])) continue;
+            if (--uses[v] == 0) {
+                (prog[v].dst == K_T3 ? free3 : free1).push_back(slot[v]);
+                live -= weight(v);
+            }
+        }
+        if (prog[i].dst == K_T1 || prog[i].dst == K_T3) {
+            std::vector<uint64_t> &fr = prog[i].dst == K_T3 ? free3 : free1;
+            uint64_t &cnt = prog[i].dst == K_T3 ? n3 : n1;
+            if (fr.empty()) slot[i] = cnt++;
+            else { slot[i] = fr.back(); fr.pop_back(); }
+            live += weight(i);
+            peak = std::max(peak, live);
+        }
+    }
+    P->stats[5] = peak;
+    P->stats[6] = n1;
+    P->stats[7] = n3;
+    P->n_words = n1 + 3 * n3;
+    auto word_of = [&](size_t v) { return prog[v].dst == K_T3 ? n1 + 3 * slot[v] : slot[v]; };
+    // ---- (5) emit
+    P->host.clear();
+    P->host.reserve(order.size());
+    for (uint32_t i : order) {
+        const MicroOp &m = prog[i];
+        DInstr d = {};
+        d.op = (uint32_t)m.cls | ((uint32_t)m.dst << 4) | ((uint32_t)m.a.k << 8) | ((uint32_t)m.b.k << 12);
+        d.dst = (m.dst == K_T1 || m.dst == K_T3) ? (uint32_t)word_of(i) : 0;
+        const HOpd *hs[2] = {&m.a, &m.b};
+        Opd *ds[2] = {&d.a, &d.b};
+        for (int s = 0; s < 2; s++) {
+            const HOpd &h = *hs[s];
+            Opd &o = *ds[s];
+            switch (h.k) {
+            case K_T1: case K_T3: o.off = word_of((size_t)src[i][s]); break;
+            case K_POL: case K_POL3:
+                MI_REQUIRE(h.v[1] < (1ull << 32), "row stride too large");
+                o.off = h.v[0]; o.stride = (uint32_t)h.v[1];
+                break;
+            case K_POLS: case K_POL3S:
+                MI_REQUIRE(h.v[3] < (1ull << 32) && h.v[1] < (1ull << 32) && h.v[2] != 0, "bad shifted-row operand");
+                o.off = h.v[0]; o.shift = (uint32_t)h.v[1]; o.mod = h.v[2]; o.stride = (uint32_t)h.v[3];
+                break;
+            case K_CONSTS:
+                MI_REQUIRE(h.v[1] < (1ull << 32) && h.v[2] != 0, "bad shifted-row operand");
+                o.off = h.v[0]; o.shift = (uint32_t)h.v[1]; o.mod = h.v[2];
+                break;
+            default: o.off = h.v[0]; break; // NUM value, CONST column, CHAL / PUB index; nothing for X / ZHINV / NONE
+            }
+        }
+        P->host.push_back(d);
+    }
+    return MI_OK;
+}
+
+} // namespace chp
+
+extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops, const uint64_t *args,
+                                   uint64_t nargs)
+{
+    if (!out) return MI_ERR_INVALID;
+    *out = nullptr;
+    MI_REQUIRE(ops && (args || nargs == 0) && nops > 0, "null program tables");
+    std::vector<chp::MicroOp> prog;
+    mi_chelpers_prog *P = new mi_chelpers_prog();
+    P->stats[0] = nops;
+    int st = chp::decode(step, ops, nops, args, nargs, prog, P->max_chal, P->max_pub);
+    if (st == MI_OK) st = chp::translate(P, prog);
+    if (st == MI_OK && c) { // a null context compiles for the host debug executor only (no GPU needed)
+        std::lock_guard<std::recursive_mutex> lock(c->mu);
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipMalloc((void **)&P->dev, P->host.size() * sizeof(chp::DInstr) + 64);
+        if (e == hipSuccess) e = hipMemcpyAsync(P->dev, P->host.data(), P->host.size() * sizeof(chp::DInstr), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            mi_set_error("mi_chelpers_compile: %s", hipGetErrorString(e));
+            st = MI_ERR_HIP;
+        }
+    }
+    if (st != MI_OK) {
+        if (P->dev) (void)hipFree(P->dev);
+        delete P;
+        return st;
+    }
+    *out = P;
+    return MI_OK;
+}
+
+extern "C" void mi_chelpers_free(mi_ctx *c, mi_chelpers_prog *p)
+{
+    if (!p) return;
+    if (p->dev && c) {
+        std::lock_guard<std::recursive_mutex> lock(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(p->dev);
+    }
+    delete p;
+}
+
+extern "C" int mi_set_chelpers_min_words(mi_ctx *c, uint64_t words)
+{
+    if (!c) return MI_ERR_INVALID;
+    MI_REQUIRE(words * 512 <= 160 * 1024, "more words than the LDS holds");
+    c->chelpers_min_words = words;
+    return MI_OK;
+}
+
+extern "C" int mi_chelpers_stats(const mi_chelpers_prog *p, uint64_t out[8])
+{
+    if (!p || !out) return MI_ERR_INVALID;
+    for (int i = 0; i < 8; i++) out[i] = p->stats[i];
+    return MI_OK;
+}
+
+static int check_params(const mi_chelpers_prog *p, const mi_chelpers_params *a, uint64_t row0, uint64_t nrows)
+{
+    MI_REQUIRE(p && a, "null program or parameters");
+    MI_REQUIRE(a->pols && a->q, "null polynomial memory or output");
+    MI_REQUIRE(a->n_challenges >= p->max_chal && (a->challenges || p->max_chal == 0), "program reads more challenges than were given");
+    MI_REQUIRE(a->n_publics >= p->max_pub && (a->publics || p->max_pub == 0), "program reads more public inputs than were given");
+    MI_REQUIRE(a->zhinv && a->n_zhinv > 0 && a->n_zhinv <= 256, "ZhInv table must hold 1..256 values");
+    MI_REQUIRE(row0 + nrows >= row0, "row range overflows");
+    return MI_OK;
+}
+
+extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const mi_chelpers_params *a, uint64_t row0, uint64_t nrows)
+{
+    if (!c) return MI_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    MI_HIP_CHECK(hipSetDevice(c->device));
+    MI_TRY(check_params(p, a, row0, nrows));
+    MI_REQUIRE(p->dev, "program was compiled without a context");
+    if (nrows == 0) return MI_OK;
+    const size_t lds = (size_t)std::max<uint64_t>(std::max<uint64_t>(p->n_words, c->chelpers_min_words), 1) * 64 * 8;
+    MI_REQUIRE(lds <= 160 * 1024, "program needs more temporaries per row than the LDS holds");
+    MI_REQUIRE((nrows + 63) / 64 < (1ull << 31), "too many rows for one launch");
+    // small host tables -> the context's scratch (challenges, publics, ZhInv): 3 * 64 + 128 + 256 words at most
+    MI_REQUIRE(p->max_chal <= 64 && p->max_pub <= 128, "more challenges / public inputs than the scratch holds");
+    if (!c->chelpers_scratch) MI_HIP_CHECK(hipMalloc((void **)&c->chelpers_scratch, (192 + 128 + 256) * 8));
+    u64 stage[192 + 128 + 256] = {0};
+    for (uint64_t i = 0; i < p->max_chal * 3; i++) stage[i] = gl::canon(a->challenges[i]);
+    for (uint64_t i = 0; i < p->max_pub; i++) stage[192 + i] = gl::canon(a->publics[i]);
+    for (uint64_t i = 0; i < a->n_zhinv; i++) stage[320 + i] = gl::canon(a->zhinv[i]);
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // an earlier run may still be reading the scratch
+    MI_HIP_CHECK(hipMemcpyAsync(c->chelpers_scratch, stage, sizeof(stage), hipMemcpyHostToDevice, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `stage` is on this stack frame
+    chp::RunArgs A = {};
+    A.pols = (const u64 *)a->pols;
+    A.cpols = (const u64 *)a->const_pols;
+    A.x = (const u64 *)a->x;
+    A.chal = c->chelpers_scratch;
+    A.pub = c->chelpers_scratch + 192;
+    A.zhinv = c->chelpers_scratch + 320;
+    A.q = (u64 *)a->q;
+    A.n_const = a->n_const;
+    A.x_stride = a->x_stride;
+    A.n_zhinv = a->n_zhinv;
+    A.row0 = row0;
+    A.row_end = row0 + nrows;
+    if (lds > 48 * 1024)
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *)chp::k_chelpers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(chp::k_chelpers, dim3((unsigned)((nrows + 63) / 64)), dim3(64), lds, c->stream, p->dev, (uint32_t)p->host.size(), A);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// ---- host debug executor (tests only): the SAME translated program and instruction semantics, run on the CPU over host
+// pointers, so that the translator (role table, copy forwarding, reschedule, slot allocation) can be checked without a GPU
+extern "C" int mi_dbg_host_chelpers_run(const mi_chelpers_prog *p, const mi_chelpers_params *a, const uint64_t *rows, uint64_t nrows)
+{
+    MI_TRY(check_params(p, a, 0, 0));
+    MI_REQUIRE(rows || nrows == 0, "null row list");
+    std::vector<u64> chal(p->max_chal * 3 + 1), pub(p->max_pub + 1), zh(a->n_zhinv);
+    for (uint64_t i = 0; i < p->max_chal * 3; i++) chal[i] = gl::canon(a->challenges[i]);
+    for (uint64_t i = 0; i < p->max_pub; i++) pub[i] = gl::canon(a->publics[i]);
+    for (uint64_t i = 0; i < a->n_zhinv; i++) zh[i] = gl::canon(a->zhinv[i]);
+    chp::RunArgs A = {};
+    A.pols = (const u64 *)a->pols;
+    A.cpols = (const u64 *)a->const_pols;
+    A.x = (const u64 *)a->x;
+    A.chal = chal.data();
+    A.pub = pub.data();
+    A.zhinv = zh.data();
+    A.q = (u64 *)a->q;
+    A.n_const = a->n_const;
+    A.x_stride = a->x_stride;
+    A.n_zhinv = a->n_zhinv;
+    std::vector<u64> words(p->n_words + 3);
+    chp::HostTmp tmp = {words.data()};
+    for (uint64_t k = 0; k < nrows; k++)
+        for (const chp::DInstr &I : p->host) chp::exec_instr(I, rows[k], true, A, tmp);
+    return MI_OK;
+}

@@ -89,6 +89,8 @@ struct mi_ctx {
     bool lde_fuse_mid = true; // extendPol: last INTT pass and first NTT pass in one kernel (k_lde_mid) when the splits line up
     uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
     bool poseidon_constants_uploaded = false; // c_rc / c_sparse on this context's device
+    u64 *chelpers_scratch = nullptr; // challenges / public inputs / ZhInv of the running constraint-evaluator program
+    uint64_t chelpers_min_words = 0; // benchmarking: LDS words per row to allocate at least (occupancy of a bigger program)
     // Entry points serialise on the context (scratch, plans, workspace and timers are shared state) and make
     // ctx->device current first, so one context may be called from several host threads like the reference's
     // static Poseidon / NTT methods; recursive because host-pointer wrappers call other entry points.

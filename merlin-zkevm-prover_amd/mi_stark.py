@@ -56,6 +56,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
+    "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run",
 ]
 
 
@@ -125,6 +126,9 @@ class Context:
 
     def set_lde_fuse(self, fuse):
         _check(lib().mi_set_lde_fuse(self.h, ctypes.c_int(int(fuse))))
+
+    def set_chelpers_min_words(self, words):
+        _check(lib().mi_set_chelpers_min_words(self.h, u64(words)))
 
     def set_ntt_tile(self, log_b):
         _check(lib().mi_set_ntt_tile(self.h, ctypes.c_int(log_b)))
@@ -273,6 +277,62 @@ class Context:
         ms = ctypes.c_float()
         _check(lib().mi_timer_elapsed_ms(self.h, ctypes.c_int(slot), ctypes.byref(ms)))
         return ms.value
+
+
+class ChelpersParams(ctypes.Structure):
+    """mi_chelpers_params (include/mi_stark.h)"""
+    _fields_ = [("pols", ctypes.c_void_p), ("const_pols", ctypes.c_void_p), ("n_const", u64),
+                ("challenges", ctypes.c_void_p), ("n_challenges", u64), ("publics", ctypes.c_void_p), ("n_publics", u64),
+                ("x", ctypes.c_void_p), ("x_stride", u64), ("zhinv", ctypes.c_void_p), ("n_zhinv", u64), ("q", ctypes.c_void_p)]
+
+
+MI_CHELPERS_STEP42NS = 42
+
+
+class ChelpersProgram:
+    """A constraint-evaluator program (the reference's generated op / args tables) translated for the GPU.
+    ctx = None compiles for the host debug executor only (no GPU needed)."""
+
+    STAT_NAMES = ("opcodes", "field_ops", "after_copy_forwarding", "instructions_per_row", "live_words_as_generated",
+                  "live_words_rescheduled", "base_temps", "ext_temps")
+
+    def __init__(self, ctx, ops, args, step=MI_CHELPERS_STEP42NS):
+        self.ctx = ctx
+        ops = np.ascontiguousarray(ops, dtype=np.uint64)
+        args = np.ascontiguousarray(args, dtype=np.uint64)
+        self.h = ctypes.c_void_p()
+        _check(lib().mi_chelpers_compile(ctx.h if ctx is not None else None, ctypes.byref(self.h), ctypes.c_int(step), _hp(ops), u64(ops.size),
+                                         _hp(args) if args.size else None, u64(args.size)))
+        st = np.zeros(8, dtype=np.uint64)
+        _check(lib().mi_chelpers_stats(self.h, _hp(st)))
+        self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}
+
+    def close(self):
+        if self.h:
+            lib().mi_chelpers_free(self.ctx.h if self.ctx is not None else None, self.h)
+            self.h = ctypes.c_void_p()
+
+    @staticmethod
+    def _params(pols_ptr, cpols_ptr, n_const, challenges, publics, x_ptr, x_stride, zhinv, q_ptr, keep):
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1)
+        pb = np.ascontiguousarray(publics, dtype=np.uint64).reshape(-1)
+        zh = np.ascontiguousarray(zhinv, dtype=np.uint64).reshape(-1)
+        keep.extend([ch, pb, zh])
+        return ChelpersParams(pols_ptr, cpols_ptr, n_const, ch.ctypes.data if ch.size else None, ch.size // 3,
+                              pb.ctypes.data if pb.size else None, pb.size, x_ptr, x_stride, zh.ctypes.data, zh.size, q_ptr)
+
+    def run(self, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, row0, nrows):
+        """pols / const_pols / x / q: device tensors (int64 containers); challenges / publics / zhinv: host arrays."""
+        keep = []
+        P = self._params(pols.data_ptr(), const_pols.data_ptr(), n_const, challenges, publics, x.data_ptr(), x_stride, zhinv, q.data_ptr(), keep)
+        _check(lib().mi_chelpers_run_dev(self.ctx.h, self.h, ctypes.byref(P), u64(row0), u64(nrows)))
+
+    def run_host(self, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, rows):
+        """The same translated program on the CPU (test hook): every array is a host numpy uint64 array."""
+        keep = []
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, publics, x.ctypes.data, x_stride, zhinv, q.ctypes.data, keep)
+        _check(lib().mi_dbg_host_chelpers_run(self.h, ctypes.byref(P), _hp(rows), u64(rows.size)))
 
 
 # ---- host debug hooks (same inline math as the kernels, run on the CPU; tests only)

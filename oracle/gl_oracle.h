@@ -103,6 +103,14 @@ void glo_zhinv(uint64_t *out, unsigned nbits, unsigned nbits_ext);
 /* LEv: out[k] = xis^k (ext), k < n   (starks.cpp:305-323) */
 void glo_geom_seq3(uint64_t *out, uint64_t n, const uint64_t ratio[3]);
 
+/* ---- constraint evaluators: the step42ns program interpreter (zkevm.chelpers.step42ns.parser.cpp:10-760, 762-1441),
+ *      restated opcode by opcode in chelpers_oracle.c.  ops / args are the generated tables; every pointer is a host
+ *      pointer; q receives rows [row0, row0 + nrows).  Returns 0, -1 (unknown opcode), -2 (argument count mismatch). */
+int glo_chelpers_step42ns(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, const uint64_t *pols,
+                          const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *publics,
+                          const uint64_t *x, uint64_t x_stride, const uint64_t *zhinv, uint64_t n_zhinv, uint64_t *q,
+                          uint64_t row0, uint64_t nrows);
+
 void glo_set_num_threads(int n); /* OpenMP threads used by the parallel loops (0 = leave as is) */
 int glo_num_threads(void);
 

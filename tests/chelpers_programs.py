@@ -1,0 +1,157 @@
+"""Test-side knowledge of the step42ns program format (TEST INFRASTRUCTURE): what every opcode of the reference interpreter
+(zkevm.chelpers.step42ns.parser.cpp, step42ns_parser_first_avx :24-748) takes as arguments, used to
+  * generate synthetic programs that exercise every opcode (the reference's own tables cannot travel to the GPU box),
+  * enumerate the memory a program touches (to run the reference's real tables on the CPU over a sparse address space),
+  * cross-check the argument counts against the reference's source text where it is present.
+A third, independent transcription of the opcode table (the product's is csrc/chelpers.hip, the oracle's
+oracle/chelpers_oracle.c): a slip in one of the three shows up as a disagreement."""
+import re
+
+import numpy as np
+
+T1, T3, POL, POLS, NUM, CONST, CONSTS, CHAL, PUB, POL3, POL3S, X = range(12)
+NARGS = {T1: 1, T3: 1, POL: 2, POLS: 4, NUM: 1, CONST: 1, CONSTS: 3, CHAL: 1, PUB: 1, POL3: 2, POL3S: 4, X: 0}
+# opcode -> (dst kind, source a, source b) in argument order; argument 0 is the destination temp
+OPS = {
+    0: (T1, T1, T1), 1: (T1, T1, POL), 2: (T1, T1, NUM), 3: (T1, T1, CONST), 4: (T1, POL, POL), 5: (T1, POLS, POLS), 6: (T1, POL, CONST),
+    7: (T1, POL, NUM), 8: (T1, CONST, CONST), 9: (T1, CONSTS, CONSTS), 10: (T1, CONST, NUM), 11: (T1, CONSTS, NUM), 12: (T3, T1, T3),
+    13: (T3, NUM, CHAL), 14: (T3, T1, CHAL), 15: (T3, POL, T3), 16: (T3, POL, CHAL), 17: (T3, T3, T3), 18: (T3, T3, CHAL), 19: (T3, POL3, T3),
+    20: (T3, POL3, CHAL), 21: (T1, T1, T1), 22: (T1, T1, POL), 23: (T1, T1, POLS), 24: (T1, POL, T1), 25: (T1, POLS, T1), 26: (T1, T1, NUM),
+    27: (T1, NUM, T1), 28: (T1, POL, NUM), 29: (T1, POLS, NUM), 30: (T1, NUM, POL), 31: (T1, NUM, POLS), 32: (T1, NUM, CONST),
+    33: (T1, NUM, CONSTS), 34: (T1, POL, PUB), 35: (T1, POLS, POL), 36: (T1, POL, POLS), 37: (T1, POL, POL), 38: (T1, POLS, POLS),
+    39: (T1, CONST, POL), 40: (T1, T1, CONST), 41: (T3, POL3, NUM), 42: (T3, T3, T3), 43: (T3, T3, CHAL), 44: (T3, T3, POL3), 45: (T1, T1, T1),
+    46: (T1, NUM, T1), 47: (T1, POL, T1), 48: (T1, POLS, T1), 49: (T1, T1, CONST), 50: (T1, POL, POL), 51: (T1, POL, POLS), 52: (T1, POLS, POLS),
+    53: (T1, NUM, POL), 54: (T1, POL, CONST), 55: (T1, POLS, CONST), 56: (T1, T1, POL), 57: (T1, T1, POLS), 58: (T1, CONST, T1),
+    59: (T3, T1, CHAL), 60: (T3, CONST, T3), 61: (T3, T1, T3), 62: (T3, POL, CHAL), 63: (T3, POLS, CHAL), 64: (T3, POL, T3), 65: (T3, POLS, T3),
+    66: (T3, NUM, CHAL), 67: (T3, X, CHAL), 68: (T3, X, T3), 69: (None, T3, None), 70: (T3, CHAL, T3), 71: (T3, T3, T3), 72: (T3, POL3, POL3),
+    73: (T3, POL3S, CHAL), 74: (T3, POL3S, T3), 75: (T3, POL3, T3), 76: (T3, POL3, CHAL), 77: (T3, POL3S, POL3), 78: (T1, T1, None),
+    79: (T1, POL, None), 80: (T1, POLS, None), 81: (T1, NUM, None), 82: (T1, CONST, None), 83: (T1, CONSTS, None),
+}
+FUSED = {84: [12, 70], 85: [0, 50], 86: [32, 47, 21, 32, 48], 87: [12, 70] * 4, 88: [21, 50, 21, 53, 0, 0, 50, 50, 0, 50, 21, 50]}
+
+
+def nargs_of(op):
+    if op in FUSED:
+        return sum(nargs_of(o) for o in FUSED[op])
+    d, a, b = OPS[op]
+    return (0 if d is None else 1) + NARGS[a] + (NARGS[b] if b is not None else 0)
+
+
+def decode(ops, args):
+    """-> [(opcode, dst kind, dst slot, [(kind, [args])])] micro-operations, and the number of arguments consumed."""
+    out, ia = [], 0
+    for op in ops:
+        for o in FUSED.get(int(op), [int(op)]):
+            d, a, b = OPS[o]
+            slot = None
+            if d is not None:
+                slot = int(args[ia]); ia += 1
+            srcs = []
+            for k in (a, b):
+                if k is None:
+                    continue
+                srcs.append((k, [int(v) for v in args[ia:ia + NARGS[k]]]))
+                ia += NARGS[k]
+            out.append((o, d, slot, srcs))
+    return out, ia
+
+
+def touched_addresses(micro, rows, numpols):
+    """Element indices a program reads in `pols` and in the constant polynomials for the given rows."""
+    pols, cpols = set(), set()
+    for (_, _, _, srcs) in micro:
+        for k, a in srcs:
+            for r in rows:
+                if k in (POL, POL3):
+                    base = a[0] + r * a[1]
+                elif k in (POLS, POL3S):
+                    base = a[0] + ((r + a[1]) % a[2]) * a[3]
+                elif k == CONST:
+                    cpols.add(a[0] + r * numpols); continue
+                elif k == CONSTS:
+                    cpols.add(a[0] + ((r + a[1]) % a[2]) * numpols); continue
+                else:
+                    continue
+                pols.update(range(base, base + (3 if k in (POL3, POL3S) else 1)))
+    return pols, cpols
+
+
+def parse_reference_tables(hpp_text, op_name="op42", args_name="args42"):
+    def arr(name):
+        m = re.search(name + r"\[[A-Za-z_0-9]*\]\s*=\s*\{([^}]*)\}", hpp_text)
+        return np.array([int(x.strip().rstrip("UL")) for x in m.group(1).replace("\n", " ").split(",") if x.strip()], dtype=np.uint64)
+    return arr(op_name), arr(args_name)
+
+
+def synthetic_program(rng, nrows, sections, n_const, n_chal, n_pub, passes=3, nt1=14, nt3=6):
+    """A random valid program that uses EVERY opcode 0..88 at least once per pass and whose every result reaches the
+    q store (each result is folded into an accumulator at once, so nothing is dead code for the translator).
+    sections: [(element offset, row stride)] of `pols`; a section's columns are [0, stride)."""
+    ops, args = [], []
+    P = 0xFFFFFFFF00000001
+    ACC = nt3                                        # accumulator ext temp, beyond the randomly used slots
+    def1, def3 = set(), set()
+
+    def gen_src(kind):
+        if kind == T1: return [int(rng.choice(sorted(def1)))]
+        if kind == T3: return [int(rng.choice(sorted(def3 | {ACC})))]
+        if kind == NUM: return [int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.5 else int(rng.integers(0, 5))]
+        if kind == CONST: return [int(rng.integers(0, n_const))]
+        if kind == CONSTS: return [int(rng.integers(0, n_const)), int(rng.integers(1, 4)), nrows]
+        if kind == CHAL: return [int(rng.integers(0, n_chal))]
+        if kind == PUB: return [int(rng.integers(0, n_pub))]
+        off, stride = sections[int(rng.integers(0, len(sections)))]
+        col = int(rng.integers(0, stride - (2 if kind in (POL3, POL3S) else 0)))
+        if kind in (POL, POL3): return [off + col, stride]
+        if kind in (POLS, POL3S): return [off + col, int(rng.integers(1, 4)), nrows, stride]
+        return []
+
+    def emit(o):
+        d, a, b = OPS[o]
+        if (a == T1 or b == T1) and not def1: return False
+        if o == 69: return False
+        dst = int(rng.integers(0, nt1 if d == T1 else nt3))
+        if o == 70:                                  # (dst, challenge, ext temp)
+            ar = [dst] + gen_src(CHAL) + gen_src(T3)
+        else:
+            ar = [dst] + gen_src(a) + (gen_src(b) if b is not None else [])
+        return o, ar, d, dst
+
+    def push(o, ar):
+        ops.append(o); args.extend(ar)
+
+    # the accumulator starts as a challenge-derived value
+    push(13, [ACC, 1, 0])
+    order = list(range(84))
+    for _ in range(passes):
+        rng.shuffle(order)
+        pending = list(order)
+        stall = 0
+        while pending and stall < 400:
+            o = pending.pop(0)
+            e = emit(o)
+            if not e:
+                if o != 69: pending.append(o)
+                stall += 1
+                continue
+            o, ar, d, dst = e
+            push(o, ar)
+            (def1 if d == T1 else def3).add(dst)
+            if d == T1: push(12, [ACC, dst, ACC])     # ACC = T1 + ACC
+            else: push(17, [ACC, dst, ACC])           # ACC = T3 + ACC
+            if rng.random() < 0.3: push(70, [ACC, int(rng.integers(0, n_chal)), ACC])
+        # the fused opcodes: their argument lists are the concatenation of their parts'
+        for f, parts in FUSED.items():
+            ar_all = []
+            ok = True
+            for part in parts:
+                e = emit(part)
+                if not e: ok = False; break
+                _, ar, d, dst = e
+                ar_all += ar
+                (def1 if d == T1 else def3).add(dst)
+            if ok:
+                push(f, ar_all)
+                push(12, [ACC, int(rng.choice(sorted(def1))), ACC])
+    push(69, [ACC])
+    return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)

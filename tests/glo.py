@@ -11,7 +11,7 @@ _p64 = ctypes.POINTER(u64)
 
 def build(flavour=""):
     so = os.path.join(ROOT, "oracle", "libgl_oracle%s.so" % ("_" + flavour if flavour else ""))
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("gl_oracle.c", "gl_oracle.h", "poseidon_constants.h", "Makefile")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("gl_oracle.c", "chelpers_oracle.c", "gl_oracle.h", "poseidon_constants.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return so
@@ -227,3 +227,16 @@ def evmap(pols, prime, lev, lpev, n, ext_bits):
                     dims.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ptr(strides),
                     pr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ptr(A(lev)), ptr(A(lpev)))
     return evals.reshape(k, 3)
+
+
+def chelpers_step42ns(ops, args, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, row0, nrows):
+    """The reference's step42ns interpreter restated (oracle/chelpers_oracle.c); q (host array) receives the rows."""
+    ops, args = A(ops), A(args)
+    ch, pb, zh = A(challenges).reshape(-1), A(publics).reshape(-1), A(zhinv).reshape(-1)
+    f = lib().glo_chelpers_step42ns
+    f.restype = ctypes.c_int
+    st = f(ptr(ops), u64(ops.size), ptr(args) if args.size else None, u64(args.size), ctypes.c_void_p(pols.ctypes.data),
+           ctypes.c_void_p(const_pols.ctypes.data), u64(n_const), ptr(ch) if ch.size else None, ptr(pb) if pb.size else None,
+           ctypes.c_void_p(x.ctypes.data), u64(x_stride), ptr(zh), u64(zh.size), ctypes.c_void_p(q.ctypes.data), u64(row0), u64(nrows))
+    if st != 0:
+        raise RuntimeError("glo_chelpers_step42ns: " + {-1: "unknown opcode", -2: "argument count mismatch"}.get(st, str(st)))
