@@ -157,7 +157,7 @@ def main():
     per_pass = len(cpg.decode(*cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8, passes=4))[0]) / 4.0
     c_ops, c_args = cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8,
                                           passes=max(1, int(round(args.chelpers_field_ops / per_pass))))
-    prog = mi_stark.ChelpersProgram(ctx, c_ops, c_args)
+    prog = mi_stark.ChelpersProgram(ctx, c_ops, c_args, sections=[(o, w, NE) for (o, w) in secs], n_const=args.n_const, nrows_ext=NE)
     ctx.set_chelpers_min_words(96)
     const_2ns = ctx.empty(NE * args.n_const)
     ctx.fill_synthetic(const_2ns, NE * args.n_const, 0x5EED0106)

@@ -116,6 +116,19 @@ int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *no
                                uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx,
                                uint64_t nqueries);
 
+/* ------------------------------------------------------------------ stage driver (host trace in, resident result out)
+ * Starks::genProof step 1 (starks.cpp:48-59: extendPol of p_cm1_n, then treesGL[0]->merkelize()) for a caller that holds
+ * the trace in HOST memory and wants the extension and the tree to STAY on the device: the n x ncols row-major host trace is
+ * uploaded in column chunks of chunk_cols (0 = 32; a multiple of 8) on a copy stream while the chunks already on the device
+ * are extended into ext (device, n_ext x ncols at row pitch ext_pitch) and their columns absorbed into the leaf sponges, so
+ * the PCIe transfer overlaps the kernels.  nodes (device, (2 n_ext - 1) * 4) receives the tree; root = its last 4 elements.
+ * Work is enqueued; mi_ctx_sync (or reading the root) waits for it.  For full PCIe speed the host range should be
+ * page-locked (mi_host_register once per buffer, or hipHostMalloc). */
+int mi_lde_merkle_host(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, const uint64_t *trace_host,
+                       uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
+int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister: page-lock a host range for DMA */
+int mi_host_unregister(mi_ctx *ctx, void *p);
+
 /* ------------------------------------------------------------------ FRI
  * Replaces the fold loop of FRIProve::prove (friProve.cpp:44-108): pol holds 2^prev_bits cubic-extension
  * elements (3 u64 each), out receives 2^cur_bits.  nbits_ext is the size of the first FRI domain, so the
@@ -156,6 +169,10 @@ int mi_zhinv(mi_ctx *ctx, uint64_t *out, unsigned nbits, unsigned nbits_ext);
  * a null ctx compiles for mi_dbg_host_chelpers_run only.  `step` names the opcode numbering of the tables. */
 #define MI_CHELPERS_STEP42NS 42
 typedef struct mi_chelpers_prog mi_chelpers_prog;
+/* A section of the polynomial area the program reads (stark_info mapOffsets / mapSectionsN, e.g. cm1_2ns): element (row, col)
+ * at pols[offset + row * ncols + col], row < nrows.  Every polynomial operand of the program must lie in a declared section:
+ * the kernel stages the sections, 64 rows at a time, in column-major order so that its per-row reads are coalesced. */
+typedef struct { uint64_t offset, ncols, nrows; } mi_chelpers_section;
 typedef struct {
     const uint64_t *pols;       /* device: params.pols, the base every polynomial offset of the program is relative to */
     const uint64_t *const_pols; /* device: params.pConstPols2ns, element (col, row) at const_pols[col + row * n_const] */
@@ -170,8 +187,11 @@ typedef struct {
     uint64_t n_zhinv;
     uint64_t *q;                /* device: params.q_2ns, row i at q[3 i .. 3 i + 3) */
 } mi_chelpers_params;
+/* sections: the n_sections (<= 6) sections of params.pols the program reads; n_const = pConstPols2ns->numPols();
+ * nrows_ext = rows of the extended domain (the constant polynomials and x_2ns have that many rows). */
 int mi_chelpers_compile(mi_ctx *ctx, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops,
-                        const uint64_t *args, uint64_t nargs);
+                        const uint64_t *args, uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections,
+                        uint64_t n_const, uint64_t nrows_ext);
 void mi_chelpers_free(mi_ctx *ctx, mi_chelpers_prog *prog);
 /* out[0..8) = opcodes in, field operations decoded, after copy forwarding, after dead-code removal (= instructions run per
  * row), live 64-bit words per row as generated, after the reschedule, base temps allocated, extension temps allocated */

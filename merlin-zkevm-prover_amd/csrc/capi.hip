@@ -88,6 +88,16 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
     if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
+    if (c->chelpers_stage) (void)hipFree(c->chelpers_stage);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        for (int i = 0; i < 2; i++) {
+            if (c->ev_uploaded[i]) (void)hipEventDestroy(c->ev_uploaded[i]);
+            if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
+        }
+        (void)hipStreamDestroy(c->copy_stream);
+    }
     for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -339,6 +349,98 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
     MI_HIP_CHECK(hipMemcpyAsync(di.p, idx, nq * 8, hipMemcpyHostToDevice, c->stream));
     MI_TRY(launch_group_proofs(c, (u64 *)proofs, (const u64 *)nodes, (const u64 *)src, pitch, height, width, (const u64 *)di.p, nq));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // di is released on return
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ stage driver: host trace in, resident extension + tree out
+// Starks::genProof step 1 (starks.cpp:48-59) with the callers unchanged hands over a HOST trace (p_cm1_n, 44.6 GB) and wants
+// the extended trace and its tree.  Done call by call (extendPol, then merkelize) that is 44.6 GB up, 89 GB down, 89 GB up
+// again.  Here the trace is streamed up in COLUMN CHUNKS on a copy stream while the GPU works on the chunks that have
+// arrived: chunk k+1 uploads (a strided 2-D copy out of the row-major host matrix into a compact staging buffer) while
+// chunk k is extended into its columns of the resident extended trace and chunk k-1's columns are absorbed into the
+// running leaf sponges (the streaming form of linear_hash: the capacity is carried in the digest buffer).  The PCIe
+// time (0.78 s at 57 GB/s) and the kernel time (0.77 s) overlap instead of adding; the extended trace and the nodes stay
+// in HBM for the later steps and only the root is read back by the caller.
+extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, const uint64_t *trace_host,
+                                  uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+{
+    CTX_OK(c);
+    if (n == 0 || ncols == 0) return MI_OK;
+    MI_REQUIRE(nodes && ext && trace_host, "null buffer");
+    MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
+    MI_REQUIRE(ext_pitch >= ncols, "pitch smaller than ncols");
+    MI_REQUIRE(ncols > 4, "rows of at most 4 columns are not hashed (linear_hash copies them): use mi_lde + mi_merkle_build");
+    if (chunk_cols == 0) chunk_cols = 32;
+    MI_REQUIRE(chunk_cols % 8 == 0, "chunk width must be a multiple of 8 (the sponge absorbs whole blocks per chunk)");
+    if (!c->copy_stream) {
+        MI_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming));
+        }
+    }
+    // two compact staging buffers [n x chunk]
+    const uint64_t stage_bytes = 2 * n * chunk_cols * 8;
+    if (c->stage_bytes < stage_bytes) {
+        MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->stage) MI_HIP_CHECK(hipFree(c->stage));
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        hipError_t e = hipMalloc((void **)&c->stage, stage_bytes);
+        if (e != hipSuccess) {
+            mi_set_error("cannot allocate %llu bytes of upload staging: %s", (unsigned long long)stage_bytes, hipGetErrorString(e));
+            return MI_ERR_NOMEM;
+        }
+        c->stage_bytes = stage_bytes;
+    }
+    const uint64_t n_chunks = (ncols + chunk_cols - 1) / chunk_cols;
+    // the copy stream must not overtake work already queued on the compute stream that still reads the staging buffers
+    MI_HIP_CHECK(hipEventRecord(c->ev_consumed[0], c->stream));
+    MI_HIP_CHECK(hipEventRecord(c->ev_consumed[1], c->stream));
+    auto upload = [&](uint64_t k) -> int {
+        const uint64_t c0 = k * chunk_cols, cw = std::min(chunk_cols, ncols - c0);
+        u64 *st = c->stage + (k & 1) * n * chunk_cols;
+        MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_consumed[k & 1], 0)); // the LDE that read this buffer is done
+        MI_HIP_CHECK(hipMemcpy2DAsync(st, cw * 8, trace_host + c0, ncols * 8, cw * 8, n, hipMemcpyHostToDevice, c->copy_stream));
+        MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k & 1], c->copy_stream));
+        return MI_OK;
+    };
+    MI_TRY(upload(0));
+    for (uint64_t k = 0; k < n_chunks; k++) {
+        const uint64_t c0 = k * chunk_cols, cw = std::min(chunk_cols, ncols - c0);
+        MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k & 1], 0));
+        MI_TRY(launch_lde(c, (u64 *)ext + c0, ext_pitch, c->stage + (k & 1) * n * chunk_cols, cw, n_ext, n, cw));
+        MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k & 1], c->stream));
+        if (k + 1 < n_chunks) MI_TRY(upload(k + 1)); // queued behind the LDE of chunk k-1 (its buffer), beside the LDE of chunk k
+        if (k >= 1) { // absorb the previous chunk while this one's successor uploads
+            const uint64_t p0 = (k - 1) * chunk_cols;
+            const u64 *base = (const u64 *)ext + p0;
+            const uint64_t pitch = ext_pitch, width = chunk_cols;
+            MI_TRY(launch_linear_hash_absorb(c, (u64 *)nodes, 1, &base, &pitch, &width, n_ext, k == 1, false));
+        }
+    }
+    {
+        const uint64_t p0 = (n_chunks - 1) * chunk_cols;
+        const u64 *base = (const u64 *)ext + p0;
+        const uint64_t pitch = ext_pitch, width = ncols - p0;
+        MI_TRY(launch_linear_hash_absorb(c, (u64 *)nodes, 1, &base, &pitch, &width, n_ext, n_chunks == 1, true));
+    }
+    return launch_merkle_levels(c, (u64 *)nodes, n_ext);
+}
+
+extern "C" int mi_host_register(mi_ctx *c, void *p, uint64_t bytes)
+{
+    CTX_OK(c);
+    MI_REQUIRE(p && bytes, "null range");
+    MI_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return MI_OK;
+}
+
+extern "C" int mi_host_unregister(mi_ctx *c, void *p)
+{
+    CTX_OK(c);
+    MI_REQUIRE(p, "null pointer");
+    MI_HIP_CHECK(hipHostUnregister(p));
     return MI_OK;
 }
 

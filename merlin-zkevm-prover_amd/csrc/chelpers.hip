@@ -24,9 +24,15 @@
 //   * One row per lane, 64-lane workgroups, temporaries in LDS as [word][lane] (conflict-free 8-byte accesses, the word
 //     index is wave-uniform).  The instruction stream is wave-uniform: it is fetched through the scalar cache and
 //     every decode branch is scalar.  All arithmetic is the same gl:: code the other kernels use.
-//   * Polynomial reads are per-lane 8-byte gathers at a stride of one row (5 320 B for the 665-column section): each
-//     touches its own 64-byte sector.  Known cost (9x read amplification on the wide sections); the rows of a
-//     workgroup are consecutive, so the sectors are re-used while they stay in L2.
+//   * Polynomial operands.  The sections are row-major, a lane owns a row: read in place, every operand is a 64-lane
+//     gather at a stride of one row (5 320 B for the 665-column section), one 64-byte sector per lane -- 12 000 operand
+//     reads per row = 13 TB of sector traffic at 2^24 rows (first version, measured: 6.3 s, exactly that bound).  So the
+//     workgroups are PERSISTENT and each, per group of 64 rows, first TRANSPOSES its rows (+ the few following rows the
+//     shifted "prime" reads need) of every section into a private column-major scratch in HBM -- rows read coalesced
+//     along the row, turned in an LDS tile, written as 576-byte column runs -- and the interpreter then reads operand
+//     (column, row) as one contiguous 512-byte run per wave.  The staged operands of 8 instructions are fetched together
+//     (16 loads in flight per wave) before those instructions execute, because with the temporaries' LDS footprint only
+//     three waves fit a CU and a dependent load per instruction would leave the kernel latency-bound.
 //
 // Parity status: UNPINNED by reference data (no input / output pair for any chelpers step exists in the reference tree;
 // zkevm.starkinfo.json and the constant polynomials are absent).  The oracle (oracle/chelpers_oracle.c) restates the
@@ -120,10 +126,33 @@ struct DInstr {
 };
 static_assert(sizeof(DInstr) == 64, "instruction must be 64 bytes");
 
-struct RunArgs {
+struct RunArgs { // host debug executor: operands read in place
     const u64 *pols, *cpols, *x, *zhinv, *chal, *pub;
     u64 *q;
     uint64_t n_const, x_stride, n_zhinv, row0, row_end;
+};
+
+// ---- device form: 32-byte instructions whose polynomial operands name STAGED columns
+enum GKind : uint32_t { G_NONE = 0, G_T1, G_T3, G_NUM, G_CHAL, G_PUB, G_ZHINV, G_ST1, G_ST3 };
+struct GInstr {
+    uint32_t op;  // bits 0-3 class, 4-7 dst kind (K_T1 / K_T3 / K_Q), 8-11 GKind of a, 12-15 GKind of b
+    uint32_t dst; // LDS word of the destination temp
+    uint64_t a, b;            // temp word | number | challenge / public index | staged column
+    uint32_t a_shift, b_shift; // row shift of a staged operand
+};
+static_assert(sizeof(GInstr) == 32, "device instruction must be 32 bytes");
+
+static constexpr int MAX_SECTIONS = 8;
+static constexpr uint32_t HALO = 8;             // rows staged beyond the group's 64 (largest row shift a program may use)
+static constexpr uint32_t RS = 64 + HALO;       // rows per staged column
+static constexpr int BATCH = 8;                 // instructions whose staged operands are fetched together
+struct GSection { const u64 *ptr; uint64_t pitch, nrows; uint32_t ncols, col0; };
+struct GArgs {
+    GSection sec[MAX_SECTIONS];
+    uint32_t n_sections, n_instr, n_words, pad;
+    const u64 *zhinv, *chal, *pub;
+    u64 *q, *scratch;           // scratch: per resident workgroup, [staged column][RS rows]
+    uint64_t n_zhinv, row0, row_end, n_groups, staged_cols;
 };
 
 // ---- host-side intermediate form
@@ -132,9 +161,14 @@ struct MicroOp { Cls cls; Kind dst; uint64_t dst_slot; HOpd a, b; };
 
 } // namespace chp
 
+struct HostSection { uint64_t offset, ncols, nrows; uint32_t col0; int role; }; // role 0: section of pols, 1: constant polynomials, 2: x
 struct mi_chelpers_prog {
-    std::vector<chp::DInstr> host; // the translated program (kept for the host debug executor)
-    chp::DInstr *dev = nullptr;
+    std::vector<chp::DInstr> host; // the translated program, operands in place (host debug executor)
+    std::vector<chp::GInstr> gpu;  // the same program over staged columns (kernel)
+    chp::GInstr *dev = nullptr;
+    std::vector<HostSection> sections; // what the kernel stages per group of rows, in staged-column order
+    uint64_t staged_cols = 0;
+    uint64_t n_const = 0, nrows_ext = 0;
     uint64_t n_words = 0;          // LDS words per row
     uint64_t stats[8] = {0};       // ops in, micro-ops, after copy forwarding, scheduled, live words before, after, t1 slots, t3 slots
     uint64_t max_chal = 0, max_pub = 0;
@@ -221,36 +255,128 @@ MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P
     }
 }
 
-struct LdsTmp { // [word][lane], 64 lanes
-    u64 *base;
-    uint32_t lane;
-    __device__ __forceinline__ u64 get(uint64_t w) const { return base[w * 64 + lane]; }
-    __device__ __forceinline__ void set(uint64_t w, u64 v) { base[w * 64 + lane] = v; }
-};
 struct HostTmp {
     u64 *base;
     u64 get(uint64_t w) const { return base[w]; }
     void set(uint64_t w, u64 v) { base[w] = v; }
 };
 
-__global__ __launch_bounds__(64) void k_chelpers(const DInstr *__restrict__ prog, uint32_t n_instr, const RunArgs P)
+// ---- the kernel.  LDS: [ temporaries: n_words x 64 | (aliased during staging) transpose tile RS x 65 ] [ prefetched
+// operands: 2 BATCH x 64 ]
+__device__ __forceinline__ void g_operand(uint32_t kind, uint64_t v, uint32_t shift, const GArgs &P, const u64 *tmp, const u64 *mycol,
+                                          uint32_t lane, uint64_t r, u64 pre, u64 (&o)[3])
+{
+    o[1] = o[2] = 0;
+    switch (kind) {
+    case G_T1: o[0] = tmp[v * 64 + lane]; break;
+    case G_T3: o[0] = tmp[v * 64 + lane]; o[1] = tmp[(v + 1) * 64 + lane]; o[2] = tmp[(v + 2) * 64 + lane]; break;
+    case G_NUM: o[0] = v; break;
+    case G_CHAL: o[0] = P.chal[v * 3]; o[1] = P.chal[v * 3 + 1]; o[2] = P.chal[v * 3 + 2]; break;
+    case G_PUB: o[0] = P.pub[v]; break;
+    case G_ZHINV: o[0] = P.zhinv[r % P.n_zhinv]; break;
+    case G_ST1: o[0] = pre; break; // fetched with its batch
+    case G_ST3: { // three neighbouring staged columns (rare: not worth prefetch registers)
+        const u64 *p = mycol + v * RS + lane + shift;
+        o[0] = p[0]; o[1] = p[RS]; o[2] = p[2 * RS];
+        break;
+    }
+    default: o[0] = 0; break;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog, const GArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     const uint32_t lane = threadIdx.x;
-    const uint64_t row = P.row0 + (uint64_t)blockIdx.x * 64 + lane;
-    const bool active = row < P.row_end;
-    const uint64_t r = active ? row : P.row0; // idle lanes shadow a valid row: every address they form is a valid one
-    LdsTmp tmp = {smem, lane};
-    // constant address space: wave-uniform loads of the instruction stream go through the scalar cache
-    const __attribute__((address_space(4))) DInstr *cp = (const __attribute__((address_space(4))) DInstr *)prog;
-    for (uint32_t pc = 0; pc < n_instr; pc++) {
-        DInstr I;
-        const __attribute__((address_space(4))) uint64_t *w = (const __attribute__((address_space(4))) uint64_t *)(cp + pc);
-        uint64_t raw[8];
+    const uint32_t tmp_words = P.n_words * 64 > RS * 65 ? P.n_words * 64 : RS * 65;
+    u64 *tmp = smem;               // [word][lane]
+    u64 *tile = smem;              // [RS][65], only while staging
+    u64 *pre = smem + tmp_words;   // [2 * BATCH][lane]
+    u64 *mycol = P.scratch + (uint64_t)blockIdx.x * P.staged_cols * RS; // this workgroup's staged columns
+    const __attribute__((address_space(4))) GInstr *cp = (const __attribute__((address_space(4))) GInstr *)prog;
+
+    for (uint64_t g = blockIdx.x; g < P.n_groups; g += gridDim.x) { // persistent: every workgroup drains its share and exits
+        const uint64_t r0 = P.row0 + g * 64;
+        const uint64_t row = r0 + lane;
+        const bool active = row < P.row_end;
+        // ---- stage: rows r0 .. r0 + RS - 1 (wrapping at the section's row count) of every section, transposed
+        for (uint32_t si = 0; si < P.n_sections; si++) {
+            const GSection S = P.sec[si];
+            for (uint32_t c0 = 0; c0 < S.ncols; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                __syncthreads(); // the tile (and, first time round, the temporaries it aliases) is free
+                if (c < S.ncols) {
+#pragma unroll 8
+                    for (uint32_t rr = 0; rr < RS; rr++) { // a row's 64 columns: one contiguous 512-byte read per wave
+                        uint64_t rw = r0 + rr;
+                        rw = rw >= S.nrows ? rw % S.nrows : rw;
+                        tile[rr * 65 + lane] = gl::canon(S.ptr[rw * S.pitch + c]);
+                    }
+                }
+                __syncthreads();
+                const uint32_t ncol = S.ncols - c0 < 64 ? S.ncols - c0 : 64;
+                for (uint32_t cc = 0; cc < ncol; cc++) { // a column's RS rows: one contiguous run per wave
+                    u64 *dst = mycol + (uint64_t)(S.col0 + c0 + cc) * RS;
+                    dst[lane] = tile[lane * 65 + cc];
+                    if (lane < HALO) dst[64 + lane] = tile[(64 + lane) * 65 + cc];
+                }
+            }
+        }
+        // the wave reads back what it just stored, and its L1 may still hold the previous group's lines of the same scratch
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+
+        // ---- interpret
+        for (uint32_t pc0 = 0; pc0 < P.n_instr; pc0 += BATCH) {
+            // fetch the staged dimension-1 operands of the next BATCH instructions: all loads are issued before any is used
+            u64 v[2 * BATCH];
 #pragma unroll
-        for (int i = 0; i < 8; i++) raw[i] = w[i];
-        memcpy(&I, raw, sizeof(I));
-        exec_instr(I, r, active, P, tmp);
+            for (int j = 0; j < BATCH; j++) {
+                v[2 * j] = v[2 * j + 1] = 0;
+                if (pc0 + j < P.n_instr) {
+                    const uint32_t op = cp[pc0 + j].op;
+                    if (((op >> 8) & 15) == G_ST1) v[2 * j] = mycol[cp[pc0 + j].a * RS + lane + cp[pc0 + j].a_shift];
+                    if (((op >> 12) & 15) == G_ST1) v[2 * j + 1] = mycol[cp[pc0 + j].b * RS + lane + cp[pc0 + j].b_shift];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * BATCH; j++) pre[j * 64 + lane] = v[j];
+            const uint32_t nb = P.n_instr - pc0 < BATCH ? P.n_instr - pc0 : BATCH;
+#pragma unroll 1
+            for (uint32_t j = 0; j < nb; j++) {
+                const uint32_t op = cp[pc0 + j].op, dst = cp[pc0 + j].dst;
+                const uint32_t cls = op & 15, dk = (op >> 4) & 15, ak = (op >> 8) & 15, bk = (op >> 12) & 15;
+                u64 a[3], b[3], o[3];
+                g_operand(ak, cp[pc0 + j].a, cp[pc0 + j].a_shift, P, tmp, mycol, lane, active ? row : r0, pre[(2 * j) * 64 + lane], a);
+                g_operand(bk, cp[pc0 + j].b, cp[pc0 + j].b_shift, P, tmp, mycol, lane, active ? row : r0, pre[(2 * j + 1) * 64 + lane], b);
+                const bool a3 = ak == G_T3 || ak == G_CHAL || ak == G_ST3, b3 = bk == G_T3 || bk == G_CHAL || bk == G_ST3;
+                switch (cls) {
+                case C_ADD: o[0] = gl::add(a[0], b[0]); o[1] = gl::add(a[1], b[1]); o[2] = gl::add(a[2], b[2]); break;
+                case C_SUB: o[0] = gl::sub(a[0], b[0]); o[1] = gl::sub(a[1], b[1]); o[2] = gl::sub(a[2], b[2]); break;
+                case C_MUL: case C_STOREQ:
+                    if (a3 && b3) {
+                        const E3 p = gl::e3_mul(E3{{a[0], a[1], a[2]}}, E3{{b[0], b[1], b[2]}});
+                        o[0] = p.v[0]; o[1] = p.v[1]; o[2] = p.v[2];
+                    } else if (a3) {
+                        o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[1], b[0]); o[2] = gl::mul(a[2], b[0]);
+                    } else if (b3) {
+                        o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[0], b[1]); o[2] = gl::mul(a[0], b[2]);
+                    } else {
+                        o[0] = gl::mul(a[0], b[0]); o[1] = o[2] = 0;
+                    }
+                    break;
+                default: o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; break;
+                }
+                if (dk == K_T1) {
+                    tmp[dst * 64 + lane] = o[0];
+                } else if (dk == K_T3) {
+                    tmp[dst * 64 + lane] = o[0]; tmp[(dst + 1) * 64 + lane] = o[1]; tmp[(dst + 2) * 64 + lane] = o[2];
+                } else if (active) {
+                    P.q[row * 3] = o[0]; P.q[row * 3 + 1] = o[1]; P.q[row * 3 + 2] = o[2];
+                }
+            }
+        }
     }
 }
 
@@ -492,24 +618,113 @@ static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
     return MI_OK;
 }
 
+// ---- the kernel's form of the program: every polynomial operand becomes a staged column of one of the sections
+static int build_staged(mi_chelpers_prog *P)
+{
+    auto find = [&](int role, uint64_t off, uint64_t stride, uint64_t width, uint32_t &col) -> const HostSection * {
+        for (const HostSection &S : P->sections) {
+            if (S.role != role) continue;
+            if (role == 0 && (stride != S.ncols || off < S.offset || off - S.offset + width > S.ncols)) continue;
+            if (role == 1 && off + width > S.ncols) continue;
+            col = S.col0 + (uint32_t)(role == 0 ? off - S.offset : off);
+            return &S;
+        }
+        return nullptr;
+    };
+    P->gpu.clear();
+    P->gpu.reserve(P->host.size());
+    for (const DInstr &d : P->host) {
+        GInstr g = {};
+        uint32_t gk[2] = {G_NONE, G_NONE};
+        const Opd *os[2] = {&d.a, &d.b};
+        uint64_t *gv[2] = {&g.a, &g.b};
+        uint32_t *gs[2] = {&g.a_shift, &g.b_shift};
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint32_t k = (d.op >> (8 + 4 * s2)) & 15;
+            const Opd &o = *os[s2];
+            uint32_t col = 0;
+            const HostSection *S = nullptr;
+            switch (k) {
+            case K_T1: gk[s2] = G_T1; *gv[s2] = o.off; break;
+            case K_T3: gk[s2] = G_T3; *gv[s2] = o.off; break;
+            case K_NUM: gk[s2] = G_NUM; *gv[s2] = o.off; break;
+            case K_CHAL: gk[s2] = G_CHAL; *gv[s2] = o.off; break;
+            case K_PUB: gk[s2] = G_PUB; *gv[s2] = o.off; break;
+            case K_ZHINV: gk[s2] = G_ZHINV; break;
+            case K_POL: case K_POLS: case K_POL3: case K_POL3S: {
+                const bool three = k == K_POL3 || k == K_POL3S, shifted = k == K_POLS || k == K_POL3S;
+                S = find(0, o.off, o.stride, three ? 3 : 1, col);
+                if (!S) {
+                    mi_set_error("mi_chelpers_compile: polynomial operand (offset %llu, stride %u) lies in none of the declared sections",
+                                 (unsigned long long)o.off, o.stride);
+                    return MI_ERR_INVALID;
+                }
+                if (shifted) MI_REQUIRE(o.mod == S->nrows && o.shift <= HALO, "shifted-row operand: modulus must be the section's row count, shift at most 8");
+                gk[s2] = three ? G_ST3 : G_ST1;
+                *gv[s2] = col;
+                *gs[s2] = shifted ? o.shift : 0;
+                break;
+            }
+            case K_CONST: case K_CONSTS:
+                S = find(1, o.off, 0, 1, col);
+                MI_REQUIRE(S, "constant-polynomial operand beyond the declared number of constant polynomials");
+                if (k == K_CONSTS) MI_REQUIRE(o.mod == S->nrows && o.shift <= HALO, "shifted-row operand: modulus must be the section's row count, shift at most 8");
+                gk[s2] = G_ST1;
+                *gv[s2] = col;
+                *gs[s2] = k == K_CONSTS ? o.shift : 0;
+                break;
+            case K_X:
+                S = find(2, 0, 0, 1, col);
+                MI_REQUIRE(S, "program reads x but no x section was declared");
+                gk[s2] = G_ST1;
+                *gv[s2] = col;
+                break;
+            default: break;
+            }
+        }
+        g.op = (d.op & 0xFF) | (gk[0] << 8) | (gk[1] << 12);
+        g.dst = d.dst;
+        P->gpu.push_back(g);
+    }
+    return MI_OK;
+}
+
 } // namespace chp
 
 extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops, const uint64_t *args,
-                                   uint64_t nargs)
+                                   uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections, uint64_t n_const, uint64_t nrows_ext)
 {
     if (!out) return MI_ERR_INVALID;
     *out = nullptr;
     MI_REQUIRE(ops && (args || nargs == 0) && nops > 0, "null program tables");
+    MI_REQUIRE(n_sections + 2 <= (uint64_t)chp::MAX_SECTIONS && (sections || n_sections == 0), "at most 6 sections");
     std::vector<chp::MicroOp> prog;
     mi_chelpers_prog *P = new mi_chelpers_prog();
     P->stats[0] = nops;
+    P->n_const = n_const;
+    P->nrows_ext = nrows_ext;
+    uint64_t col0 = 0;
+    for (uint64_t i = 0; i < n_sections; i++) {
+        P->sections.push_back({sections[i].offset, sections[i].ncols, sections[i].nrows, (uint32_t)col0, 0});
+        col0 += sections[i].ncols;
+    }
     int st = chp::decode(step, ops, nops, args, nargs, prog, P->max_chal, P->max_pub);
+    bool uses_const = false, uses_x = false;
+    for (const chp::MicroOp &m : prog)
+        for (const chp::HOpd *o : {&m.a, &m.b}) {
+            uses_const |= o->k == chp::K_CONST || o->k == chp::K_CONSTS;
+            uses_x |= o->k == chp::K_X;
+        }
+    if (uses_const && n_const) { P->sections.push_back({0, n_const, nrows_ext, (uint32_t)col0, 1}); col0 += n_const; }
+    if (uses_x) { P->sections.push_back({0, 1, nrows_ext, (uint32_t)col0, 2}); col0 += 1; }
+    P->staged_cols = col0;
     if (st == MI_OK) st = chp::translate(P, prog);
-    if (st == MI_OK && c) { // a null context compiles for the host debug executor only (no GPU needed)
+    if (st == MI_OK && c) st = chp::build_staged(P); // a null context compiles for the host debug executor only (no GPU, no sections needed)
+    if (st == MI_OK && c) {
         std::lock_guard<std::recursive_mutex> lock(c->mu);
         hipError_t e = hipSetDevice(c->device);
-        if (e == hipSuccess) e = hipMalloc((void **)&P->dev, P->host.size() * sizeof(chp::DInstr) + 64);
-        if (e == hipSuccess) e = hipMemcpyAsync(P->dev, P->host.data(), P->host.size() * sizeof(chp::DInstr), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&P->dev, P->gpu.size() * sizeof(chp::GInstr) + 64);
+        if (e == hipSuccess) e = hipMemcpyAsync(P->dev, P->gpu.data(), P->gpu.size() * sizeof(chp::GInstr), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
             mi_set_error("mi_chelpers_compile: %s", hipGetErrorString(e));
@@ -571,9 +786,11 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     MI_TRY(check_params(p, a, row0, nrows));
     MI_REQUIRE(p->dev, "program was compiled without a context");
     if (nrows == 0) return MI_OK;
-    const size_t lds = (size_t)std::max<uint64_t>(std::max<uint64_t>(p->n_words, c->chelpers_min_words), 1) * 64 * 8;
+    MI_REQUIRE(a->n_const == p->n_const, "number of constant polynomials differs from what the program was compiled for");
+    MI_REQUIRE(row0 + nrows <= p->nrows_ext, "rows beyond the extended domain the program was compiled for");
+    const uint64_t tmp_words = std::max<uint64_t>(std::max<uint64_t>(p->n_words, c->chelpers_min_words) * 64, (uint64_t)chp::RS * 65);
+    const size_t lds = (size_t)(tmp_words + 2 * chp::BATCH * 64) * 8;
     MI_REQUIRE(lds <= 160 * 1024, "program needs more temporaries per row than the LDS holds");
-    MI_REQUIRE((nrows + 63) / 64 < (1ull << 31), "too many rows for one launch");
     // small host tables -> the context's scratch (challenges, publics, ZhInv): 3 * 64 + 128 + 256 words at most
     MI_REQUIRE(p->max_chal <= 64 && p->max_pub <= 128, "more challenges / public inputs than the scratch holds");
     if (!c->chelpers_scratch) MI_HIP_CHECK(hipMalloc((void **)&c->chelpers_scratch, (192 + 128 + 256) * 8));
@@ -584,22 +801,49 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // an earlier run may still be reading the scratch
     MI_HIP_CHECK(hipMemcpyAsync(c->chelpers_scratch, stage, sizeof(stage), hipMemcpyHostToDevice, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `stage` is on this stack frame
-    chp::RunArgs A = {};
-    A.pols = (const u64 *)a->pols;
-    A.cpols = (const u64 *)a->const_pols;
-    A.x = (const u64 *)a->x;
+    // persistent workgroups: as many as are resident at once (LDS bound), each with a private staging area
+    const uint64_t n_groups = (nrows + 63) / 64;
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / lds));
+    const uint64_t grid = std::min<uint64_t>(n_groups, per_cu * (uint64_t)c->cu_count);
+    const uint64_t scratch_bytes = grid * p->staged_cols * chp::RS * 8 + 4096;
+    if (c->chelpers_stage_bytes < scratch_bytes) {
+        if (c->chelpers_stage) MI_HIP_CHECK(hipFree(c->chelpers_stage));
+        c->chelpers_stage = nullptr;
+        c->chelpers_stage_bytes = 0;
+        hipError_t e = hipMalloc((void **)&c->chelpers_stage, scratch_bytes);
+        if (e != hipSuccess) {
+            mi_set_error("cannot allocate %llu bytes of operand staging: %s", (unsigned long long)scratch_bytes, hipGetErrorString(e));
+            return MI_ERR_NOMEM;
+        }
+        c->chelpers_stage_bytes = scratch_bytes;
+    }
+    chp::GArgs A = {};
+    A.n_sections = (uint32_t)p->sections.size();
+    for (size_t i = 0; i < p->sections.size(); i++) {
+        const HostSection &S = p->sections[i];
+        chp::GSection &G = A.sec[i];
+        G.ncols = (uint32_t)S.ncols;
+        G.col0 = S.col0;
+        G.nrows = S.nrows;
+        if (S.role == 0) { G.ptr = (const u64 *)a->pols + S.offset; G.pitch = S.ncols; }
+        else if (S.role == 1) { MI_REQUIRE(a->const_pols, "null constant polynomials"); G.ptr = (const u64 *)a->const_pols; G.pitch = a->n_const; }
+        else { MI_REQUIRE(a->x, "null x"); G.ptr = (const u64 *)a->x; G.pitch = a->x_stride; }
+    }
+    A.n_instr = (uint32_t)p->gpu.size();
+    A.n_words = (uint32_t)std::max<uint64_t>(p->n_words, c->chelpers_min_words);
     A.chal = c->chelpers_scratch;
     A.pub = c->chelpers_scratch + 192;
     A.zhinv = c->chelpers_scratch + 320;
     A.q = (u64 *)a->q;
-    A.n_const = a->n_const;
-    A.x_stride = a->x_stride;
+    A.scratch = c->chelpers_stage;
     A.n_zhinv = a->n_zhinv;
     A.row0 = row0;
     A.row_end = row0 + nrows;
+    A.n_groups = n_groups;
+    A.staged_cols = p->staged_cols;
     if (lds > 48 * 1024)
         MI_HIP_CHECK(hipFuncSetAttribute((const void *)chp::k_chelpers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(chp::k_chelpers, dim3((unsigned)((nrows + 63) / 64)), dim3(64), lds, c->stream, p->dev, (uint32_t)p->host.size(), A);
+    hipLaunchKernelGGL(chp::k_chelpers, dim3((unsigned)grid), dim3(64), lds, c->stream, p->dev, A);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

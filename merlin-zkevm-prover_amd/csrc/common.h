@@ -90,6 +90,13 @@ struct mi_ctx {
     uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
     bool poseidon_constants_uploaded = false; // c_rc / c_sparse on this context's device
     u64 *chelpers_scratch = nullptr; // challenges / public inputs / ZhInv of the running constraint-evaluator program
+    // mi_lde_merkle_host: upload stream, two staging buffers [n x chunk] and their hand-over events
+    hipStream_t copy_stream = nullptr;
+    u64 *stage = nullptr;
+    uint64_t stage_bytes = 0;
+    hipEvent_t ev_uploaded[2] = {}, ev_consumed[2] = {};
+    u64 *chelpers_stage = nullptr;   // constraint evaluators: per-workgroup transposed operand staging
+    uint64_t chelpers_stage_bytes = 0;
     uint64_t chelpers_min_words = 0; // benchmarking: LDS words per row to allocate at least (occupancy of a bigger program)
     // Entry points serialise on the context (scratch, plans, workspace and timers are shared state) and make
     // ctx->device current first, so one context may be called from several host threads like the reference's

@@ -56,7 +56,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
-    "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run",
+    "mi_lde_merkle_host", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run",
 ]
 
 
@@ -168,6 +168,17 @@ class Context:
         idx = np.ascontiguousarray(idx, dtype=np.uint64)
         _check(lib().mi_merkle_group_proofs_dev(self.h, _dp(proofs), _dp(nodes), _dp(src), u64(pitch or width),
                                                 u64(height), u64(width), _hp(idx), u64(idx.size)))
+
+    def lde_merkle_host(self, nodes, ext, host_trace_ptr, n, n_ext, ncols, ext_pitch=None, chunk_cols=0):
+        """host_trace_ptr: address of the row-major n x ncols host trace (e.g. a pinned torch tensor's data_ptr())."""
+        _check(lib().mi_lde_merkle_host(self.h, _dp(nodes), _dp(ext), u64(ext_pitch or ncols), ctypes.c_void_p(host_trace_ptr),
+                                        u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
+
+    def host_register(self, ptr, nbytes):
+        _check(lib().mi_host_register(self.h, ctypes.c_void_p(ptr), u64(nbytes)))
+
+    def host_unregister(self, ptr):
+        _check(lib().mi_host_unregister(self.h, ctypes.c_void_p(ptr)))
 
     # ---- host-pointer (drop-in) variants
     def ntt_host(self, src, n, ncols, inverse=False):
@@ -296,13 +307,16 @@ class ChelpersProgram:
     STAT_NAMES = ("opcodes", "field_ops", "after_copy_forwarding", "instructions_per_row", "live_words_as_generated",
                   "live_words_rescheduled", "base_temps", "ext_temps")
 
-    def __init__(self, ctx, ops, args, step=MI_CHELPERS_STEP42NS):
+    def __init__(self, ctx, ops, args, sections=(), n_const=0, nrows_ext=0, step=MI_CHELPERS_STEP42NS):
+        """sections: [(element offset in pols, columns, rows)] the program reads (needed for the GPU form only)."""
         self.ctx = ctx
         ops = np.ascontiguousarray(ops, dtype=np.uint64)
         args = np.ascontiguousarray(args, dtype=np.uint64)
+        sec = np.ascontiguousarray(np.array(list(sections), dtype=np.uint64).reshape(-1, 3))
         self.h = ctypes.c_void_p()
         _check(lib().mi_chelpers_compile(ctx.h if ctx is not None else None, ctypes.byref(self.h), ctypes.c_int(step), _hp(ops), u64(ops.size),
-                                         _hp(args) if args.size else None, u64(args.size)))
+                                         _hp(args) if args.size else None, u64(args.size), _hp(sec.reshape(-1)) if sec.size else None,
+                                         u64(sec.shape[0]), u64(n_const), u64(nrows_ext)))
         st = np.zeros(8, dtype=np.uint64)
         _check(lib().mi_chelpers_stats(self.h, _hp(st)))
         self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}

@@ -37,6 +37,10 @@ def _synthetic_case(seed, nrows, passes=3):
     return ops, args, pols, cpols, n_const, chal, pub, x, 2, zhinv
 
 
+def _synthetic_sections(nrows):
+    return [(0, 40, nrows), (nrows * 40, 9, nrows), (nrows * 49, 3, nrows)]
+
+
 def test_opcode_table_argument_counts():
     micro_total = sum(len(cp.FUSED.get(o, [o])) for o in range(89))
     assert micro_total == 84 + 2 + 2 + 5 + 8 + 12
@@ -142,7 +146,7 @@ def test_chelpers_on_gpu_matches_oracle_over_2pow16_rows():
         ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(seed, nrows, passes=4)
         want = np.zeros(nrows * 3, dtype=np.uint64)
         glo.chelpers_step42ns(ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv, want, 0, nrows)
-        prog = mi_stark.ChelpersProgram(ctx, ops, args)
+        prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows)
         q = ctx.to_device(np.full(nrows * 3 + 6, 0xABCD, dtype=np.uint64))
         d_pols, d_c, d_x = ctx.to_device(pols), ctx.to_device(cpols), ctx.to_device(x)
         prog.run(d_pols, d_c, n_const, chal, pub, d_x, xs, zhinv, q, 0, nrows)
@@ -154,4 +158,7 @@ def test_chelpers_on_gpu_matches_oracle_over_2pow16_rows():
         got2 = ctx.to_host(q2)
         assert np.array_equal(got2[3000:3000 + 3 * 777], want[3000:3000 + 3 * 777]) and not got2[:3000].any() and not got2[3000 + 3 * 777:].any()
         prog.close()
+    # operands outside every declared section are refused at compile time
+    with pytest.raises(mi_stark.MiStarkError, match="none of the declared sections"):
+        mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows)[:2], n_const=n_const, nrows_ext=nrows)
     ctx.close()

@@ -437,6 +437,32 @@ def test_lde_column_chunks_and_pitches(ctx):
     mid.close()
 
 
+@pytest.mark.parametrize("n,n_ext,ncols,chunk,pinned", [(1 << 10, 1 << 11, 70, 32, True), (1 << 10, 1 << 11, 70, 8, False), (1 << 12, 1 << 13, 100, 0, True),
+                                                     (1 << 9, 1 << 11, 33, 16, True), (1 << 8, 1 << 9, 5, 8, False), (1 << 11, 1 << 12, 64, 32, True)])
+def test_stage_driver_streams_a_host_trace(ctx, n, n_ext, ncols, chunk, pinned):
+    """mi_lde_merkle_host: host trace in column chunks on a copy stream, LDE + streaming leaf absorption behind it; the
+    resident extension and the whole node array equal the oracle's, with pinned and pageable host memory, ragged last chunk,
+    one chunk only, a pitched output, and when called twice in a row (buffers and events are reused)."""
+    import torch
+    rng = np.random.default_rng(n + ncols + chunk)
+    trace = glo.rand_fe(rng, (n, ncols))
+    want_ext = glo.extend_pol(trace, n_ext, n, ncols)
+    want_nodes = glo.merkletree(want_ext, ncols, n_ext)
+    host = torch.from_numpy(trace.view(np.int64).reshape(-1).copy())
+    if pinned:
+        host = host.pin_memory()
+    pitch = ncols + 3
+    for _ in range(2):
+        ext = ctx.to_device(np.full(n_ext * pitch, 0x5151, dtype=np.uint64))
+        nodes = ctx.empty((2 * n_ext - 1) * 4)
+        ctx.lde_merkle_host(nodes, ext, host.data_ptr(), n, n_ext, ncols, ext_pitch=pitch, chunk_cols=chunk)
+        ctx.sync()
+        got = ctx.to_host(ext).reshape(n_ext, pitch)
+        assert np.array_equal(got[:, :ncols], want_ext)
+        assert np.all(got[:, ncols:] == 0x5151)
+        assert np.array_equal(ctx.to_host(nodes), want_nodes)
+
+
 def test_config3_shape_at_2pow18_rows_bit_exact():
     """BASELINE configs[2] with fewer rows: 2^18 x 665 trace -> LDE to 2^19 -> Poseidon Merkle tree, the whole result
     compared with the oracle (Merkle root = a checksum of all 2^19 x 665 extended values, plus sampled rows).  A small
