@@ -111,7 +111,8 @@ static inline uint64_t mi_merkle_proof_levels(uint64_t nrows)
 }
 /* Replaces MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for a batch of queries:
  * proofs[q] = row idx[q] (width values) followed by levels x 4 siblings; proof stride = width + 4*levels.
- * idx is a HOST array; src/nodes/proofs are device pointers. */
+ * idx is a HOST array; src/nodes/proofs are device pointers.  width = 0 (src may then be NULL) returns the sibling paths
+ * alone: the row-sharded multi-GPU tree opens a row's values from its column windows and its path from a rank's subtree. */
 int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src,
                                uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx,
                                uint64_t nqueries);
@@ -135,6 +136,10 @@ int mi_host_unregister(mi_ctx *ctx, void *p);
  * coset factor is shift^-(2^(nbits_ext - prev_bits)) (friProve.cpp:143-147). */
 int mi_fri_fold_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *pol, unsigned prev_bits, unsigned cur_bits,
                     unsigned nbits_ext, const uint64_t special_x[3] /* host */);
+/* The same fold restricted to outputs g in [g0, g0 + g_count) (out is still the base of the whole folded polynomial): the
+ * outputs are independent, so the ranks of a multi-GPU run fold disjoint ranges and all-gather them. */
+int mi_fri_fold_range_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *pol, unsigned prev_bits, unsigned cur_bits,
+                          unsigned nbits_ext, const uint64_t special_x[3] /* host */, uint64_t g0, uint64_t g_count);
 /* FRIProve::getTransposed (friProve.cpp:252-271): aux[i*h+j] = pol[j*w+i], w = 2^transpose_bits */
 int mi_fri_transpose_dev(mi_ctx *ctx, uint64_t *aux, const uint64_t *pol, uint64_t degree, unsigned transpose_bits);
 

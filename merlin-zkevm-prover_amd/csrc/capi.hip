@@ -342,7 +342,7 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
 {
     CTX_OK(c);
     if (nq == 0) return MI_OK;
-    MI_REQUIRE(proofs && nodes && src && idx, "null buffer");
+    MI_REQUIRE(proofs && nodes && (src || width == 0) && idx, "null buffer"); // width 0: sibling paths only
     for (uint64_t q = 0; q < nq; q++) MI_REQUIRE(idx[q] < height, "query index out of range");
     DevBuf di;
     MI_TRY(di.alloc(nq * 8));
@@ -451,7 +451,17 @@ extern "C" int mi_fri_fold_dev(mi_ctx *c, uint64_t *out, const uint64_t *pol, un
     CTX_OK(c);
     MI_REQUIRE(out && pol && x, "null buffer");
     const u64 xe[3] = {x[0], x[1], x[2]};
-    return launch_fri_fold(c, (u64 *)out, (const u64 *)pol, prev_bits, cur_bits, nbits_ext, xe);
+    MI_REQUIRE(cur_bits <= 40, "bad FRI step sizes");
+    return launch_fri_fold(c, (u64 *)out, (const u64 *)pol, prev_bits, cur_bits, nbits_ext, xe, 0, 1ull << cur_bits);
+}
+
+extern "C" int mi_fri_fold_range_dev(mi_ctx *c, uint64_t *out, const uint64_t *pol, unsigned prev_bits, unsigned cur_bits,
+                                     unsigned nbits_ext, const uint64_t x[3], uint64_t g0, uint64_t g_count)
+{
+    CTX_OK(c);
+    MI_REQUIRE(out && pol && x, "null buffer");
+    const u64 xe[3] = {x[0], x[1], x[2]};
+    return launch_fri_fold(c, (u64 *)out, (const u64 *)pol, prev_bits, cur_bits, nbits_ext, xe, g0, g_count);
 }
 
 extern "C" int mi_fri_transpose_dev(mi_ctx *c, uint64_t *aux, const uint64_t *pol, uint64_t degree, unsigned tbits)

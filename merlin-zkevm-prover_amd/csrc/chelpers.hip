@@ -262,18 +262,18 @@ struct HostTmp {
 };
 
 // ---- the kernel.  LDS: [ temporaries: n_words x 64 | (aliased during staging) transpose tile RS x 65 ] [ prefetched
-// operands: 2 BATCH x 64 ]
-__device__ __forceinline__ void g_operand(uint32_t kind, uint64_t v, uint32_t shift, const GArgs &P, const u64 *tmp, const u64 *mycol,
-                                          uint32_t lane, uint64_t r, u64 pre, u64 (&o)[3])
+// operands: 2 BATCH x 64 ] [ challenges, public inputs, ZhInv: 576 ]
+__device__ __forceinline__ void g_operand(uint32_t kind, uint64_t v, uint32_t shift, const GArgs &P, const u64 *tmp, const u64 *cst,
+                                          const u64 *mycol, uint32_t lane, uint64_t r, u64 pre, u64 (&o)[3])
 {
     o[1] = o[2] = 0;
     switch (kind) {
     case G_T1: o[0] = tmp[v * 64 + lane]; break;
     case G_T3: o[0] = tmp[v * 64 + lane]; o[1] = tmp[(v + 1) * 64 + lane]; o[2] = tmp[(v + 2) * 64 + lane]; break;
     case G_NUM: o[0] = v; break;
-    case G_CHAL: o[0] = P.chal[v * 3]; o[1] = P.chal[v * 3 + 1]; o[2] = P.chal[v * 3 + 2]; break;
-    case G_PUB: o[0] = P.pub[v]; break;
-    case G_ZHINV: o[0] = P.zhinv[r % P.n_zhinv]; break;
+    case G_CHAL: o[0] = cst[v * 3]; o[1] = cst[v * 3 + 1]; o[2] = cst[v * 3 + 2]; break; // LDS copies: see k_chelpers
+    case G_PUB: o[0] = cst[192 + v]; break;
+    case G_ZHINV: o[0] = cst[320 + r % P.n_zhinv]; break;
     case G_ST1: o[0] = pre; break; // fetched with its batch
     case G_ST3: { // three neighbouring staged columns (rare: not worth prefetch registers)
         const u64 *p = mycol + v * RS + lane + shift;
@@ -292,8 +292,11 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
     u64 *tmp = smem;               // [word][lane]
     u64 *tile = smem;              // [RS][65], only while staging
     u64 *pre = smem + tmp_words;   // [2 * BATCH][lane]
+    u64 *cst = pre + 2 * BATCH * 64; // challenges (192 words), public inputs (128), ZhInv (256): broadcast reads instead of
+                                     // a dependent global load inside the instruction loop
+    for (uint32_t i = lane; i < 576; i += 64) cst[i] = P.chal[i]; // the context's scratch holds the three tables back to back
     u64 *mycol = P.scratch + (uint64_t)blockIdx.x * P.staged_cols * RS; // this workgroup's staged columns
-    const __attribute__((address_space(4))) GInstr *cp = (const __attribute__((address_space(4))) GInstr *)prog;
+    const uint32_t *progw = (const uint32_t *)prog; // 8 dwords per instruction
 
     for (uint64_t g = blockIdx.x; g < P.n_groups; g += gridDim.x) { // persistent: every workgroup drains its share and exits
         const uint64_t r0 = P.row0 + g * 64;
@@ -327,29 +330,48 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
 
-        // ---- interpret
-        for (uint32_t pc0 = 0; pc0 < P.n_instr; pc0 += BATCH) {
-            // fetch the staged dimension-1 operands of the next BATCH instructions: all loads are issued before any is used
-            u64 v[2 * BATCH];
+        // ---- interpret.  Software pipeline over batches of BATCH instructions: while batch b executes, the staged operands
+        // of batch b + 1 and the instruction words of batch b + 2 are in flight.  A batch's 8 x 32-byte instructions are ONE
+        // coalesced vector load (lane l holds dword l of the batch) and their fields are read back with v_readlane: fetching
+        // them through the scalar cache cost a dependent L2 round trip per field and per instruction (first version of
+        // this loop: 1.3 us per instruction, 7 s for 2^24 rows).
+        const uint32_t n_batches = (P.n_instr + BATCH - 1) / BATCH;
+        auto load_words = [&](uint32_t bi) -> uint32_t { // the program buffer is zero-padded by two batches
+            return progw[(uint64_t)bi * (BATCH * 8) + lane];
+        };
+        auto field = [&](uint32_t iw, uint32_t j, uint32_t f) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)iw, (int)(j * 8 + f)); };
+        auto issue_operands = [&](uint32_t iw, u64 (&v)[2 * BATCH]) {
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
+                const uint32_t op = field(iw, j, 0);
                 v[2 * j] = v[2 * j + 1] = 0;
-                if (pc0 + j < P.n_instr) {
-                    const uint32_t op = cp[pc0 + j].op;
-                    if (((op >> 8) & 15) == G_ST1) v[2 * j] = mycol[cp[pc0 + j].a * RS + lane + cp[pc0 + j].a_shift];
-                    if (((op >> 12) & 15) == G_ST1) v[2 * j + 1] = mycol[cp[pc0 + j].b * RS + lane + cp[pc0 + j].b_shift];
+                if (((op >> 8) & 15) == G_ST1) {
+                    const uint64_t col = ((uint64_t)field(iw, j, 3) << 32) | field(iw, j, 2);
+                    v[2 * j] = mycol[col * RS + lane + field(iw, j, 6)];
+                }
+                if (((op >> 12) & 15) == G_ST1) {
+                    const uint64_t col = ((uint64_t)field(iw, j, 5) << 32) | field(iw, j, 4);
+                    v[2 * j + 1] = mycol[col * RS + lane + field(iw, j, 7)];
                 }
             }
+        };
+        uint32_t iw_cur = load_words(0), iw_nxt = load_words(1);
+        u64 v_cur[2 * BATCH], v_nxt[2 * BATCH];
+        issue_operands(iw_cur, v_cur);
+        for (uint32_t bi = 0; bi < n_batches; bi++) {
+            issue_operands(iw_nxt, v_nxt);                 // batch bi + 1: 16 loads in flight during this batch's arithmetic
+            const uint32_t iw_nn = load_words(bi + 2);     // batch bi + 2's instruction words
 #pragma unroll
-            for (int j = 0; j < 2 * BATCH; j++) pre[j * 64 + lane] = v[j];
-            const uint32_t nb = P.n_instr - pc0 < BATCH ? P.n_instr - pc0 : BATCH;
+            for (int j = 0; j < 2 * BATCH; j++) pre[j * 64 + lane] = v_cur[j];
 #pragma unroll 1
-            for (uint32_t j = 0; j < nb; j++) {
-                const uint32_t op = cp[pc0 + j].op, dst = cp[pc0 + j].dst;
+            for (uint32_t j = 0; j < BATCH; j++) {
+                const uint32_t op = field(iw_cur, j, 0), dst = field(iw_cur, j, 1);
+                const uint64_t av = ((uint64_t)field(iw_cur, j, 3) << 32) | field(iw_cur, j, 2);
+                const uint64_t bv = ((uint64_t)field(iw_cur, j, 5) << 32) | field(iw_cur, j, 4);
                 const uint32_t cls = op & 15, dk = (op >> 4) & 15, ak = (op >> 8) & 15, bk = (op >> 12) & 15;
                 u64 a[3], b[3], o[3];
-                g_operand(ak, cp[pc0 + j].a, cp[pc0 + j].a_shift, P, tmp, mycol, lane, active ? row : r0, pre[(2 * j) * 64 + lane], a);
-                g_operand(bk, cp[pc0 + j].b, cp[pc0 + j].b_shift, P, tmp, mycol, lane, active ? row : r0, pre[(2 * j + 1) * 64 + lane], b);
+                g_operand(ak, av, field(iw_cur, j, 6), P, tmp, cst, mycol, lane, active ? row : r0, pre[(2 * j) * 64 + lane], a);
+                g_operand(bk, bv, field(iw_cur, j, 7), P, tmp, cst, mycol, lane, active ? row : r0, pre[(2 * j + 1) * 64 + lane], b);
                 const bool a3 = ak == G_T3 || ak == G_CHAL || ak == G_ST3, b3 = bk == G_T3 || bk == G_CHAL || bk == G_ST3;
                 switch (cls) {
                 case C_ADD: o[0] = gl::add(a[0], b[0]); o[1] = gl::add(a[1], b[1]); o[2] = gl::add(a[2], b[2]); break;
@@ -372,10 +394,14 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
                     tmp[dst * 64 + lane] = o[0];
                 } else if (dk == K_T3) {
                     tmp[dst * 64 + lane] = o[0]; tmp[(dst + 1) * 64 + lane] = o[1]; tmp[(dst + 2) * 64 + lane] = o[2];
-                } else if (active) {
+                } else if (dk == K_Q && active) { // (the zero padding of the last batch decodes to "no destination")
                     P.q[row * 3] = o[0]; P.q[row * 3 + 1] = o[1]; P.q[row * 3 + 2] = o[2];
                 }
             }
+            iw_cur = iw_nxt;
+            iw_nxt = iw_nn;
+#pragma unroll
+            for (int j = 0; j < 2 * BATCH; j++) v_cur[j] = v_nxt[j];
         }
     }
 }
@@ -723,7 +749,10 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
     if (st == MI_OK && c) {
         std::lock_guard<std::recursive_mutex> lock(c->mu);
         hipError_t e = hipSetDevice(c->device);
-        if (e == hipSuccess) e = hipMalloc((void **)&P->dev, P->gpu.size() * sizeof(chp::GInstr) + 64);
+        // zero padding: the kernel's pipeline reads up to three batches past the end (an all-zero instruction has no destination)
+        const size_t padded = (P->gpu.size() / chp::BATCH + 4) * chp::BATCH * sizeof(chp::GInstr);
+        if (e == hipSuccess) e = hipMalloc((void **)&P->dev, padded);
+        if (e == hipSuccess) e = hipMemsetAsync(P->dev, 0, padded, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(P->dev, P->gpu.data(), P->gpu.size() * sizeof(chp::GInstr), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
@@ -789,7 +818,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     MI_REQUIRE(a->n_const == p->n_const, "number of constant polynomials differs from what the program was compiled for");
     MI_REQUIRE(row0 + nrows <= p->nrows_ext, "rows beyond the extended domain the program was compiled for");
     const uint64_t tmp_words = std::max<uint64_t>(std::max<uint64_t>(p->n_words, c->chelpers_min_words) * 64, (uint64_t)chp::RS * 65);
-    const size_t lds = (size_t)(tmp_words + 2 * chp::BATCH * 64) * 8;
+    const size_t lds = (size_t)(tmp_words + 2 * chp::BATCH * 64 + 576) * 8;
     MI_REQUIRE(lds <= 160 * 1024, "program needs more temporaries per row than the LDS holds");
     // small host tables -> the context's scratch (challenges, publics, ZhInv): 3 * 64 + 128 + 256 words at most
     MI_REQUIRE(p->max_chal <= 64 && p->max_pub <= 128, "more challenges / public inputs than the scratch holds");

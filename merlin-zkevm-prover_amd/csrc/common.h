@@ -130,7 +130,7 @@ int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_
                uint64_t ncols);
 int launch_fill_pow(mi_ctx *ctx, u64 *out, uint64_t count, u64 s0, u64 g, uint64_t stride_exp);
 int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, unsigned cur_bits, unsigned nbits_ext,
-                    const u64 x[3]);
+                    const u64 x[3], uint64_t g0, uint64_t g_count);
 int launch_fri_transpose(mi_ctx *ctx, u64 *aux, const u64 *pol, uint64_t degree, unsigned tbits);
 int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg);
 int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,

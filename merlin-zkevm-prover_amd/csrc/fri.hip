@@ -17,14 +17,14 @@ using gl::E3;
 // equals sum_k (c_k * sinv_g^k) * x^k of polMulAxi + evalPol.
 template <int LOG_NX>
 __global__ __launch_bounds__(64) void k_fri_fold(u64 *__restrict__ out, const u64 *__restrict__ pol, uint32_t cur_bits,
-                                                 u64 sinv0, u64 wi, E3 x, u64 nx_inv)
+                                                 u64 sinv0, u64 wi, E3 x, u64 nx_inv, uint64_t g0, uint64_t g_end)
 {
     constexpr int NX = 1 << LOG_NX;
     extern __shared__ __attribute__((aligned(16))) u64 smem[]; // [NX][3][64]
     const uint32_t lane = threadIdx.x;
-    const uint64_t g = (uint64_t)blockIdx.x * 64 + lane;
+    const uint64_t g = g0 + (uint64_t)blockIdx.x * 64 + lane; // outputs [g0, g_end): a rank's share when the fold is sharded
     const uint64_t pol2n = 1ull << cur_bits;
-    if (g >= pol2n) return;
+    if (g >= g_end) return;
 #pragma unroll 1
     for (int d = 0; d < 3; d++) {
         u64 v[NX];
@@ -54,16 +54,18 @@ __global__ __launch_bounds__(256) void k_copy_canon_flat(u64 *dst, const u64 *sr
 }
 
 int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, unsigned cur_bits, unsigned nbits_ext,
-                    const u64 x[3])
+                    const u64 x[3], uint64_t g0, uint64_t g_count)
 {
     MI_REQUIRE(prev_bits >= cur_bits && nbits_ext >= prev_bits && prev_bits <= 40, "bad FRI step sizes");
     const unsigned lnx = prev_bits - cur_bits;
     MI_REQUIRE(lnx <= 6, "FRI reduction of more than 6 bits per step is not supported");
     const uint64_t pol2n = 1ull << cur_bits;
+    MI_REQUIRE(g0 <= pol2n && g_count <= pol2n - g0, "output range beyond the folded polynomial");
+    if (g_count == 0) return MI_OK;
     if (lnx == 0) { // friProve.cpp:82-85 (step 0 is a copy)
-        MI_REQUIRE_1D_GRID(pol2n * 3);
-        hipLaunchKernelGGL(k_copy_canon_flat, dim3((unsigned)((pol2n * 3 + 255) / 256)), dim3(256), 0, ctx->stream, out, pol,
-                           pol2n * 3);
+        MI_REQUIRE_1D_GRID(g_count * 3);
+        hipLaunchKernelGGL(k_copy_canon_flat, dim3((unsigned)((g_count * 3 + 255) / 256)), dim3(256), 0, ctx->stream, out + g0 * 3,
+                           pol + g0 * 3, g_count * 3);
         MI_HIP_CHECK(hipGetLastError());
         return MI_OK;
     }
@@ -74,7 +76,7 @@ int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, u
     const u64 wi = gl::inv(w);
     const u64 nx_inv = gl::inv(1ull << lnx);
     const E3 xe = {{gl::canon(x[0]), gl::canon(x[1]), gl::canon(x[2])}};
-    const unsigned grid = (unsigned)((pol2n + 63) / 64);
+    const unsigned grid = (unsigned)((g_count + 63) / 64);
     const size_t lds = (size_t)(1u << lnx) * 3 * 64 * 8;
 #define FOLD(Q)                                                                                                         \
     case Q:                                                                                                             \
@@ -82,7 +84,7 @@ int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, u
             MI_HIP_CHECK(hipFuncSetAttribute((const void *)k_fri_fold<Q>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                              (int)lds));                                                                \
         hipLaunchKernelGGL(k_fri_fold<Q>, dim3(grid), dim3(64), lds, ctx->stream, out, pol, (uint32_t)cur_bits, sinv0,  \
-                           wi, xe, nx_inv);                                                                             \
+                           wi, xe, nx_inv, g0, g0 + g_count);                                                           \
         break;
     switch (lnx) {
         FOLD(1) FOLD(2) FOLD(3) FOLD(4) FOLD(5) FOLD(6)

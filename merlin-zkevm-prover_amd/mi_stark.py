@@ -50,7 +50,7 @@ EXPORTS = [
     "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
     "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
     "mi_merkle_group_proofs_dev",
-    "mi_fri_fold_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev",
+    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
@@ -222,6 +222,16 @@ class Context:
         x = np.ascontiguousarray(x, dtype=np.uint64)
         _check(lib().mi_fri_fold_dev(self.h, _dp(out), _dp(pol), ctypes.c_uint(prev_bits), ctypes.c_uint(cur_bits),
                                      ctypes.c_uint(nbits_ext), _hp(x)))
+
+    def fri_fold_range(self, out, pol, prev_bits, cur_bits, nbits_ext, x, g0, g_count):
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        _check(lib().mi_fri_fold_range_dev(self.h, _dp(out), _dp(pol), ctypes.c_uint(prev_bits), ctypes.c_uint(cur_bits),
+                                           ctypes.c_uint(nbits_ext), _hp(x), u64(g0), u64(g_count)))
+
+    def merkle_paths(self, paths, nodes, height, idx):
+        """sibling paths only (levels x 4 per query) of the tree in `nodes`"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        _check(lib().mi_merkle_group_proofs_dev(self.h, _dp(paths), _dp(nodes), None, u64(0), u64(height), u64(0), _hp(idx), u64(idx.size)))
 
     def fri_transpose(self, aux, pol, degree, tbits):
         _check(lib().mi_fri_transpose_dev(self.h, _dp(aux), _dp(pol), u64(degree), ctypes.c_uint(tbits)))

@@ -225,3 +225,86 @@ def lde_merkle_sharded(plan: ShardPlan, ops, dist, trace_shard, bufs, always_exc
         return my_root
     dist.all_gather_into_tensor(bufs["roots"][:p.world * 4], my_root.contiguous())
     return phase_top(p, ops, bufs)
+
+
+# ------------------------------------------------------------------ query openings over the row-sharded tree
+def merkle_levels_of(n: int) -> int:
+    return max(n - 1, 0).bit_length()
+
+
+def group_proofs_sharded(plan: ShardPlan, ops, dist, bufs, idx):
+    """MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for a batch of query rows `idx` (host list) of the sharded tree
+    that lde_merkle_sharded built: proof = the row's ncols values, then the sibling of every level, leaves upward.
+
+    The row lives on ONE rank (rows_per_rank consecutive rows each) as column windows (plan.row_windows()); that rank
+    gathers the row's values out of its windows and the siblings of the lower log2(rows_per_rank) levels out of its
+    subtree; the top log2(world) levels come from the G subtree roots every rank holds (bufs['roots']).  Every rank
+    fills the proofs of the rows it owns into a zero tensor and one all-reduce (sum) of that small tensor leaves the
+    complete set on every rank (nq x (ncols + 4 levels) words: 128 queries of the 665-column tree = 780 KB).
+    ops: gather_rows(windows, rows) -> [len(rows), ncols] tensor; merkle_paths(nodes, height, idx) -> [len(idx), 4 levels];
+    zeros(n) -> tensor on the ops' device."""
+    p = plan
+    lv_sub, lv_top = merkle_levels_of(p.rows_per_rank), merkle_levels_of(p.world)
+    stride = p.ncols + 4 * (lv_sub + lv_top)
+    nq = len(idx)
+    out = ops.zeros(nq * stride).view(nq, stride)
+    mine = [q for q in range(nq) if p.row0 <= int(idx[q]) < p.row0 + p.rows_per_rank]
+    if mine:
+        local = [int(idx[q]) - p.row0 for q in mine]
+        wins = [(bufs[name], off, w, pitch) for (name, off, w, pitch) in p.row_windows()]
+        vals = ops.gather_rows(wins, local)                                   # [len(mine), ncols]
+        sub = ops.merkle_paths(bufs["nodes"], p.rows_per_rank, local)         # [len(mine), 4 * lv_sub]
+        for j, q in enumerate(mine):
+            out[q, :p.ncols] = vals[j]
+            out[q, p.ncols:p.ncols + 4 * lv_sub] = sub[j]
+            if lv_top:
+                out[q, p.ncols + 4 * lv_sub:] = ops.merkle_paths(bufs["roots"], p.world, [p.rank])[0]
+    if p.world > 1:
+        dist.all_reduce(out)     # sum of one rank's values and zeros elsewhere: exact in the int64 container
+    return out
+
+
+# ------------------------------------------------------------------ FRI commit, fold sharded by output index
+def fri_fold_sharded(plan_world: int, rank: int, ops, dist, nxt, pol, prev_bits: int, cur_bits: int, nbits_ext: int, x, min_per_rank: int = 1024):
+    """One fold step (friProve.cpp:44-108).  Output g depends on pol[i * 2^cur + g], i < 2^(prev - cur): the outputs are
+    independent, every rank holds the whole input, so rank r folds the outputs [r * cnt, (r + 1) * cnt) and the slices are
+    all-gathered; small steps (fewer than min_per_rank outputs per rank) are folded whole by every rank --
+    cheaper than a collective and the ranks stay in lockstep by construction."""
+    n_out = 1 << cur_bits
+    if plan_world == 1 or prev_bits == cur_bits or n_out // plan_world < min_per_rank:
+        ops.fri_fold(nxt, pol, prev_bits, cur_bits, nbits_ext, x)
+        return
+    cnt = n_out // plan_world
+    g0 = rank * cnt
+    ops.fri_fold_range(nxt, pol, prev_bits, cur_bits, nbits_ext, x, g0, cnt)
+    mine = nxt[3 * g0:3 * (g0 + cnt)].clone()                  # the gather writes the whole of nxt, my slice included
+    dist.all_gather_into_tensor(nxt[:3 * n_out], mine)
+
+
+def fri_commit_sharded(plan_world: int, rank: int, ops, dist, transcript, pol, steps_bits, nbits_ext: int, min_per_rank: int = 1024):
+    """The fold / commit loop of FRIProve::prove (friProve.cpp:20-134) on every rank in lockstep: per step a challenge from
+    the (replicated, deterministic) transcript, the fold -- sharded by output index while it is large -- then the step
+    tree over the transposed polynomial (friProve.cpp:110-126), whose root goes into the transcript.  The trees after the
+    first fold are tiny (2^19 leaves at zkEVM size) and are built by every rank.  Returns (final polynomial tensor,
+    [(nodes, transposed source, groups, group size)] per step tree, [challenges])."""
+    trees, challenges = [], []
+    pol_bits = nbits_ext
+    cur_pol = pol
+    for si, cur in enumerate(steps_bits):
+        x = transcript.get_field()
+        challenges.append(x)
+        nxt = ops.zeros(3 << cur)
+        fri_fold_sharded(plan_world, rank, ops, dist, nxt, cur_pol, pol_bits, cur, nbits_ext, x, min_per_rank)
+        if si < len(steps_bits) - 1:
+            nb = steps_bits[si + 1]
+            groups, gsz = 1 << nb, (1 << (cur - nb)) * 3
+            src = ops.zeros(3 << cur)
+            ops.fri_transpose(src, nxt, 1 << cur, nb)
+            nodes = ops.zeros((2 * groups - 1) * 4)
+            ops.merkle_build(nodes, src, gsz, groups)
+            transcript.put(ops.to_host(nodes[(2 * groups - 2) * 4:(2 * groups - 1) * 4]))
+            trees.append((nodes, src, groups, gsz))
+        else:
+            transcript.put(ops.to_host(nxt[:3 << cur]))
+        cur_pol, pol_bits = nxt, cur
+    return cur_pol, trees, challenges
