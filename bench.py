@@ -216,17 +216,9 @@ def main():
     assert plan.n_rounds <= 28
     comm = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()} if dist is not None else None
 
-    class Ops:
-        @staticmethod
-        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
-            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+    from shard import device_ops
 
-        @staticmethod
-        def absorb(digests, windows, nrows, first, final, chunk=0):
-            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
-
-        merkle_levels = staticmethod(ctx.merkle_levels)
-
+    class Ops(device_ops(ctx)):
         @staticmethod
         def merkle_build(nodes, src, c, rows):
             # same two launches as mi_merkle_build_dev, split so the dominant kernel can be timed alone
@@ -331,9 +323,10 @@ def main():
             pcie = {"ms_per_step": 1e3 * dt, "value": n * ncols / dt, "unit": "field-elements/s", "steps": args.pcie_steps,
                     "ratio_to_device_resident_step": dt / (elapsed / max(args.steps, 1)),
                     "host_memory": "page-locked (hipHostMalloc), %.1f GB, allocated in %.1f s; D2H fill %.1f GB/s" % (n * ncols * 8 / 1e9, t_b - t_a, n * ncols * 8 / 1e9 / (t_c - t_b)),
-                    "h2d_bytes_per_step": n * ncols * 8, "h2d_floor_ms_at_57GBps": 1e3 * n * ncols * 8 / 57e9,
+                    "h2d_bytes_per_step": n * ncols * 8, "h2d_floor_ms_at_55GBps": 1e3 * n * ncols * 8 / 55e9,
                     "root_matches": [int(v) for v in root_p] == root_host,
-                    "path": "mi_lde_merkle_host: 32-column chunks, H2D of chunk k+1 || LDE of chunk k || leaf absorption of chunk k-1; extension + tree stay in HBM"}
+                    "path": "mi_lde_merkle_host: column chunks of 32, 96, 128 ... columns, H2D of chunk k+1 (two copy streams) || LDE of chunk k || leaf absorption of chunk k-1; extension + tree stay in HBM",
+                    "h2d_note": "the chunks are 2-D copies out of the row-major host trace: 52.7 GB/s at 128 columns against 55 GB/s for whole rows (profiles/r02_pcie_chunk_sweep.json)"}
             del host_trace
         except Exception as e:  # a box without enough page-lockable host memory must not lose the headline number
             pcie = {"error": repr(e)}

@@ -90,14 +90,15 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
     if (c->chelpers_stage) (void)hipFree(c->chelpers_stage);
     if (c->stage) (void)hipFree(c->stage);
-    if (c->copy_stream) {
-        (void)hipStreamSynchronize(c->copy_stream);
-        for (int i = 0; i < 2; i++) {
-            if (c->ev_uploaded[i]) (void)hipEventDestroy(c->ev_uploaded[i]);
-            if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
-        }
-        (void)hipStreamDestroy(c->copy_stream);
+    for (int s = 0; s < 2; s++)
+        if (c->copy_stream[s]) (void)hipStreamSynchronize(c->copy_stream[s]);
+    for (int i = 0; i < 2; i++) {
+        for (int s = 0; s < 2; s++)
+            if (c->ev_uploaded[i][s]) (void)hipEventDestroy(c->ev_uploaded[i][s]);
+        if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
     }
+    for (int s = 0; s < 2; s++)
+        if (c->copy_stream[s]) (void)hipStreamDestroy(c->copy_stream[s]);
     for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -370,12 +371,25 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
     MI_REQUIRE(ext_pitch >= ncols, "pitch smaller than ncols");
     MI_REQUIRE(ncols > 4, "rows of at most 4 columns are not hashed (linear_hash copies them): use mi_lde + mi_merkle_build");
-    if (chunk_cols == 0) chunk_cols = 32;
+    if (chunk_cols == 0) chunk_cols = 128;
     MI_REQUIRE(chunk_cols % 8 == 0, "chunk width must be a multiple of 8 (the sponge absorbs whole blocks per chunk)");
-    if (!c->copy_stream) {
-        MI_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // Chunk schedule.  A chunk is a 2-D copy whose rows are (8 x width) bytes at the trace's row pitch, and the DMA engines
+    // move short rows slower (measured on MI355X, profiles/r02_pcie_chunk_sweep.json: 39.5 GB/s at 32 columns, 49 at 64,
+    // 52.7 at 128, 55 for whole rows) -- but nothing can run before the first chunk is up.  So: a narrow first chunk (32),
+    // a middle one (96), then full-width chunks; the remainder goes last (a short tail after the last upload).
+    std::vector<uint64_t> c0s, cws;
+    for (uint64_t c0 = 0, k = 0; c0 < ncols; k++) {
+        uint64_t w = k == 0 ? 32 : k == 1 ? 96 : chunk_cols;
+        w = std::min(std::min(w, chunk_cols), ncols - c0);
+        c0s.push_back(c0);
+        cws.push_back(w);
+        c0 += w;
+    }
+    const uint64_t n_chunks = c0s.size();
+    if (!c->copy_stream[0]) {
+        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream[s], hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) {
-            MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
+            for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_uploaded[i][s], hipEventDisableTiming));
             MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming));
         }
     }
@@ -393,38 +407,36 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
         }
         c->stage_bytes = stage_bytes;
     }
-    const uint64_t n_chunks = (ncols + chunk_cols - 1) / chunk_cols;
-    // the copy stream must not overtake work already queued on the compute stream that still reads the staging buffers
+    u64 *const st[2] = {c->stage, c->stage + n * chunk_cols};
+    // the copy streams must not overtake work already queued on the compute stream that still reads the staging buffers
     MI_HIP_CHECK(hipEventRecord(c->ev_consumed[0], c->stream));
     MI_HIP_CHECK(hipEventRecord(c->ev_consumed[1], c->stream));
-    auto upload = [&](uint64_t k) -> int {
-        const uint64_t c0 = k * chunk_cols, cw = std::min(chunk_cols, ncols - c0);
-        u64 *st = c->stage + (k & 1) * n * chunk_cols;
-        MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_consumed[k & 1], 0)); // the LDE that read this buffer is done
-        MI_HIP_CHECK(hipMemcpy2DAsync(st, cw * 8, trace_host + c0, ncols * 8, cw * 8, n, hipMemcpyHostToDevice, c->copy_stream));
-        MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k & 1], c->copy_stream));
+    auto upload = [&](uint64_t k) -> int { // the chunk's upper and lower rows on two copy streams (two DMA engines)
+        const uint64_t cw = cws[k], half = n / 2 ? n / 2 : n;
+        for (int s = 0; s < 2; s++) {
+            const uint64_t r0 = s * half, nr = s == 0 ? half : n - half;
+            MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[s], c->ev_consumed[k & 1], 0)); // the LDE that read this buffer is done
+            if (nr)
+                MI_HIP_CHECK(hipMemcpy2DAsync(st[k & 1] + r0 * cw, cw * 8, trace_host + r0 * ncols + c0s[k], ncols * 8, cw * 8, nr,
+                                              hipMemcpyHostToDevice, c->copy_stream[s]));
+            MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k & 1][s], c->copy_stream[s]));
+        }
         return MI_OK;
+    };
+    auto absorb = [&](uint64_t k) -> int {
+        const u64 *base = (const u64 *)ext + c0s[k];
+        const uint64_t pitch = ext_pitch, width = cws[k];
+        return launch_linear_hash_absorb(c, (u64 *)nodes, 1, &base, &pitch, &width, n_ext, k == 0, k + 1 == n_chunks);
     };
     MI_TRY(upload(0));
     for (uint64_t k = 0; k < n_chunks; k++) {
-        const uint64_t c0 = k * chunk_cols, cw = std::min(chunk_cols, ncols - c0);
-        MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k & 1], 0));
-        MI_TRY(launch_lde(c, (u64 *)ext + c0, ext_pitch, c->stage + (k & 1) * n * chunk_cols, cw, n_ext, n, cw));
+        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k & 1][s], 0));
+        MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k & 1], cws[k], n_ext, n, cws[k]));
         MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k & 1], c->stream));
-        if (k + 1 < n_chunks) MI_TRY(upload(k + 1)); // queued behind the LDE of chunk k-1 (its buffer), beside the LDE of chunk k
-        if (k >= 1) { // absorb the previous chunk while this one's successor uploads
-            const uint64_t p0 = (k - 1) * chunk_cols;
-            const u64 *base = (const u64 *)ext + p0;
-            const uint64_t pitch = ext_pitch, width = chunk_cols;
-            MI_TRY(launch_linear_hash_absorb(c, (u64 *)nodes, 1, &base, &pitch, &width, n_ext, k == 1, false));
-        }
+        if (k >= 1) MI_TRY(absorb(k - 1));          // enqueued before the (possibly host-blocking) upload call below
+        if (k + 1 < n_chunks) MI_TRY(upload(k + 1)); // runs beside the LDE of chunk k and the absorption of chunk k-1
     }
-    {
-        const uint64_t p0 = (n_chunks - 1) * chunk_cols;
-        const u64 *base = (const u64 *)ext + p0;
-        const uint64_t pitch = ext_pitch, width = ncols - p0;
-        MI_TRY(launch_linear_hash_absorb(c, (u64 *)nodes, 1, &base, &pitch, &width, n_ext, n_chunks == 1, true));
-    }
+    MI_TRY(absorb(n_chunks - 1));
     return launch_merkle_levels(c, (u64 *)nodes, n_ext);
 }
 

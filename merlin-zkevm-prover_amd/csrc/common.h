@@ -91,10 +91,10 @@ struct mi_ctx {
     bool poseidon_constants_uploaded = false; // c_rc / c_sparse on this context's device
     u64 *chelpers_scratch = nullptr; // challenges / public inputs / ZhInv of the running constraint-evaluator program
     // mi_lde_merkle_host: upload stream, two staging buffers [n x chunk] and their hand-over events
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream[2] = {};
     u64 *stage = nullptr;
     uint64_t stage_bytes = 0;
-    hipEvent_t ev_uploaded[2] = {}, ev_consumed[2] = {};
+    hipEvent_t ev_uploaded[2][2] = {}, ev_consumed[2] = {}; // [staging buffer][copy stream], [staging buffer]
     u64 *chelpers_stage = nullptr;   // constraint evaluators: per-workgroup transposed operand staging
     uint64_t chelpers_stage_bytes = 0;
     uint64_t chelpers_min_words = 0; // benchmarking: LDS words per row to allocate at least (occupancy of a bigger program)

@@ -308,3 +308,45 @@ def fri_commit_sharded(plan_world: int, rank: int, ops, dist, transcript, pol, s
             transcript.put(ops.to_host(nxt[:3 << cur]))
         cur_pol, pol_bits = nxt, cur
     return cur_pol, trees, challenges
+
+
+# ------------------------------------------------------------------ the orchestration's compute steps on the HIP library
+def device_ops(ctx):
+    """`ops` for lde_merkle_sharded / group_proofs_sharded / fri_commit_sharded over an mi_stark.Context (torch int64
+    tensors as u64 containers, work enqueued on torch's current stream)."""
+    import numpy as np
+    import torch
+
+    class Ops:
+        @staticmethod
+        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
+            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
+
+        @staticmethod
+        def absorb(digests, windows, nrows, first, final, chunk=0):
+            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
+
+        merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
+        merkle_levels = staticmethod(ctx.merkle_levels)
+        zeros = staticmethod(ctx.zeros)
+        to_host = staticmethod(ctx.to_host)
+        fri_fold = staticmethod(ctx.fri_fold)
+        fri_fold_range = staticmethod(ctx.fri_fold_range)
+        fri_transpose = staticmethod(ctx.fri_transpose)
+
+        @staticmethod
+        def gather_rows(windows, rows):
+            """rows of the row-sharded extended trace out of its column windows (device-side strided gathers: plumbing)"""
+            r = torch.tensor(rows, dtype=torch.int64, device=ctx.device)
+            parts = [torch.as_strided(t, (int(r.numel()) and (t.numel() - off - w) // pitch + 1, w), (pitch, 1), off)[r] for (t, off, w, pitch) in windows]
+            return torch.cat(parts, dim=1)
+
+        @staticmethod
+        def merkle_paths(nodes, height, idx):
+            lv = merkle_levels_of(height)
+            out = ctx.zeros(max(len(idx) * 4 * lv, 1))
+            if lv:
+                ctx.merkle_paths(out, nodes, height, np.asarray(idx, dtype=np.uint64))
+            return out[:len(idx) * 4 * lv].view(len(idx), 4 * lv)
+
+    return Ops

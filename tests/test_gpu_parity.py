@@ -643,19 +643,8 @@ def test_genproof_shaped_flow_small():
 
 
 def _device_ops(ctx):
-    class Ops:
-        @staticmethod
-        def lde(out, inp, ne, nn, c, out_pitch=None, in_pitch=None, out_off=0, in_off=0, chunk=0):
-            ctx.lde(out, inp, ne, nn, c, out_pitch=out_pitch, in_pitch=in_pitch, out_off=out_off, in_off=in_off)
-
-        @staticmethod
-        def absorb(digests, windows, nrows, first, final, chunk=0):
-            ctx.linear_hash_absorb(digests, windows, nrows, first, final)
-
-        merkle_build = staticmethod(lambda nodes, src, c, rows: ctx.merkle_build(nodes, src, c, rows))
-        merkle_levels = staticmethod(ctx.merkle_levels)
-
-    return Ops
+    from shard import device_ops
+    return device_ops(ctx)
 
 
 @pytest.mark.parametrize("world,ncols,tile", [(2, 37, 8), (4, 150, 32), (8, 665, 32), (4, 70, 8)])
@@ -710,6 +699,19 @@ def test_sharded_path_emulated_on_one_gpu(ctx, world, ncols, tile):
             bufs[p.rank]["roots"][4 * r:4 * r + 4] = roots[r]
         got = phase_top(p, Ops, bufs[p.rank])
         assert np.array_equal(ctx.to_host(got), want_root), p.rank
+    # query openings over the row-sharded tree: each emulated rank contributes the rows it owns, the all-reduce is their sum
+    from shard import group_proofs_sharded
+
+    class NoComm:
+        @staticmethod
+        def all_reduce(t):
+            pass
+    idx = sorted({0, 1, n_ext - 1, n_ext // 2, plans[0].rows_per_rank - 1, plans[0].rows_per_rank % n_ext, 777 % n_ext})
+    total = sum(group_proofs_sharded(p, Ops, NoComm, bufs[p.rank], idx) for p in plans)
+    levels = 11
+    want = ctx.empty(len(idx) * (ncols + 4 * levels))
+    ctx.merkle_group_proofs(want, nodes1, ext1, n_ext, ncols, np.array(idx, dtype=np.uint64))
+    assert torch.equal(total.reshape(-1), want)
 
 
 def test_pipelined_path_with_real_rccl_calls_on_one_rank(ctx):
@@ -738,9 +740,33 @@ def test_pipelined_path_with_real_rccl_calls_on_one_rank(ctx):
         for _ in range(2):
             root = lde_merkle_sharded(plan, _device_ops(ctx), dist, trace, bufs, always_exchange=True)
             torch.cuda.synchronize()
-        want = glo.merkletree(glo.extend_pol(ctx.to_host(trace).reshape(n, ncols), n_ext, n, ncols), ncols, n_ext)
+        want_ext = glo.extend_pol(ctx.to_host(trace).reshape(n, ncols), n_ext, n, ncols)
+        want = glo.merkletree(want_ext, ncols, n_ext)
         assert np.array_equal(ctx.to_host(root), want[-4:])
         assert np.array_equal(ctx.to_host(bufs["nodes"]), want)
+        # openings and the FRI commit through the same orchestration and the real collectives (one rank)
+        from shard import group_proofs_sharded, fri_commit_sharded
+        Ops = _device_ops(ctx)
+        idx = [0, 5, n_ext - 1, 4097]
+        pr = ctx.to_host(group_proofs_sharded(plan, Ops, dist, bufs, idx)).reshape(len(idx), -1)
+        for j, i in enumerate(idx):
+            assert np.array_equal(pr[j], glo.merkle_group_proof(want, want_ext, n_ext, ncols, i)), i
+        fb, steps = 13, [13, 9, 6, 3]
+        hpol = glo.splitmix64(0xF00D, 3 << fb)
+        t_dev, t_ref = glo.Transcript(), glo.Transcript()
+        final, trees, _ = fri_commit_sharded(1, 0, Ops, dist, t_dev, ctx.to_device(hpol), steps, fb)
+        cur, bits = hpol, fb
+        for si, cb in enumerate(steps):                                   # the oracle's fold / transpose / tree, same transcript
+            cur = glo.fri_fold(cur, bits, cb, fb, t_ref.get_field()).reshape(-1)
+            if si < len(steps) - 1:
+                nb = steps[si + 1]
+                wn = glo.merkletree(glo.fri_transpose(cur, 1 << cb, nb), (1 << (cb - nb)) * 3, 1 << nb)
+                assert np.array_equal(ctx.to_host(trees[si][0]), wn), si
+                t_ref.put(wn[-4:])
+            else:
+                t_ref.put(cur)
+            bits = cb
+        assert np.array_equal(ctx.to_host(final)[:cur.size], cur) and t_dev.get_fields1() == t_ref.get_fields1()
         t = torch.arange(8, dtype=torch.int64, device="cuda")        # and one real collective on the same stream
         o = torch.zeros(8, dtype=torch.int64, device="cuda")
         dist.all_gather_into_tensor(o, t)

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import glo
-from shard import ShardPlan, lde_merkle_sharded
+from shard import ShardPlan, lde_merkle_sharded, group_proofs_sharded, fri_commit_sharded, merkle_levels_of
 
 
 def test_tile_dealing_and_buffer_layouts():
@@ -104,6 +104,49 @@ class OracleOps:
             n //= 2
 
 
+    # ---- query openings and FRI (stand-ins for mi_merkle_group_proofs_dev / mi_fri_fold*_dev / mi_fri_transpose_dev)
+    @staticmethod
+    def zeros(k):
+        return torch.zeros(k, dtype=torch.int64)
+
+    @staticmethod
+    def to_host(t):
+        return t.numpy().view(np.uint64).copy()
+
+    @staticmethod
+    def gather_rows(windows, rows):
+        out = []
+        for r in rows:
+            out.append(np.concatenate([OracleOps._np(t)[off + r * pitch:off + r * pitch + w] for (t, off, w, pitch) in windows]))
+        return torch.from_numpy(np.stack(out).view(np.int64))
+
+    @staticmethod
+    def merkle_paths(nodes, height, idx):
+        v = OracleOps._np(nodes)
+        lv = merkle_levels_of(height)
+        out = np.zeros((len(idx), 4 * lv), dtype=np.uint64)
+        for j, i in enumerate(idx):
+            off, n = 0, height
+            for l in range(lv):
+                out[j, 4 * l:4 * l + 4] = v[off + ((i >> l) ^ 1) * 4:off + ((i >> l) ^ 1) * 4 + 4]
+                off += n * 4
+                n //= 2
+        return torch.from_numpy(out.view(np.int64))
+
+    @staticmethod
+    def fri_fold(nxt, pol, prev_bits, cur_bits, nbits_ext, x):
+        OracleOps._np(nxt)[:3 << cur_bits] = glo.fri_fold(OracleOps._np(pol)[:3 << prev_bits], prev_bits, cur_bits, nbits_ext, x).reshape(-1)
+
+    @staticmethod
+    def fri_fold_range(nxt, pol, prev_bits, cur_bits, nbits_ext, x, g0, cnt):
+        full = glo.fri_fold(OracleOps._np(pol)[:3 << prev_bits], prev_bits, cur_bits, nbits_ext, x).reshape(-1)
+        OracleOps._np(nxt)[3 * g0:3 * (g0 + cnt)] = full[3 * g0:3 * (g0 + cnt)]
+
+    @staticmethod
+    def fri_transpose(src, pol, degree, tbits):
+        OracleOps._np(src)[:3 * degree] = glo.fri_transpose(OracleOps._np(pol)[:3 * degree], degree, tbits)
+
+
 def _worker(rank, world, port, n, ncols, q):
     import shard
     if ncols == 70:
@@ -121,7 +164,17 @@ def _worker(rank, world, port, n, ncols, q):
     bufs = {"ext": z(plan.ext_elems()), "nodes": z((2 * plan.rows_per_rank - 1) * 4), "recv": z(plan.recv_elems()),
             "roots": z((2 * world - 1) * 4)}
     root = lde_merkle_sharded(plan, OracleOps, dist, trace, bufs)
-    q.put((rank, root.numpy().view(np.uint64).copy(), bufs["nodes"].numpy().view(np.uint64)[:plan.rows_per_rank * 4].copy()))
+    # query openings over the row-sharded tree: rows of every rank, first / last rows of shards, a repeated index
+    idx = sorted({0, 1, n_ext - 1, plan.rows_per_rank - 1, plan.rows_per_rank % n_ext, (3 * n_ext) // 4, 5 % n_ext}) + [1]
+    proofs = group_proofs_sharded(plan, OracleOps, dist, bufs, idx).numpy().view(np.uint64).copy()
+    # FRI commit with the first fold sharded by output index (min_per_rank lowered so that the small test sizes shard)
+    fb = 10
+    pol = torch.from_numpy(glo.splitmix64(0xF00D, 3 << fb).view(np.int64).copy())
+    tr = glo.Transcript()
+    tr.put(root.numpy().view(np.uint64))
+    final, trees, chal = fri_commit_sharded(world, rank, OracleOps, dist, tr, pol, [fb, fb - 3, fb - 5, fb - 7], fb, min_per_rank=8)
+    fri = (final.numpy().view(np.uint64)[:3 << (fb - 7)].copy(), [t[0].numpy().view(np.uint64)[-4:].copy() for t in trees], tr.get_fields1())
+    q.put((rank, root.numpy().view(np.uint64).copy(), bufs["nodes"].numpy().view(np.uint64)[:plan.rows_per_rank * 4].copy(), idx, proofs, fri))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -151,9 +204,20 @@ def test_sharded_path_reproduces_single_process_tree(world, ncols):
         p.join(timeout=60)
         assert p.exitcode == 0
     rows = 2 * n // world
-    for rank, root, leaves in res:
+    # single-process FRI commit of the same polynomial with the same transcript
+    fb = 10
+    tr = glo.Transcript()
+    tr.put(nodes[-4:])
+    pol = torch.from_numpy(glo.splitmix64(0xF00D, 3 << fb).view(np.int64).copy())
+    want_final, want_trees, _ = fri_commit_sharded(1, 0, OracleOps, None, tr, pol, [fb, fb - 3, fb - 5, fb - 7], fb)
+    want_fri = (want_final.numpy().view(np.uint64)[:3 << (fb - 7)], [t[0].numpy().view(np.uint64)[-4:] for t in want_trees], tr.get_fields1())
+    for rank, root, leaves, idx, proofs, fri in res:
         assert np.array_equal(root, nodes[-4:]), rank                       # every rank ends with the global root
         assert np.array_equal(leaves, nodes[rank * rows * 4:(rank + 1) * rows * 4])   # and owns its slice of level 0
+        for j, i in enumerate(idx):                                         # every rank holds every opening = the single-process one
+            assert np.array_equal(proofs[j], glo.merkle_group_proof(nodes, ext, 2 * n, ncols, i)), (rank, i)
+            assert glo.merkle_verify(nodes[-4:], proofs[j][:ncols], proofs[j][ncols:], i)
+        assert np.array_equal(fri[0], want_fri[0]) and all(np.array_equal(a, b) for a, b in zip(fri[1], want_fri[1])) and fri[2] == want_fri[2], rank
 
 
 def test_world_one_pipelined_path_without_peers():
