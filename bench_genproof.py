@@ -14,7 +14,7 @@ zkEVM shape, in the reference's order and with its host/device synchronisation p
 The step42ns PROGRAM is synthetic too -- the reference's generated tables are reference source and do not travel --
 but of the real one's size and shape: as many field operations per row (17 986 after copy forwarding), every opcode,
 reading the three committed sections at their zkEVM widths and a 360-column constant section, at the real program's LDS
-footprint (96 words per row: mi_set_chelpers_min_words).  The stage-2/3 witness columns and f_2ns that the other chelpers
+footprint (24 KB of LDS per workgroup: mi_set_chelpers_min_words).  The stage-2/3 witness columns and f_2ns that the other chelpers
 steps would produce are still synthetic fills (their cost is NOT included).  Prints one JSON line: wall time of the device phases, per-phase milliseconds
 named after the reference's timers, and a few size-independent checks (Merkle paths verify against the roots,
 FRI fold relation holds on the opened groups).
@@ -158,7 +158,7 @@ def main():
     c_ops, c_args = cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8,
                                           passes=max(1, int(round(args.chelpers_field_ops / per_pass))))
     prog = mi_stark.ChelpersProgram(ctx, c_ops, c_args, sections=[(o, w, NE) for (o, w) in secs], n_const=args.n_const, nrows_ext=NE)
-    ctx.set_chelpers_min_words(96)
+    ctx.set_chelpers_min_words(48)      # LDS footprint of the zkEVM program after live-range splitting (24 KB per workgroup)
     const_2ns = ctx.empty(NE * args.n_const)
     ctx.fill_synthetic(const_2ns, NE * args.n_const, 0x5EED0106)
     x_2ns_c = ctx.empty(NE)
@@ -346,7 +346,7 @@ def main():
         "field_elements_per_s_lde_merkle_fri": N * total_cols / sum(phases.values()) * 1e3,
         "phase_ms": phases, "device_phase_ms_total": sum(phases.values()), "checks": checks,
         "chelpers_step42ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers_stats,
-                              "lds_words_per_row": 96, "rows": NE, "ms": phases.get("STARK_STEP_4_CALCULATE_EXPS_2NS")},
+                              "lds_words_per_row": 48, "rows": NE, "ms": phases.get("STARK_STEP_4_CALCULATE_EXPS_2NS")},
     }
     print(json.dumps(out))
     ctx.close()

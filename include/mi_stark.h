@@ -198,9 +198,11 @@ int mi_chelpers_compile(mi_ctx *ctx, mi_chelpers_prog **out, int step, const uin
                         const uint64_t *args, uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections,
                         uint64_t n_const, uint64_t nrows_ext);
 void mi_chelpers_free(mi_ctx *ctx, mi_chelpers_prog *prog);
-/* out[0..8) = opcodes in, field operations decoded, after copy forwarding, after dead-code removal (= instructions run per
- * row), live 64-bit words per row as generated, after the reschedule, base temps allocated, extension temps allocated */
-int mi_chelpers_stats(const mi_chelpers_prog *prog, uint64_t out[8]);
+/* out[0..8) = opcodes in, field operations decoded, after copy forwarding, after dead-code removal, live 64-bit words per
+ * row as generated, after the reschedule, base temps, extension temps (host form); out[8..16) = device instructions per row,
+ * base / extension temporaries kept in LDS, base temporaries spilled to HBM, temporary reads per row and how many of them
+ * from the spill, LDS bytes per workgroup (without the constant tables), staged columns (0 when compiled without a ctx) */
+int mi_chelpers_stats(const mi_chelpers_prog *prog, uint64_t out[16]);
 /* Benchmarking knob: allocate at least `words` 64-bit LDS words of temporaries per row whatever the program needs (0 = off),
  * so that a synthetic program runs at the occupancy of a larger one (the zkEVM step42ns program needs 96: 3 workgroups
  * per CU).  Results are unaffected. */

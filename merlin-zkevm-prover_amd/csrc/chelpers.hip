@@ -132,27 +132,37 @@ struct RunArgs { // host debug executor: operands read in place
     uint64_t n_const, x_stride, n_zhinv, row0, row_end;
 };
 
-// ---- device form: 32-byte instructions whose polynomial operands name STAGED columns
-enum GKind : uint32_t { G_NONE = 0, G_T1, G_T3, G_NUM, G_CHAL, G_PUB, G_ZHINV, G_ST1, G_ST3 };
+// ---- device form.  Every operand of an instruction is, by the time it executes, up to three 64-bit words in LDS:
+//   a hot temporary ([word][lane]), a prefetch slot ([slot][lane]: a staged polynomial value, an immediate, a cold
+//   temporary or 1/Z_H, put there one batch ahead), a challenge / public input (one word for all lanes), or the all-zero
+//   word that pads a base-field operand to an extension element.  So the executing loop has no operand-kind branches: it
+//   reads addresses.  An LDS address field is a byte offset with bit 31 = "add 8 x lane".
+enum GCls : uint32_t { G_ADD1 = 0, G_ADD3, G_SUB1, G_SUB3, G_MUL11, G_MUL13, G_MUL31, G_MUL33, G_COPY1, G_COPY3 };
+enum GDst : uint32_t { D_NONE = 0, D_HOT, D_COLD, D_Q };
+enum GPre : uint32_t { P_NONE = 0, P_STAGED, P_IMM, P_ZHINV };
 struct GInstr {
-    uint32_t op;  // bits 0-3 class, 4-7 dst kind (K_T1 / K_T3 / K_Q), 8-11 GKind of a, 12-15 GKind of b
-    uint32_t dst; // LDS word of the destination temp
-    uint64_t a, b;            // temp word | number | challenge / public index | staged column
-    uint32_t a_shift, b_shift; // row shift of a staged operand
+    uint32_t op;      // bits 0-3 GCls, 4-5 GDst, 6 "also write pad[0] of the spill", 8-10 GPre of a, 12-14 GPre of b
+    uint32_t dst;     // D_HOT: LDS byte offset (lane-indexed, 1 or 3 consecutive words); D_COLD: spill word
+    uint32_t a[3], b[3]; // LDS address fields of the operands' words
+    uint64_t a_imm, b_imm; // P_STAGED: element index into the workgroup's scratch (staged column or spilled temporary); P_IMM: the value
+    uint32_t pad[4];
 };
-static_assert(sizeof(GInstr) == 32, "device instruction must be 32 bytes");
+static_assert(sizeof(GInstr) == 64, "device instruction must be 64 bytes");
+static constexpr uint32_t LANE_FLAG = 0x80000000u;
 
 static constexpr int MAX_SECTIONS = 8;
 static constexpr uint32_t HALO = 8;             // rows staged beyond the group's 64 (largest row shift a program may use)
 static constexpr uint32_t RS = 64 + HALO;       // rows per staged column
-static constexpr int BATCH = 8;                 // instructions whose staged operands are fetched together
+static constexpr uint32_t TILE_ROWS = 24;       // rows transposed per pass of the staging tile (RS = 3 passes)
+static constexpr int BATCH = 8;                 // instructions whose prefetch slots are filled together
 struct GSection { const u64 *ptr; uint64_t pitch, nrows; uint32_t ncols, col0; };
 struct GArgs {
     GSection sec[MAX_SECTIONS];
-    uint32_t n_sections, n_instr, n_words, pad;
-    const u64 *zhinv, *chal, *pub;
-    u64 *q, *scratch;           // scratch: per resident workgroup, [staged column][RS rows]
-    uint64_t n_zhinv, row0, row_end, n_groups, staged_cols;
+    uint32_t n_sections, n_instr;
+    uint32_t tile_off, pre_off, cst_off, cst_words, zh_off, lds_bytes; // LDS layout (bytes / words), see build_staged
+    const u64 *consts;          // device copy of [challenges | public inputs | ZhInv] = the cst region
+    u64 *q, *scratch;           // scratch: per resident workgroup, [staged column][RS rows] then [cold word][64 lanes]
+    uint64_t n_zhinv, row0, row_end, n_groups, staged_cols, wg_stride;
 };
 
 // ---- host-side intermediate form
@@ -169,6 +179,9 @@ struct mi_chelpers_prog {
     std::vector<HostSection> sections; // what the kernel stages per group of rows, in staged-column order
     uint64_t staged_cols = 0;
     uint64_t n_const = 0, nrows_ext = 0;
+    // LDS layout of the kernel (bytes) and the cold spill, see build_staged
+    uint32_t hot_t1 = 0, hot_t3 = 0, cold_words = 0, tile_off = 0, pre_off = 0, cst_off = 0, lds_fixed = 0;
+    uint64_t cold_reads = 0, temp_reads = 0;
     uint64_t n_words = 0;          // LDS words per row
     uint64_t stats[8] = {0};       // ops in, micro-ops, after copy forwarding, scheduled, live words before, after, t1 slots, t3 slots
     uint64_t max_chal = 0, max_pub = 0;
@@ -261,42 +274,24 @@ struct HostTmp {
     void set(uint64_t w, u64 v) { base[w] = v; }
 };
 
-// ---- the kernel.  LDS: [ temporaries: n_words x 64 | (aliased during staging) transpose tile RS x 65 ] [ prefetched
-// operands: 2 BATCH x 64 ] [ challenges, public inputs, ZhInv: 576 ]
-__device__ __forceinline__ void g_operand(uint32_t kind, uint64_t v, uint32_t shift, const GArgs &P, const u64 *tmp, const u64 *cst,
-                                          const u64 *mycol, uint32_t lane, uint64_t r, u64 pre, u64 (&o)[3])
+// ---- the kernel
+__device__ __forceinline__ u64 lds_word(const char *lds, uint32_t field, uint32_t lane8)
 {
-    o[1] = o[2] = 0;
-    switch (kind) {
-    case G_T1: o[0] = tmp[v * 64 + lane]; break;
-    case G_T3: o[0] = tmp[v * 64 + lane]; o[1] = tmp[(v + 1) * 64 + lane]; o[2] = tmp[(v + 2) * 64 + lane]; break;
-    case G_NUM: o[0] = v; break;
-    case G_CHAL: o[0] = cst[v * 3]; o[1] = cst[v * 3 + 1]; o[2] = cst[v * 3 + 2]; break; // LDS copies: see k_chelpers
-    case G_PUB: o[0] = cst[192 + v]; break;
-    case G_ZHINV: o[0] = cst[320 + r % P.n_zhinv]; break;
-    case G_ST1: o[0] = pre; break; // fetched with its batch
-    case G_ST3: { // three neighbouring staged columns (rare: not worth prefetch registers)
-        const u64 *p = mycol + v * RS + lane + shift;
-        o[0] = p[0]; o[1] = p[RS]; o[2] = p[2 * RS];
-        break;
-    }
-    default: o[0] = 0; break;
-    }
+    return *(const u64 *)(lds + (field & ~LANE_FLAG) + ((field & LANE_FLAG) ? lane8 : 0));
 }
 
 __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog, const GArgs P)
 {
-    extern __shared__ __attribute__((aligned(16))) u64 smem[];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t tmp_words = P.n_words * 64 > RS * 65 ? P.n_words * 64 : RS * 65;
-    u64 *tmp = smem;               // [word][lane]
-    u64 *tile = smem;              // [RS][65], only while staging
-    u64 *pre = smem + tmp_words;   // [2 * BATCH][lane]
-    u64 *cst = pre + 2 * BATCH * 64; // challenges (192 words), public inputs (128), ZhInv (256): broadcast reads instead of
-                                     // a dependent global load inside the instruction loop
-    for (uint32_t i = lane; i < 576; i += 64) cst[i] = P.chal[i]; // the context's scratch holds the three tables back to back
-    u64 *mycol = P.scratch + (uint64_t)blockIdx.x * P.staged_cols * RS; // this workgroup's staged columns
-    const uint32_t *progw = (const uint32_t *)prog; // 8 dwords per instruction
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t lane = threadIdx.x, lane8 = lane * 8;
+    u64 *tile = (u64 *)(lds + P.tile_off);   // [TILE_ROWS][65], only while staging (aliases hot temporaries + prefetch slots)
+    u64 *pre = (u64 *)(lds + P.pre_off);     // [2 * BATCH][lane]
+    u64 *cst = (u64 *)(lds + P.cst_off);     // challenges, public inputs, ZhInv: one word for all lanes
+    u64 *mycol = P.scratch + (uint64_t)blockIdx.x * P.wg_stride; // this workgroup's staged columns, then its cold temporaries
+    u64 *mycold = mycol + P.staged_cols * RS;
+    const uint32_t *progw = (const uint32_t *)prog; // 16 dwords per instruction
+    *(u64 *)(lds + lane8) = 0;                      // the zero word
+    for (uint32_t i = lane; i < P.cst_words; i += 64) cst[i] = P.consts[i];
 
     for (uint64_t g = blockIdx.x; g < P.n_groups; g += gridDim.x) { // persistent: every workgroup drains its share and exits
         const uint64_t r0 = P.row0 + g * 64;
@@ -307,94 +302,111 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
             const GSection S = P.sec[si];
             for (uint32_t c0 = 0; c0 < S.ncols; c0 += 64) {
                 const uint32_t c = c0 + lane;
-                __syncthreads(); // the tile (and, first time round, the temporaries it aliases) is free
-                if (c < S.ncols) {
-#pragma unroll 8
-                    for (uint32_t rr = 0; rr < RS; rr++) { // a row's 64 columns: one contiguous 512-byte read per wave
-                        uint64_t rw = r0 + rr;
-                        rw = rw >= S.nrows ? rw % S.nrows : rw;
-                        tile[rr * 65 + lane] = gl::canon(S.ptr[rw * S.pitch + c]);
-                    }
-                }
-                __syncthreads();
                 const uint32_t ncol = S.ncols - c0 < 64 ? S.ncols - c0 : 64;
-                for (uint32_t cc = 0; cc < ncol; cc++) { // a column's RS rows: one contiguous run per wave
-                    u64 *dst = mycol + (uint64_t)(S.col0 + c0 + cc) * RS;
-                    dst[lane] = tile[lane * 65 + cc];
-                    if (lane < HALO) dst[64 + lane] = tile[(64 + lane) * 65 + cc];
+                for (uint32_t rb = 0; rb < RS; rb += TILE_ROWS) {
+                    __syncthreads(); // the tile (and, first time round, the temporaries it aliases) is free
+                    if (c < S.ncols) {
+#pragma unroll 8
+                        for (uint32_t rr = 0; rr < TILE_ROWS; rr++) { // a row's 64 columns: one contiguous 512-byte read per wave
+                            uint64_t rw = r0 + rb + rr;
+                            while (rw >= S.nrows) rw -= S.nrows; // at most the halo past the end (a division here is 60 scalar instructions)
+                            tile[rr * 65 + lane] = gl::canon(S.ptr[rw * S.pitch + c]);
+                        }
+                    }
+                    __syncthreads();
+                    if (lane < TILE_ROWS)
+                        for (uint32_t cc = 0; cc < ncol; cc++) // a column's 24 rows: a contiguous 192-byte run
+                            mycol[(uint64_t)(S.col0 + c0 + cc) * RS + rb + lane] = tile[lane * 65 + cc];
                 }
             }
         }
-        // the wave reads back what it just stored, and its L1 may still hold the previous group's lines of the same scratch
+        // the wave reads back what it just stored: the stores must have left the wave (the reads bypass its L1: agent scope)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
 
-        // ---- interpret.  Software pipeline over batches of BATCH instructions: while batch b executes, the staged operands
-        // of batch b + 1 and the instruction words of batch b + 2 are in flight.  A batch's 8 x 32-byte instructions are ONE
-        // coalesced vector load (lane l holds dword l of the batch) and their fields are read back with v_readlane: fetching
-        // them through the scalar cache cost a dependent L2 round trip per field and per instruction (first version of
-        // this loop: 1.3 us per instruction, 7 s for 2^24 rows).
+        // ---- interpret.  Software pipeline over batches of BATCH instructions: while batch b executes, the prefetch values of
+        // batch b + 1 and the instruction words of batch b + 2 are in flight.  A batch's 8 x 64-byte instructions are two
+        // coalesced vector loads (lane l holds dwords l and 64 + l of the batch) and their fields are read back with v_readlane:
+        // fetching them through the scalar cache cost a dependent L2 round trip per field (an early version of this loop).
         const uint32_t n_batches = (P.n_instr + BATCH - 1) / BATCH;
-        auto load_words = [&](uint32_t bi) -> uint32_t { // the program buffer is zero-padded by two batches
-            return progw[(uint64_t)bi * (BATCH * 8) + lane];
+        const u64 zh_val = cst[P.zh_off + ((active ? row : r0) & (P.n_zhinv - 1))]; // zi.zhInv(i) of this lane's row (table size 2^k)
+        struct Words { uint32_t lo, hi; }; // dwords lane and 64 + lane of a batch: instruction j field f at dword 16 j + f
+        auto load_words = [&](uint32_t bi) -> Words { // the program buffer is zero-padded by three batches
+            const uint32_t *p = progw + (uint64_t)bi * (BATCH * 16);
+            return {p[lane], p[64 + lane]};
         };
-        auto field = [&](uint32_t iw, uint32_t j, uint32_t f) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)iw, (int)(j * 8 + f)); };
-        auto issue_operands = [&](uint32_t iw, u64 (&v)[2 * BATCH]) {
+        auto field = [&](const Words &w, uint32_t j, uint32_t f) -> uint32_t { // j wave-uniform
+            const uint32_t idx = j * 16 + f;
+            return (uint32_t)__builtin_amdgcn_readlane((int)(idx < 64 ? w.lo : w.hi), (int)(idx & 63));
+        };
+        auto issue_prefetch = [&](const Words &w, u64 (&v)[2 * BATCH]) {
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
-                const uint32_t op = field(iw, j, 0);
-                v[2 * j] = v[2 * j + 1] = 0;
-                if (((op >> 8) & 15) == G_ST1) {
-                    const uint64_t col = ((uint64_t)field(iw, j, 3) << 32) | field(iw, j, 2);
-                    v[2 * j] = mycol[col * RS + lane + field(iw, j, 6)];
-                }
-                if (((op >> 12) & 15) == G_ST1) {
-                    const uint64_t col = ((uint64_t)field(iw, j, 5) << 32) | field(iw, j, 4);
-                    v[2 * j + 1] = mycol[col * RS + lane + field(iw, j, 7)];
+                const uint32_t op = (uint32_t)__builtin_amdgcn_readlane((int)(j < 4 ? w.lo : w.hi), (j & 3) * 16);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const uint32_t kind = (op >> (8 + 4 * s2)) & 7;
+                    const int fl = (j & 3) * 16 + 8 + 2 * s2;
+                    const uint64_t imm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(j < 4 ? w.lo : w.hi), fl + 1) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readlane((int)(j < 4 ? w.lo : w.hi), fl);
+                    // P_STAGED and P_COLD are the same load (the spill follows the staged columns in the workgroup's scratch):
+                    // agent scope, because both were written by this wave a moment ago and its L1 may hold older lines
+                    u64 val = kind == P_IMM ? imm : zh_val;
+                    if (kind == P_STAGED) val = __hip_atomic_load(mycol + imm + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[2 * j + s2] = val;
                 }
             }
         };
-        uint32_t iw_cur = load_words(0), iw_nxt = load_words(1);
+        Words iw_cur = load_words(0), iw_nxt = load_words(1);
         u64 v_cur[2 * BATCH], v_nxt[2 * BATCH];
-        issue_operands(iw_cur, v_cur);
+        issue_prefetch(iw_cur, v_cur);
         for (uint32_t bi = 0; bi < n_batches; bi++) {
-            issue_operands(iw_nxt, v_nxt);                 // batch bi + 1: 16 loads in flight during this batch's arithmetic
-            const uint32_t iw_nn = load_words(bi + 2);     // batch bi + 2's instruction words
+            issue_prefetch(iw_nxt, v_nxt);                 // batch bi + 1: 16 loads in flight during this batch's arithmetic
+            const Words iw_nn = load_words(bi + 2);        // batch bi + 2's instruction words
 #pragma unroll
             for (int j = 0; j < 2 * BATCH; j++) pre[j * 64 + lane] = v_cur[j];
 #pragma unroll 1
             for (uint32_t j = 0; j < BATCH; j++) {
                 const uint32_t op = field(iw_cur, j, 0), dst = field(iw_cur, j, 1);
-                const uint64_t av = ((uint64_t)field(iw_cur, j, 3) << 32) | field(iw_cur, j, 2);
-                const uint64_t bv = ((uint64_t)field(iw_cur, j, 5) << 32) | field(iw_cur, j, 4);
-                const uint32_t cls = op & 15, dk = (op >> 4) & 15, ak = (op >> 8) & 15, bk = (op >> 12) & 15;
-                u64 a[3], b[3], o[3];
-                g_operand(ak, av, field(iw_cur, j, 6), P, tmp, cst, mycol, lane, active ? row : r0, pre[(2 * j) * 64 + lane], a);
-                g_operand(bk, bv, field(iw_cur, j, 7), P, tmp, cst, mycol, lane, active ? row : r0, pre[(2 * j + 1) * 64 + lane], b);
-                const bool a3 = ak == G_T3 || ak == G_CHAL || ak == G_ST3, b3 = bk == G_T3 || bk == G_CHAL || bk == G_ST3;
+                const uint32_t cls = op & 15, dk = (op >> 4) & 3;
+                u64 o[3];
+                const u64 a0 = lds_word(lds, field(iw_cur, j, 2), lane8), b0 = lds_word(lds, field(iw_cur, j, 5), lane8);
+                bool three = true;
                 switch (cls) {
-                case C_ADD: o[0] = gl::add(a[0], b[0]); o[1] = gl::add(a[1], b[1]); o[2] = gl::add(a[2], b[2]); break;
-                case C_SUB: o[0] = gl::sub(a[0], b[0]); o[1] = gl::sub(a[1], b[1]); o[2] = gl::sub(a[2], b[2]); break;
-                case C_MUL: case C_STOREQ:
-                    if (a3 && b3) {
-                        const E3 p = gl::e3_mul(E3{{a[0], a[1], a[2]}}, E3{{b[0], b[1], b[2]}});
-                        o[0] = p.v[0]; o[1] = p.v[1]; o[2] = p.v[2];
-                    } else if (a3) {
-                        o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[1], b[0]); o[2] = gl::mul(a[2], b[0]);
-                    } else if (b3) {
-                        o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[0], b[1]); o[2] = gl::mul(a[0], b[2]);
-                    } else {
-                        o[0] = gl::mul(a[0], b[0]); o[1] = o[2] = 0;
-                    }
+                case G_ADD1: o[0] = gl::add(a0, b0); three = false; break;
+                case G_SUB1: o[0] = gl::sub(a0, b0); three = false; break;
+                case G_MUL11: o[0] = gl::mul(a0, b0); three = false; break;
+                case G_COPY1: o[0] = a0; three = false; break;
+                case G_MUL13: { // base times extension
+                    const u64 b1 = lds_word(lds, field(iw_cur, j, 6), lane8), b2 = lds_word(lds, field(iw_cur, j, 7), lane8);
+                    o[0] = gl::mul(a0, b0); o[1] = gl::mul(a0, b1); o[2] = gl::mul(a0, b2);
                     break;
-                default: o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; break;
                 }
-                if (dk == K_T1) {
-                    tmp[dst * 64 + lane] = o[0];
-                } else if (dk == K_T3) {
-                    tmp[dst * 64 + lane] = o[0]; tmp[(dst + 1) * 64 + lane] = o[1]; tmp[(dst + 2) * 64 + lane] = o[2];
-                } else if (dk == K_Q && active) { // (the zero padding of the last batch decodes to "no destination")
+                case G_MUL31: {
+                    const u64 a1 = lds_word(lds, field(iw_cur, j, 3), lane8), a2 = lds_word(lds, field(iw_cur, j, 4), lane8);
+                    o[0] = gl::mul(a0, b0); o[1] = gl::mul(a1, b0); o[2] = gl::mul(a2, b0);
+                    break;
+                }
+                default: {
+                    const u64 a1 = lds_word(lds, field(iw_cur, j, 3), lane8), a2 = lds_word(lds, field(iw_cur, j, 4), lane8);
+                    const u64 b1 = lds_word(lds, field(iw_cur, j, 6), lane8), b2 = lds_word(lds, field(iw_cur, j, 7), lane8);
+                    if (cls == G_ADD3) { o[0] = gl::add(a0, b0); o[1] = gl::add(a1, b1); o[2] = gl::add(a2, b2); }
+                    else if (cls == G_SUB3) { o[0] = gl::sub(a0, b0); o[1] = gl::sub(a1, b1); o[2] = gl::sub(a2, b2); }
+                    else if (cls == G_MUL33) {
+                        const E3 p = gl::e3_mul(E3{{a0, a1, a2}}, E3{{b0, b1, b2}});
+                        o[0] = p.v[0]; o[1] = p.v[1]; o[2] = p.v[2];
+                    } else { o[0] = a0; o[1] = a1; o[2] = a2; } // G_COPY3
+                    break;
+                }
+                }
+                if (dk == D_HOT) {
+                    *(u64 *)(lds + dst + lane8) = o[0];
+                    if (three) { *(u64 *)(lds + dst + 512 + lane8) = o[1]; *(u64 *)(lds + dst + 1024 + lane8) = o[2]; }
+                    if (op & 64) // read again much later: a second home in the spill (word in field 12)
+                        __hip_atomic_store(mycold + (uint64_t)field(iw_cur, j, 12) * 64 + lane, o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (dk == D_COLD) { // a base-field value that lives long and is read rarely: spilled beside the staged columns
+                    __hip_atomic_store(mycold + (uint64_t)dst * 64 + lane, o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (dk == D_Q && active) {
                     P.q[row * 3] = o[0]; P.q[row * 3 + 1] = o[1]; P.q[row * 3 + 2] = o[2];
                 }
             }
@@ -644,9 +656,24 @@ static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
     return MI_OK;
 }
 
-// ---- the kernel's form of the program: every polynomial operand becomes a staged column of one of the sections
-static int build_staged(mi_chelpers_prog *P)
+// ---- the kernel's form of the program.
+//   * every polynomial operand becomes a staged column (+ row shift) of one of the sections; a dimension-3 polynomial operand
+//     is first copied, word by word, into an extension temporary;
+//   * temporaries are re-allocated: extension values and short-lived base values in LDS ("hot"), base values that live long
+//     and are read rarely in a per-workgroup spill in HBM ("cold", fetched through the prefetch slots one batch ahead, so a
+//     cold value's first read must lie more than three batches after its definition);
+//   * every operand is resolved to LDS address fields (see GInstr).
+// LDS layout (bytes): [0,512) the zero word | hot base temps | hot extension temps (3 words each) | prefetch slots | constants.
+static constexpr uint32_t HOT_T1_DEFAULT = 24; // hot base-field words (raised when the program's short-lived values need more)
+static constexpr uint32_t HOT_SPAN = 64;        // a base value read for the last time within this many instructions stays hot
+
+static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
 {
+    struct Val { int dim; int64_t def = -1, first = -1, last = -1; uint32_t nreads = 0; int loc = 0; uint32_t where = 0; }; // loc 1 hot, 2 cold
+    struct GOpd { int kind = 0; int64_t val = -1; uint64_t imm = 0; int dim = 1; uint32_t cst = 0; }; // kind: 0 none, 1 value, 2 staged, 3 imm, 4 challenge, 5 public, 6 zhinv
+    struct GOp { uint32_t cls; int dk; int64_t dval; GOpd a, b; };
+    std::vector<Val> vals;
+    std::vector<GOp> ops;
     auto find = [&](int role, uint64_t off, uint64_t stride, uint64_t width, uint32_t &col) -> const HostSection * {
         for (const HostSection &S : P->sections) {
             if (S.role != role) continue;
@@ -657,59 +684,180 @@ static int build_staged(mi_chelpers_prog *P)
         }
         return nullptr;
     };
-    P->gpu.clear();
-    P->gpu.reserve(P->host.size());
+    std::map<uint64_t, int64_t> cur; // host temp word -> value id (the host program re-uses words)
+    auto new_val = [&](int dim) { vals.push_back(Val{dim}); return (int64_t)vals.size() - 1; };
     for (const DInstr &d : P->host) {
-        GInstr g = {};
-        uint32_t gk[2] = {G_NONE, G_NONE};
+        const uint32_t hcls = d.op & 15, hdk = (d.op >> 4) & 15;
+        GOpd go[2];
         const Opd *os[2] = {&d.a, &d.b};
-        uint64_t *gv[2] = {&g.a, &g.b};
-        uint32_t *gs[2] = {&g.a_shift, &g.b_shift};
         for (int s2 = 0; s2 < 2; s2++) {
             const uint32_t k = (d.op >> (8 + 4 * s2)) & 15;
             const Opd &o = *os[s2];
+            GOpd &g = go[s2];
             uint32_t col = 0;
             const HostSection *S = nullptr;
             switch (k) {
-            case K_T1: gk[s2] = G_T1; *gv[s2] = o.off; break;
-            case K_T3: gk[s2] = G_T3; *gv[s2] = o.off; break;
-            case K_NUM: gk[s2] = G_NUM; *gv[s2] = o.off; break;
-            case K_CHAL: gk[s2] = G_CHAL; *gv[s2] = o.off; break;
-            case K_PUB: gk[s2] = G_PUB; *gv[s2] = o.off; break;
-            case K_ZHINV: gk[s2] = G_ZHINV; break;
-            case K_POL: case K_POLS: case K_POL3: case K_POL3S: {
-                const bool three = k == K_POL3 || k == K_POL3S, shifted = k == K_POLS || k == K_POL3S;
-                S = find(0, o.off, o.stride, three ? 3 : 1, col);
+            case K_T1: case K_T3: {
+                auto it = cur.find(o.off);
+                MI_REQUIRE(it != cur.end(), "internal: temporary without a definition");
+                g.kind = 1; g.val = it->second; g.dim = k == K_T3 ? 3 : 1;
+                break;
+            }
+            case K_NUM: g.kind = 3; g.imm = o.off; break;
+            case K_CHAL: g.kind = 4; g.cst = (uint32_t)o.off; g.dim = 3; break;
+            case K_PUB: g.kind = 5; g.cst = (uint32_t)o.off; break;
+            case K_ZHINV: g.kind = 6; break;
+            case K_POL: case K_POLS: case K_POL3: case K_POL3S: case K_CONST: case K_CONSTS: case K_X: {
+                const bool three = k == K_POL3 || k == K_POL3S, shifted = k == K_POLS || k == K_POL3S || k == K_CONSTS;
+                const int role = (k == K_CONST || k == K_CONSTS) ? 1 : k == K_X ? 2 : 0;
+                S = find(role, o.off, o.stride, three ? 3 : 1, col);
                 if (!S) {
-                    mi_set_error("mi_chelpers_compile: polynomial operand (offset %llu, stride %u) lies in none of the declared sections",
+                    mi_set_error("mi_chelpers_compile: operand (offset %llu, stride %u) lies in none of the declared sections / constant polynomials / x",
                                  (unsigned long long)o.off, o.stride);
                     return MI_ERR_INVALID;
                 }
                 if (shifted) MI_REQUIRE(o.mod == S->nrows && o.shift <= HALO, "shifted-row operand: modulus must be the section's row count, shift at most 8");
-                gk[s2] = three ? G_ST3 : G_ST1;
-                *gv[s2] = col;
-                *gs[s2] = shifted ? o.shift : 0;
+                const uint64_t elem = (uint64_t)col * RS + (shifted ? o.shift : 0);
+                if (!three) { g.kind = 2; g.imm = elem; break; }
+                const int64_t v3 = new_val(3); // three staged columns -> one extension temporary, a word per copy
+                for (int w = 0; w < 3; w++) {
+                    GOp c = {};
+                    c.cls = G_COPY1; c.dk = D_HOT; c.dval = v3;
+                    c.a.kind = 2; c.a.imm = elem + (uint64_t)w * RS;
+                    c.b.kind = 0; c.b.imm = (uint64_t)w; // b.imm: which word of the destination
+                    ops.push_back(c);
+                }
+                g.kind = 1; g.val = v3; g.dim = 3;
                 break;
             }
-            case K_CONST: case K_CONSTS:
-                S = find(1, o.off, 0, 1, col);
-                MI_REQUIRE(S, "constant-polynomial operand beyond the declared number of constant polynomials");
-                if (k == K_CONSTS) MI_REQUIRE(o.mod == S->nrows && o.shift <= HALO, "shifted-row operand: modulus must be the section's row count, shift at most 8");
-                gk[s2] = G_ST1;
-                *gv[s2] = col;
-                *gs[s2] = k == K_CONSTS ? o.shift : 0;
-                break;
-            case K_X:
-                S = find(2, 0, 0, 1, col);
-                MI_REQUIRE(S, "program reads x but no x section was declared");
-                gk[s2] = G_ST1;
-                *gv[s2] = col;
-                break;
             default: break;
             }
         }
-        g.op = (d.op & 0xFF) | (gk[0] << 8) | (gk[1] << 12);
-        g.dst = d.dst;
+        GOp op = {};
+        op.a = go[0]; op.b = go[1];
+        const bool a3 = go[0].dim == 3, b3 = go[1].dim == 3;
+        const int rdim = (hdk == K_T3 || hdk == K_Q) ? 3 : 1;
+        switch (hcls) {
+        case C_ADD: op.cls = rdim == 3 ? G_ADD3 : G_ADD1; break;
+        case C_SUB: op.cls = rdim == 3 ? G_SUB3 : G_SUB1; break;
+        case C_MUL: case C_STOREQ: op.cls = a3 && b3 ? G_MUL33 : a3 ? G_MUL31 : b3 ? G_MUL13 : G_MUL11; break;
+        default: op.cls = rdim == 3 ? G_COPY3 : G_COPY1; break;
+        }
+        if (hdk == K_T1 || hdk == K_T3) {
+            op.dk = D_HOT; // decided below
+            op.dval = new_val(rdim);
+            cur[d.dst] = op.dval;
+            // a T3 destination occupies host words dst .. dst + 2: they belong to this value now
+        } else if (hdk == K_Q) { op.dk = D_Q; op.dval = -1; }
+        ops.push_back(op);
+    }
+    // ---- lifetimes.  A base value read again long after its definition gets a COLD home (written at the definition, read
+    // through the prefetch slots); the reads that follow the definition closely -- closer than the prefetch runs ahead, or
+    // simply soon -- are served from a HOT home that is released after the last of them.
+    struct Life { int64_t def = -1, last = -1, early_last = -1; bool late = false; };
+    std::vector<Life> life(vals.size());
+    for (size_t i = 0; i < ops.size(); i++)
+        if (ops[i].dval >= 0 && life[ops[i].dval].def < 0) life[ops[i].dval].def = (int64_t)i;
+    for (size_t i = 0; i < ops.size(); i++)
+        for (const GOpd *o : {&ops[i].a, &ops[i].b})
+            if (o->kind == 1) {
+                Life &L = life[o->val];
+                L.last = (int64_t)i;
+                if (vals[o->val].dim == 3 || (int64_t)i - L.def <= (int64_t)HOT_SPAN) L.early_last = (int64_t)i;
+                else L.late = true;
+            }
+    // ---- allocation by linear scan over three pools: hot base words, hot extension groups, cold base words
+    std::vector<uint32_t> free1, free3, freec;
+    uint32_t n1 = 0, n3 = 0, nc = 0;
+    std::vector<uint32_t> hot_where(vals.size(), 0), cold_where(vals.size(), 0);
+    std::vector<uint8_t> has_hot(vals.size(), 0), has_cold(vals.size(), 0);
+    std::vector<std::vector<int64_t>> hot_dies(ops.size()), cold_dies(ops.size());
+    for (size_t v = 0; v < vals.size(); v++) {
+        const Life &L = life[v];
+        if (L.def < 0) continue;
+        has_cold[v] = vals[v].dim == 1 && L.late;
+        has_hot[v] = !has_cold[v] || L.early_last >= 0;
+        if (has_hot[v]) hot_dies[has_cold[v] ? L.early_last : (L.last < 0 ? L.def : L.last)].push_back((int64_t)v);
+        if (has_cold[v]) cold_dies[L.last].push_back((int64_t)v);
+    }
+    for (size_t i = 0; i < ops.size(); i++) {
+        // homes whose last read is this instruction are free for its destination (operands are read before the result is written)
+        for (int64_t v : hot_dies[i]) if (life[v].def < (int64_t)i) (vals[v].dim == 3 ? free3 : free1).push_back(hot_where[v]);
+        for (int64_t v : cold_dies[i]) freec.push_back(cold_where[v]);
+        const int64_t dv = ops[i].dval;
+        if (dv < 0 || life[dv].def != (int64_t)i) continue;
+        if (has_hot[dv]) {
+            std::vector<uint32_t> &fr = vals[dv].dim == 3 ? free3 : free1;
+            uint32_t &cnt = vals[dv].dim == 3 ? n3 : n1;
+            if (fr.empty()) hot_where[dv] = cnt++; else { hot_where[dv] = fr.back(); fr.pop_back(); }
+            if (life[dv].last < 0) fr.push_back(hot_where[dv]); // never read
+        }
+        if (has_cold[dv]) {
+            if (freec.empty()) cold_where[dv] = nc++; else { cold_where[dv] = freec.back(); freec.pop_back(); }
+        }
+    }
+    // ---- layout
+    const uint32_t hot1_off = 512, hot3_off = hot1_off + 512 * n1, hot_end = hot3_off + 3 * 512 * n3;
+    const uint32_t tile_bytes = TILE_ROWS * 65 * 8;
+    const uint32_t pre_off = hot_end, pre_end = pre_off + 2 * BATCH * 512;
+    const uint32_t region_end = std::max(pre_end, hot1_off + tile_bytes); // the staging tile aliases [512, ...)
+    const uint32_t cst_off = region_end;
+    const uint32_t chal_words = (uint32_t)P->max_chal * 3, pub_words = (uint32_t)P->max_pub;
+    P->hot_t1 = n1; P->hot_t3 = n3; P->cold_words = nc;
+    (void)HOT_T1_DEFAULT;
+    P->tile_off = hot1_off; P->pre_off = pre_off; P->cst_off = cst_off;
+    P->lds_fixed = cst_off + (chal_words + pub_words + (uint32_t)n_zhinv_max) * 8;
+    // ---- emit
+    P->gpu.clear();
+    P->gpu.reserve(ops.size());
+    P->cold_reads = P->temp_reads = 0;
+    const uint32_t Z = 0; // the zero word, same for all lanes
+    for (size_t i = 0; i < ops.size(); i++) {
+        const GOp &op = ops[i];
+        GInstr g = {};
+        uint32_t pk[2] = {P_NONE, P_NONE};
+        uint32_t *fa[2] = {g.a, g.b};
+        uint64_t *im[2] = {&g.a_imm, &g.b_imm};
+        const GOpd *os[2] = {&op.a, &op.b};
+        const uint32_t slot_in_batch = (uint32_t)(i % BATCH);
+        for (int s2 = 0; s2 < 2; s2++) {
+            const GOpd &o = *os[s2];
+            uint32_t *f = fa[s2];
+            const uint32_t pre_field = (pre_off + (2 * slot_in_batch + s2) * 512) | LANE_FLAG;
+            f[0] = f[1] = f[2] = Z;
+            switch (o.kind) {
+            case 1: {
+                const Val &v = vals[o.val];
+                P->temp_reads++;
+                if (has_cold[o.val] && (int64_t)i - life[o.val].def > (int64_t)HOT_SPAN) {
+                    // a load like a staged column: the spill follows the staged columns in the workgroup's scratch
+                    pk[s2] = P_STAGED; *im[s2] = P->staged_cols * RS + (uint64_t)cold_where[o.val] * 64; f[0] = pre_field; P->cold_reads++;
+                    break;
+                }
+                const uint32_t base = v.dim == 3 ? hot3_off + 3 * 512 * hot_where[o.val] : hot1_off + 512 * hot_where[o.val];
+                f[0] = base | LANE_FLAG;
+                if (v.dim == 3) { f[1] = (base + 512) | LANE_FLAG; f[2] = (base + 1024) | LANE_FLAG; }
+                break;
+            }
+            case 2: pk[s2] = P_STAGED; *im[s2] = o.imm; f[0] = pre_field; break;
+            case 3: pk[s2] = P_IMM; *im[s2] = o.imm; f[0] = pre_field; break;
+            case 4: f[0] = cst_off + (o.cst * 3) * 8; f[1] = f[0] + 8; f[2] = f[0] + 16; break;
+            case 5: f[0] = cst_off + (chal_words + o.cst) * 8; break;
+            case 6: pk[s2] = P_ZHINV; f[0] = pre_field; break;
+            default: break;
+            }
+        }
+        uint32_t dk = (uint32_t)op.dk, also_cold = 0;
+        if (op.dval >= 0) {
+            const Val &v = vals[op.dval];
+            if (has_hot[op.dval]) {
+                dk = D_HOT;
+                g.dst = v.dim == 3 ? hot3_off + 3 * 512 * hot_where[op.dval] : hot1_off + 512 * hot_where[op.dval];
+                if (op.cls == G_COPY1 && v.dim == 3) g.dst += 512 * (uint32_t)op.b.imm; // one word of an extension temporary
+                if (has_cold[op.dval]) { also_cold = 1; g.pad[0] = cold_where[op.dval]; }
+            } else { dk = D_COLD; g.dst = cold_where[op.dval]; }
+        }
+        g.op = op.cls | (dk << 4) | (also_cold << 6) | (pk[0] << 8) | (pk[1] << 12);
         P->gpu.push_back(g);
     }
     return MI_OK;
@@ -745,7 +893,8 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
     if (uses_x) { P->sections.push_back({0, 1, nrows_ext, (uint32_t)col0, 2}); col0 += 1; }
     P->staged_cols = col0;
     if (st == MI_OK) st = chp::translate(P, prog);
-    if (st == MI_OK && c) st = chp::build_staged(P); // a null context compiles for the host debug executor only (no GPU, no sections needed)
+    // the kernel's form needs the sections; a null context without sections compiles for the host debug executor only
+    if (st == MI_OK && (c || n_sections)) st = chp::build_staged(P, 256);
     if (st == MI_OK && c) {
         std::lock_guard<std::recursive_mutex> lock(c->mu);
         hipError_t e = hipSetDevice(c->device);
@@ -789,10 +938,18 @@ extern "C" int mi_set_chelpers_min_words(mi_ctx *c, uint64_t words)
     return MI_OK;
 }
 
-extern "C" int mi_chelpers_stats(const mi_chelpers_prog *p, uint64_t out[8])
+extern "C" int mi_chelpers_stats(const mi_chelpers_prog *p, uint64_t out[16])
 {
     if (!p || !out) return MI_ERR_INVALID;
     for (int i = 0; i < 8; i++) out[i] = p->stats[i];
+    out[8] = p->gpu.size();   // device instructions per row (dimension-3 polynomial operands cost three copies each)
+    out[9] = p->hot_t1;       // base temporaries in LDS
+    out[10] = p->hot_t3;      // extension temporaries in LDS
+    out[11] = p->cold_words;  // base temporaries spilled to HBM
+    out[12] = p->temp_reads;  // reads of temporaries per row ...
+    out[13] = p->cold_reads;  // ... of which from the spill
+    out[14] = p->cst_off;     // LDS bytes per workgroup before the constant tables
+    out[15] = p->staged_cols;
     return MI_OK;
 }
 
@@ -802,7 +959,7 @@ static int check_params(const mi_chelpers_prog *p, const mi_chelpers_params *a, 
     MI_REQUIRE(a->pols && a->q, "null polynomial memory or output");
     MI_REQUIRE(a->n_challenges >= p->max_chal && (a->challenges || p->max_chal == 0), "program reads more challenges than were given");
     MI_REQUIRE(a->n_publics >= p->max_pub && (a->publics || p->max_pub == 0), "program reads more public inputs than were given");
-    MI_REQUIRE(a->zhinv && a->n_zhinv > 0 && a->n_zhinv <= 256, "ZhInv table must hold 1..256 values");
+    MI_REQUIRE(a->zhinv && a->n_zhinv > 0 && a->n_zhinv <= 256 && is_pow2(a->n_zhinv), "ZhInv table must hold 2^k <= 256 values (zhInv.cpp:7-31)");
     MI_REQUIRE(row0 + nrows >= row0, "row range overflows");
     return MI_OK;
 }
@@ -817,24 +974,28 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     if (nrows == 0) return MI_OK;
     MI_REQUIRE(a->n_const == p->n_const, "number of constant polynomials differs from what the program was compiled for");
     MI_REQUIRE(row0 + nrows <= p->nrows_ext, "rows beyond the extended domain the program was compiled for");
-    const uint64_t tmp_words = std::max<uint64_t>(std::max<uint64_t>(p->n_words, c->chelpers_min_words) * 64, (uint64_t)chp::RS * 65);
-    const size_t lds = (size_t)(tmp_words + 2 * chp::BATCH * 64 + 576) * 8;
+    // LDS: the program's layout (build_staged) + the three small tables; the benchmarking knob can only enlarge it
+    const uint32_t chal_words = (uint32_t)p->max_chal * 3, pub_words = (uint32_t)p->max_pub;
+    const uint32_t cst_words = chal_words + pub_words + (uint32_t)a->n_zhinv;
+    size_t lds = (size_t)p->cst_off + (size_t)cst_words * 8;
+    lds = std::max(lds, (size_t)c->chelpers_min_words * 512);
     MI_REQUIRE(lds <= 160 * 1024, "program needs more temporaries per row than the LDS holds");
-    // small host tables -> the context's scratch (challenges, publics, ZhInv): 3 * 64 + 128 + 256 words at most
-    MI_REQUIRE(p->max_chal <= 64 && p->max_pub <= 128, "more challenges / public inputs than the scratch holds");
-    if (!c->chelpers_scratch) MI_HIP_CHECK(hipMalloc((void **)&c->chelpers_scratch, (192 + 128 + 256) * 8));
-    u64 stage[192 + 128 + 256] = {0};
-    for (uint64_t i = 0; i < p->max_chal * 3; i++) stage[i] = gl::canon(a->challenges[i]);
-    for (uint64_t i = 0; i < p->max_pub; i++) stage[192 + i] = gl::canon(a->publics[i]);
-    for (uint64_t i = 0; i < a->n_zhinv; i++) stage[320 + i] = gl::canon(a->zhinv[i]);
+    // challenges | public inputs | ZhInv, back to back, in the context's scratch
+    MI_REQUIRE(cst_words <= 576, "more challenges / public inputs than the scratch holds");
+    if (!c->chelpers_scratch) MI_HIP_CHECK(hipMalloc((void **)&c->chelpers_scratch, 576 * 8));
+    u64 stage[576] = {0};
+    for (uint64_t i = 0; i < chal_words; i++) stage[i] = gl::canon(a->challenges[i]);
+    for (uint64_t i = 0; i < pub_words; i++) stage[chal_words + i] = gl::canon(a->publics[i]);
+    for (uint64_t i = 0; i < a->n_zhinv; i++) stage[chal_words + pub_words + i] = gl::canon(a->zhinv[i]);
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // an earlier run may still be reading the scratch
     MI_HIP_CHECK(hipMemcpyAsync(c->chelpers_scratch, stage, sizeof(stage), hipMemcpyHostToDevice, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `stage` is on this stack frame
-    // persistent workgroups: as many as are resident at once (LDS bound), each with a private staging area
+    // persistent workgroups: as many as are resident at once (LDS bound), each with a private staging + spill area
     const uint64_t n_groups = (nrows + 63) / 64;
-    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / lds));
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(16, (160 * 1024) / lds));
     const uint64_t grid = std::min<uint64_t>(n_groups, per_cu * (uint64_t)c->cu_count);
-    const uint64_t scratch_bytes = grid * p->staged_cols * chp::RS * 8 + 4096;
+    const uint64_t wg_stride = p->staged_cols * chp::RS + (uint64_t)p->cold_words * 64 + 64;
+    const uint64_t scratch_bytes = grid * wg_stride * 8 + 4096;
     if (c->chelpers_stage_bytes < scratch_bytes) {
         if (c->chelpers_stage) MI_HIP_CHECK(hipFree(c->chelpers_stage));
         c->chelpers_stage = nullptr;
@@ -859,10 +1020,13 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
         else { MI_REQUIRE(a->x, "null x"); G.ptr = (const u64 *)a->x; G.pitch = a->x_stride; }
     }
     A.n_instr = (uint32_t)p->gpu.size();
-    A.n_words = (uint32_t)std::max<uint64_t>(p->n_words, c->chelpers_min_words);
-    A.chal = c->chelpers_scratch;
-    A.pub = c->chelpers_scratch + 192;
-    A.zhinv = c->chelpers_scratch + 320;
+    A.tile_off = p->tile_off;
+    A.pre_off = p->pre_off;
+    A.cst_off = p->cst_off;
+    A.cst_words = cst_words;
+    A.zh_off = chal_words + pub_words;
+    A.lds_bytes = (uint32_t)lds;
+    A.consts = c->chelpers_scratch;
     A.q = (u64 *)a->q;
     A.scratch = c->chelpers_stage;
     A.n_zhinv = a->n_zhinv;
@@ -870,6 +1034,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     A.row_end = row0 + nrows;
     A.n_groups = n_groups;
     A.staged_cols = p->staged_cols;
+    A.wg_stride = wg_stride;
     if (lds > 48 * 1024)
         MI_HIP_CHECK(hipFuncSetAttribute((const void *)chp::k_chelpers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(chp::k_chelpers, dim3((unsigned)grid), dim3(64), lds, c->stream, p->dev, A);

@@ -1,0 +1,136 @@
+// starks_device.hpp -- device-resident driver of the hot-path stages of Starks::genProof.
+//
+// The Level-0 shims let src/starkpil compile unchanged, but then every extendPol / merkelize moves its operands over PCIe
+// (stage 1 alone: 44.6 GB up, 89 GB down, 89 GB up again).  This class is the few lines a maintainer puts in place of
+// the stage bodies of starks.cpp so that the extended sections (cm1_2ns .. cm4_2ns, q_2ns), their trees and the FRI
+// polynomial never leave HBM:
+//
+//   starks.cpp:48-59    extendPol(p_cm1_2ns, p_cm1_n ..) + treesGL[0]->merkelize() + getRoot      -> commitStage(0, p_cm1_n, root)
+//   starks.cpp:133-140  the same for cm2                                                          -> commitStage(1, ..)
+//   starks.cpp:214-221  the same for cm3                                                          -> commitStage(2, ..)
+//   starks.cpp:237-248  steps->step42ns_parser_first_avx(params, NExtended, nrowsStepBatch)       -> setStep42nsProgram + step42ns
+//   starks.cpp:261-292  INTT(qq1, q_2ns) / split / NTT(cm4_2ns, qq2) / treesGL[3]->merkelize()    -> commitQ(root)
+//   friProve.cpp:219-250 treesGL[t]->getGroupProof(..)                                            -> getGroupProofs(t, ..)
+//
+// One polynomial area in HBM holds the sections in the reference's order and row-major layout (element (row, col) of
+// section s at area[offset_s + row * cols_s + col], stark_info.cpp:473-482), so that the constraint program's offsets --
+// which are relative to the start of cm1_2ns here -- address it directly.  The host trace of a stage is streamed up in
+// column chunks behind the kernels (mi_lde_merkle_host).  Errors follow the reference: log + exit.
+#ifndef STARKS_DEVICE_HPP
+#define STARKS_DEVICE_HPP
+#include <vector>
+#include "goldilocks_base_field.hpp"
+#include "goldilocks_cubic_extension.hpp"
+#include "merklehash_goldilocks.hpp"
+#include "mi_runtime.hpp"
+
+class StarksDevice
+{
+    uint64_t N, NExtended, nBits, nBitsExt;
+    std::vector<uint64_t> cols, offset; // sections 0..2 = cm1..cm3 (_2ns), 3 = cm4_2ns (qDeg * qDim), 4 = q_2ns (qDim)
+    uint64_t *d_area = nullptr;
+    std::vector<uint64_t *> d_nodes;
+    mi_chelpers_prog *prog42 = nullptr;
+    uint64_t nConst = 0;
+    uint64_t *d_const = nullptr, *d_x2ns = nullptr;
+
+    static uint64_t *alloc(uint64_t elems, const char *what)
+    {
+        uint64_t *p = (uint64_t *)mi_dev_alloc(mi::ctx(), elems * 8);
+        if (!p) mi::fail(what);
+        return p;
+    }
+
+public:
+    // sectionCols: columns of cm1, cm2, cm3; qDeg, qDim as in StarkInfo (zkEVM: 665, 128, 371; 2, 3)
+    StarksDevice(uint64_t _nBits, uint64_t _nBitsExt, const std::vector<uint64_t> &sectionCols, uint64_t qDeg = 2, uint64_t qDim = FIELD_EXTENSION)
+        : N(1ULL << _nBits), NExtended(1ULL << _nBitsExt), nBits(_nBits), nBitsExt(_nBitsExt)
+    {
+        cols = sectionCols;
+        cols.push_back(qDeg * qDim);
+        cols.push_back(qDim);
+        uint64_t o = 0;
+        for (uint64_t c : cols) { offset.push_back(o); o += NExtended * c; }
+        d_area = alloc(o, "StarksDevice (polynomial area)");
+        d_nodes.assign(cols.size() - 1, nullptr);
+        for (size_t i = 0; i + 1 < cols.size(); i++) d_nodes[i] = alloc(MerklehashGoldilocks::getTreeNumElements(NExtended), "StarksDevice (tree nodes)");
+    }
+    StarksDevice(const StarksDevice &) = delete;
+    StarksDevice &operator=(const StarksDevice &) = delete;
+    ~StarksDevice()
+    {
+        mi_ctx *c = mi::ctx();
+        if (prog42) mi_chelpers_free(c, prog42);
+        for (uint64_t *p : d_nodes) mi_dev_free(c, p);
+        mi_dev_free(c, d_area); mi_dev_free(c, d_const); mi_dev_free(c, d_x2ns);
+    }
+    uint64_t *section(unsigned s) { return d_area + offset[s]; } // device pointer: cm_{s+1}_2ns, cm4_2ns, q_2ns
+    uint64_t sectionOffset(unsigned s) const { return offset[s]; }
+    uint64_t *nodes(unsigned t) { return d_nodes[t]; }
+
+    // stages 1-3: host trace section (N x cols[s], row-major) -> resident extension + tree; 32 bytes come back
+    void commitStage(unsigned s, const Goldilocks::Element *p_cm_n, Goldilocks::Element *root)
+    {
+        mi_ctx *c = mi::ctx();
+        mi::check(mi_lde_merkle_host(c, d_nodes[s], section(s), cols[s], (const uint64_t *)p_cm_n, N, NExtended, cols[s], 0), "StarksDevice::commitStage");
+        getRoot(s, root);
+    }
+    void getRoot(unsigned t, Goldilocks::Element *root)
+    {
+        const uint64_t ne = MerklehashGoldilocks::getTreeNumElements(NExtended);
+        mi::check(mi_copy_d2h(mi::ctx(), root, d_nodes[t] + ne - HASH_SIZE, HASH_SIZE * 8), "StarksDevice::getRoot");
+    }
+
+    // step 4a: the generated constraint program (tables of zkevm.chelpers.step42ns.parser.hpp) and what it reads besides the
+    // committed sections: the extended constant polynomials (host, NExtended x nConst) and x_2ns (built here: shift * w^i)
+    void setStep42nsProgram(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, const Goldilocks::Element *pConstPols2ns,
+                            uint64_t _nConst)
+    {
+        mi_ctx *c = mi::ctx();
+        nConst = _nConst;
+        std::vector<mi_chelpers_section> secs;
+        for (unsigned s = 0; s < 3; s++) secs.push_back({offset[s], cols[s], NExtended});
+        mi::check(mi_chelpers_compile(c, &prog42, MI_CHELPERS_STEP42NS, ops, nops, args, nargs, secs.data(), secs.size(), nConst, NExtended),
+                  "StarksDevice::setStep42nsProgram");
+        if (nConst) {
+            d_const = alloc(NExtended * nConst, "StarksDevice (constant polynomials)");
+            mi::check(mi_copy_h2d(c, d_const, pConstPols2ns, NExtended * nConst * 8), "StarksDevice (constant polynomials h2d)");
+        }
+        d_x2ns = alloc(NExtended, "StarksDevice (x_2ns)");
+        mi::check(mi_geom_seq_dev(c, d_x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))),
+                  "StarksDevice (x_2ns)"); // starks.hpp:176-183
+    }
+    // step 4b: q_2ns = constraint polynomial over the extended domain (starks.cpp:237-248)
+    void step42ns(const Goldilocks::Element *challenges, uint64_t nChallenges, const Goldilocks::Element *publicInputs, uint64_t nPublics)
+    {
+        mi_ctx *c = mi::ctx();
+        std::vector<uint64_t> zh(1ULL << (nBitsExt - nBits));
+        mi::check(mi_zhinv(c, zh.data(), (unsigned)nBits, (unsigned)nBitsExt), "StarksDevice::step42ns (ZhInv)");
+        mi_chelpers_params p = {d_area, d_const, nConst, (const uint64_t *)challenges, nChallenges, (const uint64_t *)publicInputs, nPublics,
+                                d_x2ns, 1, zh.data(), zh.size(), section(4)};
+        mi::check(mi_chelpers_run_dev(c, prog42, &p, 0, NExtended), "StarksDevice::step42ns");
+    }
+    // step 4c (starks.cpp:261-292): INTT of q, split into qDeg chunks with shift^-N, NTT over qDeg * qDim columns, merkelize
+    void commitQ(Goldilocks::Element *root, uint64_t qDeg = 2, uint64_t qDim = FIELD_EXTENSION)
+    {
+        mi_ctx *c = mi::ctx();
+        uint64_t *qq1 = alloc(NExtended * qDim, "StarksDevice::commitQ"), *qq2 = alloc(NExtended * qDim * qDeg, "StarksDevice::commitQ");
+        mi::check(mi_ntt_dev(c, qq1, qDim, section(4), qDim, NExtended, qDim, 1), "StarksDevice::commitQ (INTT)");
+        mi::check(mi_q_split_dev(c, qq2, qq1, N, NExtended, (unsigned)qDeg), "StarksDevice::commitQ (split)");
+        mi::check(mi_ntt_dev(c, section(3), qDim * qDeg, qq2, qDim * qDeg, NExtended, qDim * qDeg, 0), "StarksDevice::commitQ (NTT)");
+        mi::check(mi_merkle_build_dev(c, d_nodes[3], section(3), qDim * qDeg, qDim * qDeg, NExtended), "StarksDevice::commitQ (merkelize)");
+        mi_dev_free(c, qq1); mi_dev_free(c, qq2);
+        getRoot(3, root);
+    }
+    // friProve.cpp:219-250: proofs[q] = row idx[q] of tree t (cols[t] values) followed by nBitsExt x 4 siblings
+    void getGroupProofs(unsigned t, Goldilocks::Element *proofs, const uint64_t *idx, uint64_t nq)
+    {
+        mi_ctx *c = mi::ctx();
+        const uint64_t stride = cols[t] + nBitsExt * HASH_SIZE;
+        uint64_t *d = alloc(nq * stride, "StarksDevice::getGroupProofs");
+        mi::check(mi_merkle_group_proofs_dev(c, d, d_nodes[t], section(t), cols[t], NExtended, cols[t], idx, nq), "StarksDevice::getGroupProofs");
+        mi::check(mi_copy_d2h(c, proofs, d, nq * stride * 8), "StarksDevice::getGroupProofs (d2h)");
+        mi_dev_free(c, d);
+    }
+};
+#endif

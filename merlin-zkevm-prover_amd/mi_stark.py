@@ -315,7 +315,8 @@ class ChelpersProgram:
     ctx = None compiles for the host debug executor only (no GPU needed)."""
 
     STAT_NAMES = ("opcodes", "field_ops", "after_copy_forwarding", "instructions_per_row", "live_words_as_generated",
-                  "live_words_rescheduled", "base_temps", "ext_temps")
+                  "live_words_rescheduled", "base_temps", "ext_temps", "device_instructions_per_row", "lds_base_temps", "lds_ext_temps",
+                  "spilled_base_temps", "temp_reads_per_row", "spill_reads_per_row", "lds_bytes_per_workgroup", "staged_columns")
 
     def __init__(self, ctx, ops, args, sections=(), n_const=0, nrows_ext=0, step=MI_CHELPERS_STEP42NS):
         """sections: [(element offset in pols, columns, rows)] the program reads (needed for the GPU form only)."""
@@ -327,7 +328,7 @@ class ChelpersProgram:
         _check(lib().mi_chelpers_compile(ctx.h if ctx is not None else None, ctypes.byref(self.h), ctypes.c_int(step), _hp(ops), u64(ops.size),
                                          _hp(args) if args.size else None, u64(args.size), _hp(sec.reshape(-1)) if sec.size else None,
                                          u64(sec.shape[0]), u64(n_const), u64(nrows_ext)))
-        st = np.zeros(8, dtype=np.uint64)
+        st = np.zeros(16, dtype=np.uint64)
         _check(lib().mi_chelpers_stats(self.h, _hp(st)))
         self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}
 

@@ -14,6 +14,7 @@
 #include "friProve.hpp"
 #include "build_const_tree.hpp"
 #include "proof2zkinStark.hpp"
+#include "starks_device.hpp"
 #include <fstream>
 #include "../../oracle/gl_oracle.h"
 
@@ -75,6 +76,70 @@ int main()
     transcript.getField(ch);
     glo_transcript_get_field(&otr, och);
     EXPECT(same(ch, och, 3), "Transcript challenge == oracle");
+
+    // ---- the same stages through the device-resident driver (host/starks_device.hpp): host trace streamed in, the
+    // extension, the trees, q_2ns and cm4_2ns stay in HBM; roots, openings and (here, for the check) sections come back
+    {
+        const uint64_t c2 = 9, nConst = 5;
+        StarksDevice sd(nBits, nBitsExt, {nCols, c2, 3});
+        Goldilocks::Element r[HASH_SIZE];
+        sd.commitStage(0, cm1_n.data(), r);
+        EXPECT(same(r, &want_nodes[want_nodes.size() - 4], 4), "StarksDevice::commitStage(0) root == oracle");
+        std::vector<Goldilocks::Element> back(NExtended * nCols);
+        mi::check(mi_copy_d2h(mi::ctx(), back.data(), sd.section(0), back.size() * 8), "d2h");
+        EXPECT(same(back.data(), want_2ns.data(), back.size()), "StarksDevice: resident cm1_2ns == oracle");
+        std::vector<Goldilocks::Element> cm2_n(N * c2), cm3_n(N * 3);
+        for (uint64_t i = 0; i < cm2_n.size(); i++) cm2_n[i] = Goldilocks::fromU64(splitmix(21, i));
+        for (uint64_t i = 0; i < cm3_n.size(); i++) cm3_n[i] = Goldilocks::fromU64(splitmix(22, i));
+        sd.commitStage(1, cm2_n.data(), r);
+        sd.commitStage(2, cm3_n.data(), r);
+        std::vector<uint64_t> w3(NExtended * 3), n3((2 * NExtended - 1) * 4);
+        glo_extend_pol(w3.data(), (const uint64_t *)cm3_n.data(), NExtended, N, 3);
+        glo_merkletree(n3.data(), w3.data(), 3, NExtended);
+        EXPECT(same(r, &n3[n3.size() - 4], 4), "StarksDevice::commitStage(2) (3 columns: copied leaves) root == oracle");
+        {   // openings straight from the resident tree
+            uint64_t idx[3] = {0, 777, NExtended - 1};
+            std::vector<Goldilocks::Element> pr(3 * (nCols + nBitsExt * 4)), wp(nCols + nBitsExt * 4);
+            sd.getGroupProofs(0, pr.data(), idx, 3);
+            bool ok = true;
+            for (int q = 0; q < 3; q++) {
+                glo_merkle_group_proof((uint64_t *)wp.data(), want_nodes.data(), (const uint64_t *)want_2ns.data(), NExtended, nCols, idx[q]);
+                ok = ok && same(&pr[q * wp.size()], wp.data(), wp.size());
+            }
+            EXPECT(ok, "StarksDevice::getGroupProofs == oracle");
+        }
+        // step 4: a small constraint program over the three sections (offsets relative to the polynomial area), then q -> cm4
+        const uint64_t o1 = sd.sectionOffset(0), o2 = sd.sectionOffset(1), o3 = sd.sectionOffset(2);
+        // tmp1[0] = cm1[3] * cm2[1];  tmp1[1] = tmp1[0] + const[2];  tmp3[0] = tmp1[1] + challenge 1;
+        // tmp3[1] = cm3 (as ext element) * tmp3[0];  tmp3[0] = x_2ns * tmp3[1];  tmp1[2] = cm1'[5] (row + 2);  tmp3[0] = tmp1[2] + tmp3[0];  q = zhInv * tmp3[0]
+        const uint64_t ops[] = {50, 3, 14, 75, 68, 80, 12, 69};
+        const uint64_t args[] = {0, o1 + 3, nCols, o2 + 1, c2,   1, 0, 2,   0, 1, 1,   1, o3, 3, 0,   0, 1,   2, o1 + 5, 2, NExtended, nCols,   0, 2, 0,   0};
+        std::vector<Goldilocks::Element> cpols(NExtended * nConst), chal(2 * 3), pub(1);
+        for (uint64_t i = 0; i < cpols.size(); i++) cpols[i] = Goldilocks::fromU64(splitmix(23, i));
+        for (uint64_t i = 0; i < chal.size(); i++) chal[i] = Goldilocks::fromU64(splitmix(24, i));
+        pub[0] = Goldilocks::fromU64(5);
+        sd.setStep42nsProgram(ops, sizeof(ops) / 8, args, sizeof(args) / 8, cpols.data(), nConst);
+        sd.step42ns(chal.data(), 2, pub.data(), 1);
+        // oracle: same program over a host copy of the polynomial area
+        std::vector<uint64_t> area(o3 + NExtended * 3), w2(NExtended * c2), x2ns(NExtended), zh(2), wq_(NExtended * 3), gq(NExtended * 3);
+        glo_extend_pol(w2.data(), (const uint64_t *)cm2_n.data(), NExtended, N, c2);
+        std::memcpy(&area[o1], want_2ns.data(), NExtended * nCols * 8);
+        std::memcpy(&area[o2], w2.data(), w2.size() * 8);
+        std::memcpy(&area[o3], w3.data(), w3.size() * 8);
+        glo_geom_seq(x2ns.data(), NExtended, 49, glo_w((unsigned)nBitsExt));
+        glo_zhinv(zh.data(), (unsigned)nBits, (unsigned)nBitsExt);
+        int st = glo_chelpers_step42ns(ops, sizeof(ops) / 8, args, sizeof(args) / 8, area.data(), (const uint64_t *)cpols.data(), nConst,
+                                       (const uint64_t *)chal.data(), (const uint64_t *)pub.data(), x2ns.data(), 1, zh.data(), 2, wq_.data(), 0, NExtended);
+        mi::check(mi_copy_d2h(mi::ctx(), gq.data(), sd.section(4), gq.size() * 8), "d2h");
+        EXPECT(st == 0 && same(gq.data(), wq_.data(), gq.size()), "StarksDevice::step42ns (constraint program on the GPU) == oracle interpreter");
+        sd.commitQ(r);
+        std::vector<uint64_t> q1(NExtended * 3), q2(NExtended * 6), c4(NExtended * 6), n4((2 * NExtended - 1) * 4);
+        glo_ntt(q1.data(), wq_.data(), NExtended, 3, 1);
+        glo_q_split(q2.data(), q1.data(), N, 2);
+        glo_ntt(c4.data(), q2.data(), NExtended, 6, 0);
+        glo_merkletree(n4.data(), c4.data(), 6, NExtended);
+        EXPECT(same(r, &n4[n4.size() - 4], 4), "StarksDevice::commitQ (INTT, split, NTT, tree) root == oracle");
+    }
 
     // ---- STEP 4 shapes (starks.cpp:261,284): INTT with the positional (NULL, 2, 1) hints, NTT over 6 columns
     std::vector<Goldilocks::Element> q_2ns(NExtended * 3), qq1(NExtended * 3), wq(NExtended * 3);
