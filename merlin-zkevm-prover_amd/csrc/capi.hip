@@ -370,8 +370,7 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     MI_REQUIRE(nodes && ext && trace_host, "null buffer");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
     MI_REQUIRE(ext_pitch >= ncols, "pitch smaller than ncols");
-    MI_REQUIRE(ncols > 4, "rows of at most 4 columns are not hashed (linear_hash copies them): use mi_lde + mi_merkle_build");
-    if (chunk_cols == 0) chunk_cols = 128;
+    if (chunk_cols == 0) chunk_cols = 256;
     MI_REQUIRE(chunk_cols % 8 == 0, "chunk width must be a multiple of 8 (the sponge absorbs whole blocks per chunk)");
     // Chunk schedule.  A chunk is a 2-D copy whose rows are (8 x width) bytes at the trace's row pitch, and the DMA engines
     // move short rows slower (measured on MI355X, profiles/r02_pcie_chunk_sweep.json: 39.5 GB/s at 32 columns, 49 at 64,
@@ -424,19 +423,25 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
         return MI_OK;
     };
     auto absorb = [&](uint64_t k) -> int {
+        if (ncols <= 4) // linear_hash copies rows of at most 4 elements instead of hashing them: one chunk, plain leaf kernel
+            return launch_linear_hash_rows(c, (u64 *)nodes, (const u64 *)ext, ext_pitch, ncols, n_ext);
         const u64 *base = (const u64 *)ext + c0s[k];
         const uint64_t pitch = ext_pitch, width = cws[k];
         return launch_linear_hash_absorb(c, (u64 *)nodes, 1, &base, &pitch, &width, n_ext, k == 0, k + 1 == n_chunks);
     };
+    // Per chunk on the compute stream: wait for its upload, extend it, absorb its columns.  The uploads run back to back
+    // on the copy streams (chunk k + 1 only needs the staging buffer the LDE of chunk k - 1 has finished reading), so what
+    // is left after the last upload is the extension and absorption of the last -- short -- chunk.
     MI_TRY(upload(0));
     for (uint64_t k = 0; k < n_chunks; k++) {
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k & 1][s], 0));
         MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k & 1], cws[k], n_ext, n, cws[k]));
         MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k & 1], c->stream));
-        if (k >= 1) MI_TRY(absorb(k - 1));          // enqueued before the (possibly host-blocking) upload call below
-        if (k + 1 < n_chunks) MI_TRY(upload(k + 1)); // runs beside the LDE of chunk k and the absorption of chunk k-1
+        MI_TRY(absorb(k));
+        // enqueued after this chunk's kernels (the copy call may block the host), but its only dependency -- the LDE of chunk
+        // k - 1 -- is long done: it starts as soon as chunk k's upload ends and runs beside the kernels above
+        if (k + 1 < n_chunks) MI_TRY(upload(k + 1));
     }
-    MI_TRY(absorb(n_chunks - 1));
     return launch_merkle_levels(c, (u64 *)nodes, n_ext);
 }
 

@@ -25,7 +25,7 @@ del trace
 ext, nodes = ctx.empty(n_ext * ncols), ctx.empty((2 * n_ext - 1) * 4)
 out = {"rows": n, "cols": ncols, "steps": []}
 hip = ctypes.CDLL("libamdhip64.so")
-for chunk in (64, 128, 160, 256):
+for chunk in (64, 128, 256, 320):
     # bare upload of every chunk, same 2-D copies, no kernels
     stage = ctx.empty(n * chunk)
     torch.cuda.synchronize()
