@@ -325,8 +325,8 @@ def main():
                     "host_memory": "page-locked (hipHostMalloc), %.1f GB, allocated in %.1f s; D2H fill %.1f GB/s" % (n * ncols * 8 / 1e9, t_b - t_a, n * ncols * 8 / 1e9 / (t_c - t_b)),
                     "h2d_bytes_per_step": n * ncols * 8, "h2d_floor_ms_at_55GBps": 1e3 * n * ncols * 8 / 55e9,
                     "root_matches": [int(v) for v in root_p] == root_host,
-                    "path": "mi_lde_merkle_host: column chunks of 32, 96, 128 ... columns, H2D of chunk k+1 (two copy streams) || LDE of chunk k || leaf absorption of chunk k-1; extension + tree stay in HBM",
-                    "h2d_note": "the chunks are 2-D copies out of the row-major host trace: 52.7 GB/s at 128 columns against 55 GB/s for whole rows (profiles/r02_pcie_chunk_sweep.json)"}
+                    "path": "mi_lde_merkle_host: column chunks of 32, 64, 64 ... columns, H2D of chunk k+1 (two copy streams) || LDE + leaf absorption of chunk k; extension + tree stay in HBM",
+                    "h2d_note": "the chunks are 2-D copies out of the row-major host trace: 49 GB/s at 64 columns against 55 GB/s for whole rows; the bare upload of all chunks takes 0.91 s (profiles/r02_pcie_chunk_sweep.json)"}
             del host_trace
         except Exception as e:  # a box without enough page-lockable host memory must not lose the headline number
             pcie = {"error": repr(e)}

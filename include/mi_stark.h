@@ -120,7 +120,7 @@ int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *no
 /* ------------------------------------------------------------------ stage driver (host trace in, resident result out)
  * Starks::genProof step 1 (starks.cpp:48-59: extendPol of p_cm1_n, then treesGL[0]->merkelize()) for a caller that holds
  * the trace in HOST memory and wants the extension and the tree to STAY on the device: the n x ncols row-major host trace is
- * uploaded in column chunks of at most chunk_cols (0 = 256; a multiple of 8) on two copy streams while the chunks already on the device
+ * uploaded in column chunks of at most chunk_cols (0 = 64; a multiple of 8) on two copy streams while the chunks already on the device
  * are extended into ext (device, n_ext x ncols at row pitch ext_pitch) and their columns absorbed into the leaf sponges, so
  * the PCIe transfer overlaps the kernels.  nodes (device, (2 n_ext - 1) * 4) receives the tree; root = its last 4 elements.
  * Work is enqueued; mi_ctx_sync (or reading the root) waits for it.  For full PCIe speed the host range should be

@@ -370,12 +370,13 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     MI_REQUIRE(nodes && ext && trace_host, "null buffer");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
     MI_REQUIRE(ext_pitch >= ncols, "pitch smaller than ncols");
-    if (chunk_cols == 0) chunk_cols = 256;
+    if (chunk_cols == 0) chunk_cols = 64;
     MI_REQUIRE(chunk_cols % 8 == 0, "chunk width must be a multiple of 8 (the sponge absorbs whole blocks per chunk)");
     // Chunk schedule.  A chunk is a 2-D copy whose rows are (8 x width) bytes at the trace's row pitch, and the DMA engines
     // move short rows slower (measured on MI355X, profiles/r02_pcie_chunk_sweep.json: 39.5 GB/s at 32 columns, 49 at 64,
-    // 52.7 at 128, 55 for whole rows) -- but nothing can run before the first chunk is up.  So: a narrow first chunk (32),
-    // a middle one (96), then full-width chunks; the remainder goes last (a short tail after the last upload).
+    // 52.7 at 128, 55 for whole rows) -- but nothing can run before the first chunk is up, and a chunk's kernels (0.91 x its
+    // upload time) only hide behind the NEXT upload, so wide chunks leave a long tail after the last one.  Measured optimum
+    // for the 665-column trace: a 32-column first chunk, then 64 (1.00 s per step against 0.91 s for the bare upload).
     std::vector<uint64_t> c0s, cws;
     for (uint64_t c0 = 0, k = 0; c0 < ncols; k++) {
         uint64_t w = k == 0 ? 32 : k == 1 ? 96 : chunk_cols;
