@@ -367,10 +367,13 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
             for (int j = 0; j < 2 * BATCH; j++) pre[j * 64 + lane] = v_cur[j];
 #pragma unroll 1
             for (uint32_t j = 0; j < BATCH; j++) {
-                const uint32_t op = field(iw_cur, j, 0), dst = field(iw_cur, j, 1);
+                // instruction j of the batch lives in dwords 16 j .. 16 j + 15: lanes of `lo` for j < 4, of `hi` otherwise
+                const uint32_t wsel = j < 4 ? iw_cur.lo : iw_cur.hi, fbase = (j & 3) * 16;
+                auto fld = [&](uint32_t f) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)wsel, (int)(fbase + f)); };
+                const uint32_t op = fld(0), dst = fld(1);
                 const uint32_t cls = op & 15, dk = (op >> 4) & 3;
                 u64 o[3];
-                const u64 a0 = lds_word(lds, field(iw_cur, j, 2), lane8), b0 = lds_word(lds, field(iw_cur, j, 5), lane8);
+                const u64 a0 = lds_word(lds, fld(2), lane8), b0 = lds_word(lds, fld(5), lane8);
                 bool three = true;
                 switch (cls) {
                 case G_ADD1: o[0] = gl::add(a0, b0); three = false; break;
@@ -378,18 +381,18 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
                 case G_MUL11: o[0] = gl::mul(a0, b0); three = false; break;
                 case G_COPY1: o[0] = a0; three = false; break;
                 case G_MUL13: { // base times extension
-                    const u64 b1 = lds_word(lds, field(iw_cur, j, 6), lane8), b2 = lds_word(lds, field(iw_cur, j, 7), lane8);
+                    const u64 b1 = lds_word(lds, fld(6), lane8), b2 = lds_word(lds, fld(7), lane8);
                     o[0] = gl::mul(a0, b0); o[1] = gl::mul(a0, b1); o[2] = gl::mul(a0, b2);
                     break;
                 }
                 case G_MUL31: {
-                    const u64 a1 = lds_word(lds, field(iw_cur, j, 3), lane8), a2 = lds_word(lds, field(iw_cur, j, 4), lane8);
+                    const u64 a1 = lds_word(lds, fld(3), lane8), a2 = lds_word(lds, fld(4), lane8);
                     o[0] = gl::mul(a0, b0); o[1] = gl::mul(a1, b0); o[2] = gl::mul(a2, b0);
                     break;
                 }
                 default: {
-                    const u64 a1 = lds_word(lds, field(iw_cur, j, 3), lane8), a2 = lds_word(lds, field(iw_cur, j, 4), lane8);
-                    const u64 b1 = lds_word(lds, field(iw_cur, j, 6), lane8), b2 = lds_word(lds, field(iw_cur, j, 7), lane8);
+                    const u64 a1 = lds_word(lds, fld(3), lane8), a2 = lds_word(lds, fld(4), lane8);
+                    const u64 b1 = lds_word(lds, fld(6), lane8), b2 = lds_word(lds, fld(7), lane8);
                     if (cls == G_ADD3) { o[0] = gl::add(a0, b0); o[1] = gl::add(a1, b1); o[2] = gl::add(a2, b2); }
                     else if (cls == G_SUB3) { o[0] = gl::sub(a0, b0); o[1] = gl::sub(a1, b1); o[2] = gl::sub(a2, b2); }
                     else if (cls == G_MUL33) {
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
                     *(u64 *)(lds + dst + lane8) = o[0];
                     if (three) { *(u64 *)(lds + dst + 512 + lane8) = o[1]; *(u64 *)(lds + dst + 1024 + lane8) = o[2]; }
                     if (op & 64) // read again much later: a second home in the spill (word in field 12)
-                        __hip_atomic_store(mycold + (uint64_t)field(iw_cur, j, 12) * 64 + lane, o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(mycold + (uint64_t)fld(12) * 64 + lane, o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else if (dk == D_COLD) { // a base-field value that lives long and is read rarely: spilled beside the staged columns
                     __hip_atomic_store(mycold + (uint64_t)dst * 64 + lane, o[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else if (dk == D_Q && active) {
