@@ -24,19 +24,20 @@ inline std::string proof2zkinStark(const FRIProof &fproof, bool withPublics = fa
         o += ",\"" + s + "_root\":" + mi_json::arr(fri.trees[i].root) + ",\"" + s + "_vals\":" + mi_json::arr(vals) + ",\"" + s +
              "_siblings\":" + mi_json::arr(sibs);
     }
-    // step-0 openings: one MerkleProof per commitment tree and query (proof2zkinStark.cpp:30-77)
+    // step-0 openings: one MerkleProof per commitment tree and query (proof2zkinStark.cpp:30-77).  Key order as the
+    // reference's ordered_json produces it: every s0_vals<t> first, then every s0_siblings<t> (trees 2 and 3 only when that
+    // stage has columns)
     static const char *names[5] = {"1", "2", "3", "4", "C"};
     const size_t nTrees = nq ? fri.trees[0].polQueries[0].size() : 0;
-    for (size_t t = 0; t < nTrees; t++) {
-        if ((t == 1 || t == 2) && fri.trees[0].polQueries[0][t].v.empty()) continue; // stage without columns
-        std::vector<std::string> vals, sibs;
-        for (size_t q = 0; q < nq; q++) {
-            vals.push_back(fri.trees[0].polQueries[q][t].valuesJson());
-            sibs.push_back(fri.trees[0].polQueries[q][t].siblingsJson());
+    for (int pass = 0; pass < 2; pass++)
+        for (size_t t = 0; t < nTrees; t++) {
+            if ((t == 1 || t == 2) && fri.trees[0].polQueries[0][t].v.empty()) continue; // stage without columns
+            std::vector<std::string> items;
+            for (size_t q = 0; q < nq; q++)
+                items.push_back(pass == 0 ? fri.trees[0].polQueries[q][t].valuesJson() : fri.trees[0].polQueries[q][t].siblingsJson());
+            const char *nm = nTrees == 5 ? names[t] : names[t < 4 ? t : 4];
+            o += std::string(pass == 0 ? ",\"s0_vals" : ",\"s0_siblings") + nm + "\":" + mi_json::arr(items);
         }
-        const char *nm = nTrees == 5 ? names[t] : names[t < 4 ? t : 4];
-        o += std::string(",\"s0_vals") + nm + "\":" + mi_json::arr(vals) + ",\"s0_siblings" + nm + "\":" + mi_json::arr(sibs);
-    }
     o += ",\"finalPol\":" + fri.polJson();
     if (withPublics) o += ",\"publics\":" + mi_json::arr(fproof.publics);
     return o + "}";

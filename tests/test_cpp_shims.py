@@ -36,6 +36,50 @@ def test_starkstruct_json_top_level_keys_only(tmp_path):
     assert r.returncode == 0 and "json ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/testvectors"), reason="/root/reference not present")
+@pytest.mark.parametrize("rel", ["aggregatedProof/recursive1.zkin.proof_0.json", "aggregatedProof/recursive1.zkin.proof_2.json",
+                                 "finalProof/recursive2.zkin.proof_01.json", "finalProof/recursive2.zkin.proof_23.json"])
+def test_zkin_serialisation_is_byte_identical_to_reference_produced_files(tmp_path, rel):
+    """the reference's own zkin files are proofs serialised by proof2zkinStark + nlohmann::ordered_json.  Their
+    VALUES are loaded into this repo's FRIProof container and written back through host/proof2zkinStark.hpp: the text must
+    equal the reference-produced file byte for byte (key order, nesting, decimal strings).  CPU only."""
+    import json
+    import numpy as np
+    raw = open(os.path.join("/root/reference/testvectors", rel)).read()
+    z = json.loads(raw)
+    nq, steps = len(z["s0_vals1"]), 5
+    U = lambda x: [int(v) for v in np.array(x, dtype=object).reshape(-1)]
+    trees = []                                         # (key suffix, width, levels) of the five commitment trees; 2 is absent
+    for nm in ("1", "2", "3", "4", "C"):
+        if "s0_vals" + nm in z:
+            trees.append((nm, len(z["s0_vals" + nm][0]), len(z["s0_siblings" + nm][0])))
+        else:
+            trees.append((nm, 0, 0))
+    blob = [nq, steps, len(z["finalPol"]), len(z["evals"]), len(z["publics"])]
+    for (_, w, l) in trees:
+        blob += [w, l]
+    for i in range(1, steps):
+        blob += [len(z[f"s{i}_vals"][0]), len(z[f"s{i}_siblings"][0])]
+    for r in ("root1", "root2", "root3", "root4"):
+        blob += U(z[r])
+    blob += U(z["evals"])
+    for i in range(1, steps):
+        blob += U(z[f"s{i}_root"])
+        for q in range(nq):
+            blob += U(z[f"s{i}_vals"][q]) + U(z[f"s{i}_siblings"][q])
+    for q in range(nq):
+        for (nm, w, l) in trees:
+            if w:
+                blob += U(z["s0_vals" + nm][q]) + U(z["s0_siblings" + nm][q])
+    blob += U(z["finalPol"]) + U(z["publics"])
+    np.array(blob, dtype=np.uint64).tofile(tmp_path / "blob.bin")
+    exe = str(tmp_path / "test_zkin_format")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "test_zkin_format.cpp"), "-o", exe])
+    subprocess.check_call([exe, str(tmp_path / "blob.bin"), str(tmp_path / "out.json")])
+    assert open(tmp_path / "out.json").read() == raw.strip()
+
+
 @pytest.mark.gpu
 def test_starkpil_flow_on_gpu(tmp_path):
     import json
