@@ -173,6 +173,7 @@ int mi_zhinv(mi_ctx *ctx, uint64_t *out, unsigned nbits, unsigned nbits_ext);
  * decode by the reference interpreter's opcode numbering, copy forwarding, Sethi-Ullman reschedule, temp re-allocation);
  * a null ctx compiles for mi_dbg_host_chelpers_run only.  `step` names the opcode numbering of the tables. */
 #define MI_CHELPERS_STEP42NS 42
+#define MI_CHELPERS_STEP52NS 52 /* ZkevmSteps::step52ns_parser_first_avx (zkevm.chelpers.step52ns.parser.cpp; starks.cpp:370): the FRI polynomial f_2ns */
 typedef struct mi_chelpers_prog mi_chelpers_prog;
 /* A section of the polynomial area the program reads (stark_info mapOffsets / mapSectionsN, e.g. cm1_2ns): element (row, col)
  * at pols[offset + row * ncols + col], row < nrows.  Every polynomial operand of the program must lie in a declared section:
@@ -190,7 +191,13 @@ typedef struct {
     uint64_t x_stride;
     const uint64_t *zhinv;      /* HOST: the ZhInv table (mi_zhinv); zi.zhInv(i) = zhinv[i % n_zhinv] (zhInv.hpp:22-25) */
     uint64_t n_zhinv;
-    uint64_t *q;                /* device: params.q_2ns, row i at q[3 i .. 3 i + 3) */
+    uint64_t *q;                /* device: params.q_2ns, row i at q[3 i .. 3 i + 3) (step42ns output) */
+    /* step52ns only */
+    const uint64_t *evals;      /* HOST: params.evals, n_evals x 3 */
+    uint64_t n_evals;
+    const uint64_t *xdiv;       /* device: params.xDivXSubXi, rows x 3 */
+    const uint64_t *xdivw;      /* device: params.xDivXSubWXi, rows x 3 */
+    uint64_t *f;                /* device: params.f_2ns, row i at f[3 i .. 3 i + 3) (step52ns output) */
 } mi_chelpers_params;
 /* sections: the n_sections (<= 6) sections of params.pols the program reads; n_const = pConstPols2ns->numPols();
  * nrows_ext = rows of the extended domain (the constant polynomials and x_2ns have that many rows). */

@@ -47,20 +47,21 @@ using gl::E3;
 
 namespace chp {
 
-enum Kind : uint32_t { K_NONE = 0, K_T1, K_T3, K_POL, K_POLS, K_NUM, K_CONST, K_CONSTS, K_CHAL, K_PUB, K_POL3, K_POL3S, K_X, K_ZHINV, K_Q };
-enum Cls : uint32_t { C_ADD = 0, C_SUB, C_MUL, C_COPY, C_STOREQ };
+enum Kind : uint32_t { K_NONE = 0, K_T1, K_T3, K_POL, K_POLS, K_NUM, K_CONST, K_CONSTS, K_CHAL, K_PUB, K_POL3, K_POL3S, K_X, K_ZHINV, K_Q,
+                       K_EVAL, K_XD, K_XDW }; // step52ns: params.evals[k], params.xDivXSubXi[i], params.xDivXSubWXi[i] (all dimension 3)
+enum Cls : uint32_t { C_ADD = 0, C_SUB, C_MUL, C_COPY, C_STOREQ, C_STOREF }; // STOREQ: q = zhInv * a; STOREF: f = a
 
 static int kind_nargs(Kind k)
 {
     switch (k) {
-    case K_T1: case K_T3: case K_NUM: case K_CONST: case K_CHAL: case K_PUB: return 1;
+    case K_T1: case K_T3: case K_NUM: case K_CONST: case K_CHAL: case K_PUB: case K_EVAL: return 1;
     case K_POL: case K_POL3: return 2;   // offset, row stride
     case K_CONSTS: return 3;             // column, row shift, modulus
     case K_POLS: case K_POL3S: return 4; // offset, row shift, modulus, row stride
     default: return 0;
     }
 }
-static int kind_dim(Kind k) { return (k == K_T3 || k == K_CHAL || k == K_POL3 || k == K_POL3S || k == K_Q) ? 3 : 1; }
+MI_HD bool kind_is3(uint32_t k) { return k == K_T3 || k == K_CHAL || k == K_POL3 || k == K_POL3S || k == K_Q || k == K_EVAL || k == K_XD || k == K_XDW; }
 
 // what one opcode of the reference interpreter does: dst kind, operation, the kinds of its two sources IN ARGUMENT ORDER
 // (argument 0 is always the destination temp; then the arguments of source a, then those of source b)
@@ -116,19 +117,57 @@ static const std::vector<uint64_t> *fused_step42ns(uint64_t op)
     return nullptr;
 }
 
+// ---- step52ns (zkevm.chelpers.step52ns.parser.cpp, step52ns_parser_first :520-690 = step52ns_parser_first_avx :10-190): an
+// accumulator machine over three extension registers tmp / tmp1 / tmp2 (here the extension temporaries 0 / 1 / 2), the
+// challenges 5 and 6, params.evals, xDivXSubXi / xDivXSubWXi at the row, and the output f_2ns.  Only the polynomial
+// operands take arguments; registers and challenge indices are fixed by the opcode.
+struct Role52 { Cls cls; uint64_t dst; Kind a; uint64_t a_fixed; Kind b; uint64_t b_fixed; };
+static bool role_step52ns(uint64_t op, Role52 &r)
+{
+#define R(c, d, ka, fa, kb, fb) r = {c, d, ka, fa, kb, fb}; return true
+    switch (op) {
+    case 0: R(C_MUL, 0, K_POL, 0, K_CHAL, 5);    // tmp = pols[..] * challenges[5]            (mul13c)
+    case 1: R(C_MUL, 0, K_T3, 0, K_CHAL, 5);     // tmp = tmp * challenges[5]
+    case 2: R(C_MUL, 0, K_T3, 0, K_CHAL, 6);     // tmp = tmp * challenges[6]
+    case 3: R(C_MUL, 1, K_T3, 0, K_CHAL, 5);     // tmp1 = tmp * challenges[5]
+    case 4: R(C_MUL, 0, K_T3, 2, K_CHAL, 6);     // tmp = tmp2 * challenges[6]
+    case 5: R(C_MUL, 0, K_T3, 0, K_XD, 0);       // tmp = tmp * xDivXSubXi[i]
+    case 6: R(C_MUL, 0, K_T3, 0, K_XDW, 0);      // tmp = tmp * xDivXSubWXi[i]
+    case 7: R(C_ADD, 0, K_T3, 0, K_T3, 2);       // tmp = tmp + tmp2
+    case 8: R(C_ADD, 0, K_T3, 1, K_T3, 0);       // tmp = tmp1 + tmp
+    case 9: R(C_ADD, 0, K_T3, 0, K_POL3, 0);     // tmp = tmp + pols[..] (extension element)
+    case 10: R(C_ADD, 0, K_T3, 0, K_POL, 0);     // tmp = tmp + pols[..] (base element)       (add31)
+    case 11: R(C_SUB, 2, K_POL, 0, K_EVAL, 0);   // tmp2 = pols[..] - evals[k]                (sub13c)
+    case 12: R(C_SUB, 2, K_POL3, 0, K_EVAL, 0);  // tmp2 = pols[..] - evals[k]                (sub33c)
+    case 13: R(C_SUB, 2, K_CONST, 0, K_EVAL, 0); // tmp2 = const[c] - evals[k]
+    case 14: R(C_SUB, 0, K_CONST, 5, K_EVAL, 0); // tmp = const[5] - evals[0]: both indices are literals in the reference
+    case 15: R(C_STOREF, 0, K_T3, 0, K_NONE, 0); // f_2ns[i] = tmp
+    }
+#undef R
+    return false;
+}
+static const std::vector<uint64_t> *fused_step52ns(uint64_t op)
+{
+    static const std::vector<uint64_t> f16 = {1, 10}, f17 = {1, 9}, f18 = {2, 11, 7}, f19 = {2, 13, 7}, f20 = {2, 12, 7};
+    switch (op) {
+    case 16: return &f16; case 17: return &f17; case 18: return &f18; case 19: return &f19; case 20: return &f20;
+    }
+    return nullptr;
+}
+
 // ---- device instruction (64 bytes, wave-uniform, fetched through the scalar cache)
 struct Opd { uint64_t off; uint32_t stride, shift; uint64_t mod; }; // meaning by kind, see load_operand
 struct DInstr {
-    uint32_t op;  // bits 0-3 class, 4-7 dst kind, 8-11 kind of a, 12-15 kind of b
-    uint32_t dst; // LDS word of the destination temp (ext temps take 3 consecutive words)
+    uint32_t op;  // bits 0-7 class, 8-15 dst kind, 16-23 kind of a, 24-31 kind of b
+    uint32_t dst; // word of the destination temp (ext temps take 3 consecutive words)
     Opd a, b;
     uint64_t pad;
 };
 static_assert(sizeof(DInstr) == 64, "instruction must be 64 bytes");
 
 struct RunArgs { // host debug executor: operands read in place
-    const u64 *pols, *cpols, *x, *zhinv, *chal, *pub;
-    u64 *q;
+    const u64 *pols, *cpols, *x, *zhinv, *chal, *pub, *evals, *xd, *xdw;
+    u64 *q, *f;
     uint64_t n_const, x_stride, n_zhinv, row0, row_end;
 };
 
@@ -184,7 +223,10 @@ struct mi_chelpers_prog {
     uint64_t cold_reads = 0, temp_reads = 0;
     uint64_t n_words = 0;          // LDS words per row
     uint64_t stats[8] = {0};       // ops in, micro-ops, after copy forwarding, scheduled, live words before, after, t1 slots, t3 slots
-    uint64_t max_chal = 0, max_pub = 0;
+    uint64_t max_chal = 0, max_pub = 0, max_eval = 0;
+    int step = 0;
+    struct Patch { uint32_t instr, eval, word; };
+    std::vector<Patch> eval_patches; // device instructions whose a_imm is evals[eval][word] of the running proof
 };
 
 namespace chp {
@@ -222,6 +264,12 @@ MI_HD void load_operand(uint32_t kind, const Opd &o, uint64_t r, const RunArgs &
     case K_CHAL: v[0] = P.chal[o.off * 3]; v[1] = P.chal[o.off * 3 + 1]; v[2] = P.chal[o.off * 3 + 2]; break;
     case K_PUB: v[0] = P.pub[o.off]; break;
     case K_X: v[0] = gl::canon(P.x[r * P.x_stride]); break;
+    case K_EVAL: v[0] = P.evals[o.off * 3]; v[1] = P.evals[o.off * 3 + 1]; v[2] = P.evals[o.off * 3 + 2]; break;
+    case K_XD: case K_XDW: {
+        const u64 *p = (kind == K_XD ? P.xd : P.xdw) + r * 3;
+        v[0] = gl::canon(p[0]); v[1] = gl::canon(p[1]); v[2] = gl::canon(p[2]);
+        break;
+    }
     case K_ZHINV: v[0] = P.zhinv[r % P.n_zhinv]; break;
     default: v[0] = 0; break;
     }
@@ -230,12 +278,11 @@ MI_HD void load_operand(uint32_t kind, const Opd &o, uint64_t r, const RunArgs &
 template <typename Tmp>
 MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P, Tmp &tmp)
 {
-    const uint32_t cls = I.op & 15, dk = (I.op >> 4) & 15, ak = (I.op >> 8) & 15, bk = (I.op >> 12) & 15;
+    const uint32_t cls = I.op & 255, dk = (I.op >> 8) & 255, ak = (I.op >> 16) & 255, bk = I.op >> 24;
     u64 a[3], b[3], o[3];
     load_operand(ak, I.a, r, P, tmp, a);
     load_operand(bk, I.b, r, P, tmp, b);
-    const bool a3 = ak == K_T3 || ak == K_CHAL || ak == K_POL3 || ak == K_POL3S;
-    const bool b3 = bk == K_T3 || bk == K_CHAL || bk == K_POL3 || bk == K_POL3S;
+    const bool a3 = kind_is3(ak), b3 = kind_is3(bk);
     switch (cls) {
     case C_ADD: // a dimension-1 operand is (v, 0, 0): Goldilocks3::add13 / add31 / add1c3c
         o[0] = gl::add(a[0], b[0]); o[1] = gl::add(a[1], b[1]); o[2] = gl::add(a[2], b[2]);
@@ -255,7 +302,7 @@ MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P
             o[0] = gl::mul(a[0], b[0]); o[1] = o[2] = 0;
         }
         break;
-    default: // C_COPY
+    default: // C_COPY, C_STOREF
         o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
         break;
     }
@@ -263,8 +310,9 @@ MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P
         tmp.set(I.dst, o[0]);
     } else if (dk == K_T3) {
         tmp.set(I.dst, o[0]); tmp.set(I.dst + 1, o[1]); tmp.set(I.dst + 2, o[2]);
-    } else if (active) { // K_Q: (Goldilocks3::Element &)params.q_2ns[i * 3]
-        P.q[r * 3] = o[0]; P.q[r * 3 + 1] = o[1]; P.q[r * 3 + 2] = o[2];
+    } else if (active && dk == K_Q) { // (Goldilocks3::Element &)params.q_2ns[i * 3] (step42ns) / params.f_2ns[i * 3] (step52ns)
+        u64 *out = cls == C_STOREF ? P.f : P.q;
+        out[r * 3] = o[0]; out[r * 3 + 1] = o[1]; out[r * 3 + 2] = o[2];
     }
 }
 
@@ -423,9 +471,9 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
 
 // ------------------------------------------------------------------ translator
 static int decode(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, std::vector<MicroOp> &out,
-                  uint64_t &max_chal, uint64_t &max_pub)
+                  uint64_t &max_chal, uint64_t &max_pub, uint64_t &max_eval)
 {
-    MI_REQUIRE(step == MI_CHELPERS_STEP42NS, "only the step42ns opcode numbering is known to this build");
+    MI_REQUIRE(step == MI_CHELPERS_STEP42NS || step == MI_CHELPERS_STEP52NS, "only the step42ns and step52ns opcode numberings are known to this build");
     uint64_t ia = 0;
     auto take = [&](Kind k, HOpd &o) -> bool {
         o.k = k;
@@ -436,8 +484,60 @@ static int decode(int step, const uint64_t *ops, uint64_t nops, const uint64_t *
         if (k == K_NUM) o.v[0] = gl::canon(o.v[0]); // Goldilocks::fromU64
         if (k == K_CHAL) max_chal = std::max(max_chal, o.v[0] + 1);
         if (k == K_PUB) max_pub = std::max(max_pub, o.v[0] + 1);
+        if (k == K_EVAL) max_eval = std::max(max_eval, o.v[0] + 1);
         return true;
     };
+    auto one52 = [&](uint64_t op) -> int { // registers and challenge indices are fixed by the opcode, only polynomials take arguments
+        Role52 r;
+        if (!role_step52ns(op, r)) {
+            mi_set_error("mi_chelpers_compile: unknown opcode %llu", (unsigned long long)op);
+            return MI_ERR_INVALID;
+        }
+        MicroOp m;
+        m.cls = r.cls;
+        m.dst = r.cls == C_STOREF ? K_Q : K_T3;
+        m.dst_slot = r.dst;
+        const Kind ks[2] = {r.a, r.b};
+        const uint64_t fixed[2] = {r.a_fixed, r.b_fixed};
+        HOpd *os[2] = {&m.a, &m.b};
+        for (int s2 = 0; s2 < 2; s2++) {
+            HOpd &o = *os[s2];
+            o.k = ks[s2];
+            switch (ks[s2]) {
+            case K_T3: o.v[0] = fixed[s2]; break;
+            case K_CHAL: o.v[0] = fixed[s2]; max_chal = std::max(max_chal, fixed[s2] + 1); break;
+            case K_POL: case K_POL3:
+                if (ia + 2 > nargs) { mi_set_error("mi_chelpers_compile: argument table too short"); return MI_ERR_INVALID; }
+                o.v[0] = args[ia]; o.v[1] = args[ia + 1]; ia += 2;
+                break;
+            case K_CONST: case K_EVAL:
+                if (op == 14) { o.v[0] = fixed[s2]; } // both literals in the reference (const column 5, evals[0])
+                else {
+                    if (ia + 1 > nargs) { mi_set_error("mi_chelpers_compile: argument table too short"); return MI_ERR_INVALID; }
+                    o.v[0] = args[ia++];
+                }
+                if (ks[s2] == K_EVAL) max_eval = std::max(max_eval, o.v[0] + 1);
+                break;
+            default: break; // K_XD, K_XDW, K_NONE
+            }
+        }
+        out.push_back(m);
+        return MI_OK;
+    };
+    if (step == MI_CHELPERS_STEP52NS) {
+        for (uint64_t k = 0; k < nops; k++) {
+            if (const std::vector<uint64_t> *f = fused_step52ns(ops[k])) {
+                for (uint64_t sub : *f) MI_TRY(one52(sub));
+            } else {
+                MI_TRY(one52(ops[k]));
+            }
+        }
+        if (ia != nargs) {
+            mi_set_error("mi_chelpers_compile: program consumes %llu arguments, table holds %llu", (unsigned long long)ia, (unsigned long long)nargs);
+            return MI_ERR_INVALID;
+        }
+        return MI_OK;
+    }
     auto one = [&](uint64_t op) -> int {
         Role r;
         if (!role_step42ns(op, r)) {
@@ -569,7 +669,7 @@ static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
         std::vector<uint8_t> done(n, 0);
         std::vector<std::pair<size_t, int>> stack;
         for (size_t root = 0; root < n; root++) {
-            if (prog[root].cls != C_STOREQ) continue; // only stores have effects: everything else is reached from them or dead
+            if (prog[root].cls != C_STOREQ && prog[root].cls != C_STOREF) continue; // only stores have effects: the rest is reached from them or dead
             stack.push_back({root, 0});
             while (!stack.empty()) {
                 auto [node, state] = stack.back();
@@ -630,7 +730,7 @@ static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
     for (uint32_t i : order) {
         const MicroOp &m = prog[i];
         DInstr d = {};
-        d.op = (uint32_t)m.cls | ((uint32_t)m.dst << 4) | ((uint32_t)m.a.k << 8) | ((uint32_t)m.b.k << 12);
+        d.op = (uint32_t)m.cls | ((uint32_t)m.dst << 8) | ((uint32_t)m.a.k << 16) | ((uint32_t)m.b.k << 24);
         d.dst = (m.dst == K_T1 || m.dst == K_T3) ? (uint32_t)word_of(i) : 0;
         const HOpd *hs[2] = {&m.a, &m.b};
         Opd *ds[2] = {&d.a, &d.b};
@@ -681,7 +781,7 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
         for (const HostSection &S : P->sections) {
             if (S.role != role) continue;
             if (role == 0 && (stride != S.ncols || off < S.offset || off - S.offset + width > S.ncols)) continue;
-            if (role == 1 && off + width > S.ncols) continue;
+            if (role != 0 && off + width > S.ncols) continue;
             col = S.col0 + (uint32_t)(role == 0 ? off - S.offset : off);
             return &S;
         }
@@ -690,11 +790,11 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
     std::map<uint64_t, int64_t> cur; // host temp word -> value id (the host program re-uses words)
     auto new_val = [&](int dim) { vals.push_back(Val{dim}); return (int64_t)vals.size() - 1; };
     for (const DInstr &d : P->host) {
-        const uint32_t hcls = d.op & 15, hdk = (d.op >> 4) & 15;
+        const uint32_t hcls = d.op & 255, hdk = (d.op >> 8) & 255;
         GOpd go[2];
         const Opd *os[2] = {&d.a, &d.b};
         for (int s2 = 0; s2 < 2; s2++) {
-            const uint32_t k = (d.op >> (8 + 4 * s2)) & 15;
+            const uint32_t k = (d.op >> (16 + 8 * s2)) & 255;
             const Opd &o = *os[s2];
             GOpd &g = go[s2];
             uint32_t col = 0;
@@ -710,10 +810,22 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
             case K_CHAL: g.kind = 4; g.cst = (uint32_t)o.off; g.dim = 3; break;
             case K_PUB: g.kind = 5; g.cst = (uint32_t)o.off; break;
             case K_ZHINV: g.kind = 6; break;
-            case K_POL: case K_POLS: case K_POL3: case K_POL3S: case K_CONST: case K_CONSTS: case K_X: {
-                const bool three = k == K_POL3 || k == K_POL3S, shifted = k == K_POLS || k == K_POL3S || k == K_CONSTS;
-                const int role = (k == K_CONST || k == K_CONSTS) ? 1 : k == K_X ? 2 : 0;
-                S = find(role, o.off, o.stride, three ? 3 : 1, col);
+            case K_EVAL: { // an extension constant of the running proof: three immediates patched in before every launch
+                const int64_t v3 = new_val(3);
+                for (int w = 0; w < 3; w++) {
+                    GOp c = {};
+                    c.cls = G_COPY1; c.dk = D_HOT; c.dval = v3;
+                    c.a.kind = 7; c.a.cst = (uint32_t)o.off; c.a.imm = (uint64_t)w; // kind 7: evals[cst][imm]
+                    c.b.kind = 0; c.b.imm = (uint64_t)w;
+                    ops.push_back(c);
+                }
+                g.kind = 1; g.val = v3; g.dim = 3;
+                break;
+            }
+            case K_POL: case K_POLS: case K_POL3: case K_POL3S: case K_CONST: case K_CONSTS: case K_X: case K_XD: case K_XDW: {
+                const bool three = k == K_POL3 || k == K_POL3S || k == K_XD || k == K_XDW, shifted = k == K_POLS || k == K_POL3S || k == K_CONSTS;
+                const int role = (k == K_CONST || k == K_CONSTS) ? 1 : k == K_X ? 2 : k == K_XD ? 3 : k == K_XDW ? 4 : 0;
+                S = find(role, role >= 2 ? 0 : o.off, o.stride, three ? 3 : 1, col);
                 if (!S) {
                     mi_set_error("mi_chelpers_compile: operand (offset %llu, stride %u) lies in none of the declared sections / constant polynomials / x",
                                  (unsigned long long)o.off, o.stride);
@@ -744,7 +856,7 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
         case C_ADD: op.cls = rdim == 3 ? G_ADD3 : G_ADD1; break;
         case C_SUB: op.cls = rdim == 3 ? G_SUB3 : G_SUB1; break;
         case C_MUL: case C_STOREQ: op.cls = a3 && b3 ? G_MUL33 : a3 ? G_MUL31 : b3 ? G_MUL13 : G_MUL11; break;
-        default: op.cls = rdim == 3 ? G_COPY3 : G_COPY1; break;
+        default: op.cls = rdim == 3 ? G_COPY3 : G_COPY1; break; // C_COPY, C_STOREF
         }
         if (hdk == K_T1 || hdk == K_T3) {
             op.dk = D_HOT; // decided below
@@ -813,6 +925,7 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
     // ---- emit
     P->gpu.clear();
     P->gpu.reserve(ops.size());
+    P->eval_patches.clear();
     P->cold_reads = P->temp_reads = 0;
     const uint32_t Z = 0; // the zero word, same for all lanes
     for (size_t i = 0; i < ops.size(); i++) {
@@ -844,6 +957,10 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
             }
             case 2: pk[s2] = P_STAGED; *im[s2] = o.imm; f[0] = pre_field; break;
             case 3: pk[s2] = P_IMM; *im[s2] = o.imm; f[0] = pre_field; break;
+            case 7: // word o.imm of evals[o.cst]: an immediate whose value mi_chelpers_run_dev patches in (operand a only)
+                pk[s2] = P_IMM; *im[s2] = 0; f[0] = pre_field;
+                P->eval_patches.push_back({(uint32_t)i, o.cst, (uint32_t)o.imm});
+                break;
             case 4: f[0] = cst_off + (o.cst * 3) * 8; f[1] = f[0] + 8; f[2] = f[0] + 16; break;
             case 5: f[0] = cst_off + (chal_words + o.cst) * 8; break;
             case 6: pk[s2] = P_ZHINV; f[0] = pre_field; break;
@@ -874,7 +991,7 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
     if (!out) return MI_ERR_INVALID;
     *out = nullptr;
     MI_REQUIRE(ops && (args || nargs == 0) && nops > 0, "null program tables");
-    MI_REQUIRE(n_sections + 2 <= (uint64_t)chp::MAX_SECTIONS && (sections || n_sections == 0), "at most 6 sections");
+    MI_REQUIRE(n_sections + 4 <= (uint64_t)chp::MAX_SECTIONS && (sections || n_sections == 0), "at most 4 sections");
     std::vector<chp::MicroOp> prog;
     mi_chelpers_prog *P = new mi_chelpers_prog();
     P->stats[0] = nops;
@@ -885,15 +1002,20 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
         P->sections.push_back({sections[i].offset, sections[i].ncols, sections[i].nrows, (uint32_t)col0, 0});
         col0 += sections[i].ncols;
     }
-    int st = chp::decode(step, ops, nops, args, nargs, prog, P->max_chal, P->max_pub);
-    bool uses_const = false, uses_x = false;
+    P->step = step;
+    int st = chp::decode(step, ops, nops, args, nargs, prog, P->max_chal, P->max_pub, P->max_eval);
+    bool uses_const = false, uses_x = false, uses_xd = false, uses_xdw = false;
     for (const chp::MicroOp &m : prog)
         for (const chp::HOpd *o : {&m.a, &m.b}) {
             uses_const |= o->k == chp::K_CONST || o->k == chp::K_CONSTS;
             uses_x |= o->k == chp::K_X;
+            uses_xd |= o->k == chp::K_XD;
+            uses_xdw |= o->k == chp::K_XDW;
         }
     if (uses_const && n_const) { P->sections.push_back({0, n_const, nrows_ext, (uint32_t)col0, 1}); col0 += n_const; }
     if (uses_x) { P->sections.push_back({0, 1, nrows_ext, (uint32_t)col0, 2}); col0 += 1; }
+    if (uses_xd) { P->sections.push_back({0, 3, nrows_ext, (uint32_t)col0, 3}); col0 += 3; }   // xDivXSubXi: nrows_ext x 3
+    if (uses_xdw) { P->sections.push_back({0, 3, nrows_ext, (uint32_t)col0, 4}); col0 += 3; } // xDivXSubWXi
     P->staged_cols = col0;
     if (st == MI_OK) st = chp::translate(P, prog);
     // the kernel's form needs the sections; a null context without sections compiles for the host debug executor only
@@ -959,10 +1081,12 @@ extern "C" int mi_chelpers_stats(const mi_chelpers_prog *p, uint64_t out[16])
 static int check_params(const mi_chelpers_prog *p, const mi_chelpers_params *a, uint64_t row0, uint64_t nrows)
 {
     MI_REQUIRE(p && a, "null program or parameters");
-    MI_REQUIRE(a->pols && a->q, "null polynomial memory or output");
+    MI_REQUIRE(a->pols && (p->step == MI_CHELPERS_STEP52NS ? a->f != nullptr : a->q != nullptr), "null polynomial memory or output");
+    MI_REQUIRE(a->n_evals >= p->max_eval && (a->evals || p->max_eval == 0), "program reads more evaluations than were given");
     MI_REQUIRE(a->n_challenges >= p->max_chal && (a->challenges || p->max_chal == 0), "program reads more challenges than were given");
     MI_REQUIRE(a->n_publics >= p->max_pub && (a->publics || p->max_pub == 0), "program reads more public inputs than were given");
-    MI_REQUIRE(a->zhinv && a->n_zhinv > 0 && a->n_zhinv <= 256 && is_pow2(a->n_zhinv), "ZhInv table must hold 2^k <= 256 values (zhInv.cpp:7-31)");
+    if (p->step == MI_CHELPERS_STEP42NS)
+        MI_REQUIRE(a->zhinv && a->n_zhinv > 0 && a->n_zhinv <= 256 && is_pow2(a->n_zhinv), "ZhInv table must hold 2^k <= 256 values (zhInv.cpp:7-31)");
     MI_REQUIRE(row0 + nrows >= row0, "row range overflows");
     return MI_OK;
 }
@@ -979,7 +1103,8 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     MI_REQUIRE(row0 + nrows <= p->nrows_ext, "rows beyond the extended domain the program was compiled for");
     // LDS: the program's layout (build_staged) + the three small tables; the benchmarking knob can only enlarge it
     const uint32_t chal_words = (uint32_t)p->max_chal * 3, pub_words = (uint32_t)p->max_pub;
-    const uint32_t cst_words = chal_words + pub_words + (uint32_t)a->n_zhinv;
+    const uint64_t n_zh = p->step == MI_CHELPERS_STEP42NS ? a->n_zhinv : 1; // step52ns reads no ZhInv: one dummy word keeps the mask valid
+    const uint32_t cst_words = chal_words + pub_words + (uint32_t)n_zh;
     size_t lds = (size_t)p->cst_off + (size_t)cst_words * 8;
     lds = std::max(lds, (size_t)c->chelpers_min_words * 512);
     MI_REQUIRE(lds <= 160 * 1024, "program needs more temporaries per row than the LDS holds");
@@ -989,7 +1114,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     u64 stage[576] = {0};
     for (uint64_t i = 0; i < chal_words; i++) stage[i] = gl::canon(a->challenges[i]);
     for (uint64_t i = 0; i < pub_words; i++) stage[chal_words + i] = gl::canon(a->publics[i]);
-    for (uint64_t i = 0; i < a->n_zhinv; i++) stage[chal_words + pub_words + i] = gl::canon(a->zhinv[i]);
+    for (uint64_t i = 0; i < n_zh && a->zhinv; i++) stage[chal_words + pub_words + i] = gl::canon(a->zhinv[i]);
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // an earlier run may still be reading the scratch
     MI_HIP_CHECK(hipMemcpyAsync(c->chelpers_scratch, stage, sizeof(stage), hipMemcpyHostToDevice, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `stage` is on this stack frame
@@ -1020,7 +1145,9 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
         G.nrows = S.nrows;
         if (S.role == 0) { G.ptr = (const u64 *)a->pols + S.offset; G.pitch = S.ncols; }
         else if (S.role == 1) { MI_REQUIRE(a->const_pols, "null constant polynomials"); G.ptr = (const u64 *)a->const_pols; G.pitch = a->n_const; }
-        else { MI_REQUIRE(a->x, "null x"); G.ptr = (const u64 *)a->x; G.pitch = a->x_stride; }
+        else if (S.role == 2) { MI_REQUIRE(a->x, "null x"); G.ptr = (const u64 *)a->x; G.pitch = a->x_stride; }
+        else if (S.role == 3) { MI_REQUIRE(a->xdiv, "null xDivXSubXi"); G.ptr = (const u64 *)a->xdiv; G.pitch = 3; }
+        else { MI_REQUIRE(a->xdivw, "null xDivXSubWXi"); G.ptr = (const u64 *)a->xdivw; G.pitch = 3; }
     }
     A.n_instr = (uint32_t)p->gpu.size();
     A.tile_off = p->tile_off;
@@ -1030,9 +1157,15 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     A.zh_off = chal_words + pub_words;
     A.lds_bytes = (uint32_t)lds;
     A.consts = c->chelpers_scratch;
-    A.q = (u64 *)a->q;
+    A.q = (u64 *)(p->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
     A.scratch = c->chelpers_stage;
-    A.n_zhinv = a->n_zhinv;
+    if (!p->eval_patches.empty()) { // this proof's evaluations into the immediates that stand for them
+        std::vector<chp::GInstr> patched(p->gpu);
+        for (const mi_chelpers_prog::Patch &pt : p->eval_patches) patched[pt.instr].a_imm = gl::canon(a->evals[(uint64_t)pt.eval * 3 + pt.word]);
+        MI_HIP_CHECK(hipMemcpyAsync(p->dev, patched.data(), patched.size() * sizeof(chp::GInstr), hipMemcpyHostToDevice, c->stream));
+        MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `patched` dies with this scope
+    }
+    A.n_zhinv = n_zh;
     A.row0 = row0;
     A.row_end = row0 + nrows;
     A.n_groups = n_groups;
@@ -1051,7 +1184,8 @@ extern "C" int mi_dbg_host_chelpers_run(const mi_chelpers_prog *p, const mi_chel
 {
     MI_TRY(check_params(p, a, 0, 0));
     MI_REQUIRE(rows || nrows == 0, "null row list");
-    std::vector<u64> chal(p->max_chal * 3 + 1), pub(p->max_pub + 1), zh(a->n_zhinv);
+    std::vector<u64> chal(p->max_chal * 3 + 1), pub(p->max_pub + 1), zh(a->n_zhinv + 1), ev(p->max_eval * 3 + 1);
+    for (uint64_t i = 0; i < p->max_eval * 3; i++) ev[i] = gl::canon(a->evals[i]);
     for (uint64_t i = 0; i < p->max_chal * 3; i++) chal[i] = gl::canon(a->challenges[i]);
     for (uint64_t i = 0; i < p->max_pub; i++) pub[i] = gl::canon(a->publics[i]);
     for (uint64_t i = 0; i < a->n_zhinv; i++) zh[i] = gl::canon(a->zhinv[i]);
@@ -1063,9 +1197,13 @@ extern "C" int mi_dbg_host_chelpers_run(const mi_chelpers_prog *p, const mi_chel
     A.pub = pub.data();
     A.zhinv = zh.data();
     A.q = (u64 *)a->q;
+    A.f = (u64 *)a->f;
+    A.evals = ev.data();
+    A.xd = (const u64 *)a->xdiv;
+    A.xdw = (const u64 *)a->xdivw;
     A.n_const = a->n_const;
     A.x_stride = a->x_stride;
-    A.n_zhinv = a->n_zhinv;
+    A.n_zhinv = a->n_zhinv ? a->n_zhinv : 1;
     std::vector<u64> words(p->n_words + 3);
     chp::HostTmp tmp = {words.data()};
     for (uint64_t k = 0; k < nrows; k++)

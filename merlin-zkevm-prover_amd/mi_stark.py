@@ -304,10 +304,12 @@ class ChelpersParams(ctypes.Structure):
     """mi_chelpers_params (include/mi_stark.h)"""
     _fields_ = [("pols", ctypes.c_void_p), ("const_pols", ctypes.c_void_p), ("n_const", u64),
                 ("challenges", ctypes.c_void_p), ("n_challenges", u64), ("publics", ctypes.c_void_p), ("n_publics", u64),
-                ("x", ctypes.c_void_p), ("x_stride", u64), ("zhinv", ctypes.c_void_p), ("n_zhinv", u64), ("q", ctypes.c_void_p)]
+                ("x", ctypes.c_void_p), ("x_stride", u64), ("zhinv", ctypes.c_void_p), ("n_zhinv", u64), ("q", ctypes.c_void_p),
+                ("evals", ctypes.c_void_p), ("n_evals", u64), ("xdiv", ctypes.c_void_p), ("xdivw", ctypes.c_void_p), ("f", ctypes.c_void_p)]
 
 
 MI_CHELPERS_STEP42NS = 42
+MI_CHELPERS_STEP52NS = 52
 
 
 class ChelpersProgram:
@@ -338,13 +340,29 @@ class ChelpersProgram:
             self.h = ctypes.c_void_p()
 
     @staticmethod
-    def _params(pols_ptr, cpols_ptr, n_const, challenges, publics, x_ptr, x_stride, zhinv, q_ptr, keep):
+    def _params(pols_ptr, cpols_ptr, n_const, challenges, publics, x_ptr, x_stride, zhinv, q_ptr, keep, evals=(), xdiv_ptr=None, xdivw_ptr=None, f_ptr=None):
         ch = np.ascontiguousarray(challenges, dtype=np.uint64).reshape(-1)
         pb = np.ascontiguousarray(publics, dtype=np.uint64).reshape(-1)
         zh = np.ascontiguousarray(zhinv, dtype=np.uint64).reshape(-1)
-        keep.extend([ch, pb, zh])
+        ev = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1)
+        keep.extend([ch, pb, zh, ev])
         return ChelpersParams(pols_ptr, cpols_ptr, n_const, ch.ctypes.data if ch.size else None, ch.size // 3,
-                              pb.ctypes.data if pb.size else None, pb.size, x_ptr, x_stride, zh.ctypes.data, zh.size, q_ptr)
+                              pb.ctypes.data if pb.size else None, pb.size, x_ptr, x_stride, zh.ctypes.data if zh.size else None, zh.size, q_ptr,
+                              ev.ctypes.data if ev.size else None, ev.size // 3, xdiv_ptr, xdivw_ptr, f_ptr)
+
+    def run52(self, pols, const_pols, n_const, challenges, evals, xdiv, xdivw, f, row0, nrows):
+        """step52ns: pols / const_pols / xdiv / xdivw / f device tensors; challenges / evals host arrays."""
+        keep = []
+        P = self._params(pols.data_ptr(), const_pols.data_ptr() if const_pols is not None else None, n_const, challenges, (), None, 0, (), None, keep,
+                         evals=evals, xdiv_ptr=xdiv.data_ptr(), xdivw_ptr=xdivw.data_ptr(), f_ptr=f.data_ptr())
+        _check(lib().mi_chelpers_run_dev(self.ctx.h, self.h, ctypes.byref(P), u64(row0), u64(nrows)))
+
+    def run52_host(self, pols, const_pols, n_const, challenges, evals, xdiv, xdivw, f, rows):
+        keep = []
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, (), None, 0, (), None, keep,
+                         evals=evals, xdiv_ptr=xdiv.ctypes.data, xdivw_ptr=xdivw.ctypes.data, f_ptr=f.ctypes.data)
+        _check(lib().mi_dbg_host_chelpers_run(self.h, ctypes.byref(P), _hp(rows), u64(rows.size)))
 
     def run(self, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, row0, nrows):
         """pols / const_pols / x / q: device tensors (int64 containers); challenges / publics / zhinv: host arrays."""

@@ -196,3 +196,67 @@ int glo_chelpers_step42ns(const uint64_t *ops, uint64_t nops, const uint64_t *ar
     }
     return status;
 }
+
+/* ------------------------------------------------------------------ step52ns: the FRI polynomial f_2ns
+ * ZkevmSteps::step52ns_parser_first (zkevm.chelpers.step52ns.parser.cpp:520-690; same 21 cases as the AVX function :10-190):
+ * three extension registers tmp / tmp1 / tmp2, challenges 5 and 6, params.evals, xDivXSubXi[i] / xDivXSubWXi[i], output
+ * f_2ns[i].  (The reference pre-adds the challenge components for its Karatsuba multiply; any exact extension multiply gives
+ * the same element.)  Returns 0, -1 (unknown opcode), -2 (argument count mismatch). */
+static int chp_step52ns_op(uint64_t op, const uint64_t *args, uint64_t ia, uint64_t i, uint64_t *tmp, uint64_t *tmp1, uint64_t *tmp2,
+                           const uint64_t *pols, const uint64_t *cpols, uint64_t numpols, const uint64_t *chal, const uint64_t *evals,
+                           const uint64_t *xd, const uint64_t *xdw, uint64_t *f)
+{
+#define P52(k) (&pols[A(k) + i * A((k) + 1)])
+    switch (op) {
+    case 0: mul13(tmp, glo_canon(*P52(0)), &chal[15]); return 2;                    /* tmp = pols * challenges[5] */
+    case 1: mul33(tmp, tmp, &chal[15]); return 0;
+    case 2: mul33(tmp, tmp, &chal[18]); return 0;
+    case 3: mul33(tmp1, tmp, &chal[15]); return 0;
+    case 4: mul33(tmp, tmp2, &chal[18]); return 0;
+    case 5: mul33(tmp, tmp, &xd[3 * i]); return 0;
+    case 6: mul33(tmp, tmp, &xdw[3 * i]); return 0;
+    case 7: add33(tmp, tmp, tmp2); return 0;
+    case 8: add33(tmp, tmp1, tmp); return 0;
+    case 9: add33(tmp, tmp, P52(0)); return 2;
+    case 10: add13(tmp, glo_canon(*P52(0)), tmp); return 2;                         /* add31: ext + base */
+    case 11: { uint64_t e[3]; ld3(e, &evals[3 * A(2)]); set3(tmp2, glo_sub(glo_canon(*P52(0)), e[0]), glo_sub(0, e[1]), glo_sub(0, e[2])); return 3; } /* sub13c */
+    case 12: sub33(tmp2, P52(0), &evals[3 * A(2)]); return 3;
+    case 13: { uint64_t e[3]; ld3(e, &evals[3 * A(1)]); set3(tmp2, glo_sub(glo_canon(cpols[A(0) + i * numpols]), e[0]), glo_sub(0, e[1]), glo_sub(0, e[2])); return 2; }
+    case 14: { uint64_t e[3]; ld3(e, &evals[0]); set3(tmp, glo_sub(glo_canon(cpols[5 + i * numpols]), e[0]), glo_sub(0, e[1]), glo_sub(0, e[2])); return 0; }
+    case 15: { uint64_t t[3]; ld3(t, tmp); set3(&f[3 * i], t[0], t[1], t[2]); return 0; }
+    }
+#undef P52
+    return -1;
+}
+
+int glo_chelpers_step52ns(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, const uint64_t *pols,
+                          const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *evals,
+                          const uint64_t *xdiv, const uint64_t *xdivw, uint64_t *f, uint64_t row0, uint64_t nrows)
+{
+    static const int G16[] = {1, 10, -1}, G17[] = {1, 9, -1}, G18[] = {2, 11, 7, -1}, G19[] = {2, 13, 7, -1}, G20[] = {2, 12, 7, -1};
+    int status = 0;
+#pragma omp parallel for schedule(static)
+    for (uint64_t r = 0; r < nrows; r++) {
+        const uint64_t i = row0 + r;
+        uint64_t tmp[3] = {0, 0, 0}, tmp1[3] = {0, 0, 0}, tmp2[3] = {0, 0, 0}, ia = 0;
+        int bad = 0;
+        for (uint64_t kk = 0; kk < nops && !bad; kk++) {
+            const int *fu = ops[kk] == 16 ? G16 : ops[kk] == 17 ? G17 : ops[kk] == 18 ? G18 : ops[kk] == 19 ? G19 : ops[kk] == 20 ? G20 : NULL;
+            if (fu) {
+                for (; *fu >= 0 && !bad; fu++) {
+                    const int n = chp_step52ns_op((uint64_t)*fu, args, ia, i, tmp, tmp1, tmp2, pols, const_pols, numpols, challenges, evals, xdiv, xdivw, f);
+                    if (n < 0) bad = -1; else ia += (uint64_t)n;
+                }
+            } else {
+                const int n = chp_step52ns_op(ops[kk], args, ia, i, tmp, tmp1, tmp2, pols, const_pols, numpols, challenges, evals, xdiv, xdivw, f);
+                if (n < 0) bad = -1; else ia += (uint64_t)n;
+            }
+        }
+        if (!bad && ia != nargs) bad = -2;
+        if (bad) {
+#pragma omp critical
+            status = bad;
+        }
+    }
+    return status;
+}

@@ -111,6 +111,11 @@ int glo_chelpers_step42ns(const uint64_t *ops, uint64_t nops, const uint64_t *ar
                           const uint64_t *x, uint64_t x_stride, const uint64_t *zhinv, uint64_t n_zhinv, uint64_t *q,
                           uint64_t row0, uint64_t nrows);
 
+/* step52ns (zkevm.chelpers.step52ns.parser.cpp:520-690): challenges holds at least 7 x 3 values (indices 5 and 6 are read) */
+int glo_chelpers_step52ns(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, const uint64_t *pols,
+                          const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *evals,
+                          const uint64_t *xdiv, const uint64_t *xdivw, uint64_t *f, uint64_t row0, uint64_t nrows);
+
 void glo_set_num_threads(int n); /* OpenMP threads used by the parallel loops (0 = leave as is) */
 int glo_num_threads(void);
 

@@ -155,3 +155,77 @@ def synthetic_program(rng, nrows, sections, n_const, n_chal, n_pub, passes=3, nt
                 push(12, [ACC, int(rng.choice(sorted(def1))), ACC])
     push(69, [ACC])
     return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)
+
+
+# ------------------------------------------------------------------ step52ns (zkevm.chelpers.step52ns.parser.cpp): arguments per opcode
+NARGS52 = {0: 2, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 0, 7: 0, 8: 0, 9: 2, 10: 2, 11: 3, 12: 3, 13: 2, 14: 0, 15: 0}
+FUSED52 = {16: [1, 10], 17: [1, 9], 18: [2, 11, 7], 19: [2, 13, 7], 20: [2, 12, 7]}
+
+
+def nargs52_of(op):
+    return sum(NARGS52[o] for o in FUSED52.get(op, [op]))
+
+
+def max_eval52(ops, args):
+    """Highest params.evals index a step52ns program reads (opcodes 11 / 12 carry it third, 13 second, 14 reads evals[0])."""
+    top, ia = 0, 0
+    for op in ops:
+        for o in FUSED52.get(int(op), [int(op)]):
+            if o in (11, 12):
+                top = max(top, int(args[ia + 2]))
+            elif o == 13:
+                top = max(top, int(args[ia + 1]))
+            ia += NARGS52[o]
+    return top
+
+
+def touched_addresses52(ops, args, rows, numpols):
+    pols, cpols, ia = set(), set(), 0
+    for op in ops:
+        for o in FUSED52.get(int(op), [int(op)]):
+            a = [int(v) for v in args[ia:ia + NARGS52[o]]]
+            ia += NARGS52[o]
+            for r in rows:
+                if o in (0, 10, 11):
+                    pols.add(a[0] + r * a[1])
+                elif o in (9, 12):
+                    pols.update(range(a[0] + r * a[1], a[0] + r * a[1] + 3))
+                elif o == 13:
+                    cpols.add(a[0] + r * numpols)
+                elif o == 14:
+                    cpols.add(5 + r * numpols)
+    return pols, cpols, ia
+
+
+def synthetic_program52(rng, sections, n_const, n_evals, length=60):
+    """A random valid step52ns program in the shape of the generated one: tmp is seeded, tmp2 is defined before it is read, every
+    opcode 0..20 occurs, the program ends by storing tmp (sections: [(offset, stride)], each with at least 3 columns)."""
+    ops, args = [], []
+
+    def pol(three):
+        off, stride = sections[int(rng.integers(0, len(sections)))]
+        return [off + int(rng.integers(0, stride - (2 if three else 0))), stride]
+
+    def emit(o):
+        for part in FUSED52.get(o, [o]):
+            if part in (0, 10): args.extend(pol(False))
+            elif part == 9: args.extend(pol(True))
+            elif part == 11: args.extend(pol(False) + [int(rng.integers(0, n_evals))])
+            elif part == 12: args.extend(pol(True) + [int(rng.integers(0, n_evals))])
+            elif part == 13: args.extend([int(rng.integers(0, n_const)), int(rng.integers(0, n_evals))])
+        ops.append(o)
+
+    emit(0)                      # tmp
+    emit(11)                     # tmp2
+    emit(3)                      # tmp1
+    body = list(range(0, 15)) + list(range(16, 21))
+    for _ in range(max(1, length // len(body))):
+        rng.shuffle(body)
+        for o in body:
+            emit(int(o))
+            if o in (0, 14):     # tmp was overwritten: fold the previous state back in through tmp1 so that nothing is dead
+                emit(8)
+            emit(3)              # tmp1 = tmp * challenge 5
+    emit(8)
+    emit(15)
+    return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)

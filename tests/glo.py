@@ -240,3 +240,16 @@ def chelpers_step42ns(ops, args, pols, const_pols, n_const, challenges, publics,
            ctypes.c_void_p(x.ctypes.data), u64(x_stride), ptr(zh), u64(zh.size), ctypes.c_void_p(q.ctypes.data), u64(row0), u64(nrows))
     if st != 0:
         raise RuntimeError("glo_chelpers_step42ns: " + {-1: "unknown opcode", -2: "argument count mismatch"}.get(st, str(st)))
+
+
+def chelpers_step52ns(ops, args, pols, const_pols, n_const, challenges, evals, xdiv, xdivw, f, row0, nrows):
+    """The reference's step52ns interpreter restated (oracle/chelpers_oracle.c); f (host array) receives the rows."""
+    ops, args = A(ops), A(args)
+    ch, ev = A(challenges).reshape(-1), A(evals).reshape(-1)
+    fn = lib().glo_chelpers_step52ns
+    fn.restype = ctypes.c_int
+    st = fn(ptr(ops), u64(ops.size), ptr(args) if args.size else None, u64(args.size), ctypes.c_void_p(pols.ctypes.data),
+            ctypes.c_void_p(const_pols.ctypes.data), u64(n_const), ptr(ch), ptr(ev), ctypes.c_void_p(xdiv.ctypes.data),
+            ctypes.c_void_p(xdivw.ctypes.data), ctypes.c_void_p(f.ctypes.data), u64(row0), u64(nrows))
+    if st != 0:
+        raise RuntimeError("glo_chelpers_step52ns: " + {-1: "unknown opcode", -2: "argument count mismatch"}.get(st, str(st)))

@@ -162,3 +162,89 @@ def test_chelpers_on_gpu_matches_oracle_over_2pow16_rows():
     with pytest.raises(mi_stark.MiStarkError, match="none of the declared sections"):
         mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows)[:2], n_const=n_const, nrows_ext=nrows)
     ctx.close()
+
+
+# ------------------------------------------------------------------ step52ns (the FRI polynomial)
+REF52_CPP = "/root/reference/src/starkpil/zkevm/chelpers/zkevm.chelpers.step52ns.parser.cpp"
+REF52_HPP = "/root/reference/src/starkpil/zkevm/chelpers/zkevm.chelpers.step52ns.parser.hpp"
+
+
+def _case52(seed, nrows):
+    rng = np.random.default_rng(seed)
+    sections = [(0, 40), (nrows * 40, 9), (nrows * 49, 3)]
+    n_const, n_evals = 7, 6
+    ops, args = cp.synthetic_program52(rng, sections, n_const, n_evals, length=80)
+    pols = glo.rand_fe(rng, nrows * 52, canonical=False)
+    cpols = glo.rand_fe(rng, nrows * n_const)
+    chal, evals = glo.rand_fe(rng, 7 * 3), glo.rand_fe(rng, n_evals * 3)
+    xd, xdw = glo.rand_fe(rng, nrows * 3), glo.rand_fe(rng, nrows * 3)
+    return ops, args, pols, cpols, n_const, chal, evals, xd, xdw
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_step52ns_translated_program_matches_oracle_on_the_host(seed):
+    import mi_stark
+    nrows = 32
+    ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(seed, nrows)
+    assert set(range(21)) <= set(int(o) for o in ops)
+    want, got = np.zeros(nrows * 3, dtype=np.uint64), np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, evals, xd, xdw, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(None, ops, args, step=mi_stark.MI_CHELPERS_STEP52NS)
+    prog.run52_host(pols, cpols, n_const, chal, evals, xd, xdw, got, np.arange(nrows))
+    assert np.array_equal(got, want) and want.any()
+    prog.close()
+
+
+@needs_ref
+def test_step52ns_tables_agree_with_the_reference_and_its_program_matches_the_oracle():
+    import mi_stark
+    src = open(REF52_CPP).read()
+    body = src[src.index("void ZkevmSteps::step52ns_parser_first_avx("):]
+    body = body[:body.index("void ZkevmSteps::", 10)]
+    cases = re.split(r"\n\s*case (\d+):", body)[1:]
+    for num, text in zip(cases[0::2], cases[1::2]):
+        assert cp.nargs52_of(int(num)) == sum(int(k) for k in re.findall(r"i_args \+= (\d+);", text.split("default:")[0])), num
+    ops, args = cp.parse_reference_tables(open(REF52_HPP).read(), "op52", "args52")
+    assert ops.size == 2675 and args.size == 6761
+    n_ext, numpols, rows = 1 << 24, 360, [0, 7, (1 << 24) - 1, 999999]
+    pa, ca, used = cp.touched_addresses52(ops, args, rows, numpols)
+    assert used == args.size
+    rng = np.random.default_rng(9)
+
+    def sparse(n_elems):
+        return np.frombuffer(mmap.mmap(-1, n_elems * 8, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | getattr(mmap, "MAP_NORESERVE", 0x4000)), dtype=np.uint64)
+    pols, cpols, xd, xdw, want, got = sparse(max(pa) + 8), sparse(max(ca) + 8), sparse(n_ext * 3), sparse(n_ext * 3), sparse(n_ext * 3), sparse(n_ext * 3)
+    pols[np.fromiter(pa, dtype=np.int64)] = glo.rand_fe(rng, len(pa))
+    cpols[np.fromiter(ca, dtype=np.int64)] = glo.rand_fe(rng, len(ca))
+    for r in rows:
+        xd[3 * r:3 * r + 3], xdw[3 * r:3 * r + 3] = glo.rand_fe(rng, 3), glo.rand_fe(rng, 3)
+    n_evals = cp.max_eval52(ops, args) + 1
+    chal, evals = glo.rand_fe(rng, 7 * 3), glo.rand_fe(rng, n_evals * 3)
+    N = 1 << 23
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=[(1435 * N, 665, 2 * N), (2765 * N, 128, 2 * N), (3021 * N, 371, 2 * N), (3763 * N, 6, 2 * N)],
+                                    n_const=numpols, nrows_ext=2 * N, step=mi_stark.MI_CHELPERS_STEP52NS)
+    assert prog.stats["field_ops"] > 6000 and prog.stats["lds_ext_temps"] <= 8
+    for r in rows:
+        glo.chelpers_step52ns(ops, args, pols, cpols, numpols, chal, evals, xd, xdw, want, r, 1)
+    prog.run52_host(pols, cpols, numpols, chal, evals, xd, xdw, got, np.array(rows))
+    for r in rows:
+        assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]) and want[3 * r:3 * r + 3].any(), r
+    prog.close()
+
+
+@pytest.mark.gpu
+def test_step52ns_on_gpu_matches_oracle():
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 14
+    ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(21, nrows)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, evals, xd, xdw, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
+    f = ctx.zeros(nrows * 3)
+    for ev in (evals, glo.rand_fe(np.random.default_rng(5), evals.size)):   # the evaluations are patched in per run
+        glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, ev, xd, xdw, want, 0, nrows)
+        prog.run52(ctx.to_device(pols), ctx.to_device(cpols), n_const, chal, ev, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
+        assert np.array_equal(ctx.to_host(f), want)
+    prog.close()
+    ctx.close()
