@@ -8,14 +8,15 @@ zkEVM shape, in the reference's order and with its host/device synchronisation p
   step 1-3  extendPol + merkelize of the 665 / 128 / 371-column sections          (starks.cpp:52-59,133-140,214-221)
   step 4    step42ns constraint evaluation (the chelpers interpreter, mi_chelpers_run_dev) over the extended sections
             -> q_2ns -> INTT of q (3 cols) -> split/shift -> NTT (6 cols) -> merkelize   (starks.cpp:237-292)
-  step 5    LEv / LpEv series + INTT, evmap, xDivXSubXi / xDivXSubWXi             (starks.cpp:305-365)
+  step 5    LEv / LpEv series + INTT, evmap, xDivXSubXi / xDivXSubWXi, step52ns -> f_2ns   (starks.cpp:305-380)
   FRI       fold steps, per-step trees, query openings                            (friProve.cpp:5-190)
 
 The step42ns PROGRAM is synthetic too -- the reference's generated tables are reference source and do not travel --
 but of the real one's size and shape: as many field operations per row (17 986 after copy forwarding), every opcode,
 reading the three committed sections at their zkEVM widths and a 360-column constant section, at the real program's LDS
-footprint (24 KB of LDS per workgroup: mi_set_chelpers_min_words).  The stage-2/3 witness columns and f_2ns that the other chelpers
-steps would produce are still synthetic fills (their cost is NOT included).  Prints one JSON line: wall time of the device phases, per-phase milliseconds
+footprint (24 KB of LDS per workgroup: mi_set_chelpers_min_words).  step52ns likewise: 7101 field operations per row over the four
+committed sections, the constants, the evaluations and the two xDivXSub series.  The stage-2/3 witness columns that the base-domain
+chelpers steps (2prev / 3prev / 3) would produce are still synthetic fills (their cost is NOT included).  Prints one JSON line: wall time of the device phases, per-phase milliseconds
 named after the reference's timers, and a few size-independent checks (Merkle paths verify against the roots,
 FRI fold relation holds on the opened groups).
 """
@@ -93,6 +94,7 @@ def main():
     ap.add_argument("--workspace-gib", type=float, default=32.0)
     ap.add_argument("--check-queries", type=int, default=4)
     ap.add_argument("--n-const", type=int, default=360, help="constant polynomials read by the step42ns program")
+    ap.add_argument("--chelpers52-field-ops", type=int, default=7101, help="field operations per row of the synthetic step52ns program")
     ap.add_argument("--chelpers-field-ops", type=int, default=17986, help="field operations per row of the synthetic step42ns program")
     args = ap.parse_args()
 
@@ -167,8 +169,6 @@ def main():
     c_chal, c_pub = glo.rand_fe(prng, 5 * 3), glo.rand_fe(prng, 8)
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS", lambda: prog.run(pols_area, const_2ns, args.n_const, c_chal, c_pub, x_2ns_c, 1, zh, q_2ns, 0, NE))
     chelpers_stats = dict(prog.stats)
-    del const_2ns
-    torch.cuda.empty_cache()
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_INTT", lambda: ctx.ntt(qq1, q_2ns, NE, qdim, inverse=True))
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_MUL", lambda: ctx.q_split(qq2, qq1, N, NE, qdeg))
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_NTT", lambda: ctx.ntt(cm4, qq2, NE, qdim * qdeg))
@@ -212,9 +212,20 @@ def main():
         ctx.x_div_x_sub(xdx1, x_2ns, NE, xi)
         ctx.x_div_x_sub(xdx2, x_2ns, NE, wxi)
     timed("STARK_STEP_5_XDIVXSUB", xdiv_phase)
-    # ---- FRI
+    # step52ns: the FRI polynomial from the committed sections (incl. q), the constants, the evaluations and xDivXSubXi / xDivXSubWXi,
+    # again a synthetic program of the real one's size (2675 opcodes -> 7101 field operations per row)
     f_2ns = ctx.empty(NE * 3)
-    ctx.fill_synthetic(f_2ns, NE * 3, 0x5EED0105)              # stands in for step52ns (chelpers)
+    secs52 = secs + [(sec_off[3], qdim * qdeg)]
+    n_ev = len(pols)
+    probe = mi_stark.ChelpersProgram(None, *cpg.synthetic_program52(np.random.default_rng(52), secs52, args.n_const, n_ev, length=200), step=52)
+    per_len = probe.stats["field_ops"] / 200.0
+    probe.close()
+    f_ops, f_args = cpg.synthetic_program52(np.random.default_rng(52), secs52, args.n_const, n_ev, length=max(20, int(round(args.chelpers52_field_ops / per_len))))
+    ctx.set_chelpers_min_words(0)
+    prog52 = mi_stark.ChelpersProgram(ctx, f_ops, f_args, sections=[(o, w, NE) for (o, w) in secs52], n_const=args.n_const, nrows_ext=NE, step=52)
+    f_chal = glo.rand_fe(prng, 7 * 3)
+    timed("STARK_STEP_5_CALCULATE_EXPS_2NS", lambda: prog52.run52(pols_area, const_2ns, args.n_const, f_chal, h_evals, xdx1, xdx2, f_2ns, 0, NE))
+    chelpers52_stats = dict(prog52.stats)
     pol_h0 = None
     fri_roots, fri_trees, fri_srcs, challenges = [], {}, {}, []
 
@@ -282,16 +293,25 @@ def main():
     h_pols, h_c, h_x, h_q = sparse(pols_area.numel()), sparse(NE * args.n_const), sparse(NE), sparse(NE * 3)
     pidx = torch.tensor(sorted(pa), dtype=torch.int64, device=pols_area.device)
     h_pols[np.array(sorted(pa))] = ctx.to_host(pols_area[pidx])
-    const_again = ctx.empty(NE * args.n_const)
-    ctx.fill_synthetic(const_again, NE * args.n_const, 0x5EED0106)
     cidx = torch.tensor(sorted(ca), dtype=torch.int64, device=pols_area.device)
-    h_c[np.array(sorted(ca))] = ctx.to_host(const_again[cidx])
-    del const_again
+    h_c[np.array(sorted(ca))] = ctx.to_host(const_2ns[cidx])
     h_x[rows_chk] = ctx.to_host(x_2ns_c[torch.tensor(rows_chk, device=pols_area.device)])
     for r in rows_chk:
         glo.chelpers_step42ns(c_ops, c_args, h_pols, h_c, args.n_const, c_chal, c_pub, h_x, 1, zh, h_q, r, 1)
         ok &= bool(np.array_equal(h_q[3 * r:3 * r + 3], ctx.to_host(q_2ns[3 * r:3 * r + 3])))
     checks["step42ns_rows_match_oracle"] = bool(ok)
+    ok = True
+    pa, ca, _ = cpg.touched_addresses52(f_ops, f_args, rows_chk, args.n_const)
+    h_pols2, h_c2, h_xd, h_xdw, h_f = sparse(pols_area.numel()), sparse(NE * args.n_const), sparse(NE * 3), sparse(NE * 3), sparse(NE * 3)
+    pidx = torch.tensor(sorted(pa), dtype=torch.int64, device=pols_area.device)
+    h_pols2[np.array(sorted(pa))] = ctx.to_host(pols_area[pidx])
+    cidx = torch.tensor(sorted(ca), dtype=torch.int64, device=pols_area.device)
+    h_c2[np.array(sorted(ca))] = ctx.to_host(const_2ns[cidx])
+    for r in rows_chk:
+        h_xd[3 * r:3 * r + 3], h_xdw[3 * r:3 * r + 3] = ctx.to_host(xdx1[3 * r:3 * r + 3]), ctx.to_host(xdx2[3 * r:3 * r + 3])
+        glo.chelpers_step52ns(f_ops, f_args, h_pols2, h_c2, args.n_const, f_chal, h_evals, h_xd, h_xdw, h_f, r, 1)
+        ok &= bool(np.array_equal(h_f[3 * r:3 * r + 3], ctx.to_host(f_2ns[3 * r:3 * r + 3])))
+    checks["step52ns_rows_match_oracle"] = bool(ok)
     ok = True
     for t in range(4):
         root = ctx.to_host(trees[t][-4:])
@@ -340,13 +360,15 @@ def main():
     out = {
         "metric": "genproof_shaped_device_phases_wall_time", "value": wall, "unit": "s", "higher_is_better": False,
         "n_gpus": 1, "data": "synthetic", "dtype": "u64 (Goldilocks)",
-        "config": {"workload": "Starks::genProof-shaped pass (BASELINE config 4 substitute; step42ns by the chelpers interpreter on a synthetic program of the real size, other chelpers outputs replaced by synthetic fills)",
+        "config": {"workload": "Starks::genProof-shaped pass (BASELINE config 4 substitute; step42ns and step52ns by the chelpers interpreter on synthetic programs of the real size, the witness-side chelpers outputs replaced by synthetic fills)",
                    "rows": N, "rows_ext": NE, "committed_widths": [w1, w2, w3, qdim * qdeg], "n_evals": len(pols),
                    "fri_steps_bits": steps, "n_queries": args.n_queries},
         "field_elements_per_s_lde_merkle_fri": N * total_cols / sum(phases.values()) * 1e3,
         "phase_ms": phases, "device_phase_ms_total": sum(phases.values()), "checks": checks,
         "chelpers_step42ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers_stats,
                               "lds_words_per_row": 48, "rows": NE, "ms": phases.get("STARK_STEP_4_CALCULATE_EXPS_2NS")},
+        "chelpers_step52ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers52_stats,
+                              "rows": NE, "ms": phases.get("STARK_STEP_5_CALCULATE_EXPS_2NS")},
     }
     print(json.dumps(out))
     ctx.close()

@@ -635,11 +635,12 @@ def test_genproof_shaped_flow_small():
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench_genproof.py"), "--log-n", "12", "--widths", "37", "9", "20",
-                        "--n-evals", "24", "--n-queries", "16", "--check-queries", "16", "--n-const", "11", "--chelpers-field-ops", "1500"],
+                        "--n-evals", "24", "--n-queries", "16", "--check-queries", "16", "--n-const", "11", "--chelpers-field-ops", "1500",
+                        "--chelpers52-field-ops", "700"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["checks"] == {"step42ns_rows_match_oracle": True, "step0_merkle_paths_verify": True, "fri_merkle_paths_verify": True,
+    assert out["checks"] == {"step42ns_rows_match_oracle": True, "step52ns_rows_match_oracle": True, "step0_merkle_paths_verify": True, "fri_merkle_paths_verify": True,
                              "fri_fold_relation_on_openings": True, "evmap_spot_check": True}
     assert out["config"]["fri_steps_bits"] == [13, 8, 3]
 
