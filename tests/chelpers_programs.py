@@ -198,8 +198,10 @@ def touched_addresses52(ops, args, rows, numpols):
 
 
 def synthetic_program52(rng, sections, n_const, n_evals, length=60):
-    """A random valid step52ns program in the shape of the generated one: tmp is seeded, tmp2 is defined before it is read, every
-    opcode 0..20 occurs, the program ends by storing tmp (sections: [(offset, stride)], each with at least 3 columns)."""
+    """A random valid step52ns program in the shape of the generated one (two Horner chains over challenge 5 / challenge 6, the
+    first closed by xDivXSubXi, the second by xDivXSubWXi, joined through tmp1), nothing dead, every opcode 0..20 present; about
+    `length` chain links in the zkEVM program's proportions (16:17 = 760:136, 18:19:20 = 1227:336:202).
+    sections: [(offset, stride)], each with at least 3 columns."""
     ops, args = [], []
 
     def pol(three):
@@ -215,17 +217,30 @@ def synthetic_program52(rng, sections, n_const, n_evals, length=60):
             elif part == 13: args.extend([int(rng.integers(0, n_const)), int(rng.integers(0, n_evals))])
         ops.append(o)
 
-    emit(0)                      # tmp
-    emit(11)                     # tmp2
-    emit(3)                      # tmp1
-    body = list(range(0, 15)) + list(range(16, 21))
-    for _ in range(max(1, length // len(body))):
-        rng.shuffle(body)
-        for o in body:
-            emit(int(o))
-            if o in (0, 14):     # tmp was overwritten: fold the previous state back in through tmp1 so that nothing is dead
-                emit(8)
-            emit(3)              # tmp1 = tmp * challenge 5
+    def chain5(k):
+        for _ in range(k):
+            emit(16 if rng.integers(0, 896) < 760 else 17)
+
+    def chain6(k):
+        for _ in range(k):
+            v = int(rng.integers(0, 1765))
+            emit(18 if v < 1227 else 19 if v < 1563 else 20)
+
+    k5 = max(2, length * 9 // 27)
+    k6 = max(4, length - k5)
+    emit(0); emit(10)            # tmp = pol * c5 + pol
+    chain5(k5)
+    for o in (1, 9, 1, 10): emit(o)                       # the unfused spellings of 17 and 16
+    emit(3)                      # tmp1 = tmp * c5
+    emit(14)                     # tmp = const[5] - evals[0]
+    chain6(k6 // 2)
+    for o in (2, 13, 7, 2, 12, 7, 2, 11, 7): emit(o)      # the unfused spellings of 19, 20, 18
+    emit(5)                      # tmp *= xDivXSubXi
+    emit(8)                      # tmp = tmp1 + tmp
+    emit(3)                      # tmp1 = tmp * c5
+    emit(11); emit(4)            # tmp2 = pol - eval; tmp = tmp2 * c6
+    chain6(k6 - k6 // 2)
+    emit(6)                      # tmp *= xDivXSubWXi
     emit(8)
     emit(15)
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
