@@ -85,7 +85,7 @@ class Transcript:
         return np.array(res, dtype=np.uint64)
 
 
-def main():
+def arg_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=23)
     ap.add_argument("--widths", type=int, nargs=3, default=[665, 128, 371])
@@ -96,7 +96,52 @@ def main():
     ap.add_argument("--n-const", type=int, default=360, help="constant polynomials read by the step42ns program")
     ap.add_argument("--chelpers52-field-ops", type=int, default=7101, help="field operations per row of the synthetic step52ns program")
     ap.add_argument("--chelpers-field-ops", type=int, default=17986, help="field operations per row of the synthetic step42ns program")
-    args = ap.parse_args()
+    ap.add_argument("--chelpers-shape", choices=("zkevm", "random"), default="zkevm",
+                    help="step42ns program: zkevm = the zkEVM program's operation mix and accumulation structure; random = every opcode equally often")
+    ap.add_argument("--chelpers-backend", choices=("native", "interpreter"), default="native",
+                    help="native: the programs compiled to gfx950 kernels (chelpers_native.hip); interpreter: the SIMT interpreter (chelpers.hip)")
+    return ap
+
+
+def chelpers_programs(args, ctx, build_native):
+    """The two synthetic constraint programs of this flow (deterministic in the arguments), translated -- and with build_native
+    compiled to gfx950 code through the in-tree cache, which tools/chelpers_precompile.py fills on a machine without a GPU."""
+    import mi_stark
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import chelpers_programs as cpg          # the program GENERATOR (test infrastructure): the reference's tables cannot travel
+    NE = 1 << (args.log_n + 1)
+    w1, w2, w3 = args.widths
+    sec_off = [0, NE * w1, NE * (w1 + w2), NE * (w1 + w2 + w3)]
+    secs = [(sec_off[0], w1), (sec_off[1], w2), (sec_off[2], w3)]
+    if args.chelpers_shape == "zkevm":
+        c_ops, c_args = cpg.synthetic_program_zkevm_shape(np.random.default_rng(42), NE, secs, args.n_const, 8, field_ops=args.chelpers_field_ops,
+                                                          long_lived=min(70, args.chelpers_field_ops // 40))
+    else:
+        per_pass = len(cpg.decode(*cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8, passes=4))[0]) / 4.0
+        c_ops, c_args = cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8,
+                                              passes=max(1, int(round(args.chelpers_field_ops / per_pass))))
+    prog = mi_stark.ChelpersProgram(ctx, c_ops, c_args, sections=[(o, w, NE) for (o, w) in secs], n_const=args.n_const, nrows_ext=NE)
+    secs52 = secs + [(sec_off[3], 6)]
+    probe = mi_stark.ChelpersProgram(None, *cpg.synthetic_program52(np.random.default_rng(52), secs52, args.n_const, args.n_evals, length=200), step=52)
+    per_len = probe.stats["field_ops"] / 200.0
+    probe.close()
+    f_ops, f_args = cpg.synthetic_program52(np.random.default_rng(52), secs52, args.n_const, args.n_evals,
+                                            length=max(20, int(round(args.chelpers52_field_ops / per_len))))
+    prog52 = mi_stark.ChelpersProgram(ctx, f_ops, f_args, sections=[(o, w, NE) for (o, w) in secs52], n_const=args.n_const, nrows_ext=NE, step=52)
+    native = {}
+    if isinstance(build_native, tuple):          # (shard, nshards): one process's share of a parallel build, cache only
+        prog.precompile_shard(*build_native)
+        prog52.precompile_shard(*build_native)
+    elif build_native:
+        native["step42ns"] = prog.build_native()
+        native["step52ns"] = prog52.build_native()
+        native["step42ns"]["lowering"] = prog.lower_stats()
+        native["step52ns"]["lowering"] = prog52.lower_stats()
+    return c_ops, c_args, prog, f_ops, f_args, prog52, native
+
+
+def main():
+    args = arg_parser().parse_args()
 
     import torch
     import mi_stark
@@ -104,6 +149,9 @@ def main():
     import glo  # oracle: used only for the size-independent CHECKS below, never inside the timed phases
 
     ctx = mi_stark.Context(0, workspace_limit=int(args.workspace_gib * (1 << 30)))
+    t_prog = time.perf_counter()
+    c_ops, c_args, prog, f_ops, f_args, prog52, native_stats = chelpers_programs(args, ctx, args.chelpers_backend == "native")
+    t_prog = time.perf_counter() - t_prog
     nbits, nbits_ext = args.log_n, args.log_n + 1
     N, NE = 1 << nbits, 1 << nbits_ext
     w1, w2, w3 = args.widths
@@ -152,21 +200,18 @@ def main():
     del trace                                                   # the committed sections are extended: 44.6 GB back
     torch.cuda.empty_cache()
     q_2ns, qq1, qq2 = ctx.empty(NE * qdim), ctx.empty(NE * qdim), ctx.empty(NE * qdim * qdeg)
-    # step42ns: a synthetic constraint program of the real one's size run by the interpreter over the extended sections
+    # step42ns / step52ns: synthetic constraint programs of the real ones' size over the extended sections (built before the clock
+    # starts: a proving key's programs are compiled once, not per proof)
     import chelpers_programs as cpg
     prng = np.random.default_rng(42)
     secs = [(sec_off[0], w1), (sec_off[1], w2), (sec_off[2], w3)]
-    per_pass = len(cpg.decode(*cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8, passes=4))[0]) / 4.0
-    c_ops, c_args = cpg.synthetic_program(np.random.default_rng(42), NE, secs, args.n_const, 5, 8,
-                                          passes=max(1, int(round(args.chelpers_field_ops / per_pass))))
-    prog = mi_stark.ChelpersProgram(ctx, c_ops, c_args, sections=[(o, w, NE) for (o, w) in secs], n_const=args.n_const, nrows_ext=NE)
-    ctx.set_chelpers_min_words(48)      # LDS footprint of the zkEVM program after live-range splitting (24 KB per workgroup)
+    ctx.set_chelpers_min_words(48)      # interpreter: LDS footprint of the zkEVM program after live-range splitting (24 KB per workgroup)
     const_2ns = ctx.empty(NE * args.n_const)
     ctx.fill_synthetic(const_2ns, NE * args.n_const, 0x5EED0106)
     x_2ns_c = ctx.empty(NE)
     ctx.geom_seq(x_2ns_c, NE, 49, glo.lib().glo_w(nbits_ext))
     zh = ctx.zhinv(nbits, nbits_ext)
-    c_chal, c_pub = glo.rand_fe(prng, 5 * 3), glo.rand_fe(prng, 8)
+    c_chal, c_pub = glo.rand_fe(prng, 6 * 3), glo.rand_fe(prng, 8)
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS", lambda: prog.run(pols_area, const_2ns, args.n_const, c_chal, c_pub, x_2ns_c, 1, zh, q_2ns, 0, NE))
     chelpers_stats = dict(prog.stats)
     timed("STARK_STEP_4_CALCULATE_EXPS_2NS_INTT", lambda: ctx.ntt(qq1, q_2ns, NE, qdim, inverse=True))
@@ -215,14 +260,7 @@ def main():
     # step52ns: the FRI polynomial from the committed sections (incl. q), the constants, the evaluations and xDivXSubXi / xDivXSubWXi,
     # again a synthetic program of the real one's size (2675 opcodes -> 7101 field operations per row)
     f_2ns = ctx.empty(NE * 3)
-    secs52 = secs + [(sec_off[3], qdim * qdeg)]
-    n_ev = len(pols)
-    probe = mi_stark.ChelpersProgram(None, *cpg.synthetic_program52(np.random.default_rng(52), secs52, args.n_const, n_ev, length=200), step=52)
-    per_len = probe.stats["field_ops"] / 200.0
-    probe.close()
-    f_ops, f_args = cpg.synthetic_program52(np.random.default_rng(52), secs52, args.n_const, n_ev, length=max(20, int(round(args.chelpers52_field_ops / per_len))))
     ctx.set_chelpers_min_words(0)
-    prog52 = mi_stark.ChelpersProgram(ctx, f_ops, f_args, sections=[(o, w, NE) for (o, w) in secs52], n_const=args.n_const, nrows_ext=NE, step=52)
     f_chal = glo.rand_fe(prng, 7 * 3)
     timed("STARK_STEP_5_CALCULATE_EXPS_2NS", lambda: prog52.run52(pols_area, const_2ns, args.n_const, f_chal, h_evals, xdx1, xdx2, f_2ns, 0, NE))
     chelpers52_stats = dict(prog52.stats)
@@ -365,10 +403,11 @@ def main():
                    "fri_steps_bits": steps, "n_queries": args.n_queries},
         "field_elements_per_s_lde_merkle_fri": N * total_cols / sum(phases.values()) * 1e3,
         "phase_ms": phases, "device_phase_ms_total": sum(phases.values()), "checks": checks,
+        "chelpers_backend": args.chelpers_backend, "chelpers_translate_and_build_s": t_prog,
         "chelpers_step42ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers_stats,
-                              "lds_words_per_row": 48, "rows": NE, "ms": phases.get("STARK_STEP_4_CALCULATE_EXPS_2NS")},
+                              "native": native_stats.get("step42ns"), "rows": NE, "ms": phases.get("STARK_STEP_4_CALCULATE_EXPS_2NS")},
         "chelpers_step52ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers52_stats,
-                              "rows": NE, "ms": phases.get("STARK_STEP_5_CALCULATE_EXPS_2NS")},
+                              "native": native_stats.get("step52ns"), "rows": NE, "ms": phases.get("STARK_STEP_5_CALCULATE_EXPS_2NS")},
     }
     print(json.dumps(out))
     ctx.close()

@@ -214,6 +214,26 @@ int mi_chelpers_stats(const mi_chelpers_prog *prog, uint64_t out[16]);
  * so that a synthetic program runs at the occupancy of a larger one (the zkEVM step42ns program needs 96: 3 workgroups
  * per CU).  Results are unaffected. */
 int mi_set_chelpers_min_words(mi_ctx *ctx, uint64_t words);
+/* Second backend: compile the translated program to gfx950 code (straight-line kernels generated from the program, built with
+ * hiprtc; the reference compiles its generated chelpers into the prover at build time).  Needs no GPU.  cache_dir (or
+ * $MI_CHELPERS_CACHE; NULL/unset = no cache) keeps the code objects, keyed by the hash of the generated source.  chunk_cost =
+ * estimated VALU instructions per kernel (0 = 25 000).  Afterwards mi_chelpers_run_dev runs the compiled kernels instead of the
+ * interpreter; results are the same field elements.  Requires shifts < 64 and power-of-two section row counts. */
+int mi_chelpers_build_native(mi_chelpers_prog *prog, const char *cache_dir, uint64_t chunk_cost);
+/* What the native backend makes of the program, without compiling anything: out = kernels, instructions evaluated as
+ * Horner-chain accumulator steps, chain pieces, estimated VALU instructions per row, chain coefficients (+- C^e), per-piece
+ * constants, folded (polynomial - evaluation) leaves, temporary words moved through the spill per row */
+int mi_chelpers_lower_stats(const mi_chelpers_prog *prog, uint64_t chunk_cost, uint64_t out[8]);
+/* Parallel builds: process `shard` of `nshards` compiles every nshards-th kernel into the cache (cache_dir required) and keeps
+ * nothing; mi_chelpers_build_native afterwards finds every kernel there. */
+int mi_chelpers_precompile_shard(mi_chelpers_prog *prog, const char *cache_dir, uint64_t chunk_cost, uint32_t shard,
+                                 uint32_t nshards);
+/* out = kernels, code-object bytes, build milliseconds, cache hits, estimated VALU instructions per row, temporary words moved
+ * through the chunk-boundary spill per row, instructions evaluated as Horner-chain accumulator steps, words of the constants
+ * table */
+int mi_chelpers_native_stats(const mi_chelpers_prog *prog, uint64_t out[8]);
+/* rows whose tile-major operand copy is made at a time by the native backend (multiple of 64; 0 = about 8 GiB worth) */
+int mi_set_chelpers_batch_rows(mi_ctx *ctx, uint64_t rows);
 /* rows [row0, row0 + nrows) of the extended domain (the reference runs all NExtended rows: starks.cpp:240) */
 int mi_chelpers_run_dev(mi_ctx *ctx, const mi_chelpers_prog *prog, const mi_chelpers_params *params, uint64_t row0,
                         uint64_t nrows);
@@ -269,6 +289,9 @@ void mi_dbg_host_dft16(uint64_t x[16], int log_size, int inverse);
 int mi_dbg_field_ops_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *a, const uint64_t *b, uint64_t n);
 /* The translated constraint-evaluator program run on the HOST CPU over host pointers (every pointer of `params` is a
  * host pointer here) for the listed rows: same translator output, same instruction semantics as the kernel. */
+/* tests only: the program as LOWERED for the native backend (Horner chains, chain pieces per kernel, spill lists), on the CPU */
+int mi_dbg_host_chelpers_run_lowered(const mi_chelpers_prog *prog, const mi_chelpers_params *params, const uint64_t *rows,
+                                     uint64_t nrows, uint64_t chunk_cost);
 int mi_dbg_host_chelpers_run(const mi_chelpers_prog *prog, const mi_chelpers_params *params, const uint64_t *rows,
                              uint64_t nrows);
 /* Verification hook: out[r] = (accumulate ? out[r] : 0) + sum_c coef[c] * src[r*pitch + c] mod p for r < nrows (device

@@ -89,6 +89,9 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->small) (void)hipFree(c->small);
     if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
     if (c->chelpers_stage) (void)hipFree(c->chelpers_stage);
+    if (c->chelpers_cst) (void)hipFree(c->chelpers_cst);
+    if (c->chelpers_tiled) (void)hipFree(c->chelpers_tiled);
+    if (c->chelpers_spill) (void)hipFree(c->chelpers_spill);
     if (c->stage) (void)hipFree(c->stage);
     for (int s = 0; s < 2; s++)
         if (c->copy_stream[s]) (void)hipStreamSynchronize(c->copy_stream[s]);

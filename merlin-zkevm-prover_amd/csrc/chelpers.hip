@@ -45,23 +45,9 @@
 
 using gl::E3;
 
+#include "chelpers_ir.h"
+
 namespace chp {
-
-enum Kind : uint32_t { K_NONE = 0, K_T1, K_T3, K_POL, K_POLS, K_NUM, K_CONST, K_CONSTS, K_CHAL, K_PUB, K_POL3, K_POL3S, K_X, K_ZHINV, K_Q,
-                       K_EVAL, K_XD, K_XDW }; // step52ns: params.evals[k], params.xDivXSubXi[i], params.xDivXSubWXi[i] (all dimension 3)
-enum Cls : uint32_t { C_ADD = 0, C_SUB, C_MUL, C_COPY, C_STOREQ, C_STOREF }; // STOREQ: q = zhInv * a; STOREF: f = a
-
-static int kind_nargs(Kind k)
-{
-    switch (k) {
-    case K_T1: case K_T3: case K_NUM: case K_CONST: case K_CHAL: case K_PUB: case K_EVAL: return 1;
-    case K_POL: case K_POL3: return 2;   // offset, row stride
-    case K_CONSTS: return 3;             // column, row shift, modulus
-    case K_POLS: case K_POL3S: return 4; // offset, row shift, modulus, row stride
-    default: return 0;
-    }
-}
-MI_HD bool kind_is3(uint32_t k) { return k == K_T3 || k == K_CHAL || k == K_POL3 || k == K_POL3S || k == K_Q || k == K_EVAL || k == K_XD || k == K_XDW; }
 
 // what one opcode of the reference interpreter does: dst kind, operation, the kinds of its two sources IN ARGUMENT ORDER
 // (argument 0 is always the destination temp; then the arguments of source a, then those of source b)
@@ -155,172 +141,11 @@ static const std::vector<uint64_t> *fused_step52ns(uint64_t op)
     return nullptr;
 }
 
-// ---- device instruction (64 bytes, wave-uniform, fetched through the scalar cache)
-struct Opd { uint64_t off; uint32_t stride, shift; uint64_t mod; }; // meaning by kind, see load_operand
-struct DInstr {
-    uint32_t op;  // bits 0-7 class, 8-15 dst kind, 16-23 kind of a, 24-31 kind of b
-    uint32_t dst; // word of the destination temp (ext temps take 3 consecutive words)
-    Opd a, b;
-    uint64_t pad;
-};
-static_assert(sizeof(DInstr) == 64, "instruction must be 64 bytes");
-
-struct RunArgs { // host debug executor: operands read in place
-    const u64 *pols, *cpols, *x, *zhinv, *chal, *pub, *evals, *xd, *xdw;
-    u64 *q, *f;
-    uint64_t n_const, x_stride, n_zhinv, row0, row_end;
-};
-
-// ---- device form.  Every operand of an instruction is, by the time it executes, up to three 64-bit words in LDS:
-//   a hot temporary ([word][lane]), a prefetch slot ([slot][lane]: a staged polynomial value, an immediate, a cold
-//   temporary or 1/Z_H, put there one batch ahead), a challenge / public input (one word for all lanes), or the all-zero
-//   word that pads a base-field operand to an extension element.  So the executing loop has no operand-kind branches: it
-//   reads addresses.  An LDS address field is a byte offset with bit 31 = "add 8 x lane".
-enum GCls : uint32_t { G_ADD1 = 0, G_ADD3, G_SUB1, G_SUB3, G_MUL11, G_MUL13, G_MUL31, G_MUL33, G_COPY1, G_COPY3 };
-enum GDst : uint32_t { D_NONE = 0, D_HOT, D_COLD, D_Q };
-enum GPre : uint32_t { P_NONE = 0, P_STAGED, P_IMM, P_ZHINV };
-struct GInstr {
-    uint32_t op;      // bits 0-3 GCls, 4-5 GDst, 6 "also write pad[0] of the spill", 8-10 GPre of a, 12-14 GPre of b
-    uint32_t dst;     // D_HOT: LDS byte offset (lane-indexed, 1 or 3 consecutive words); D_COLD: spill word
-    uint32_t a[3], b[3]; // LDS address fields of the operands' words
-    uint64_t a_imm, b_imm; // P_STAGED: element index into the workgroup's scratch (staged column or spilled temporary); P_IMM: the value
-    uint32_t pad[4];
-};
-static_assert(sizeof(GInstr) == 64, "device instruction must be 64 bytes");
-static constexpr uint32_t LANE_FLAG = 0x80000000u;
-
-static constexpr int MAX_SECTIONS = 8;
-static constexpr uint32_t HALO = 8;             // rows staged beyond the group's 64 (largest row shift a program may use)
-static constexpr uint32_t RS = 64 + HALO;       // rows per staged column
-static constexpr uint32_t TILE_ROWS = 24;       // rows transposed per pass of the staging tile (RS = 3 passes)
-static constexpr int BATCH = 8;                 // instructions whose prefetch slots are filled together
-struct GSection { const u64 *ptr; uint64_t pitch, nrows; uint32_t ncols, col0; };
-struct GArgs {
-    GSection sec[MAX_SECTIONS];
-    uint32_t n_sections, n_instr;
-    uint32_t tile_off, pre_off, cst_off, cst_words, zh_off, lds_bytes; // LDS layout (bytes / words), see build_staged
-    const u64 *consts;          // device copy of [challenges | public inputs | ZhInv] = the cst region
-    u64 *q, *scratch;           // scratch: per resident workgroup, [staged column][RS rows] then [cold word][64 lanes]
-    uint64_t n_zhinv, row0, row_end, n_groups, staged_cols, wg_stride;
-};
-
-// ---- host-side intermediate form
-struct HOpd { Kind k = K_NONE; uint64_t v[4] = {0, 0, 0, 0}; };
-struct MicroOp { Cls cls; Kind dst; uint64_t dst_slot; HOpd a, b; };
-
 } // namespace chp
 
-struct HostSection { uint64_t offset, ncols, nrows; uint32_t col0; int role; }; // role 0: section of pols, 1: constant polynomials, 2: x
-struct mi_chelpers_prog {
-    std::vector<chp::DInstr> host; // the translated program, operands in place (host debug executor)
-    std::vector<chp::GInstr> gpu;  // the same program over staged columns (kernel)
-    chp::GInstr *dev = nullptr;
-    std::vector<HostSection> sections; // what the kernel stages per group of rows, in staged-column order
-    uint64_t staged_cols = 0;
-    uint64_t n_const = 0, nrows_ext = 0;
-    // LDS layout of the kernel (bytes) and the cold spill, see build_staged
-    uint32_t hot_t1 = 0, hot_t3 = 0, cold_words = 0, tile_off = 0, pre_off = 0, cst_off = 0, lds_fixed = 0;
-    uint64_t cold_reads = 0, temp_reads = 0;
-    uint64_t n_words = 0;          // LDS words per row
-    uint64_t stats[8] = {0};       // ops in, micro-ops, after copy forwarding, scheduled, live words before, after, t1 slots, t3 slots
-    uint64_t max_chal = 0, max_pub = 0, max_eval = 0;
-    int step = 0;
-    struct Patch { uint32_t instr, eval, word; };
-    std::vector<Patch> eval_patches; // device instructions whose a_imm is evals[eval][word] of the running proof
-};
 
 namespace chp {
 
-// one operand at row r.  Memory is read through M so that the same code runs in the kernel (LDS temporaries) and in the
-// host debug executor (a plain array).
-template <typename Tmp>
-MI_HD void load_operand(uint32_t kind, const Opd &o, uint64_t r, const RunArgs &P, const Tmp &tmp, u64 (&v)[3])
-{
-    v[1] = v[2] = 0;
-    switch (kind) {
-    case K_T1: v[0] = tmp.get(o.off); break;
-    case K_T3: v[0] = tmp.get(o.off); v[1] = tmp.get(o.off + 1); v[2] = tmp.get(o.off + 2); break;
-    case K_NUM: v[0] = o.off; break; // canonicalised by the translator (Goldilocks::fromU64)
-    case K_POL: v[0] = gl::canon(P.pols[o.off + r * o.stride]); break;
-    case K_POL3: {
-        const u64 *p = P.pols + o.off + r * o.stride;
-        v[0] = gl::canon(p[0]); v[1] = gl::canon(p[1]); v[2] = gl::canon(p[2]);
-        break;
-    }
-    case K_POLS: case K_POL3S: {
-        // ((i + shift) % modulus): the modulus is the extended domain size in every generated program, a power of two
-        const uint64_t rs = (o.mod & (o.mod - 1)) == 0 ? ((r + o.shift) & (o.mod - 1)) : ((r + o.shift) % o.mod);
-        const u64 *p = P.pols + o.off + rs * o.stride;
-        v[0] = gl::canon(p[0]);
-        if (kind == K_POL3S) { v[1] = gl::canon(p[1]); v[2] = gl::canon(p[2]); }
-        break;
-    }
-    case K_CONST: v[0] = gl::canon(P.cpols[o.off + r * P.n_const]); break;
-    case K_CONSTS: {
-        const uint64_t rs = (o.mod & (o.mod - 1)) == 0 ? ((r + o.shift) & (o.mod - 1)) : ((r + o.shift) % o.mod);
-        v[0] = gl::canon(P.cpols[o.off + rs * P.n_const]);
-        break;
-    }
-    case K_CHAL: v[0] = P.chal[o.off * 3]; v[1] = P.chal[o.off * 3 + 1]; v[2] = P.chal[o.off * 3 + 2]; break;
-    case K_PUB: v[0] = P.pub[o.off]; break;
-    case K_X: v[0] = gl::canon(P.x[r * P.x_stride]); break;
-    case K_EVAL: v[0] = P.evals[o.off * 3]; v[1] = P.evals[o.off * 3 + 1]; v[2] = P.evals[o.off * 3 + 2]; break;
-    case K_XD: case K_XDW: {
-        const u64 *p = (kind == K_XD ? P.xd : P.xdw) + r * 3;
-        v[0] = gl::canon(p[0]); v[1] = gl::canon(p[1]); v[2] = gl::canon(p[2]);
-        break;
-    }
-    case K_ZHINV: v[0] = P.zhinv[r % P.n_zhinv]; break;
-    default: v[0] = 0; break;
-    }
-}
-
-template <typename Tmp>
-MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P, Tmp &tmp)
-{
-    const uint32_t cls = I.op & 255, dk = (I.op >> 8) & 255, ak = (I.op >> 16) & 255, bk = I.op >> 24;
-    u64 a[3], b[3], o[3];
-    load_operand(ak, I.a, r, P, tmp, a);
-    load_operand(bk, I.b, r, P, tmp, b);
-    const bool a3 = kind_is3(ak), b3 = kind_is3(bk);
-    switch (cls) {
-    case C_ADD: // a dimension-1 operand is (v, 0, 0): Goldilocks3::add13 / add31 / add1c3c
-        o[0] = gl::add(a[0], b[0]); o[1] = gl::add(a[1], b[1]); o[2] = gl::add(a[2], b[2]);
-        break;
-    case C_SUB: // Goldilocks3::sub31c / sub13c: component-wise on (v, 0, 0)
-        o[0] = gl::sub(a[0], b[0]); o[1] = gl::sub(a[1], b[1]); o[2] = gl::sub(a[2], b[2]);
-        break;
-    case C_MUL: case C_STOREQ:
-        if (a3 && b3) {
-            const E3 p = gl::e3_mul(E3{{a[0], a[1], a[2]}}, E3{{b[0], b[1], b[2]}});
-            o[0] = p.v[0]; o[1] = p.v[1]; o[2] = p.v[2];
-        } else if (a3) { // Goldilocks3::mul31 / mul13: scalar times extension element
-            o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[1], b[0]); o[2] = gl::mul(a[2], b[0]);
-        } else if (b3) {
-            o[0] = gl::mul(a[0], b[0]); o[1] = gl::mul(a[0], b[1]); o[2] = gl::mul(a[0], b[2]);
-        } else {
-            o[0] = gl::mul(a[0], b[0]); o[1] = o[2] = 0;
-        }
-        break;
-    default: // C_COPY, C_STOREF
-        o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
-        break;
-    }
-    if (dk == K_T1) {
-        tmp.set(I.dst, o[0]);
-    } else if (dk == K_T3) {
-        tmp.set(I.dst, o[0]); tmp.set(I.dst + 1, o[1]); tmp.set(I.dst + 2, o[2]);
-    } else if (active && dk == K_Q) { // (Goldilocks3::Element &)params.q_2ns[i * 3] (step42ns) / params.f_2ns[i * 3] (step52ns)
-        u64 *out = cls == C_STOREF ? P.f : P.q;
-        out[r * 3] = o[0]; out[r * 3 + 1] = o[1]; out[r * 3 + 2] = o[2];
-    }
-}
-
-struct HostTmp {
-    u64 *base;
-    u64 get(uint64_t w) const { return base[w]; }
-    void set(uint64_t w, u64 v) { base[w] = v; }
-};
 
 // ---- the kernel
 __device__ __forceinline__ u64 lds_word(const char *lds, uint32_t field, uint32_t lane8)
@@ -1046,13 +871,63 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
 extern "C" void mi_chelpers_free(mi_ctx *c, mi_chelpers_prog *p)
 {
     if (!p) return;
-    if (p->dev && c) {
+    if (c) {
         std::lock_guard<std::recursive_mutex> lock(c->mu);
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(p->dev);
+        if (p->dev) (void)hipFree(p->dev);
+        chp::native_free(c, p);
+    } else {
+        chp::native_free(nullptr, p);
     }
     delete p;
+}
+
+static int check_params(const mi_chelpers_prog *p, const mi_chelpers_params *a, uint64_t row0, uint64_t nrows);
+
+// Compile the translated program to gfx950 code (chelpers_native.hip).  Needs no GPU; cache_dir (or $MI_CHELPERS_CACHE) keeps the
+// code objects between processes.  Afterwards mi_chelpers_run_dev runs the compiled kernels instead of the interpreter.
+extern "C" int mi_chelpers_build_native(mi_chelpers_prog *p, const char *cache_dir, uint64_t chunk_cost)
+{
+    if (!p) return MI_ERR_INVALID;
+    return chp::native_build(p, cache_dir, chunk_cost, 0, 1);
+}
+
+// Parallel builds: process `shard` of `nshards` compiles every nshards-th kernel into the cache and keeps nothing; a final
+// mi_chelpers_build_native then finds every kernel in the cache.
+extern "C" int mi_chelpers_precompile_shard(mi_chelpers_prog *p, const char *cache_dir, uint64_t chunk_cost, uint32_t shard, uint32_t nshards)
+{
+    if (!p) return MI_ERR_INVALID;
+    return chp::native_build(p, cache_dir, chunk_cost, shard, nshards);
+}
+
+extern "C" int mi_chelpers_lower_stats(const mi_chelpers_prog *p, uint64_t chunk_cost, uint64_t out[8])
+{
+    if (!p || !out) return MI_ERR_INVALID;
+    return chp::native_lower_stats(p, chunk_cost, out);
+}
+
+// tests only: the lowered program (Horner chains, pieces, spill lists) run on the CPU, see chp::native_host_run
+extern "C" int mi_dbg_host_chelpers_run_lowered(const mi_chelpers_prog *p, const mi_chelpers_params *a, const uint64_t *rows, uint64_t nrows, uint64_t chunk_cost)
+{
+    MI_TRY(check_params(p, a, 0, 0));
+    MI_REQUIRE(rows || nrows == 0, "null row list");
+    return chp::native_host_run(p, a, rows, nrows, chunk_cost);
+}
+
+extern "C" int mi_chelpers_native_stats(const mi_chelpers_prog *p, uint64_t out[8])
+{
+    if (!p || !out) return MI_ERR_INVALID;
+    chp::native_stats(p, out);
+    return MI_OK;
+}
+
+extern "C" int mi_set_chelpers_batch_rows(mi_ctx *c, uint64_t rows)
+{
+    if (!c) return MI_ERR_INVALID;
+    MI_REQUIRE(rows % 64 == 0, "batch must be a multiple of 64 rows");
+    c->chelpers_batch_rows = rows;
+    return MI_OK;
 }
 
 extern "C" int mi_set_chelpers_min_words(mi_ctx *c, uint64_t words)
@@ -1097,6 +972,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     MI_HIP_CHECK(hipSetDevice(c->device));
     MI_TRY(check_params(p, a, row0, nrows));
+    if (p->native) return chp::native_run(c, p, a, row0, nrows);
     MI_REQUIRE(p->dev, "program was compiled without a context");
     if (nrows == 0) return MI_OK;
     MI_REQUIRE(a->n_const == p->n_const, "number of constant polynomials differs from what the program was compiled for");

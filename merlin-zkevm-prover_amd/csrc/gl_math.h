@@ -9,8 +9,10 @@
 // or Barrett constants.  Everything here is __host__ __device__ so the very same inline code can be
 // exercised on a machine without a GPU (mi_dbg_host_* in capi.hip; test use only).
 #pragma once
+#ifndef __HIPCC_RTC__ // hiprtc (the constraint-program compiler in chelpers.hip) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -31,9 +33,15 @@ namespace gl {
 // true in at least one lane of the wave?  A correction that is needed with probability ~2^-32 per value (x >= p,
 // lo < hh after a multiply) is put behind a wave-uniform branch: the common path pays one compare instead of a
 // compare, two selects and a 64-bit add.  Host build: plain condition.
+// MI_NO_RARE_BRANCH (the generated constraint-evaluator kernels): always take the select form -- thousands of wave-uniform
+// branches in one straight-line kernel split it into as many basic blocks and wreck register allocation (measured: 512 VGPRs
+// and 4 500 spills with the branches, 146 VGPRs without).
 MI_HD bool rare(bool c)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MI_NO_RARE_BRANCH)
+    (void)c;
+    return true;
+#elif defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ballot_w64(c) != 0;
 #else
     return c;
@@ -41,7 +49,7 @@ MI_HD bool rare(bool c)
 }
 
 // keeps the compiler from turning a rare() block back into selects
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_NO_RARE_BRANCH)
 #define MI_KEEP_BRANCH() asm volatile("" ::: "memory")
 #else
 #define MI_KEEP_BRANCH() do { } while (0)

@@ -56,7 +56,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
-    "mi_lde_merkle_host", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run",
+    "mi_lde_merkle_host", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows",
 ]
 
 
@@ -126,6 +126,9 @@ class Context:
 
     def set_lde_fuse(self, fuse):
         _check(lib().mi_set_lde_fuse(self.h, ctypes.c_int(int(fuse))))
+
+    def set_chelpers_batch_rows(self, rows):
+        _check(lib().mi_set_chelpers_batch_rows(self.h, u64(rows)))
 
     def set_chelpers_min_words(self, words):
         _check(lib().mi_set_chelpers_min_words(self.h, u64(words)))
@@ -312,6 +315,11 @@ MI_CHELPERS_STEP42NS = 42
 MI_CHELPERS_STEP52NS = 52
 
 
+def default_chelpers_cache():
+    """Code objects of compiled constraint programs, next to the library (in-tree, so a cache filled on the build machine travels)."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_chelpers_cache")
+
+
 class ChelpersProgram:
     """A constraint-evaluator program (the reference's generated op / args tables) translated for the GPU.
     ctx = None compiles for the host debug executor only (no GPU needed)."""
@@ -333,6 +341,32 @@ class ChelpersProgram:
         st = np.zeros(16, dtype=np.uint64)
         _check(lib().mi_chelpers_stats(self.h, _hp(st)))
         self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}
+
+    NATIVE_STAT_NAMES = ("kernels", "code_bytes", "build_ms", "cache_hits", "estimated_valu_per_row", "spill_words_moved_per_row",
+                         "horner_chain_steps", "constant_words")
+
+    def lower_stats(self, chunk_cost=0):
+        st = np.zeros(8, dtype=np.uint64)
+        _check(lib().mi_chelpers_lower_stats(self.h, u64(chunk_cost), _hp(st)))
+        return dict(zip(("kernels", "horner_chain_steps", "chain_pieces", "estimated_valu_per_row", "chain_coefficients", "piece_constants",
+                         "folded_leaves", "spill_words_moved_per_row"), (int(v) for v in st)))
+
+    def precompile_shard(self, shard, nshards, cache_dir=None, chunk_cost=0):
+        """One process's share of a parallel build: fills the cache, keeps nothing."""
+        if cache_dir is None:
+            cache_dir = os.environ.get("MI_CHELPERS_CACHE", default_chelpers_cache())
+        _check(lib().mi_chelpers_precompile_shard(self.h, cache_dir.encode(), u64(chunk_cost), ctypes.c_uint32(shard), ctypes.c_uint32(nshards)))
+
+    def build_native(self, cache_dir=None, chunk_cost=0):
+        """Compile the translated program to gfx950 code (no GPU needed); run / run52 then use the compiled kernels.
+        cache_dir None = the in-tree cache next to the library (or $MI_CHELPERS_CACHE)."""
+        if cache_dir is None:
+            cache_dir = os.environ.get("MI_CHELPERS_CACHE", default_chelpers_cache())
+        _check(lib().mi_chelpers_build_native(self.h, cache_dir.encode() if cache_dir else None, u64(chunk_cost)))
+        st = np.zeros(8, dtype=np.uint64)
+        _check(lib().mi_chelpers_native_stats(self.h, _hp(st)))
+        self.native_stats = {k: int(v) for k, v in zip(self.NATIVE_STAT_NAMES, st)}
+        return self.native_stats
 
     def close(self):
         if self.h:
@@ -369,6 +403,20 @@ class ChelpersProgram:
         keep = []
         P = self._params(pols.data_ptr(), const_pols.data_ptr(), n_const, challenges, publics, x.data_ptr(), x_stride, zhinv, q.data_ptr(), keep)
         _check(lib().mi_chelpers_run_dev(self.ctx.h, self.h, ctypes.byref(P), u64(row0), u64(nrows)))
+
+    def run_lowered_host(self, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, rows, chunk_cost=0):
+        """step42ns, the program as lowered for the native backend, on the CPU (test hook)."""
+        keep = []
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, publics, x.ctypes.data, x_stride, zhinv, q.ctypes.data, keep)
+        _check(lib().mi_dbg_host_chelpers_run_lowered(self.h, ctypes.byref(P), _hp(rows), u64(rows.size), u64(chunk_cost)))
+
+    def run52_lowered_host(self, pols, const_pols, n_const, challenges, evals, xdiv, xdivw, f, rows, chunk_cost=0):
+        keep = []
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, (), None, 0, (), None, keep,
+                         evals=evals, xdiv_ptr=xdiv.ctypes.data, xdivw_ptr=xdivw.ctypes.data, f_ptr=f.ctypes.data)
+        _check(lib().mi_dbg_host_chelpers_run_lowered(self.h, ctypes.byref(P), _hp(rows), u64(rows.size), u64(chunk_cost)))
 
     def run_host(self, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, rows):
         """The same translated program on the CPU (test hook): every array is a host numpy uint64 array."""

@@ -157,6 +157,88 @@ def synthetic_program(rng, nrows, sections, n_const, n_chal, n_pub, passes=3, nt
     return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)
 
 
+def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_ops=17986, next_shift=2, vc=4, long_lived=70):
+    """A random valid step42ns program in the SHAPE of the zkEVM one (the real tables cannot travel to the GPU box): ~2 200
+    constraint values, each a short base-field expression (on average 5.6 multiplications / additions / subtractions) over
+    polynomial elements, shifted ("prime") elements, constants and numbers, every one folded into the running extension
+    accumulator as acc = (acc + value) * challenge[vc] (opcode 84, the pattern behind 2 185 of the real program's 2 402 extension
+    multiplications); about 9 % of the constraints are extension-valued (value * challenge, an extension product, an extension
+    sum or difference, folded with an extension addition).  Operand columns follow a skewed distribution (the real program reads
+    1 766 distinct elements 12 525 times).  `long_lived` base values are computed up front and read throughout, so that the
+    rescheduled program keeps about as many words live as the real one (86).  Uses challenges 0..vc; ends with the q store."""
+    ops, args = [], []
+    ACC = 0
+    cls_of = lambda o: "add" if o <= 20 else "sub" if o <= 44 else "mul" if o <= 77 else "copy"
+    base_ops = [o for o, (d, a, b) in OPS.items() if d == T1 and o < 78 and b is not None]
+    first = {c: [o for o in base_ops if cls_of(o) == c and T1 not in OPS[o][1:]] for c in ("add", "sub", "mul")}
+    later = {c: [o for o in base_ops if cls_of(o) == c and T1 in OPS[o][1:]] for c in ("add", "sub", "mul")}
+    n_atoms = max(8, field_ops // 12)
+
+    def zipf_pick(pool):
+        w = 1.0 / (np.arange(len(pool)) + 10.0) ** 0.8
+        return pool[int(rng.choice(len(pool), p=w / w.sum()))]
+
+    def rand_col(three=False):
+        off, stride = sections[int(rng.integers(0, len(sections)))]
+        return off + int(rng.integers(0, stride - (2 if three else 0))), stride
+    pol_pool = [rand_col() for _ in range(n_atoms)]
+    pols_pool = [rand_col() for _ in range(max(4, n_atoms // 6))]
+    const_pool = [int(rng.integers(0, n_const)) for _ in range(max(4, min(n_const, n_atoms // 4)))]
+
+    def gen_src(kind, temps):
+        if kind == T1: return [temps.pop()]
+        if kind == NUM: return [int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.3 else int(rng.integers(0, 9))]
+        if kind == CONST: return [zipf_pick(const_pool)]
+        if kind == CONSTS: return [zipf_pick(const_pool), next_shift, nrows]
+        if kind == PUB: return [int(rng.integers(0, n_pub))]
+        if kind == POL: return list(zipf_pick(pol_pool))
+        if kind == POLS:
+            c, st = zipf_pick(pols_pool)
+            return [c, next_shift, nrows, st]
+        raise ValueError(kind)
+
+    def push(o, ar):
+        ops.append(o); args.extend(ar)
+
+    push(13, [ACC, 1, vc])                       # acc = 1 + challenge[vc]
+    LL0 = 10
+    for k in range(long_lived):
+        push(50, [LL0 + k] + list(zipf_pick(pol_pool)) + list(zipf_pick(pol_pool)))
+    count, slot, eslot = 1 + long_lived, 0, 1
+    while count < field_ops - 1:
+        g = min(14, 1 + int(rng.geometric(1 / 4.6)))
+        cur = None
+        for k in range(g):
+            c = ("mul", "add", "sub")[int(rng.choice(3, p=[0.46, 0.29, 0.25]))]
+            o = int(rng.choice(first[c] if cur is None else later[c]))
+            d, a, b = OPS[o]
+            dst = slot % 10
+            slot += 1
+            temps = [cur, cur] if cur is not None else []
+            if cur is not None and a == T1 and b == T1:
+                if long_lived and rng.random() < 0.5: temps = [cur, LL0 + int(rng.integers(0, long_lived))]
+                elif k >= 2: temps = [cur, prev] # a product / sum of two values of this constraint
+            ar = [dst] + gen_src(a, temps) + gen_src(b, temps)
+            push(o, ar)
+            prev, cur = (cur if cur is not None else dst), dst
+            count += 1
+        if rng.random() < 0.09:                  # extension-valued constraint
+            e1, e2 = 1 + eslot % 4, 1 + (eslot + 1) % 4
+            eslot += 2
+            push(59, [e1, cur, int(rng.integers(0, vc))])                   # e1 = value * challenge
+            push(62, [e2] + list(zipf_pick(pol_pool)) + [int(rng.integers(0, vc))])  # e2 = pol * challenge
+            push(71, [e1, e1, e2])                                          # e1 = e1 * e2
+            push(42 if rng.random() < 0.4 else 17, [e1, e1, e2])            # e1 = e1 -/+ e2
+            push(17, [ACC, e1, ACC])
+            push(70, [ACC, vc, ACC])
+            count += 6
+        else:
+            push(84, [ACC, cur, ACC, ACC, vc, ACC])                         # acc = (value + acc) * challenge[vc]
+            count += 2
+    push(69, [ACC])
+    return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)
+
+
 # ------------------------------------------------------------------ step52ns (zkevm.chelpers.step52ns.parser.cpp): arguments per opcode
 NARGS52 = {0: 2, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 0, 7: 0, 8: 0, 9: 2, 10: 2, 11: 3, 12: 3, 13: 2, 14: 0, 15: 0}
 FUSED52 = {16: [1, 10], 17: [1, 9], 18: [2, 11, 7], 19: [2, 13, 7], 20: [2, 12, 7]}

@@ -135,6 +135,18 @@ def test_reference_program_translates_and_matches_oracle():
     for r in rows:
         assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]) and want[3 * r:3 * r + 3].any(), r
     prog.close()
+    # the same program as the native backend lowers it: the (acc + constraint) * vc accumulation becomes Horner-chain pieces
+    N = 1 << 23
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=[(1435 * N, 665, 2 * N), (2765 * N, 128, 2 * N), (3021 * N, 371, 2 * N)], n_const=numpols, nrows_ext=2 * N)
+    ls = prog.lower_stats()
+    assert ls["horner_chain_steps"] > 4000 and ls["estimated_valu_per_row"] < 350000 and ls["kernels"] >= 10, ls
+    for cc in (0, 9000):
+        for r in rows:
+            got[3 * r:3 * r + 3] = 0
+        prog.run_lowered_host(pols, cpols, numpols, chal, pub, x, 1, zhinv, got, np.array(rows), chunk_cost=cc)
+        for r in rows:
+            assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]), (cc, r)
+    prog.close()
 
 
 @pytest.mark.gpu
@@ -229,6 +241,15 @@ def test_step52ns_tables_agree_with_the_reference_and_its_program_matches_the_or
     prog.run52_host(pols, cpols, numpols, chal, evals, xd, xdw, got, np.array(rows))
     for r in rows:
         assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]) and want[3 * r:3 * r + 3].any(), r
+    # as lowered for the native backend: three Horner chains, the (polynomial - evaluation) leaves folded into per-piece constants
+    ls = prog.lower_stats()
+    assert ls["horner_chain_steps"] > 5000 and ls["folded_leaves"] > 1700 and ls["estimated_valu_per_row"] < 120000, ls
+    for cc in (0, 7000):
+        for r in rows:
+            got[3 * r:3 * r + 3] = 0
+        prog.run52_lowered_host(pols, cpols, numpols, chal, evals, xd, xdw, got, np.array(rows), chunk_cost=cc)
+        for r in rows:
+            assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]), (cc, r)
     prog.close()
 
 
@@ -243,6 +264,93 @@ def test_step52ns_on_gpu_matches_oracle():
     prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
     f = ctx.zeros(nrows * 3)
     for ev in (evals, glo.rand_fe(np.random.default_rng(5), evals.size)):   # the evaluations are patched in per run
+        glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, ev, xd, xdw, want, 0, nrows)
+        prog.run52(ctx.to_device(pols), ctx.to_device(cpols), n_const, chal, ev, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
+        assert np.array_equal(ctx.to_host(f), want)
+    prog.close()
+    ctx.close()
+
+
+# ------------------------------------------------------------------ native-code backend (chelpers_native.hip)
+@pytest.mark.parametrize("chunk_cost", [0, 2500, 400])
+def test_lowered_programs_match_oracle_on_the_host(chunk_cost):
+    """Chains, pieces cut at kernel boundaries, folded leaves, coefficient / K tables and spill lists (poisoned between kernels)."""
+    import mi_stark
+    nrows = 48
+    ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(5, nrows, passes=3)
+    want, got = np.zeros(nrows * 3, dtype=np.uint64), np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step42ns(ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows)
+    prog.run_lowered_host(pols, cpols, n_const, chal, pub, x, xs, zhinv, got, np.arange(nrows), chunk_cost=chunk_cost)
+    assert np.array_equal(got, want)
+    prog.close()
+    ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(6, nrows)
+    glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, evals, xd, xdw, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
+    assert prog.lower_stats(chunk_cost)["horner_chain_steps"] > 100
+    got[:] = 0
+    prog.run52_lowered_host(pols, cpols, n_const, chal, evals, xd, xdw, got, np.arange(nrows), chunk_cost=chunk_cost)
+    assert np.array_equal(got, want)
+    prog.close()
+
+
+def test_native_backend_builds_without_a_gpu(tmp_path):
+    """The generated kernels compile (hiprtc needs no device); a second build of the same program is served from the cache."""
+    import mi_stark
+    nrows = 1 << 8
+    ops, args, *_ = _synthetic_case(3, nrows, passes=1)
+    stats = []
+    for _ in range(2):
+        prog = mi_stark.ChelpersProgram(None, ops, args, sections=_synthetic_sections(nrows), n_const=7, nrows_ext=nrows)
+        stats.append(prog.build_native(cache_dir=str(tmp_path), chunk_cost=6000))
+        with pytest.raises(mi_stark.MiStarkError, match="already built"):
+            prog.build_native(cache_dir=str(tmp_path))
+        prog.close()
+    assert stats[0]["kernels"] >= 2 and stats[0]["cache_hits"] == 0 and stats[1]["cache_hits"] == stats[1]["kernels"] == stats[0]["kernels"]
+    assert stats[0]["code_bytes"] == stats[1]["code_bytes"] > 0
+
+
+@pytest.mark.gpu
+def test_native_step42ns_matches_oracle_and_interpreter(tmp_path):
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 13
+    ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(31, nrows, passes=3)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step42ns(ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows)
+    st = prog.build_native(cache_dir=str(tmp_path), chunk_cost=7000)
+    assert st["kernels"] >= 3                      # temporaries cross chunk boundaries through the spill
+    d_pols, d_c, d_x = ctx.to_device(pols), ctx.to_device(cpols), ctx.to_device(x)
+    for batch in (0, 1024, 64):                     # one batch; eight batches; one tile per batch (every shifted read crosses into the halo)
+        ctx.set_chelpers_batch_rows(batch)
+        q = ctx.to_device(np.full(nrows * 3 + 6, 0xABCD, dtype=np.uint64))
+        prog.run(d_pols, d_c, n_const, chal, pub, d_x, xs, zhinv, q, 0, nrows)
+        got = ctx.to_host(q)
+        assert np.array_equal(got[:nrows * 3], want) and np.all(got[nrows * 3:] == 0xABCD), batch
+    # a row range that starts and ends inside tiles and includes the last rows (shifted reads wrap to row 0)
+    ctx.set_chelpers_batch_rows(512)
+    q2 = ctx.to_device(np.zeros(nrows * 3, dtype=np.uint64))
+    r0 = nrows - 1000
+    prog.run(d_pols, d_c, n_const, chal, pub, d_x, xs, zhinv, q2, r0, 1000)
+    got2 = ctx.to_host(q2)
+    assert np.array_equal(got2[3 * r0:], want[3 * r0:]) and not got2[:3 * r0].any()
+    prog.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_native_step52ns_matches_oracle(tmp_path):
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 13
+    ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(41, nrows)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=9000)["kernels"] >= 2
+    f = ctx.zeros(nrows * 3)
+    ctx.set_chelpers_batch_rows(2048)
+    for ev in (evals, glo.rand_fe(np.random.default_rng(5), evals.size)):
         glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, ev, xd, xdw, want, 0, nrows)
         prog.run52(ctx.to_device(pols), ctx.to_device(cpols), n_const, chal, ev, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
         assert np.array_equal(ctx.to_host(f), want)
