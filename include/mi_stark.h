@@ -232,6 +232,8 @@ int mi_chelpers_precompile_shard(mi_chelpers_prog *prog, const char *cache_dir, 
  * through the chunk-boundary spill per row, instructions evaluated as Horner-chain accumulator steps, words of the constants
  * table */
 int mi_chelpers_native_stats(const mi_chelpers_prog *prog, uint64_t out[8]);
+/* allocate the device buffers a native run over nrows rows needs now rather than inside the first run */
+int mi_chelpers_reserve(mi_ctx *ctx, const mi_chelpers_prog *prog, uint64_t nrows);
 /* rows whose tile-major operand copy is made at a time by the native backend (multiple of 64; 0 = about 8 GiB worth) */
 int mi_set_chelpers_batch_rows(mi_ctx *ctx, uint64_t rows);
 /* rows [row0, row0 + nrows) of the extended domain (the reference runs all NExtended rows: starks.cpp:240) */

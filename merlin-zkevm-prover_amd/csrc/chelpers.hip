@@ -922,6 +922,16 @@ extern "C" int mi_chelpers_native_stats(const mi_chelpers_prog *p, uint64_t out[
     return MI_OK;
 }
 
+// Allocate what a native run over nrows rows needs (operand copy, spill, constants) now instead of inside the first run.
+extern "C" int mi_chelpers_reserve(mi_ctx *c, const mi_chelpers_prog *p, uint64_t nrows)
+{
+    if (!c || !p) return MI_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    MI_HIP_CHECK(hipSetDevice(c->device));
+    if (!p->native) return MI_OK; // the interpreter sizes its staging by what is resident: nothing to reserve ahead
+    return chp::native_reserve(c, p, nrows, nullptr);
+}
+
 extern "C" int mi_set_chelpers_batch_rows(mi_ctx *c, uint64_t rows)
 {
     if (!c) return MI_ERR_INVALID;

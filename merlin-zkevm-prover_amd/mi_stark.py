@@ -56,7 +56,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
-    "mi_lde_merkle_host", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows",
+    "mi_lde_merkle_host", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
 ]
 
 
@@ -344,6 +344,9 @@ class ChelpersProgram:
 
     NATIVE_STAT_NAMES = ("kernels", "code_bytes", "build_ms", "cache_hits", "estimated_valu_per_row", "spill_words_moved_per_row",
                          "horner_chain_steps", "constant_words")
+
+    def reserve(self, nrows):
+        _check(lib().mi_chelpers_reserve(self.ctx.h, self.h, u64(nrows)))
 
     def lower_stats(self, chunk_cost=0):
         st = np.zeros(8, dtype=np.uint64)

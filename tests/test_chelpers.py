@@ -347,7 +347,7 @@ def test_native_step52ns_matches_oracle(tmp_path):
     ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(41, nrows)
     want = np.zeros(nrows * 3, dtype=np.uint64)
     prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
-    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=9000)["kernels"] >= 2
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=1500)["kernels"] >= 2
     f = ctx.zeros(nrows * 3)
     ctx.set_chelpers_batch_rows(2048)
     for ev in (evals, glo.rand_fe(np.random.default_rng(5), evals.size)):

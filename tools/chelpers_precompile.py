@@ -26,7 +26,11 @@ def main():
     ap.add_argument("--jobs", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--shard", type=int, default=-1, help="internal: run one shard of one configuration")
     ap.add_argument("--config", type=int, default=-1)
+    ap.add_argument("--only", type=int, default=-1, help="precompile only this configuration")
+    ap.add_argument("--extra", nargs=argparse.REMAINDER, default=[], help="further bench_genproof.py arguments for every configuration")
     a = ap.parse_args()
+    for c in CONFIGS:
+        c.extend(a.extra)
     import bench_genproof
     if a.shard >= 0:
         args = bench_genproof.arg_parser().parse_args(CONFIGS[a.config])
@@ -34,7 +38,10 @@ def main():
         return
     for ci, argv in enumerate(CONFIGS):
         t0 = time.time()
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--jobs", str(a.jobs), "--shard", str(s), "--config", str(ci)])
+        if a.only >= 0 and ci != a.only:
+            continue
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--jobs", str(a.jobs), "--shard", str(s), "--config", str(ci)] +
+                                  (["--extra"] + a.extra if a.extra else []))
                  for s in range(a.jobs)]
         bad = [p.wait() for p in procs]
         if any(bad):
