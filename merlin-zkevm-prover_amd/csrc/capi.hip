@@ -92,6 +92,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->chelpers_cst) (void)hipFree(c->chelpers_cst);
     if (c->chelpers_tiled) (void)hipFree(c->chelpers_tiled);
     if (c->chelpers_spill) (void)hipFree(c->chelpers_spill);
+    if (c->chelpers_lin) (void)hipFree(c->chelpers_lin);
     if (c->stage) (void)hipFree(c->stage);
     for (int s = 0; s < 2; s++)
         if (c->copy_stream[s]) (void)hipStreamSynchronize(c->copy_stream[s]);

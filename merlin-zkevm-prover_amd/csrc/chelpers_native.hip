@@ -68,10 +68,25 @@ DEV void mul33(u64 &o0, u64 &o1, u64 &o2, u64 a0, u64 a1, u64 a2, u64 b0, u64 b1
 // one per-piece constant K.  zkEVM step42ns: 2 185 of its 2 402 extension multiplications are such steps ((acc + constraint) * vc),
 // step52ns: all but a handful.
 enum StepT : uint8_t { ST_NONE = 0, ST_M, ST_A, ST_S, ST_FOLDED };
-struct Mark { uint8_t type = ST_NONE, yside = 0; int32_t chain = -1, folded = -1; };
-struct Coef { uint32_t chal, exp; bool neg; };
+struct Mark { uint8_t type = ST_NONE, yside = 0, lin = 0; int32_t chain = -1, folded = -1; };
+struct Coef { uint32_t chal, exp; bool neg; uint32_t xk; bool zero; }; // (+-) C^exp * x^xk, or 0
 struct KTerm { uint32_t eval, coef; };
-struct Piece { int32_t chain; uint32_t first, last, n_m; int32_t begin_coef = -1, k_slot = -1; };
+struct Piece { int32_t chain; uint32_t first, last, n_m; int32_t begin_coef = -1, k_slot = -1, lin_sum = -1; };
+
+// ---- linear terms.  A chain step whose leaf is a polynomial element at the row itself (step52ns: every one of them -- the FRI
+// polynomial is a random linear combination of the committed polynomials) needs no generated code at all: the sum of such terms
+// of a piece is  sum_j pol_j(row) * W_j  with constants W_j, a matrix-vector product over the row-major sections.  One kernel
+// (k_chp_linear) streams the sections once, slab by slab through LDS, and accumulates up to four such sums per row with the same
+// limb accumulators; the generated kernel adds the result at the end of the piece.  An extension-valued polynomial (three
+// adjacent columns) is three base terms with coefficients W, x W, x^2 W.  This also removes those columns from the tile-major
+// copy: for step52ns only xDivXSubXi / xDivXSubWXi and one constant column are left in it.
+static constexpr uint32_t LIN_COLS = 16;  // columns per staged slab
+static constexpr int LIN_MAX_SUMS = 4;
+static constexpr uint32_t LIN_MIN_TERMS = 256; // below this a pass over the sections costs more than the generated terms
+struct LinTermH { uint32_t staged_col, coef, sum; };
+struct LinTerm { uint32_t lds_off, coef; };    // device: byte offset of the column inside a staged row; word offset of the coefficient in the constants table
+struct LinSlabD { uint32_t section, col0, ncols, t0[LIN_MAX_SUMS + 1]; };
+struct LinSections { const u64 *ptr[MAX_SECTIONS]; uint64_t pitch[MAX_SECTIONS], row_mask[MAX_SECTIONS]; };
 
 struct Chunk {
     size_t i0 = 0, i1 = 0;          // instructions [i0, i1) of mi_chelpers_prog::host
@@ -89,6 +104,14 @@ struct NativeProg {
     std::vector<Piece> pieces;
     std::vector<Coef> coefs;
     std::vector<std::vector<KTerm>> kslots;
+    std::vector<LinTermH> lin_terms;          // as collected (host executor)
+    std::vector<int32_t> lin_first;           // instruction -> its first entry in lin_terms
+    std::vector<LinTerm> lin_dev;             // sorted by slab and sum, padded to pairs (kernel)
+    std::vector<LinSlabD> lin_slabs;
+    uint32_t n_lin_sums = 0;
+    LinTerm *d_lin_terms = nullptr;
+    LinSlabD *d_lin_slabs = nullptr;
+    std::vector<uint32_t> sec_slab_mask;      // per section: 64-column slabs the generated kernels read (tile-major copy)
     uint32_t sc = 0, nw = 0;                     // staged columns per tile, temp words per row
     uint32_t pub_off = 0, ev_off = 0, zh_off = 0, coef_off = 0, k_off = 0, cst_words = 0; // word offsets into the constants table (challenges first)
     double compile_s = 0;
@@ -104,11 +127,30 @@ static uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull)
 
 static bool is_pol_kind(uint32_t k) { return k == K_POL || k == K_POLS || k == K_POL3 || k == K_POL3S || k == K_CONST || k == K_CONSTS || k == K_X || k == K_XD || k == K_XDW; }
 
+// a polynomial operand -> its section, first staged column, dimension and row shift (nullptr: in no declared section)
+static const HostSection *resolve_pol(const mi_chelpers_prog *P, uint32_t k, const Opd &o, uint32_t &col, int &dim, uint32_t &shift)
+{
+    const bool three = k == K_POL3 || k == K_POL3S || k == K_XD || k == K_XDW, shifted = k == K_POLS || k == K_POL3S || k == K_CONSTS;
+    const int role = (k == K_CONST || k == K_CONSTS) ? 1 : k == K_X ? 2 : k == K_XD ? 3 : k == K_XDW ? 4 : 0;
+    const uint64_t off = role >= 2 ? 0 : o.off, width = three ? 3 : 1;
+    dim = three ? 3 : 1;
+    shift = shifted ? o.shift : 0;
+    for (const HostSection &S : P->sections) {
+        if (S.role != role) continue;
+        if (role == 0 && (o.stride != S.ncols || off < S.offset || off - S.offset + width > S.ncols)) continue;
+        if (role != 0 && off + width > S.ncols) continue;
+        if (shifted && (o.mod != S.nrows || o.shift >= 64)) continue;
+        col = S.col0 + (uint32_t)(role == 0 ? off - S.offset : off);
+        return &S;
+    }
+    return nullptr;
+}
+
 // estimated VALU instructions of one translated instruction (chunk sizing only)
 static uint64_t cost_of(const DInstr &d, const Mark &m, const std::vector<DInstr> &H)
 {
     const uint32_t cls = d.op & 255, dk = (d.op >> 8) & 255, ak = (d.op >> 16) & 255, bk = d.op >> 24;
-    if (m.type == ST_M || m.type == ST_FOLDED) return 0;
+    if (m.type == ST_M || m.type == ST_FOLDED || m.lin) return 0;
     if (m.type == ST_A || m.type == ST_S) {
         uint32_t lk = m.yside == 0 ? bk : ak;
         if (m.folded >= 0) lk = (H[m.folded].op >> 16) & 255;
@@ -130,7 +172,7 @@ static void words_of(uint32_t kind, const Opd &o, std::vector<uint32_t> &out)
 }
 
 // chains, chunks, pieces, spill lists, constants layout: everything the generator and the host debug executor share
-static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, bool chains_on)
+static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, bool chains_on, bool lin_on = true)
 {
     const std::vector<DInstr> &H = P->host;
     const size_t n = H.size();
@@ -144,6 +186,7 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
     N->step_coef.assign(n, -1);
     N->piece_first.assign(n, -1);
     N->piece_last.assign(n, -1);
+    N->lin_first.assign(n, -1);
     // ---- definitions and use counts of temporaries
     std::vector<int32_t> defi(N->nw + 3, -1);
     std::vector<std::array<int32_t, 2>> src(n, {-1, -1});
@@ -218,65 +261,130 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
                 chains[ci].steps.clear();
             }
     }
-    // ---- chunks by estimated cost
-    if (chunk_cost == 0) chunk_cost = 11000; // ~90 KB of code: measured best of 3 000 / 5 500 / 11 000 / 25 000 (instruction cache vs spill traffic)
+    // ---- linear terms: chain steps whose leaf is a polynomial element at the row itself
     {
-        uint64_t acc = 0;
-        Chunk cur;
-        for (size_t i = 0; i < n; i++) {
-            const uint64_t c = cost_of(H[i], N->marks[i], H);
-            N->est_valu += c;
-            if (N->marks[i].type == ST_M || N->marks[i].type == ST_A || N->marks[i].type == ST_S) N->chain_steps++;
-            if (acc && acc + c > chunk_cost) {
-                cur.i1 = i;
-                N->chunks.push_back(cur);
-                cur = Chunk();
-                cur.i0 = i;
-                acc = 0;
-            }
-            acc += c;
-        }
-        cur.i1 = n;
-        N->chunks.push_back(cur);
+        uint32_t cand = 0;
+        auto leaf_kind = [&](size_t i) {
+            const Mark &m = N->marks[i];
+            return m.folded >= 0 ? (H[m.folded].op >> 16) & 255 : (H[i].op >> (16 + 8 * (1 - m.yside))) & 255;
+        };
+        auto is_lin = [&](size_t i) {
+            const Mark &m = N->marks[i];
+            if (m.type != ST_A && m.type != ST_S) return false;
+            const uint32_t lk = leaf_kind(i);
+            if (!(lk == K_POL || lk == K_POL3 || lk == K_CONST || lk == K_X)) return false;
+            uint32_t col, sh;
+            int dim;
+            return resolve_pol(P, lk, m.folded >= 0 ? H[m.folded].a : (m.yside == 0 ? H[i].b : H[i].a), col, dim, sh) != nullptr;
+        };
+        for (size_t i = 0; i < n; i++) cand += is_lin(i);
+        uint32_t lin_min = LIN_MIN_TERMS;
+        if (const char *e = getenv("MI_CHELPERS_LIN_MIN")) lin_min = (uint32_t)atoi(e);
+        if (lin_on && cand >= lin_min)
+            for (size_t i = 0; i < n; i++) N->marks[i].lin = is_lin(i);
     }
-    // ---- pieces: the steps of one chain inside one chunk; exponents, coefficients, K constants
-    std::map<std::tuple<uint32_t, uint32_t, bool>, int32_t> coef_ix;
-    auto coef = [&](uint32_t c, uint32_t e, bool neg) {
-        auto key = std::make_tuple(c, e, neg);
+    std::map<std::tuple<uint32_t, uint32_t, bool, uint32_t>, int32_t> coef_ix;
+    auto coef = [&](uint32_t c, uint32_t e, bool neg, uint32_t xk = 0) {
+        auto key = std::make_tuple(c, e, neg, xk);
         auto it = coef_ix.find(key);
         if (it != coef_ix.end()) return it->second;
-        N->coefs.push_back({c, e, neg});
+        N->coefs.push_back({c, e, neg, xk, false});
         return coef_ix[key] = (int32_t)N->coefs.size() - 1;
     };
-    for (size_t k = 0; k < N->chunks.size(); k++) {
-        std::map<int32_t, std::vector<uint32_t>> by_chain;
-        for (size_t i = N->chunks[k].i0; i < N->chunks[k].i1; i++)
-            if (N->marks[i].type == ST_M || N->marks[i].type == ST_A || N->marks[i].type == ST_S) by_chain[N->marks[i].chain].push_back((uint32_t)i);
-        for (auto &kv : by_chain) {
-            const std::vector<uint32_t> &st = kv.second;
-            Piece pc;
-            pc.chain = kv.first;
-            pc.first = st.front();
-            pc.last = st.back();
-            pc.n_m = 0;
-            for (uint32_t i : st) pc.n_m += N->marks[i].type == ST_M;
-            const uint32_t c = (uint32_t)chains[kv.first].chal;
-            if (pc.n_m) pc.begin_coef = coef(c, pc.n_m, false);
-            std::vector<KTerm> kt;
-            uint32_t after = pc.n_m;
-            for (uint32_t i : st) {
-                const Mark &m = N->marks[i];
-                if (m.type == ST_M) { after--; continue; }
-                const bool neg = m.type == ST_S;
-                N->step_coef[i] = (after == 0 && !neg) ? -1 : coef(c, after, neg);
-                if (m.folded >= 0) kt.push_back({(uint32_t)H[m.folded].b.off, (uint32_t)coef(c, after, !neg)}); // y +- (pol - eval): the evaluation enters with the opposite sign
+    if (chunk_cost == 0) chunk_cost = 11000; // ~90 KB of code: measured best of 3 000 / 5 500 / 11 000 / 25 000 (instruction cache vs spill traffic)
+    for (int attempt = 0; attempt < 2; attempt++) {
+        N->chunks.clear(); N->pieces.clear(); N->coefs.clear(); N->kslots.clear(); N->lin_terms.clear(); coef_ix.clear();
+        N->est_valu = N->chain_steps = 0; N->n_lin_sums = 0;
+        std::fill(N->step_coef.begin(), N->step_coef.end(), -1);
+        std::fill(N->piece_first.begin(), N->piece_first.end(), -1);
+        std::fill(N->piece_last.begin(), N->piece_last.end(), -1);
+        // ---- chunks by estimated cost
+        {
+            uint64_t acc = 0;
+            Chunk cur;
+            for (size_t i = 0; i < n; i++) {
+                const uint64_t c = cost_of(H[i], N->marks[i], H);
+                N->est_valu += c;
+                if (N->marks[i].type == ST_M || N->marks[i].type == ST_A || N->marks[i].type == ST_S) N->chain_steps++;
+                if (acc && acc + c > chunk_cost) {
+                    cur.i1 = i;
+                    N->chunks.push_back(cur);
+                    cur = Chunk();
+                    cur.i0 = i;
+                    acc = 0;
+                }
+                acc += c;
             }
-            if (!kt.empty()) { N->kslots.push_back(kt); pc.k_slot = (int32_t)N->kslots.size() - 1; }
-            N->pieces.push_back(pc);
-            const uint32_t pi = (uint32_t)N->pieces.size() - 1;
-            N->piece_first[pc.first] = (int32_t)pi;
-            N->piece_last[pc.last] = (int32_t)pi;
-            N->chunks[k].pieces.push_back(pi);
+            cur.i1 = n;
+            N->chunks.push_back(cur);
+        }
+        // ---- pieces: the steps of one chain inside one chunk; exponents, coefficients, K constants, linear terms
+        for (size_t k = 0; k < N->chunks.size(); k++) {
+            std::map<int32_t, std::vector<uint32_t>> by_chain;
+            for (size_t i = N->chunks[k].i0; i < N->chunks[k].i1; i++)
+                if (N->marks[i].type == ST_M || N->marks[i].type == ST_A || N->marks[i].type == ST_S) by_chain[N->marks[i].chain].push_back((uint32_t)i);
+            for (auto &kv : by_chain) {
+                const std::vector<uint32_t> &st = kv.second;
+                Piece pc;
+                pc.chain = kv.first;
+                pc.first = st.front();
+                pc.last = st.back();
+                pc.n_m = 0;
+                for (uint32_t i : st) pc.n_m += N->marks[i].type == ST_M;
+                const uint32_t c = (uint32_t)chains[kv.first].chal;
+                if (pc.n_m) pc.begin_coef = coef(c, pc.n_m, false);
+                std::vector<KTerm> kt;
+                uint32_t after = pc.n_m;
+                for (uint32_t i : st) {
+                    const Mark &m = N->marks[i];
+                    if (m.type == ST_M) { after--; continue; }
+                    const bool neg = m.type == ST_S;
+                    if (m.folded >= 0) kt.push_back({(uint32_t)H[m.folded].b.off, (uint32_t)coef(c, after, !neg)}); // y +- (pol - eval): the evaluation enters with the opposite sign
+                    if (!m.lin) {
+                        N->step_coef[i] = (after == 0 && !neg) ? -1 : coef(c, after, neg);
+                        continue;
+                    }
+                    if (pc.lin_sum < 0) pc.lin_sum = (int32_t)N->n_lin_sums++;
+                    const uint32_t lk = m.folded >= 0 ? (H[m.folded].op >> 16) & 255 : (H[i].op >> (16 + 8 * (1 - m.yside))) & 255;
+                    uint32_t col = 0, sh = 0;
+                    int dim = 1;
+                    (void)resolve_pol(P, lk, m.folded >= 0 ? H[m.folded].a : (m.yside == 0 ? H[i].b : H[i].a), col, dim, sh);
+                    N->lin_first[i] = (int32_t)N->lin_terms.size();
+                    for (int j = 0; j < dim; j++) N->lin_terms.push_back({col + (uint32_t)j, (uint32_t)coef(c, after, neg, (uint32_t)j), (uint32_t)pc.lin_sum});
+                }
+                if (!kt.empty()) { N->kslots.push_back(kt); pc.k_slot = (int32_t)N->kslots.size() - 1; }
+                N->pieces.push_back(pc);
+                const uint32_t pi = (uint32_t)N->pieces.size() - 1;
+                N->piece_first[pc.first] = (int32_t)pi;
+                N->piece_last[pc.last] = (int32_t)pi;
+                N->chunks[k].pieces.push_back(pi);
+            }
+        }
+        if (N->n_lin_sums <= (uint32_t)LIN_MAX_SUMS) break;
+        for (Mark &m : N->marks) m.lin = 0; // more sums than one pass of the linear kernel carries: generated terms after all
+    }
+    // ---- the linear kernel's tables: terms by (section, slab of LIN_COLS columns, sum), every range padded to pairs with zero terms
+    if (!N->lin_terms.empty()) {
+        N->coefs.push_back({0, 0, false, 0, true});
+        const uint32_t zero_coef = (uint32_t)N->coefs.size() - 1;
+        for (size_t si = 0; si < P->sections.size(); si++) {
+            const HostSection &S = P->sections[si];
+            for (uint32_t c0 = 0; c0 < S.ncols; c0 += LIN_COLS) {
+                LinSlabD d = {};
+                d.section = (uint32_t)si; d.col0 = c0; d.ncols = std::min<uint32_t>(LIN_COLS, (uint32_t)S.ncols - c0);
+                bool any = false;
+                for (int sum = 0; sum < LIN_MAX_SUMS; sum++) {
+                    d.t0[sum] = (uint32_t)N->lin_dev.size();
+                    for (const LinTermH &t : N->lin_terms)
+                        if (t.sum == (uint32_t)sum && t.staged_col >= S.col0 + c0 && t.staged_col < S.col0 + c0 + d.ncols) {
+                            N->lin_dev.push_back({(t.staged_col - S.col0 - c0) * 8, t.coef});
+                            any = true;
+                        }
+                    if ((N->lin_dev.size() - d.t0[sum]) & 1) N->lin_dev.push_back({0, zero_coef});
+                }
+                d.t0[LIN_MAX_SUMS] = (uint32_t)N->lin_dev.size();
+                if (any) N->lin_slabs.push_back(d);
+            }
         }
     }
     N->k_off = N->coef_off + 3 * (uint32_t)N->coefs.size();
@@ -320,6 +428,28 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
         mi_set_error("mi_chelpers_build_native: internal: temporary %u is read before it is written", *live_in[0].begin());
         return MI_ERR_INVALID;
     }
+    // ---- which 64-column slabs of every section the generated kernels read: only those go into the tile-major copy
+    N->sec_slab_mask.assign(P->sections.size(), 0);
+    for (size_t i = 0; i < n; i++) {
+        const Mark &m = N->marks[i];
+        if (m.type == ST_FOLDED || m.type == ST_M || m.lin) continue;
+        const DInstr &d = H[i];
+        const Opd *os[2] = {&d.a, &d.b};
+        uint32_t kk[2] = {(d.op >> 16) & 255, d.op >> 24};
+        if ((m.type == ST_A || m.type == ST_S)) {
+            kk[m.yside] = K_NONE; // the chain value
+            if (m.folded >= 0) { kk[1 - m.yside] = (H[m.folded].op >> 16) & 255; os[1 - m.yside] = &H[m.folded].a; }
+        }
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (!is_pol_kind(kk[s2])) continue;
+            uint32_t col = 0, sh = 0;
+            int dim = 1;
+            const HostSection *S = resolve_pol(P, kk[s2], *os[s2], col, dim, sh);
+            if (!S) continue; // reported by the generator
+            MI_REQUIRE(S->ncols <= 2048, "sections wider than 2048 columns are not supported by the tile-major copy");
+            for (int j = 0; j < dim; j++) N->sec_slab_mask[S - P->sections.data()] |= 1u << ((col + j - S->col0) / 64);
+        }
+    }
     return MI_OK;
 }
 
@@ -334,6 +464,7 @@ static void fill_constants(const mi_chelpers_prog *P, const NativeProg *N, const
     for (uint64_t i = 0; i < n_zh && i < 256 && a->zhinv; i++) cst[N->zh_off + i] = gl::canon(a->zhinv[i]);
     std::map<uint32_t, std::vector<E3>> pw;
     for (const Coef &c : N->coefs) {
+        if (c.zero) continue;
         std::vector<E3> &v = pw[c.chal];
         if (v.empty()) v.push_back(E3{{1, 0, 0}});
         const E3 C = {{cst[c.chal * 3], cst[c.chal * 3 + 1], cst[c.chal * 3 + 2]}};
@@ -341,7 +472,9 @@ static void fill_constants(const mi_chelpers_prog *P, const NativeProg *N, const
     }
     for (size_t i = 0; i < N->coefs.size(); i++) {
         const Coef &c = N->coefs[i];
-        const E3 &p = pw[c.chal][c.exp];
+        if (c.zero) continue;
+        E3 p = pw[c.chal][c.exp];
+        for (uint32_t k = 0; k < c.xk; k++) p = E3{{p.v[2], gl::add(p.v[0], p.v[2]), p.v[1]}}; // times x: x^3 = x + 1
         for (int j = 0; j < 3; j++) cst[N->coef_off + 3 * i + j] = c.neg ? gl::neg(p.v[j]) : p.v[j];
     }
     for (size_t s = 0; s < N->kslots.size(); s++) {
@@ -426,20 +559,15 @@ struct Gen {
         case K_ZHINV: uses_zh = true; v.e[0] = "zh"; return MI_OK;
         default: break;
         }
-        const bool three = k == K_POL3 || k == K_POL3S || k == K_XD || k == K_XDW, shifted = k == K_POLS || k == K_POL3S || k == K_CONSTS;
-        const int role = (k == K_CONST || k == K_CONSTS) ? 1 : k == K_X ? 2 : k == K_XD ? 3 : k == K_XDW ? 4 : 0;
-        uint32_t col = 0;
-        const HostSection *S = find(role, role >= 2 ? 0 : o.off, o.stride, three ? 3 : 1, col);
+        uint32_t col = 0, sh = 0;
+        int pdim = 1;
+        const HostSection *S = resolve_pol(P, k, o, col, pdim, sh);
         if (!S) {
-            mi_set_error("mi_chelpers_build_native: operand (offset %llu, stride %u) lies in none of the declared sections / constant polynomials / x",
-                         (unsigned long long)o.off, o.stride);
+            mi_set_error("mi_chelpers_build_native: operand (offset %llu, stride %u, shift %u) lies in none of the declared sections / constant polynomials / x, "
+                         "or is shifted by 64 rows or more", (unsigned long long)o.off, o.stride, o.shift);
             return MI_ERR_INVALID;
         }
-        uint32_t sh = 0;
-        if (shifted) {
-            MI_REQUIRE(o.mod == S->nrows && o.shift < 64, "shifted-row operand: modulus must be the section's row count, shift below 64");
-            sh = o.shift;
-        }
+        const bool three = pdim == 3;
         if (sh) shifts.insert(sh);
         v.dim = three ? 3 : 1;
         for (int j = 0; j < v.dim; j++) {
@@ -485,7 +613,7 @@ struct Gen {
             if (N->pieces[q].chain == m.chain && N->pieces[q].first <= i && i <= N->pieces[q].last) { pi = (int32_t)q; break; }
         MI_REQUIRE(pi >= 0, "internal: chain step outside every piece");
         name(pi);
-        if (m.type != ST_M) {
+        if (m.type != ST_M && !m.lin) {
             V v;
             if (m.folded >= 0) MI_TRY(operand((P->host[m.folded].op >> 16) & 255, P->host[m.folded].a, v));
             else MI_TRY(operand(kk[1 - m.yside], *os[1 - m.yside], v));
@@ -506,6 +634,10 @@ struct Gen {
                 const std::string lhs = buf; // cstw() formats into buf too
                 std::string r = std::string("chpa::acc_reduce(") + acc[j] + ")";
                 if (pc.k_slot >= 0) r = "gl::add_wc(" + r + ", " + cstw(N->k_off + 3 * (uint64_t)pc.k_slot + j) + ")";
+                if (pc.lin_sum >= 0) { // the polynomial terms of the piece, summed by k_chp_linear (canonical)
+                    snprintf(buf, sizeof buf, ", LIN[%u])", (unsigned)((pc.lin_sum * 3 + j) * 64));
+                    r = "gl::add_wc(" + r + buf;
+                }
                 body += lhs + r + "; ";
                 canon[d.dst + j] = 0;
             }
@@ -583,7 +715,7 @@ struct Gen {
 
 static int compile_source(const std::string &src, const std::string &cache_dir, std::vector<char> &code, NativeProg &N)
 {
-    const std::string opts = "gfx950 -O3 c++17 v6";
+    const std::string opts = "gfx950 -O3 c++17 v7";
     char name[64];
     snprintf(name, sizeof name, "%016llx%016llx.hsaco", (unsigned long long)fnv1a(src + opts), (unsigned long long)fnv1a(opts + src, 0x9E3779B97F4A7C15ull));
     const std::string path = cache_dir.empty() ? "" : cache_dir + "/" + name;
@@ -666,7 +798,7 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
     char line[1024];
     snprintf(line, sizeof line,
              "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(%u, %u))) void chelpers_chunk(const u64 *__restrict__ tiled, u64 *__restrict__ spill, "
-             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask)\n{\n"
+             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin)\n{\n"
              "  const u32 lane = threadIdx.x;\n  const u64 tile = blockIdx.x;\n  const u64 row = row_base + tile * 64 + lane;\n"
              "  const u64 *__restrict__ T0 = tiled + tile * %lluULL + lane;\n  u64 *__restrict__ S = spill + tile * %lluULL + lane;\n",
              waves, waves, (unsigned long long)N->sc * 64, (unsigned long long)N->nw * 64);
@@ -678,6 +810,10 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
     }
     if (g.uses_zh) {
         snprintf(line, sizeof line, "  const u64 zh = cst[%u + (u32)(row & zmask)];\n", N->zh_off);
+        src += line;
+    }
+    if (N->n_lin_sums) {
+        snprintf(line, sizeof line, "  const u64 *__restrict__ LIN = lin + tile * %uULL + lane;\n", N->n_lin_sums * 3 * 64);
         src += line;
     }
     std::set<uint32_t> loads(C.loads.begin(), C.loads.end());
@@ -768,6 +904,8 @@ void native_free(mi_ctx *c, mi_chelpers_prog *P)
     if (!N) return;
     for (Chunk &C : N->chunks)
         if (C.mod) (void)hipModuleUnload(C.mod);
+    if (N->d_lin_terms) (void)hipFree(N->d_lin_terms);
+    if (N->d_lin_slabs) (void)hipFree(N->d_lin_slabs);
     (void)c;
     delete N;
     P->native = nullptr;
@@ -826,7 +964,16 @@ int native_host_run(const mi_chelpers_prog *P, const mi_chelpers_params *a, cons
                     if (N->pieces[q].chain == m.chain && N->pieces[q].first <= i && i <= N->pieces[q].last) { pi = (int32_t)q; break; }
                 MI_REQUIRE(pi >= 0, "internal: chain step outside every piece");
                 chpa::Acc *p = &acc[3 * pi];
-                if (m.type != ST_M) {
+                if (m.type != ST_M && m.lin) { // as k_chp_linear does it: one base term per column, coefficients W, x W, x^2 W
+                    const uint32_t lk = m.folded >= 0 ? (P->host[m.folded].op >> 16) & 255 : kk[1 - m.yside];
+                    load_operand(lk, m.folded >= 0 ? P->host[m.folded].a : *os[1 - m.yside], r, A, tmp, v);
+                    const int dim = kind_is3(lk) ? 3 : 1;
+                    for (int j = 0; j < dim; j++) {
+                        const LinTermH &lt = N->lin_terms[N->lin_first[i] + j];
+                        const u64 *w = &cst[N->coef_off + 3 * lt.coef];
+                        chpa::acc_mul13_s(p[0], p[1], p[2], v[j], w[0], w[1], w[2]);
+                    }
+                } else if (m.type != ST_M) {
                     uint32_t lk = kk[1 - m.yside];
                     if (m.folded >= 0) { lk = (P->host[m.folded].op >> 16) & 255; load_operand(lk, P->host[m.folded].a, r, A, tmp, v); }
                     else load_operand(lk, *os[1 - m.yside], r, A, tmp, v);
@@ -856,8 +1003,9 @@ int native_host_run(const mi_chelpers_prog *P, const mi_chelpers_params *a, cons
 
 // [rows x ncols] row-major (pitch words per row, rows taken modulo nrows) -> tiles [tile][SC columns][64 rows], canonical
 __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ src, uint64_t pitch, uint32_t ncols, uint64_t row_mask,
-                                                        u64 *__restrict__ tiled, uint32_t sc, uint32_t col0, uint64_t row_base)
+                                                        u64 *__restrict__ tiled, uint32_t sc, uint32_t col0, uint64_t row_base, uint32_t slab_mask)
 {
+    if (!((slab_mask >> blockIdx.y) & 1)) return; // no generated kernel reads a column of this slab
     __shared__ u64 t[64][65];
     const uint32_t l = threadIdx.x & 63, q = threadIdx.x >> 6;
     const uint64_t tile = blockIdx.x;
@@ -874,6 +1022,72 @@ __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ s
 #pragma unroll 4
     for (uint32_t cc = q; cc < 64; cc += 4)
         if (c0 + cc < ncols) dst[(uint64_t)cc * 64] = t[l][cc];
+}
+
+
+// sums of polynomial elements times constants, straight from the row-major sections (see "linear terms" above).  One wave per
+// tile of 64 rows; per slab of LIN_COLS columns: 64 x LIN_COLS elements are fetched along the rows (128-byte runs), turned
+// through LDS (two buffers: the next slab's loads are in flight during the arithmetic), and every lane multiplies its row's
+// elements by the terms' coefficients (scalar loads) into the limb accumulators of the term's sum.
+template <int S>
+__global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ slabs, uint32_t n_slabs, const LinTerm *__restrict__ terms,
+                                                     const u64 *__restrict__ cst, const LinSections sec, u64 *__restrict__ lin, uint64_t row_base,
+                                                     uint32_t n_sums)
+{
+    __shared__ u64 buf[2][64 * (LIN_COLS + 1)];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t tile = blockIdx.x;
+    chpa::Acc acc[S][3];
+#pragma unroll
+    for (int s2 = 0; s2 < S; s2++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) chpa::acc_set(acc[s2][j], 0);
+    u64 stage[LIN_COLS]; // 64 x LIN_COLS elements / 64 lanes
+    auto issue = [&](uint32_t sl) {
+        const uint32_t si = slabs[sl].section, c0 = slabs[sl].col0, nc = slabs[sl].ncols;
+        const u64 *src = sec.ptr[si];
+        const uint64_t pitch = sec.pitch[si], mask = sec.row_mask[si];
+#pragma unroll
+        for (uint32_t i = 0; i < LIN_COLS; i++) {
+            const uint32_t e = i * 64 + lane, r = e / LIN_COLS, cc = e % LIN_COLS;
+            const uint64_t row = (row_base + tile * 64 + r) & mask;
+            stage[i] = cc < nc ? src[row * pitch + c0 + cc] : 0;
+        }
+    };
+    issue(0);
+    for (uint32_t sl = 0; sl < n_slabs; sl++) {
+        u64 *b = buf[sl & 1];
+#pragma unroll
+        for (uint32_t i = 0; i < LIN_COLS; i++) {
+            const uint32_t e = i * 64 + lane;
+            b[(e / LIN_COLS) * (LIN_COLS + 1) + e % LIN_COLS] = stage[i];
+        }
+        __syncthreads();
+        if (sl + 1 < n_slabs) issue(sl + 1);
+        const char *rowp = (const char *)(b + lane * (LIN_COLS + 1));
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) {
+            const uint32_t t0 = slabs[sl].t0[s2], t1 = slabs[sl].t0[s2 + 1];
+            for (uint32_t t = t0; t < t1; t += 2) { // ranges are padded to pairs
+                const LinTerm ta = terms[t], tb = terms[t + 1];
+                const u64 xa = *(const u64 *)(rowp + ta.lds_off), xb = *(const u64 *)(rowp + tb.lds_off);
+                const u64 *wa = cst + ta.coef, *wb = cst + tb.coef;
+                const u64 wa0 = wa[0], wa1 = wa[1], wa2 = wa[2], wb0 = wb[0], wb1 = wb[1], wb2 = wb[2];
+                chpa::acc_mac_s(acc[s2][0], xa, wa0);
+                chpa::acc_mac_s(acc[s2][1], xa, wa1);
+                chpa::acc_mac_s(acc[s2][2], xa, wa2);
+                chpa::acc_mac_s(acc[s2][0], xb, wb0);
+                chpa::acc_mac_s(acc[s2][1], xb, wb1);
+                chpa::acc_mac_s(acc[s2][2], xb, wb2);
+            }
+        }
+        __syncthreads();
+    }
+    u64 *o = lin + tile * ((uint64_t)n_sums * 3 * 64) + lane;
+#pragma unroll
+    for (int s2 = 0; s2 < S; s2++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o[(s2 * 3 + j) * 64] = gl::canon(chpa::acc_reduce(acc[s2][j]));
 }
 
 static int grow(u64 **buf, uint64_t *have, uint64_t need, const char *what)
@@ -907,6 +1121,7 @@ int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_
     MI_TRY(grow(&c->chelpers_tiled, &c->chelpers_tiled_bytes, (max_tiles + 1) * N->sc * 512, "the tile-major operand copy"));
     MI_TRY(grow(&c->chelpers_spill, &c->chelpers_spill_bytes, max_tiles * N->nw * 512, "the chunk-boundary spill"));
     MI_TRY(grow(&c->chelpers_cst, &c->chelpers_cst_bytes, (uint64_t)N->cst_words * 8 + 64, "the constraint program's constants"));
+    if (N->n_lin_sums) MI_TRY(grow(&c->chelpers_lin, &c->chelpers_lin_bytes, max_tiles * N->n_lin_sums * 3 * 512, "the linear sums"));
     if (batch_out) *batch_out = batch;
     return MI_OK;
 }
@@ -923,6 +1138,14 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
         for (Chunk &C : N->chunks) {
             MI_HIP_CHECK(hipModuleLoadData(&C.mod, C.code.data()));
             MI_HIP_CHECK(hipModuleGetFunction(&C.fn, C.mod, "chelpers_chunk"));
+        }
+        if (!N->lin_dev.empty()) { // the linear kernel's tables, coefficient indices turned into word offsets of the constants table
+            std::vector<LinTerm> t(N->lin_dev);
+            for (LinTerm &x : t) x.coef = N->coef_off + 3 * x.coef;
+            MI_HIP_CHECK(hipMalloc((void **)&N->d_lin_terms, t.size() * sizeof(LinTerm)));
+            MI_HIP_CHECK(hipMalloc((void **)&N->d_lin_slabs, N->lin_slabs.size() * sizeof(LinSlabD)));
+            MI_HIP_CHECK(hipMemcpy(N->d_lin_terms, t.data(), t.size() * sizeof(LinTerm), hipMemcpyHostToDevice));
+            MI_HIP_CHECK(hipMemcpy(N->d_lin_slabs, N->lin_slabs.data(), N->lin_slabs.size() * sizeof(LinSlabD), hipMemcpyHostToDevice));
         }
         N->loaded_device = c->device;
     }
@@ -943,7 +1166,9 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     const uint64_t row_end = row0 + nrows;
     for (uint64_t b0 = row0; b0 < row_end; b0 += batch) {
         const uint64_t rows = std::min(batch, row_end - b0), tiles = (rows + 63) / 64;
-        for (const HostSection &S : P->sections) {
+        LinSections ls = {};
+        for (size_t si = 0; si < P->sections.size(); si++) {
+            const HostSection &S = P->sections[si];
             const u64 *ptr;
             uint64_t pitch;
             if (S.role == 0) { ptr = (const u64 *)a->pols + S.offset; pitch = S.ncols; }
@@ -952,15 +1177,29 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             else if (S.role == 3) { MI_REQUIRE(a->xdiv, "null xDivXSubXi"); ptr = (const u64 *)a->xdiv; pitch = 3; }
             else { MI_REQUIRE(a->xdivw, "null xDivXSubWXi"); ptr = (const u64 *)a->xdivw; pitch = 3; }
             MI_REQUIRE(is_pow2(S.nrows), "section row counts must be powers of two");
+            ls.ptr[si] = ptr; ls.pitch[si] = pitch; ls.row_mask[si] = S.nrows - 1;
+            if (!N->sec_slab_mask[si]) continue;
             hipLaunchKernelGGL(k_chp_transpose, dim3((unsigned)(tiles + 1), (unsigned)((S.ncols + 63) / 64)), dim3(256), 0, c->stream, ptr, pitch,
-                               (uint32_t)S.ncols, S.nrows - 1, c->chelpers_tiled, N->sc, S.col0, b0);
+                               (uint32_t)S.ncols, S.nrows - 1, c->chelpers_tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        if (N->n_lin_sums) {
+            const dim3 g((unsigned)tiles), bl(64);
+            const uint32_t ns = (uint32_t)N->lin_slabs.size();
+            switch (N->n_lin_sums) {
+            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 1u); break;
+            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 2u); break;
+            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 3u); break;
+            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 4u); break;
+            }
             MI_HIP_CHECK(hipGetLastError());
         }
         for (Chunk &C : N->chunks) {
             const u64 *tiled = c->chelpers_tiled, *cstp = c->chelpers_cst;
             u64 *spill = c->chelpers_spill, *outp = out;
             uint64_t row_base = b0, rend = row_end;
-            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask};
+            const u64 *linp = c->chelpers_lin;
+            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp};
             MI_HIP_CHECK(hipModuleLaunchKernel(C.fn, (unsigned)tiles, 1, 1, 64, 1, 1, 0, c->stream, args, nullptr));
         }
     }

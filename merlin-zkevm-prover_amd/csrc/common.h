@@ -98,8 +98,8 @@ struct mi_ctx {
     u64 *chelpers_stage = nullptr;   // constraint evaluators: per-workgroup transposed operand staging
     uint64_t chelpers_stage_bytes = 0;
     // native-code constraint evaluators (chelpers_native.hip): constants table, tile-major operand copy of one batch of rows, chunk spill
-    u64 *chelpers_cst = nullptr, *chelpers_tiled = nullptr, *chelpers_spill = nullptr;
-    uint64_t chelpers_cst_bytes = 0, chelpers_tiled_bytes = 0, chelpers_spill_bytes = 0;
+    u64 *chelpers_cst = nullptr, *chelpers_tiled = nullptr, *chelpers_spill = nullptr, *chelpers_lin = nullptr;
+    uint64_t chelpers_cst_bytes = 0, chelpers_tiled_bytes = 0, chelpers_spill_bytes = 0, chelpers_lin_bytes = 0;
     uint64_t chelpers_batch_rows = 0; // rows per batch (0: sized for about 8 GiB of operand copy)
     uint64_t chelpers_min_words = 0; // benchmarking: LDS words per row to allocate at least (occupancy of a bigger program)
     // Entry points serialise on the context (scratch, plans, workspace and timers are shared state) and make

@@ -272,10 +272,13 @@ def test_step52ns_on_gpu_matches_oracle():
 
 
 # ------------------------------------------------------------------ native-code backend (chelpers_native.hip)
-@pytest.mark.parametrize("chunk_cost", [0, 2500, 400])
-def test_lowered_programs_match_oracle_on_the_host(chunk_cost):
-    """Chains, pieces cut at kernel boundaries, folded leaves, coefficient / K tables and spill lists (poisoned between kernels)."""
+@pytest.mark.parametrize("chunk_cost,lin_min", [(0, None), (2500, None), (400, None), (0, 1), (300, 1)])
+def test_lowered_programs_match_oracle_on_the_host(chunk_cost, lin_min, monkeypatch):
+    """Chains, pieces cut at kernel boundaries, folded leaves, coefficient / K tables and spill lists (poisoned between kernels);
+    lin_min = 1: the polynomial-leaf chain terms go to the linear kernel's tables whatever their number."""
     import mi_stark
+    if lin_min is not None:
+        monkeypatch.setenv("MI_CHELPERS_LIN_MIN", str(lin_min))
     nrows = 48
     ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(5, nrows, passes=3)
     want, got = np.zeros(nrows * 3, dtype=np.uint64), np.zeros(nrows * 3, dtype=np.uint64)
@@ -340,14 +343,18 @@ def test_native_step42ns_matches_oracle_and_interpreter(tmp_path):
 
 
 @pytest.mark.gpu
-def test_native_step52ns_matches_oracle(tmp_path):
+@pytest.mark.parametrize("lin_min", [None, 1])
+def test_native_step52ns_matches_oracle(tmp_path, lin_min, monkeypatch):
+    """lin_min = 1: the polynomial terms of the chains are summed by the linear kernel (k_chp_linear) instead of generated code."""
     import mi_stark
+    if lin_min is not None:
+        monkeypatch.setenv("MI_CHELPERS_LIN_MIN", str(lin_min))
     ctx = mi_stark.Context(0)
     nrows = 1 << 13
     ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(41, nrows)
     want = np.zeros(nrows * 3, dtype=np.uint64)
     prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
-    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=1500)["kernels"] >= 2
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=1500)["kernels"] >= (2 if lin_min is None else 1)
     f = ctx.zeros(nrows * 3)
     ctx.set_chelpers_batch_rows(2048)
     for ev in (evals, glo.rand_fe(np.random.default_rng(5), evals.size)):
