@@ -222,8 +222,10 @@ int mi_set_chelpers_min_words(mi_ctx *ctx, uint64_t words);
 int mi_chelpers_build_native(mi_chelpers_prog *prog, const char *cache_dir, uint64_t chunk_cost);
 /* What the native backend makes of the program, without compiling anything: out = kernels, instructions evaluated as
  * Horner-chain accumulator steps, chain pieces, estimated VALU instructions per row, chain coefficients (+- C^e), per-piece
- * constants, folded (polynomial - evaluation) leaves, temporary words moved through the spill per row */
-int mi_chelpers_lower_stats(const mi_chelpers_prog *prog, uint64_t chunk_cost, uint64_t out[8]);
+ * constants, folded (polynomial - evaluation) leaves, temporary words moved through the spill per row, polynomial elements
+ * loaded per row (distinct per kernel, summed), distinct polynomial elements the generated kernels read, terms handed to the
+ * linear kernel, sums it carries */
+int mi_chelpers_lower_stats(const mi_chelpers_prog *prog, uint64_t chunk_cost, uint64_t out[12]);
 /* Parallel builds: process `shard` of `nshards` compiles every nshards-th kernel into the cache (cache_dir required) and keeps
  * nothing; mi_chelpers_build_native afterwards finds every kernel there. */
 int mi_chelpers_precompile_shard(mi_chelpers_prog *prog, const char *cache_dir, uint64_t chunk_cost, uint32_t shard,

@@ -901,7 +901,7 @@ extern "C" int mi_chelpers_precompile_shard(mi_chelpers_prog *p, const char *cac
     return chp::native_build(p, cache_dir, chunk_cost, shard, nshards);
 }
 
-extern "C" int mi_chelpers_lower_stats(const mi_chelpers_prog *p, uint64_t chunk_cost, uint64_t out[8])
+extern "C" int mi_chelpers_lower_stats(const mi_chelpers_prog *p, uint64_t chunk_cost, uint64_t out[12])
 {
     if (!p || !out) return MI_ERR_INVALID;
     return chp::native_lower_stats(p, chunk_cost, out);

@@ -109,13 +109,13 @@ struct NativeProg {
     std::vector<LinTerm> lin_dev;             // sorted by slab and sum, padded to pairs (kernel)
     std::vector<LinSlabD> lin_slabs;
     uint32_t n_lin_sums = 0;
-    LinTerm *d_lin_terms = nullptr;
+    struct LinTermW *d_lin_terms = nullptr;   // rewritten per run: the coefficients are constants of the running proof
     LinSlabD *d_lin_slabs = nullptr;
     std::vector<uint32_t> sec_slab_mask;      // per section: 64-column slabs the generated kernels read (tile-major copy)
     uint32_t sc = 0, nw = 0;                     // staged columns per tile, temp words per row
     uint32_t pub_off = 0, ev_off = 0, zh_off = 0, coef_off = 0, k_off = 0, cst_words = 0; // word offsets into the constants table (challenges first)
     double compile_s = 0;
-    uint64_t code_bytes = 0, cache_hits = 0, est_valu = 0, spill_words_moved = 0, chain_steps = 0;
+    uint64_t code_bytes = 0, cache_hits = 0, est_valu = 0, spill_words_moved = 0, chain_steps = 0, operand_loads = 0, operand_distinct = 0;
     int loaded_device = -1;
 };
 
@@ -370,20 +370,33 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
         for (size_t si = 0; si < P->sections.size(); si++) {
             const HostSection &S = P->sections[si];
             for (uint32_t c0 = 0; c0 < S.ncols; c0 += LIN_COLS) {
-                LinSlabD d = {};
-                d.section = (uint32_t)si; d.col0 = c0; d.ncols = std::min<uint32_t>(LIN_COLS, (uint32_t)S.ncols - c0);
-                bool any = false;
-                for (int sum = 0; sum < LIN_MAX_SUMS; sum++) {
-                    d.t0[sum] = (uint32_t)N->lin_dev.size();
-                    for (const LinTermH &t : N->lin_terms)
-                        if (t.sum == (uint32_t)sum && t.staged_col >= S.col0 + c0 && t.staged_col < S.col0 + c0 + d.ncols) {
-                            N->lin_dev.push_back({(t.staged_col - S.col0 - c0) * 8, t.coef});
-                            any = true;
+                // the slab's terms by sum; more than the kernel's LDS block holds: further entries over the same columns
+                const uint32_t ncols = std::min<uint32_t>(LIN_COLS, (uint32_t)S.ncols - c0);
+                std::vector<std::vector<LinTerm>> by_sum(LIN_MAX_SUMS);
+                size_t total = 0;
+                for (const LinTermH &t : N->lin_terms)
+                    if (t.staged_col >= S.col0 + c0 && t.staged_col < S.col0 + c0 + ncols) {
+                        by_sum[t.sum].push_back({(t.staged_col - S.col0 - c0) * 8, t.coef});
+                        total++;
+                    }
+                std::vector<size_t> pos(LIN_MAX_SUMS, 0);
+                while (total) {
+                    LinSlabD d = {};
+                    d.section = (uint32_t)si; d.col0 = c0; d.ncols = ncols;
+                    uint32_t room = 126; // of LIN_TMAX, leaving the pair padding
+                    for (int sum = 0; sum < LIN_MAX_SUMS; sum++) {
+                        d.t0[sum] = (uint32_t)N->lin_dev.size();
+                        while (pos[sum] < by_sum[sum].size() && room) {
+                            N->lin_dev.push_back(by_sum[sum][pos[sum]++]);
+                            room--;
+                            total--;
                         }
-                    if ((N->lin_dev.size() - d.t0[sum]) & 1) N->lin_dev.push_back({0, zero_coef});
+                        if ((N->lin_dev.size() - d.t0[sum]) & 1) { N->lin_dev.push_back({0, zero_coef}); if (room) room--; }
+                    }
+                    d.t0[LIN_MAX_SUMS] = (uint32_t)N->lin_dev.size();
+                    MI_REQUIRE(d.t0[LIN_MAX_SUMS] - d.t0[0] <= 128, "internal: linear slab entry over its LDS block");
+                    N->lin_slabs.push_back(d);
                 }
-                d.t0[LIN_MAX_SUMS] = (uint32_t)N->lin_dev.size();
-                if (any) N->lin_slabs.push_back(d);
             }
         }
     }
@@ -430,7 +443,10 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
     }
     // ---- which 64-column slabs of every section the generated kernels read: only those go into the tile-major copy
     N->sec_slab_mask.assign(P->sections.size(), 0);
+    std::set<uint64_t> chunk_ops, all_ops; // (staged column, shift) read by the current kernel / by any: what CSE leaves of the operand reads
+    size_t chunk_of = 0;
     for (size_t i = 0; i < n; i++) {
+        while (chunk_of + 1 < N->chunks.size() && i >= N->chunks[chunk_of].i1) { N->operand_loads += chunk_ops.size(); chunk_ops.clear(); chunk_of++; }
         const Mark &m = N->marks[i];
         if (m.type == ST_FOLDED || m.type == ST_M || m.lin) continue;
         const DInstr &d = H[i];
@@ -447,9 +463,15 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
             const HostSection *S = resolve_pol(P, kk[s2], *os[s2], col, dim, sh);
             if (!S) continue; // reported by the generator
             MI_REQUIRE(S->ncols <= 2048, "sections wider than 2048 columns are not supported by the tile-major copy");
-            for (int j = 0; j < dim; j++) N->sec_slab_mask[S - P->sections.data()] |= 1u << ((col + j - S->col0) / 64);
+            for (int j = 0; j < dim; j++) {
+                N->sec_slab_mask[S - P->sections.data()] |= 1u << ((col + j - S->col0) / 64);
+                chunk_ops.insert(((uint64_t)(col + j) << 8) | sh);
+                all_ops.insert(((uint64_t)(col + j) << 8) | sh);
+            }
         }
     }
+    N->operand_loads += chunk_ops.size();
+    N->operand_distinct = all_ops.size();
     return MI_OK;
 }
 
@@ -872,7 +894,7 @@ int native_build(mi_chelpers_prog *P, const char *cache_dir_arg, uint64_t chunk_
     return MI_OK;
 }
 
-int native_lower_stats(const mi_chelpers_prog *P, uint64_t chunk_cost, uint64_t out[8])
+int native_lower_stats(const mi_chelpers_prog *P, uint64_t chunk_cost, uint64_t out[12])
 {
     NativeProg N;
     MI_TRY(lower(P, &N, chunk_cost, true));
@@ -880,6 +902,7 @@ int native_lower_stats(const mi_chelpers_prog *P, uint64_t chunk_cost, uint64_t 
     for (const Mark &m : N.marks) folded += m.type == ST_FOLDED;
     out[0] = N.chunks.size(); out[1] = N.chain_steps; out[2] = N.pieces.size(); out[3] = N.est_valu;
     out[4] = N.coefs.size(); out[5] = N.kslots.size(); out[6] = folded; out[7] = N.spill_words_moved;
+    out[8] = N.operand_loads; out[9] = N.operand_distinct; out[10] = N.lin_terms.size(); out[11] = N.n_lin_sums;
     return MI_OK;
 }
 
@@ -1026,15 +1049,21 @@ __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ s
 
 
 // sums of polynomial elements times constants, straight from the row-major sections (see "linear terms" above).  One wave per
-// tile of 64 rows; per slab of LIN_COLS columns: 64 x LIN_COLS elements are fetched along the rows (128-byte runs), turned
-// through LDS (two buffers: the next slab's loads are in flight during the arithmetic), and every lane multiplies its row's
-// elements by the terms' coefficients (scalar loads) into the limb accumulators of the term's sum.
+// tile of 64 rows; per slab of LIN_COLS columns: 64 x LIN_COLS elements are fetched along the rows (128-byte runs) and turned
+// through LDS, and every lane multiplies its row's elements by the terms' coefficients into the limb accumulators of the term's
+// sum.  The slab's terms (column offset + coefficient, 32 bytes each, rewritten per run) travel through LDS as well -- read back
+// as broadcasts -- because scalar loads inside the term loop (descriptor, then the coefficient it points to) left the kernel
+// latency-bound at three times its HBM time.  Everything of slab s + 1 is in flight during the arithmetic of slab s.
+struct LinTermW { uint32_t lds_off, pad; u64 w[3]; };
+static_assert(sizeof(LinTermW) == 32, "term must be 32 bytes");
+static constexpr uint32_t LIN_TMAX = 128; // terms per slab the LDS block holds
+
 template <int S>
-__global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ slabs, uint32_t n_slabs, const LinTerm *__restrict__ terms,
-                                                     const u64 *__restrict__ cst, const LinSections sec, u64 *__restrict__ lin, uint64_t row_base,
-                                                     uint32_t n_sums)
+__global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ slabs, uint32_t n_slabs, const LinTermW *__restrict__ terms,
+                                                     const LinSections sec, u64 *__restrict__ lin, uint64_t row_base, uint32_t n_sums)
 {
     __shared__ u64 buf[2][64 * (LIN_COLS + 1)];
+    __shared__ __attribute__((aligned(16))) u64 cb[2][(LIN_TMAX + 4) * 4]; // + slack: the term loop reads one pair ahead
     const uint32_t lane = threadIdx.x;
     const uint64_t tile = blockIdx.x;
     chpa::Acc acc[S][3];
@@ -1042,7 +1071,12 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
     for (int s2 = 0; s2 < S; s2++)
 #pragma unroll
         for (int j = 0; j < 3; j++) chpa::acc_set(acc[s2][j], 0);
+    if (threadIdx.x < 32) { // the slack stays zero (offset 0, coefficient 0)
+        const uint32_t b2 = threadIdx.x >> 4, k = threadIdx.x & 15;
+        cb[b2][LIN_TMAX * 4 + k] = 0;
+    }
     u64 stage[LIN_COLS]; // 64 x LIN_COLS elements / 64 lanes
+    uint4 cstage[LIN_TMAX * 32 / 1024];
     auto issue = [&](uint32_t sl) {
         const uint32_t si = slabs[sl].section, c0 = slabs[sl].col0, nc = slabs[sl].ncols;
         const u64 *src = sec.ptr[si];
@@ -1051,34 +1085,55 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
         for (uint32_t i = 0; i < LIN_COLS; i++) {
             const uint32_t e = i * 64 + lane, r = e / LIN_COLS, cc = e % LIN_COLS;
             const uint64_t row = (row_base + tile * 64 + r) & mask;
-            stage[i] = cc < nc ? src[row * pitch + c0 + cc] : 0;
+            stage[i] = src[row * pitch + c0 + (cc < nc ? cc : 0)]; // no term reads a column past the section's last: any valid address will do
+        }
+        const uint32_t tb = slabs[sl].t0[0], n16 = (slabs[sl].t0[LIN_MAX_SUMS] - tb) * 2; // 16-byte pieces of this slab's terms
+        const uint4 *tp = (const uint4 *)(terms + tb);
+#pragma unroll
+        for (uint32_t k = 0; k < LIN_TMAX * 32 / 1024; k++) {
+            const uint32_t e = k * 64 + lane;
+            const uint4 v = tp[e < n16 ? e : 0]; // unconditional load (a predicated one becomes a branch per load)
+            cstage[k] = e < n16 ? v : make_uint4(0, 0, 0, 0);
         }
     };
     issue(0);
     for (uint32_t sl = 0; sl < n_slabs; sl++) {
         u64 *b = buf[sl & 1];
+        uint4 *c4 = (uint4 *)cb[sl & 1];
 #pragma unroll
         for (uint32_t i = 0; i < LIN_COLS; i++) {
             const uint32_t e = i * 64 + lane;
             b[(e / LIN_COLS) * (LIN_COLS + 1) + e % LIN_COLS] = stage[i];
         }
+#pragma unroll
+        for (uint32_t k = 0; k < LIN_TMAX * 32 / 1024; k++) c4[k * 64 + lane] = cstage[k];
         __syncthreads();
         if (sl + 1 < n_slabs) issue(sl + 1);
         const char *rowp = (const char *)(b + lane * (LIN_COLS + 1));
+        const uint32_t tb = slabs[sl].t0[0];
 #pragma unroll
         for (int s2 = 0; s2 < S; s2++) {
-            const uint32_t t0 = slabs[sl].t0[s2], t1 = slabs[sl].t0[s2 + 1];
+            const uint32_t t0 = slabs[sl].t0[s2] - tb, t1 = slabs[sl].t0[s2 + 1] - tb;
+            if (t0 >= t1) continue;
+            // software pipeline: the descriptors of pair k + 1 are read before, its elements in the middle of, the arithmetic of pair k
+            const uint4 *q = (const uint4 *)cb[sl & 1] + 2 * t0;
+            uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
+            u64 xa = *(const u64 *)(rowp + a0.x), xb = *(const u64 *)(rowp + b0.x);
             for (uint32_t t = t0; t < t1; t += 2) { // ranges are padded to pairs
-                const LinTerm ta = terms[t], tb = terms[t + 1];
-                const u64 xa = *(const u64 *)(rowp + ta.lds_off), xb = *(const u64 *)(rowp + tb.lds_off);
-                const u64 *wa = cst + ta.coef, *wb = cst + tb.coef;
-                const u64 wa0 = wa[0], wa1 = wa[1], wa2 = wa[2], wb0 = wb[0], wb1 = wb[1], wb2 = wb[2];
-                chpa::acc_mac_s(acc[s2][0], xa, wa0);
-                chpa::acc_mac_s(acc[s2][1], xa, wa1);
-                chpa::acc_mac_s(acc[s2][2], xa, wa2);
-                chpa::acc_mac_s(acc[s2][0], xb, wb0);
-                chpa::acc_mac_s(acc[s2][1], xb, wb1);
-                chpa::acc_mac_s(acc[s2][2], xb, wb2);
+                q += 4;
+                const uint4 na0 = q[0], na1 = q[1], nb0 = q[2], nb1 = q[3];
+                __builtin_amdgcn_sched_barrier(0); // keep the reads up here: the scheduler sinks them below the arithmetic otherwise
+                chpa::acc_mac(acc[s2][0], xa, ((u64)a0.w << 32) | a0.z);
+                chpa::acc_mac(acc[s2][1], xa, ((u64)a1.y << 32) | a1.x);
+                chpa::acc_mac(acc[s2][2], xa, ((u64)a1.w << 32) | a1.z);
+                __builtin_amdgcn_sched_barrier(0);
+                const u64 nxa = *(const u64 *)(rowp + na0.x), nxb = *(const u64 *)(rowp + nb0.x);
+                __builtin_amdgcn_sched_barrier(0);
+                chpa::acc_mac(acc[s2][0], xb, ((u64)b0.w << 32) | b0.z);
+                chpa::acc_mac(acc[s2][1], xb, ((u64)b1.y << 32) | b1.x);
+                chpa::acc_mac(acc[s2][2], xb, ((u64)b1.w << 32) | b1.z);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                xa = nxa; xb = nxb;
             }
         }
         __syncthreads();
@@ -1140,11 +1195,8 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             MI_HIP_CHECK(hipModuleGetFunction(&C.fn, C.mod, "chelpers_chunk"));
         }
         if (!N->lin_dev.empty()) { // the linear kernel's tables, coefficient indices turned into word offsets of the constants table
-            std::vector<LinTerm> t(N->lin_dev);
-            for (LinTerm &x : t) x.coef = N->coef_off + 3 * x.coef;
-            MI_HIP_CHECK(hipMalloc((void **)&N->d_lin_terms, t.size() * sizeof(LinTerm)));
+            MI_HIP_CHECK(hipMalloc((void **)&N->d_lin_terms, (N->lin_dev.size() + 64) * sizeof(LinTermW)));
             MI_HIP_CHECK(hipMalloc((void **)&N->d_lin_slabs, N->lin_slabs.size() * sizeof(LinSlabD)));
-            MI_HIP_CHECK(hipMemcpy(N->d_lin_terms, t.data(), t.size() * sizeof(LinTerm), hipMemcpyHostToDevice));
             MI_HIP_CHECK(hipMemcpy(N->d_lin_slabs, N->lin_slabs.data(), N->lin_slabs.size() * sizeof(LinSlabD), hipMemcpyHostToDevice));
         }
         N->loaded_device = c->device;
@@ -1157,6 +1209,15 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     MI_TRY(grow(&c->chelpers_cst, &c->chelpers_cst_bytes, cst_words * 8 + 64, "the constraint program's constants"));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // an earlier run may still be reading the table
     MI_HIP_CHECK(hipMemcpyAsync(c->chelpers_cst, cst.data(), cst_words * 8, hipMemcpyHostToDevice, c->stream));
+    if (!N->lin_dev.empty()) { // the linear kernel's terms with this proof's coefficients
+        std::vector<LinTermW> tw(N->lin_dev.size());
+        for (size_t i = 0; i < tw.size(); i++) {
+            tw[i].lds_off = N->lin_dev[i].lds_off;
+            tw[i].pad = 0;
+            for (int j = 0; j < 3; j++) tw[i].w[j] = cst[N->coef_off + 3 * N->lin_dev[i].coef + j];
+        }
+        MI_HIP_CHECK(hipMemcpy(N->d_lin_terms, tw.data(), tw.size() * sizeof(LinTermW), hipMemcpyHostToDevice));
+    }
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `cst` dies with this call
     // ---- batches of rows: tile-major copy (+ halo tile) and the spill
     uint64_t batch = 0;
@@ -1187,10 +1248,10 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             const dim3 g((unsigned)tiles), bl(64);
             const uint32_t ns = (uint32_t)N->lin_slabs.size();
             switch (N->n_lin_sums) {
-            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 1u); break;
-            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 2u); break;
-            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 3u); break;
-            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, c->chelpers_cst, ls, c->chelpers_lin, b0, 4u); break;
+            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 1u); break;
+            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 2u); break;
+            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 3u); break;
+            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 4u); break;
             }
             MI_HIP_CHECK(hipGetLastError());
         }

@@ -349,10 +349,11 @@ class ChelpersProgram:
         _check(lib().mi_chelpers_reserve(self.ctx.h, self.h, u64(nrows)))
 
     def lower_stats(self, chunk_cost=0):
-        st = np.zeros(8, dtype=np.uint64)
+        st = np.zeros(12, dtype=np.uint64)
         _check(lib().mi_chelpers_lower_stats(self.h, u64(chunk_cost), _hp(st)))
         return dict(zip(("kernels", "horner_chain_steps", "chain_pieces", "estimated_valu_per_row", "chain_coefficients", "piece_constants",
-                         "folded_leaves", "spill_words_moved_per_row"), (int(v) for v in st)))
+                         "folded_leaves", "spill_words_moved_per_row", "operand_loads_per_row", "distinct_operands", "linear_terms", "linear_sums"),
+                        (int(v) for v in st)))
 
     def precompile_shard(self, shard, nshards, cache_dir=None, chunk_cost=0):
         """One process's share of a parallel build: fills the cache, keeps nothing."""

@@ -172,28 +172,38 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     base_ops = [o for o, (d, a, b) in OPS.items() if d == T1 and o < 78 and b is not None]
     first = {c: [o for o in base_ops if cls_of(o) == c and T1 not in OPS[o][1:]] for c in ("add", "sub", "mul")}
     later = {c: [o for o in base_ops if cls_of(o) == c and T1 in OPS[o][1:]] for c in ("add", "sub", "mul")}
-    n_atoms = max(8, field_ops // 12)
+    # operand locality like the real program's (2 167 distinct polynomial elements, 12 525 reads, 4 327 loads left after common-
+    # subexpression elimination within each of 28 kernels): the constraints come in runs -- one per state machine -- and a run
+    # draws its operands from its own pool of elements, plus a few that the whole program shares
+    n_runs = max(1, field_ops // 750)
+    per_run = max(6, min(130, field_ops // 30))
+    cur_pool = {"pol": [], "pols": [], "const": []}
 
     def zipf_pick(pool):
-        w = 1.0 / (np.arange(len(pool)) + 10.0) ** 0.8
+        w = 1.0 / (np.arange(len(pool)) + 4.0) ** 0.7
         return pool[int(rng.choice(len(pool), p=w / w.sum()))]
 
     def rand_col(three=False):
         off, stride = sections[int(rng.integers(0, len(sections)))]
         return off + int(rng.integers(0, stride - (2 if three else 0))), stride
-    pol_pool = [rand_col() for _ in range(n_atoms)]
-    pols_pool = [rand_col() for _ in range(max(4, n_atoms // 6))]
-    const_pool = [int(rng.integers(0, n_const)) for _ in range(max(4, min(n_const, n_atoms // 4)))]
+    shared = {"pol": [rand_col() for _ in range(12)], "pols": [rand_col() for _ in range(4)], "const": [int(rng.integers(0, n_const)) for _ in range(4)]}
+
+    def new_run():
+        cur_pool["pol"] = [rand_col() for _ in range(max(3, per_run * 6 // 10))] + shared["pol"]
+        cur_pool["pols"] = [rand_col() for _ in range(max(2, per_run * 2 // 10))] + shared["pols"]
+        cur_pool["const"] = [int(rng.integers(0, n_const)) for _ in range(max(2, per_run * 2 // 10))] + shared["const"]
+    new_run()
+    pol_pool, pols_pool, const_pool = cur_pool["pol"], cur_pool["pols"], cur_pool["const"]
 
     def gen_src(kind, temps):
         if kind == T1: return [temps.pop()]
         if kind == NUM: return [int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.3 else int(rng.integers(0, 9))]
-        if kind == CONST: return [zipf_pick(const_pool)]
-        if kind == CONSTS: return [zipf_pick(const_pool), next_shift, nrows]
+        if kind == CONST: return [zipf_pick(cur_pool["const"])]
+        if kind == CONSTS: return [zipf_pick(cur_pool["const"]), next_shift, nrows]
         if kind == PUB: return [int(rng.integers(0, n_pub))]
-        if kind == POL: return list(zipf_pick(pol_pool))
+        if kind == POL: return list(zipf_pick(cur_pool["pol"]))
         if kind == POLS:
-            c, st = zipf_pick(pols_pool)
+            c, st = zipf_pick(cur_pool["pols"])
             return [c, next_shift, nrows, st]
         raise ValueError(kind)
 
@@ -205,7 +215,11 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     for k in range(long_lived):
         push(50, [LL0 + k] + list(zipf_pick(pol_pool)) + list(zipf_pick(pol_pool)))
     count, slot, eslot = 1 + long_lived, 0, 1
+    next_run = count + field_ops // n_runs
     while count < field_ops - 1:
+        if count >= next_run:
+            new_run()
+            next_run += field_ops // n_runs
         g = min(14, 1 + int(rng.geometric(1 / 4.6)))
         cur = None
         for k in range(g):
@@ -226,7 +240,7 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
             e1, e2 = 1 + eslot % 4, 1 + (eslot + 1) % 4
             eslot += 2
             push(59, [e1, cur, int(rng.integers(0, vc))])                   # e1 = value * challenge
-            push(62, [e2] + list(zipf_pick(pol_pool)) + [int(rng.integers(0, vc))])  # e2 = pol * challenge
+            push(62, [e2] + list(zipf_pick(cur_pool["pol"])) + [int(rng.integers(0, vc))])  # e2 = pol * challenge
             push(71, [e1, e1, e2])                                          # e1 = e1 * e2
             push(42 if rng.random() < 0.4 else 17, [e1, e1, e2])            # e1 = e1 -/+ e2
             push(17, [ACC, e1, ACC])
@@ -286,8 +300,10 @@ def synthetic_program52(rng, sections, n_const, n_evals, length=60):
     sections: [(offset, stride)], each with at least 3 columns."""
     ops, args = [], []
 
-    def pol(three):
-        off, stride = sections[int(rng.integers(0, len(sections)))]
+    widths = np.array([st for _, st in sections], dtype=np.float64)
+
+    def pol(three):                                # a column of the committed polynomials, uniformly over all of them
+        off, stride = sections[int(rng.choice(len(sections), p=widths / widths.sum()))]
         return [off + int(rng.integers(0, stride - (2 if three else 0))), stride]
 
     def emit(o):
