@@ -9,6 +9,7 @@
 //   starks.cpp:133-140  the same for cm2                                                          -> commitStage(1, ..)
 //   starks.cpp:214-221  the same for cm3                                                          -> commitStage(2, ..)
 //   starks.cpp:237-248  steps->step42ns_parser_first_avx(params, NExtended, nrowsStepBatch)       -> setStep42nsProgram + step42ns
+//   starks.cpp:350-380  xDivXSubXi / xDivXSubWXi, steps->step52ns_parser_first_avx(params, ...)     -> setStep52nsProgram + step52ns
 //   starks.cpp:261-292  INTT(qq1, q_2ns) / split / NTT(cm4_2ns, qq2) / treesGL[3]->merkelize()    -> commitQ(root)
 //   friProve.cpp:219-250 treesGL[t]->getGroupProof(..)                                            -> getGroupProofs(t, ..)
 //
@@ -30,9 +31,9 @@ class StarksDevice
     std::vector<uint64_t> cols, offset; // sections 0..2 = cm1..cm3 (_2ns), 3 = cm4_2ns (qDeg * qDim), 4 = q_2ns (qDim)
     uint64_t *d_area = nullptr;
     std::vector<uint64_t *> d_nodes;
-    mi_chelpers_prog *prog42 = nullptr;
+    mi_chelpers_prog *prog42 = nullptr, *prog52 = nullptr;
     uint64_t nConst = 0;
-    uint64_t *d_const = nullptr, *d_x2ns = nullptr;
+    uint64_t *d_const = nullptr, *d_x2ns = nullptr, *d_xdiv = nullptr, *d_xdivw = nullptr, *d_f2ns = nullptr;
 
     static uint64_t *alloc(uint64_t elems, const char *what)
     {
@@ -61,6 +62,8 @@ public:
     {
         mi_ctx *c = mi::ctx();
         if (prog42) mi_chelpers_free(c, prog42);
+        if (prog52) mi_chelpers_free(c, prog52);
+        mi_dev_free(c, d_xdiv); mi_dev_free(c, d_xdivw); mi_dev_free(c, d_f2ns);
         for (uint64_t *p : d_nodes) mi_dev_free(c, p);
         mi_dev_free(c, d_area); mi_dev_free(c, d_const); mi_dev_free(c, d_x2ns);
     }
@@ -109,6 +112,40 @@ public:
         mi_chelpers_params p = {d_area, d_const, nConst, (const uint64_t *)challenges, nChallenges, (const uint64_t *)publicInputs, nPublics,
                                 d_x2ns, 1, zh.data(), zh.size(), section(4)};
         mi::check(mi_chelpers_run_dev(c, prog42, &p, 0, NExtended), "StarksDevice::step42ns");
+    }
+    // Optional, once per proving key: compile the constraint programs set so far to gfx950 code (hiprtc; cacheDir keeps the code
+    // objects between runs).  step42ns / step52ns then launch the compiled kernels instead of the interpreter; same results.
+    void buildNative(const char *cacheDir = nullptr)
+    {
+        if (prog42) mi::check(mi_chelpers_build_native(prog42, cacheDir, 0), "StarksDevice::buildNative (step42ns)");
+        if (prog52) mi::check(mi_chelpers_build_native(prog52, cacheDir, 0), "StarksDevice::buildNative (step52ns)");
+    }
+    // step 5a: the FRI-polynomial program (tables of zkevm.chelpers.step52ns.parser.hpp); call after setStep42nsProgram (it reads
+    // the same constant polynomials) and after commitQ has filled cm4_2ns
+    void setStep52nsProgram(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs)
+    {
+        std::vector<mi_chelpers_section> secs;
+        for (unsigned s = 0; s < 4; s++) secs.push_back({offset[s], cols[s], NExtended});
+        mi::check(mi_chelpers_compile(mi::ctx(), &prog52, MI_CHELPERS_STEP52NS, ops, nops, args, nargs, secs.data(), secs.size(), nConst, NExtended),
+                  "StarksDevice::setStep52nsProgram");
+    }
+    // step 5b (starks.cpp:350-380): xDivXSubXi / xDivXSubWXi over the extended domain, then f_2ns = the program's output, resident
+    // (xi: challenges[7], wxi = xi * w(nBits): starks.cpp:308-309,352-353)
+    uint64_t *step52ns(const Goldilocks::Element *challenges, uint64_t nChallenges, const Goldilocks::Element *evals, uint64_t nEvals,
+                       const Goldilocks::Element *xi, const Goldilocks::Element *wxi)
+    {
+        mi_ctx *c = mi::ctx();
+        if (!d_xdiv) {
+            d_xdiv = alloc(NExtended * 3, "StarksDevice (xDivXSubXi)");
+            d_xdivw = alloc(NExtended * 3, "StarksDevice (xDivXSubWXi)");
+            d_f2ns = alloc(NExtended * 3, "StarksDevice (f_2ns)");
+        }
+        mi::check(mi_x_div_x_sub_dev(c, d_xdiv, d_x2ns, NExtended, (const uint64_t *)xi), "StarksDevice::step52ns (xDivXSubXi)");
+        mi::check(mi_x_div_x_sub_dev(c, d_xdivw, d_x2ns, NExtended, (const uint64_t *)wxi), "StarksDevice::step52ns (xDivXSubWXi)");
+        mi_chelpers_params p = {d_area, d_const, nConst, (const uint64_t *)challenges, nChallenges, nullptr, 0, nullptr, 0, nullptr, 0, nullptr,
+                                (const uint64_t *)evals, nEvals, d_xdiv, d_xdivw, d_f2ns};
+        mi::check(mi_chelpers_run_dev(c, prog52, &p, 0, NExtended), "StarksDevice::step52ns");
+        return d_f2ns;
     }
     // step 4c (starks.cpp:261-292): INTT of q, split into qDeg chunks with shift^-N, NTT over qDeg * qDim columns, merkelize
     void commitQ(Goldilocks::Element *root, uint64_t qDeg = 2, uint64_t qDim = FIELD_EXTENSION)

@@ -139,6 +139,46 @@ int main()
         glo_ntt(c4.data(), q2.data(), NExtended, 6, 0);
         glo_merkletree(n4.data(), c4.data(), 6, NExtended);
         EXPECT(same(r, &n4[n4.size() - 4], 4), "StarksDevice::commitQ (INTT, split, NTT, tree) root == oracle");
+        // step 5: a small FRI-polynomial program over cm1..cm4 (zkevm.chelpers.step52ns opcodes), interpreter and compiled kernels
+        //   tmp = cm1[3]*c5; tmp += cm2[1]; tmp = tmp*c5 + cm3[0..2]; tmp1 = tmp*c5; tmp2 = cm1[7] - evals[1]; tmp = tmp2*c6;
+        //   tmp = tmp*c6 + (cm4[0..2] - evals[2]); tmp = tmp*c6 + (const[4] - evals[0]); tmp *= xDivXSubXi; tmp = tmp1 + tmp; f = tmp
+        const uint64_t o4 = sd.sectionOffset(3);
+        const uint64_t ops52[] = {0, 10, 17, 3, 11, 4, 20, 19, 5, 8, 15};
+        const uint64_t args52[] = {o1 + 3, nCols,   o2 + 1, c2,   o3, 3,   o1 + 7, nCols, 1,   o4, 6, 2,   4, 0};
+        std::vector<Goldilocks::Element> chal7(7 * 3), ev(3 * 3), xi(3), wxi(3);
+        for (uint64_t i = 0; i < chal7.size(); i++) chal7[i] = Goldilocks::fromU64(splitmix(25, i));
+        for (uint64_t i = 0; i < ev.size(); i++) ev[i] = Goldilocks::fromU64(splitmix(26, i));
+        for (uint64_t i = 0; i < 3; i++) { xi[i] = Goldilocks::fromU64(splitmix(27, i)); wxi[i] = Goldilocks::fromU64(splitmix(28, i)); }
+        sd.setStep52nsProgram(ops52, sizeof(ops52) / 8, args52, sizeof(args52) / 8);
+        std::vector<uint64_t> area52(o4 + NExtended * 6), xd(NExtended * 3), xdw(NExtended * 3), wf(NExtended * 3), gf(NExtended * 3);
+        std::memcpy(area52.data(), area.data(), area.size() * 8);
+        std::memcpy(&area52[o4], c4.data(), c4.size() * 8);
+        auto x_div_x_sub = [&](std::vector<uint64_t> &out, const Goldilocks::Element *z) { // x / (x - z), starks.cpp:350-365
+            std::vector<uint64_t> den(NExtended * 3);
+            for (uint64_t k = 0; k < NExtended; k++) {
+                den[3 * k] = glo_sub(x2ns[k], Goldilocks::toU64(z[0]));
+                den[3 * k + 1] = glo_sub(0, Goldilocks::toU64(z[1]));
+                den[3 * k + 2] = glo_sub(0, Goldilocks::toU64(z[2]));
+            }
+            glo_batch_inverse3(out.data(), den.data(), NExtended);
+            for (uint64_t k = 0; k < NExtended * 3; k++) out[k] = glo_mul(out[k], x2ns[k / 3]);
+        };
+        x_div_x_sub(xd, xi.data());
+        x_div_x_sub(xdw, wxi.data());
+        st = glo_chelpers_step52ns(ops52, sizeof(ops52) / 8, args52, sizeof(args52) / 8, area52.data(), (const uint64_t *)cpols.data(), nConst,
+                                   (const uint64_t *)chal7.data(), (const uint64_t *)ev.data(), xd.data(), xdw.data(), wf.data(), 0, NExtended);
+        uint64_t *d_f = sd.step52ns(chal7.data(), 7, ev.data(), 3, xi.data(), wxi.data());
+        mi::check(mi_copy_d2h(mi::ctx(), gf.data(), d_f, gf.size() * 8), "d2h");
+        EXPECT(st == 0 && same(gf.data(), wf.data(), gf.size()), "StarksDevice::step52ns (FRI-polynomial program, interpreter) == oracle interpreter");
+        // the same two programs compiled to gfx950 kernels (hiprtc): same q, same f
+        sd.buildNative(nullptr);
+        sd.step42ns(chal.data(), 2, pub.data(), 1);
+        mi::check(mi_copy_d2h(mi::ctx(), gq.data(), sd.section(4), gq.size() * 8), "d2h");
+        EXPECT(same(gq.data(), wq_.data(), gq.size()), "StarksDevice::step42ns after buildNative (compiled kernels) == oracle interpreter");
+        d_f = sd.step52ns(chal7.data(), 7, ev.data(), 3, xi.data(), wxi.data());
+        std::fill(gf.begin(), gf.end(), 0);
+        mi::check(mi_copy_d2h(mi::ctx(), gf.data(), d_f, gf.size() * 8), "d2h");
+        EXPECT(same(gf.data(), wf.data(), gf.size()), "StarksDevice::step52ns after buildNative (compiled kernels) == oracle interpreter");
     }
 
     // ---- STEP 4 shapes (starks.cpp:261,284): INTT with the positional (NULL, 2, 1) hints, NTT over 6 columns
