@@ -27,21 +27,20 @@ MI_HD void acc_add(Acc &A, u64 v)
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// VALU writes a carry mask to an SGPR pair -> a VALU instruction reads it as carry-in: two wait states on gfx950; the order
-// below keeps two instructions between every v_mad and the v_addc that consumes its carry (one s_nop for the last pair)
+// VALU writes a carry mask to an SGPR pair -> a VALU instruction reads it as carry-in: two wait states on gfx950; in the order
+// below three instructions lie between every v_mad and the v_addc that consumes its carry, so no s_nop is needed
 #define CHPA_MAC_ASM(WC)                                                                                                        \
-    u64 s0, s1, s2;                                                                                                             \
-    asm("v_mad_u64_u32 %[a0], %[s0], %[x0], %[w0], %[a0]\n\t"                                                                   \
-        "v_mad_u64_u32 %[a1], %[s1], %[x0], %[w1], %[a1]\n\t"                                                                   \
+    u64 s0, s1, s2, s3;                                                                                                         \
+    asm("v_mad_u64_u32 %[a1], %[s1], %[x0], %[w1], %[a1]\n\t"                                                                   \
+        "v_mad_u64_u32 %[a0], %[s0], %[x0], %[w0], %[a0]\n\t"                                                                   \
+        "v_mad_u64_u32 %[a1], %[s3], %[x1], %[w0], %[a1]\n\t"                                                                   \
         "v_mad_u64_u32 %[a2], %[s2], %[x1], %[w1], %[a2]\n\t"                                                                   \
-        "v_addc_co_u32_e64 %[c0], %[s0], %[c0], 0, %[s0]\n\t"                                                                   \
         "v_addc_co_u32_e64 %[c1], %[s1], %[c1], 0, %[s1]\n\t"                                                                   \
-        "v_mad_u64_u32 %[a1], %[s0], %[x1], %[w0], %[a1]\n\t"                                                                   \
-        "v_addc_co_u32_e64 %[c2], %[s2], %[c2], 0, %[s2]\n\t"                                                                   \
-        "s_nop 0\n\t"                                                                                                           \
-        "v_addc_co_u32_e64 %[c1], %[s0], %[c1], 0, %[s0]"                                                                       \
+        "v_addc_co_u32_e64 %[c0], %[s0], %[c0], 0, %[s0]\n\t"                                                                   \
+        "v_addc_co_u32_e64 %[c1], %[s3], %[c1], 0, %[s3]\n\t"                                                                   \
+        "v_addc_co_u32_e64 %[c2], %[s2], %[c2], 0, %[s2]"                                                                       \
         : [a0] "+v"(A.a0), [a1] "+v"(A.a1), [a2] "+v"(A.a2), [c0] "+v"(A.c0), [c1] "+v"(A.c1), [c2] "+v"(A.c2), [s0] "=&s"(s0),  \
-          [s1] "=&s"(s1), [s2] "=&s"(s2)                                                                                        \
+          [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)                                                                        \
         : [x0] "v"((u32)x), [x1] "v"((u32)(x >> 32)), [w0] WC((u32)w), [w1] WC((u32)(w >> 32)))
 // w a constant of the running proof (an SGPR pair: one scalar operand per instruction fits the constant bus)
 MI_HD void acc_mac_s(Acc &A, u64 x, u64 w) { CHPA_MAC_ASM("s"); }

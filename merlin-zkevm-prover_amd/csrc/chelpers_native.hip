@@ -80,7 +80,10 @@ struct Piece { int32_t chain; uint32_t first, last, n_m; int32_t begin_coef = -1
 // limb accumulators; the generated kernel adds the result at the end of the piece.  An extension-valued polynomial (three
 // adjacent columns) is three base terms with coefficients W, x W, x^2 W.  This also removes those columns from the tile-major
 // copy: for step52ns only xDivXSubXi / xDivXSubWXi and one constant column are left in it.
-static constexpr uint32_t LIN_COLS = 16;  // columns per staged slab
+#ifndef MI_LIN_COLS
+#define MI_LIN_COLS 16
+#endif
+static constexpr uint32_t LIN_COLS = MI_LIN_COLS;  // columns per staged slab
 static constexpr int LIN_MAX_SUMS = 4;
 static constexpr uint32_t LIN_MIN_TERMS = 256; // below this a pass over the sections costs more than the generated terms
 struct LinTermH { uint32_t staged_col, coef, sum; };
@@ -1062,8 +1065,9 @@ template <int S>
 __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ slabs, uint32_t n_slabs, const LinTermW *__restrict__ terms,
                                                      const LinSections sec, u64 *__restrict__ lin, uint64_t row_base, uint32_t n_sums)
 {
-    __shared__ u64 buf[2][64 * (LIN_COLS + 1)];
-    __shared__ __attribute__((aligned(16))) u64 cb[2][(LIN_TMAX + 4) * 4]; // + slack: the term loop reads one pair ahead
+    // one buffer each: the next slab waits in registers (stage / cstage) until the arithmetic on this one is done
+    __shared__ u64 buf[64 * (LIN_COLS + 1)];
+    __shared__ __attribute__((aligned(16))) u64 cb[(LIN_TMAX + 4) * 4]; // + slack: the term loop reads one pair ahead
     const uint32_t lane = threadIdx.x;
     const uint64_t tile = blockIdx.x;
     chpa::Acc acc[S][3];
@@ -1071,10 +1075,7 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
     for (int s2 = 0; s2 < S; s2++)
 #pragma unroll
         for (int j = 0; j < 3; j++) chpa::acc_set(acc[s2][j], 0);
-    if (threadIdx.x < 32) { // the slack stays zero (offset 0, coefficient 0)
-        const uint32_t b2 = threadIdx.x >> 4, k = threadIdx.x & 15;
-        cb[b2][LIN_TMAX * 4 + k] = 0;
-    }
+    if (threadIdx.x < 16) cb[LIN_TMAX * 4 + threadIdx.x] = 0; // the slack stays zero (offset 0, coefficient 0)
     u64 stage[LIN_COLS]; // 64 x LIN_COLS elements / 64 lanes
     uint4 cstage[LIN_TMAX * 32 / 1024];
     auto issue = [&](uint32_t sl) {
@@ -1098,8 +1099,8 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
     };
     issue(0);
     for (uint32_t sl = 0; sl < n_slabs; sl++) {
-        u64 *b = buf[sl & 1];
-        uint4 *c4 = (uint4 *)cb[sl & 1];
+        u64 *b = buf;
+        uint4 *c4 = (uint4 *)cb;
 #pragma unroll
         for (uint32_t i = 0; i < LIN_COLS; i++) {
             const uint32_t e = i * 64 + lane;
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
             const uint32_t t0 = slabs[sl].t0[s2] - tb, t1 = slabs[sl].t0[s2 + 1] - tb;
             if (t0 >= t1) continue;
             // software pipeline: the descriptors of pair k + 1 are read before, its elements in the middle of, the arithmetic of pair k
-            const uint4 *q = (const uint4 *)cb[sl & 1] + 2 * t0;
+            const uint4 *q = (const uint4 *)cb + 2 * t0;
             uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
             u64 xa = *(const u64 *)(rowp + a0.x), xb = *(const u64 *)(rowp + b0.x);
             for (uint32_t t = t0; t < t1; t += 2) { // ranges are padded to pairs
