@@ -8,6 +8,7 @@ PARITY UNPINNED: the reference holds no input / output pair for this step.  What
     reference's source text, and product vs oracle on the reference's OWN program (11 959 opcodes) over a sparse address
     space the size of the zkEVM memory map."""
 import mmap
+import tempfile
 import os
 import re
 
@@ -146,6 +147,10 @@ def test_reference_program_translates_and_matches_oracle():
         prog.run_lowered_host(pols, cpols, numpols, chal, pub, x, 1, zhinv, got, np.array(rows), chunk_cost=cc)
         for r in rows:
             assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]), (cc, r)
+    # ... and the generated kernels compile (two of the 28 here: a share of a parallel build; the full build takes ~25 s on 8 cores)
+    with tempfile.TemporaryDirectory() as td:
+        prog.precompile_shard(3, 14, cache_dir=td)
+        assert len([f for f in os.listdir(td) if f.endswith(".hsaco")]) == 2
     prog.close()
 
 
@@ -250,6 +255,9 @@ def test_step52ns_tables_agree_with_the_reference_and_its_program_matches_the_or
         prog.run52_lowered_host(pols, cpols, numpols, chal, evals, xd, xdw, got, np.array(rows), chunk_cost=cc)
         for r in rows:
             assert np.array_equal(got[3 * r:3 * r + 3], want[3 * r:3 * r + 3]), (cc, r)
+    with tempfile.TemporaryDirectory() as td:      # 3 338 linear terms in 3 sums + one generated kernel for the remaining ten operations
+        st = prog.build_native(cache_dir=td)
+        assert st["kernels"] == 1 and prog.lower_stats()["linear_terms"] > 3000 and prog.lower_stats()["linear_sums"] == 3
     prog.close()
 
 
