@@ -200,6 +200,7 @@ def main():
     # warm-up, untimed: NTT plans (twiddle tables) of both domain sizes and the Poseidon constants, as a resident prover has them
     ctx.lde(pols_area[:NE], trace[:N], NE, N, 1)
     ctx.merkle_build(trees[0], pols_area[:NE], 1, NE)
+    ctx.lde(ext[0], trace, NE, N, w1)            # ... and the NTT workspace at the size the widest section needs
     if args.chelpers_backend == "native":
         prog.reserve(NE)
         prog52.reserve(NE)
