@@ -803,11 +803,14 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
     g.canon.assign(N->nw + 3, 0);
     for (uint32_t w : C.loads) g.canon[w] = 1; // the spill holds canonical values
     {
-        uint64_t acc = 0;
+        uint64_t acc = 0, group_cost = GROUP_COST;
+        size_t group_loads = GROUP_LOADS;
+        if (const char *e = getenv("MI_CHELPERS_GROUP_COST")) group_cost = (uint64_t)atoll(e);   // experiments
+        if (const char *e = getenv("MI_CHELPERS_GROUP_LOADS")) group_loads = (size_t)atoll(e);
         for (size_t i = C.i0; i < C.i1; i++) {
             MI_TRY(g.instr(i));
             acc += cost_of(P->host[i], N->marks[i], P->host);
-            if (acc >= GROUP_COST || g.group_loads.size() >= GROUP_LOADS) { g.end_group(); acc = 0; }
+            if (acc >= group_cost || g.group_loads.size() >= group_loads) { g.end_group(); acc = 0; }
         }
         g.end_group();
     }
