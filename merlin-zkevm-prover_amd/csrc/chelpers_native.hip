@@ -740,7 +740,9 @@ struct Gen {
 
 static int compile_source(const std::string &src, const std::string &cache_dir, std::vector<char> &code, NativeProg &N)
 {
-    const std::string opts = "gfx950 -O3 c++17 v7";
+    int rtc_major = 0, rtc_minor = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor); // a code object is only as good as the compiler that made it: part of the key
+    const std::string opts = "gfx950 -O3 c++17 v7 hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
     char name[64];
     snprintf(name, sizeof name, "%016llx%016llx.hsaco", (unsigned long long)fnv1a(src + opts), (unsigned long long)fnv1a(opts + src, 0x9E3779B97F4A7C15ull));
     const std::string path = cache_dir.empty() ? "" : cache_dir + "/" + name;

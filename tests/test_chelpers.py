@@ -322,6 +322,39 @@ def test_native_backend_builds_without_a_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_native_backend_on_a_tiny_domain_with_linear_terms(tmp_path, monkeypatch):
+    """128 rows, one tile per batch: a step52ns program whose polynomial terms go through the linear kernel, and a step42ns
+    program (x_2ns at a stride of 2, shifted reads wrapping around the end of the domain) through generated kernels only."""
+    import mi_stark
+    monkeypatch.setenv("MI_CHELPERS_LIN_MIN", "1")
+    ctx = mi_stark.Context(0)
+    nrows = 128
+    ctx.set_chelpers_batch_rows(64)
+    ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(78, nrows)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, evals, xd, xdw, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
+    ls = prog.lower_stats()
+    assert ls["linear_terms"] > 50 and 1 <= ls["linear_sums"] <= 4, ls
+    prog.build_native(cache_dir=str(tmp_path))
+    f = ctx.to_device(np.full(nrows * 3 + 6, 0xABCD, dtype=np.uint64))
+    prog.run52(ctx.to_device(pols), ctx.to_device(cpols), n_const, chal, evals, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
+    got = ctx.to_host(f)
+    assert np.array_equal(got[:nrows * 3], want) and np.all(got[nrows * 3:] == 0xABCD)
+    prog.close()
+    ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(77, nrows, passes=2)
+    glo.chelpers_step42ns(ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv, want, 0, nrows)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows)
+    prog.build_native(cache_dir=str(tmp_path), chunk_cost=4000)
+    q = ctx.to_device(np.full(nrows * 3 + 6, 0xABCD, dtype=np.uint64))
+    prog.run(ctx.to_device(pols), ctx.to_device(cpols), n_const, chal, pub, ctx.to_device(x), xs, zhinv, q, 0, nrows)
+    got = ctx.to_host(q)
+    assert np.array_equal(got[:nrows * 3], want) and np.all(got[nrows * 3:] == 0xABCD)
+    prog.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_native_step42ns_matches_oracle_and_interpreter(tmp_path):
     import mi_stark
     ctx = mi_stark.Context(0)
