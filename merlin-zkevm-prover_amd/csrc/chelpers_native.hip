@@ -856,9 +856,11 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
         snprintf(line, sizeof line, "  chpa::Acc p%u_0, p%u_1, p%u_2;\n", pi, pi, pi);
         src += line;
     }
-    src += g.groups[0].loads;
+    size_t ahead = 1; // groups whose loads are in flight ahead of the arithmetic
+    if (const char *e = getenv("MI_CHELPERS_PREFETCH")) ahead = (size_t)std::max(1, std::min(4, atoi(e)));
+    for (size_t gi = 0; gi < ahead && gi < g.groups.size(); gi++) src += g.groups[gi].loads;
     for (size_t gi = 0; gi < g.groups.size(); gi++) {
-        if (gi + 1 < g.groups.size()) src += g.groups[gi + 1].loads;
+        if (gi + ahead < g.groups.size()) src += g.groups[gi + ahead].loads;
         src += "  __builtin_amdgcn_sched_barrier(0);\n";
         src += g.groups[gi].compute;
         src += "  __builtin_amdgcn_sched_barrier(0);\n";
