@@ -340,7 +340,11 @@ def main():
     # ... the rows' operands are gathered to the host into a sparse copy of the polynomial area
     ok = True
     micro = cpg.decode(c_ops, c_args)[0]
-    rows_chk = [0, 1, NE // 2, NE - 1] + [int(v) for v in np.random.default_rng(7).integers(0, NE, 4)]
+    # first / last rows (the shifted reads wrap), tile edges, the edges of the native backend's row batches (8 GiB of operand
+    # copy: 704 512 rows for 1 525 staged columns, 699 008 for 1 536), random rows
+    rows_chk = sorted(set(r for r in [0, 1, 62, 63, 64, 65, NE // 2, NE - 3, NE - 2, NE - 1] +
+                          [b * k + d for b in (704512, 699008) for k in (1, 2, 23) for d in (-2, -1, 0, 1)] +
+                          [int(v) for v in np.random.default_rng(7).integers(0, NE, 8)] if 0 <= r < NE))
     pa, ca = cpg.touched_addresses(micro, rows_chk, args.n_const)
     import mmap
     def sparse(n_elems):
