@@ -1,0 +1,329 @@
+"""A complete small STARK, end to end (TEST INFRASTRUCTURE).
+
+The reference's full proof run (BASELINE config 4) needs inputs that are not in the tree, and `bench_genproof.py` runs the device phases
+on programs that are shaped like the zkEVM's but do not describe a satisfiable system -- its q is not a low-degree polynomial and no
+verifier would accept the result.  This module closes that gap at small size: an AIR with a real witness, its two constraint programs
+written in the reference's own opcode formats (step42ns, step52ns), a PROVER that strings the product's device entry points together in
+`Starks::genProof`'s order (starks.cpp:9-403: commit, constraint polynomial, quotient split, evaluations, FRI polynomial, FRI, queries),
+and an independent VERIFIER on the oracle's arithmetic (pil-stark's stark_verify: transcript replay, constraint identity at the
+challenge point, Merkle openings, the FRI polynomial recomputed at the query points from the opened rows, fold consistency, degree of
+the final polynomial).  A proof made on the GPU must verify; a tampered one must not.
+
+AIR (N rows, columns a, b; constant polynomials L1 = first-row selector, LLAST = last-row selector):
+    (1 - LLAST) * (a' - b) = 0,   (1 - LLAST) * (b' - a - b) = 0,   L1 * (a - 1) = 0,   L1 * (b - 1) = 0        (x' = value at the next row)
+"""
+import numpy as np
+
+import glo
+import chelpers_programs as cp
+
+P = 0xFFFFFFFF00000001
+SHIFT = 49
+
+
+# ------------------------------------------------------------------ extension-field helpers (python ints; x^3 = x + 1)
+def e3(v):
+    return [int(v[0]) % P, int(v[1]) % P, int(v[2]) % P]
+
+
+def e3_add(a, b):
+    return [(a[i] + b[i]) % P for i in range(3)]
+
+
+def e3_sub(a, b):
+    return [(a[i] - b[i]) % P for i in range(3)]
+
+
+def e3_mul(a, b):
+    return [int(v) for v in glo.e3_mul(np.array(a, dtype=np.uint64), np.array(b, dtype=np.uint64))]
+
+
+def e3_from_base(v):
+    return [int(v) % P, 0, 0]
+
+
+def e3_pow(a, e):
+    r = [1, 0, 0]
+    while e:
+        if e & 1:
+            r = e3_mul(r, a)
+        a = e3_mul(a, a)
+        e >>= 1
+    return r
+
+
+# ------------------------------------------------------------------ the AIR's programs in the reference's table formats
+def step42ns_program(n_ext, next_shift):
+    """q * Z_H = ((C1 vc + C2) vc + C3) vc + C4 with vc = challenge 0; sections: cm1_2ns (a, b) at offset 0."""
+    A_, B_, ST = 0, 1, 2                      # columns of cm1_2ns, its row stride
+    L1, LLAST = 0, 1                          # constant polynomials
+    ops, args = [], []
+
+    def push(o, ar):
+        ops.append(o); args.extend(ar)
+    push(35, [0, A_, next_shift, n_ext, ST, B_, ST])      # t0 = a' - b
+    push(32, [1, 1, LLAST])                               # t1 = 1 - LLAST
+    push(45, [0, 0, 1])                                   # t0 = t0 * t1
+    push(59, [0, 0, 0])                                   # acc = t0 * vc
+    push(35, [2, B_, next_shift, n_ext, ST, A_, ST])      # t2 = b' - a
+    push(22, [2, 2, B_, ST])                              # t2 = t2 - b
+    push(45, [2, 2, 1])                                   # t2 = t2 * t1
+    push(84, [0, 2, 0, 0, 0, 0])                          # acc = (t2 + acc) * vc
+    push(28, [3, A_, ST, 1])                              # t3 = a - 1
+    push(49, [3, 3, L1])                                  # t3 = t3 * L1
+    push(84, [0, 3, 0, 0, 0, 0])                          # acc = (t3 + acc) * vc
+    push(28, [4, B_, ST, 1])                              # t4 = b - 1
+    push(49, [4, 4, L1])                                  # t4 = t4 * L1
+    push(12, [0, 4, 0])                                   # acc = t4 + acc
+    push(69, [0])                                         # q = zhInv * acc
+    return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
+
+
+EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1 = range(8)
+
+
+def step52ns_program(nrows):
+    """f = ((H c5 + E_xi xDivXSubXi) c5 + E_wxi xDivXSubWXi), H = Horner_c5(a, b, q0, q1), E_* = Horner_c6(pol - eval); sections: cm1_2ns
+    (2 columns) at offset 0, cm4_2ns (two extension-valued chunks, 6 columns) at offset 2 * nrows; constants L1, LLAST."""
+    o4 = 2 * nrows
+    ops, args = [], []
+
+    def push(o, ar):
+        ops.append(o); args.extend(ar)
+    push(0, [0, 2]); push(16, [1, 2]); push(17, [o4, 6]); push(17, [o4 + 3, 6])      # H
+    push(3, [])                                                                       # tmp1 = H c5
+    push(11, [0, 2, EV_A]); push(4, [])                                               # tmp = (a - a(xi)) c6
+    push(18, [1, 2, EV_B]); push(19, [0, EV_L1]); push(19, [1, EV_LLAST])
+    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1])
+    push(5, []); push(8, []); push(3, [])                                             # * xDivXSubXi; tmp = tmp1 + tmp; tmp1 = tmp c5
+    push(11, [0, 2, EV_AW]); push(4, []); push(18, [1, 2, EV_BW])
+    push(6, []); push(8, []); push(15, [])                                            # * xDivXSubWXi; tmp = tmp1 + tmp; f = tmp
+    return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
+
+
+def witness(n):
+    a, b = np.zeros(n, dtype=object), np.zeros(n, dtype=object)
+    a[0] = b[0] = 1
+    for i in range(1, n):
+        a[i], b[i] = b[i - 1], (a[i - 1] + b[i - 1]) % P
+    return np.stack([a, b], axis=1).astype(np.uint64)
+
+
+def constants(n):
+    c = np.zeros((n, 2), dtype=np.uint64)
+    c[0, 0] = 1
+    c[n - 1, 1] = 1
+    return c
+
+
+def fri_steps(nbits_ext):
+    steps = [nbits_ext]
+    for d in (4, 4):
+        if steps[-1] - d >= 3:
+            steps.append(steps[-1] - d)
+    return steps
+
+
+# ------------------------------------------------------------------ prover: the product's device entry points in genProof's order
+def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
+    """Returns the proof (host data only).  native: the constraint programs through the compiled-kernel backend."""
+    import mi_stark
+    from bench_genproof import Transcript
+    L = glo.lib()
+    nbits_ext = nbits + 1
+    N, NE = 1 << nbits, 1 << nbits_ext
+    steps = fri_steps(nbits_ext)
+    # constant polynomials: extended and committed once (the verification key is their root)
+    d_const_n = ctx.to_device(constants(N))
+    const_2ns, const_nodes = ctx.empty(NE * 2), ctx.empty((2 * NE - 1) * 4)
+    ctx.lde(const_2ns, d_const_n, NE, N, 2)
+    ctx.merkle_build(const_nodes, const_2ns, 2, NE)
+    area = ctx.empty(NE * (2 + 6))                       # cm1_2ns | cm4_2ns, one polynomial area
+    cm1, cm4 = area[:NE * 2], area[NE * 2:]
+    nodes1, nodes4 = ctx.empty((2 * NE - 1) * 4), ctx.empty((2 * NE - 1) * 4)
+    tr = Transcript(ctx)
+    # ---- step 1: commit the witness
+    ctx.lde(cm1, ctx.to_device(witness(N)), NE, N, 2)
+    ctx.merkle_build(nodes1, cm1, 2, NE)
+    root1 = ctx.to_host(nodes1[-4:])
+    tr.put(root1)
+    vc = tr.get_field()
+    # ---- step 4: constraint polynomial q = C / Z_H on the extended domain, split, committed
+    ops42, args42 = step42ns_program(NE, 2)
+    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 2, NE)], n_const=2, nrows_ext=NE)
+    ops52, args52 = step52ns_program(NE)
+    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 2, NE), (2 * NE, 6, NE)], n_const=2, nrows_ext=NE, step=52)
+    if native:
+        prog42.build_native(cache_dir=cache_dir)
+        prog52.build_native(cache_dir=cache_dir)
+    x_2ns = ctx.empty(NE)
+    ctx.geom_seq(x_2ns, NE, SHIFT, L.glo_w(nbits_ext))
+    zh = ctx.zhinv(nbits, nbits_ext)
+    q_2ns, qq1, qq2 = ctx.empty(NE * 3), ctx.empty(NE * 3), ctx.empty(NE * 6)
+    chal = np.zeros(7 * 3, dtype=np.uint64)
+    chal[0:3] = vc
+    prog42.run(area, const_2ns, 2, chal, np.zeros(1, dtype=np.uint64), x_2ns, 1, zh, q_2ns, 0, NE)
+    ctx.ntt(qq1, q_2ns, NE, 3, inverse=True)
+    ctx.q_split(qq2, qq1, N, NE, 2)
+    ctx.ntt(cm4, qq2, NE, 6)
+    ctx.merkle_build(nodes4, cm4, 6, NE)
+    root4 = ctx.to_host(nodes4[-4:])
+    tr.put(root4)
+    xi = tr.get_field()
+    # ---- step 5: evaluations at xi and w xi, then the FRI polynomial
+    sinv, wN = L.glo_inv(SHIFT), L.glo_w(nbits)
+    xis = np.array([L.glo_mul(int(v), sinv) for v in xi], dtype=np.uint64)
+    wxi = np.array([L.glo_mul(int(v), wN) for v in xi], dtype=np.uint64)
+    wxis = np.array([L.glo_mul(int(v), sinv) for v in wxi], dtype=np.uint64)
+    lev, lpev = ctx.empty(N * 3), ctx.empty(N * 3)
+    ctx.geom_seq3(lev, N, xis)
+    ctx.geom_seq3(lpev, N, wxis)
+    ctx.ntt(lev, lev, N, 3, inverse=True)
+    ctx.ntt(lpev, lpev, N, 3, inverse=True)
+    pols = [(cm1, 0, 1, 2), (cm1, 1, 1, 2), (cm1, 0, 1, 2), (cm1, 1, 1, 2), (const_2ns, 0, 1, 2), (const_2ns, 1, 1, 2), (cm4, 0, 3, 6), (cm4, 3, 3, 6)]
+    prime = [0, 0, 1, 1, 0, 0, 0, 0]
+    d_evals = ctx.empty(len(pols) * 3)
+    ctx.evmap(d_evals, pols, prime, lev, lpev, N, 1)
+    evals = ctx.to_host(d_evals)
+    if tamper == "eval":
+        evals[3 * EV_B] ^= np.uint64(1)
+    tr.put(evals)
+    chal[15:18] = tr.get_field()
+    chal[18:21] = tr.get_field()
+    xd, xdw, f_2ns = ctx.empty(NE * 3), ctx.empty(NE * 3), ctx.empty(NE * 3)
+    ctx.x_div_x_sub(xd, x_2ns, NE, xi)
+    ctx.x_div_x_sub(xdw, x_2ns, NE, wxi)
+    prog52.run52(area, const_2ns, 2, chal, evals, xd, xdw, f_2ns, 0, NE)
+    if tamper == "f":                                   # a value that is not on the low-degree polynomial
+        h = ctx.to_host(f_2ns)
+        h[3 * 5] ^= np.uint64(1)
+        f_2ns = ctx.to_device(h)
+    # ---- FRI (friProve.cpp:5-190)
+    fri_roots, fri_trees, fri_srcs = [], {}, {}
+    pol, nxt, pol_bits = f_2ns, ctx.empty(NE * 3), nbits_ext
+    for si, cur in enumerate(steps):
+        x = tr.get_field()
+        ctx.fri_fold(nxt, pol, pol_bits, cur, nbits_ext, x)
+        if si < len(steps) - 1:
+            nb = steps[si + 1]
+            groups, gsz = 1 << nb, (1 << (cur - nb)) * 3
+            src = ctx.empty((1 << cur) * 3)
+            ctx.fri_transpose(src, nxt, 1 << cur, nb)
+            nodes = ctx.empty((2 * groups - 1) * 4)
+            ctx.merkle_build(nodes, src, gsz, groups)
+            root = ctx.to_host(nodes[-4:])
+            tr.put(root)
+            fri_roots.append(root)
+            fri_trees[si + 1], fri_srcs[si + 1] = nodes, src
+        else:
+            final_pol = ctx.to_host(nxt[:(1 << cur) * 3])
+            if tamper == "final":
+                final_pol[0] ^= np.uint64(1)
+            tr.put(final_pol)
+        pol, nxt = nxt, ctx.empty(NE * 3)
+        pol_bits = cur
+    ys = tr.get_permutations(n_queries, steps[0])
+    # ---- queries (friProve.cpp:219-250)
+    def open_tree(nodes, src, height, width, idx):
+        buf = ctx.empty(len(idx) * (width + 4 * (height - 1).bit_length()))
+        ctx.merkle_group_proofs(buf, nodes, src, height, width, idx)
+        return ctx.to_host(buf).reshape(len(idx), -1)
+    proof = {"nbits": nbits, "root1": root1, "root4": root4, "evals": evals, "fri_roots": fri_roots, "final_pol": final_pol,
+             "s0": {"cm1": open_tree(nodes1, cm1, NE, 2, ys), "cm4": open_tree(nodes4, cm4, NE, 6, ys), "const": open_tree(const_nodes, const_2ns, NE, 2, ys)},
+             "fri": {}, "const_root": ctx.to_host(const_nodes[-4:])}
+    y = ys.copy()
+    for si in range(1, len(steps)):
+        y = y % np.uint64(1 << steps[si])
+        gsz = (1 << (steps[si - 1] - steps[si])) * 3
+        proof["fri"][si] = open_tree(fri_trees[si], fri_srcs[si], 1 << steps[si], gsz, y)
+    if tamper == "opening":
+        proof["s0"]["cm1"][0][0] ^= np.uint64(1)
+    prog42.close()
+    prog52.close()
+    return proof
+
+
+# ------------------------------------------------------------------ verifier: oracle arithmetic only (pil-stark stark_verify)
+def verify(proof, const_root, n_queries=12):
+    """Returns (ok, reason)."""
+    L = glo.lib()
+    nbits = proof["nbits"]
+    nbits_ext = nbits + 1
+    N, NE = 1 << nbits, 1 << nbits_ext
+    steps = fri_steps(nbits_ext)
+    if not np.array_equal(proof["const_root"], const_root):
+        return False, "constant-polynomial root is not the verification key's"
+    # ---- transcript replay
+    tr = glo.Transcript()
+    tr.put(proof["root1"])
+    vc = e3(tr.get_field())
+    tr.put(proof["root4"])
+    xi = e3(tr.get_field())
+    ev = proof["evals"]
+    tr.put(ev)
+    c5 = tr.get_field()
+    c6 = tr.get_field()
+    fri_chal = []
+    for si in range(len(steps)):
+        fri_chal.append(tr.get_field())
+        if si < len(steps) - 1:
+            tr.put(proof["fri_roots"][si])
+        else:
+            tr.put(proof["final_pol"])
+    ys = tr.get_permutations(n_queries, steps[0])
+    E = lambda k: e3(ev[3 * k:3 * k + 3])
+    # ---- constraint identity at xi: ((C1 vc + C2) vc + C3) vc + C4 == Q(xi) * (xi^N - 1)
+    one = [1, 0, 0]
+    not_last = e3_sub(one, E(EV_LLAST))
+    C1 = e3_mul(not_last, e3_sub(E(EV_AW), E(EV_B)))
+    C2 = e3_mul(not_last, e3_sub(e3_sub(E(EV_BW), E(EV_A)), E(EV_B)))
+    C3 = e3_mul(E(EV_L1), e3_sub(E(EV_A), one))
+    C4 = e3_mul(E(EV_L1), e3_sub(E(EV_B), one))
+    C = e3_add(e3_mul(e3_add(e3_mul(e3_add(e3_mul(C1, vc), C2), vc), C3), vc), C4)
+    xiN = e3_pow(xi, N)
+    Q = e3_add(E(EV_Q0), e3_mul(xiN, E(EV_Q1)))
+    if C != e3_mul(Q, e3_sub(xiN, one)):
+        return False, "constraint identity fails at the challenge point"
+    # ---- queries
+    ops52, args52 = step52ns_program(1)
+    chal = np.zeros(21, dtype=np.uint64)
+    chal[15:18], chal[18:21] = c5, c6
+    wN = L.glo_w(nbits)
+    wxi = [L.glo_mul(v, wN) for v in xi]
+    h1, h4, hc = proof["s0"]["cm1"], proof["s0"]["cm4"], proof["s0"]["const"]
+    y = [int(v) for v in ys]
+    for q in range(n_queries):
+        idx = y[q]
+        for (pr, w, root, name) in ((h1, 2, proof["root1"], "cm1"), (h4, 6, proof["root4"], "cm4"), (hc, 2, const_root, "const")):
+            if not glo.merkle_verify(root, pr[q][:w], pr[q][w:], idx):
+                return False, "Merkle opening of %s fails at query %d" % (name, q)
+        # the FRI polynomial at x = shift * w^idx from the opened rows (the same program, over one row)
+        x = L.glo_mul(SHIFT, L.glo_pow(L.glo_w(nbits_ext), idx))
+        def xdiv(z):
+            den = np.array([(x - z[0]) % P, (-z[1]) % P, (-z[2]) % P], dtype=np.uint64)
+            return np.array(e3_mul([int(v) for v in glo.e3_inv(den)], [x, 0, 0]), dtype=np.uint64)
+        row = np.concatenate([h1[q][:2], h4[q][:6]]).astype(np.uint64)
+        f = np.zeros(3, dtype=np.uint64)
+        glo.chelpers_step52ns(ops52, args52, row, np.ascontiguousarray(hc[q][:2]), 2, chal, ev, xdiv(xi), xdiv(wxi), f, 0, 1)
+        # level by level: the value must sit in the next group, the group must fold to the value after it
+        val, g = f, idx
+        for si in range(1, len(steps)):
+            prev, cur = steps[si - 1], steps[si]
+            gsz = (1 << (prev - cur)) * 3
+            pr = proof["fri"][si][q]
+            gi = g % (1 << cur)
+            if not glo.merkle_verify(proof["fri_roots"][si - 1], pr[:gsz], pr[gsz:], gi):
+                return False, "Merkle opening of FRI step %d fails at query %d" % (si, q)
+            j = g >> cur
+            if not np.array_equal(pr[3 * j:3 * j + 3], val):
+                return False, "FRI step %d: the opened group does not contain the previous value (query %d)" % (si, q)
+            val = glo.fri_fold_group(pr[:gsz], prev - cur, prev, nbits_ext, gi, fri_chal[si])
+            g = gi
+        if not np.array_equal(proof["final_pol"][3 * g:3 * g + 3], val):
+            return False, "the last fold does not land on the final polynomial (query %d)" % q
+    # ---- the final polynomial has degree < 2^(last - (nBitsExt - nBits))
+    last = steps[-1]
+    coef = glo.ntt(proof["final_pol"].reshape(1 << last, 3), 1 << last, 3, inverse=True).reshape(-1, 3)
+    if coef[1 << (last - (nbits_ext - nbits)):].any():
+        return False, "final polynomial is not low-degree"
+    return True, "ok"

@@ -1,0 +1,56 @@
+"""End to end: a STARK proof made by the device path verifies; a tampered one does not (tests/ministark.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "merlin-zkevm-prover_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import glo
+import ministark as ms
+
+
+def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
+    """CPU: the witness satisfies the four constraints on every row, and the two programs are well-formed tables."""
+    import chelpers_programs as cp
+    n = 1 << 6
+    w, c = ms.witness(n).astype(object), ms.constants(n).astype(object)
+    P = ms.P
+    for i in range(n):
+        a, b, an, bn = w[i][0], w[i][1], w[(i + 1) % n][0], w[(i + 1) % n][1]
+        l1, ll = c[i][0], c[i][1]
+        assert ((1 - ll) * (an - b)) % P == 0 and ((1 - ll) * (bn - a - b)) % P == 0 and (l1 * (a - 1)) % P == 0 and (l1 * (b - 1)) % P == 0
+    ops, args = ms.step42ns_program(2 * n, 2)
+    assert cp.decode(ops, args)[1] == args.size
+    ops, args = ms.step52ns_program(2 * n)
+    assert sum(cp.nargs52_of(int(o)) for o in ops) == args.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native,nbits", [(False, 10), (True, 10), (False, 7), (True, 13)])
+def test_a_proof_from_the_device_path_verifies(native, nbits, tmp_path):
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    proof = ms.prove(ctx, nbits, native=native, cache_dir=str(tmp_path))
+    ok, why = ms.verify(proof, proof["const_root"])
+    assert ok, why
+    # the verification key is part of the statement
+    ok, why = ms.verify(proof, np.zeros(4, dtype=np.uint64))
+    assert not ok
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tamper,expect", [("eval", "constraint identity"), ("opening", "Merkle opening of cm1"), ("final", "final polynomial"),
+                                           ("f", "")])
+def test_a_tampered_proof_is_rejected(tamper, expect):
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    proof = ms.prove(ctx, 10, n_queries=32, tamper=tamper)
+    ok, why = ms.verify(proof, proof["const_root"], n_queries=32)
+    assert not ok and expect in why, why
+    ctx.close()
