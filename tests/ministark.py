@@ -102,11 +102,12 @@ def step52ns_program(nrows):
 
 
 def witness(n):
-    a, b = np.zeros(n, dtype=object), np.zeros(n, dtype=object)
-    a[0] = b[0] = 1
-    for i in range(1, n):
-        a[i], b[i] = b[i - 1], (a[i - 1] + b[i - 1]) % P
-    return np.stack([a, b], axis=1).astype(np.uint64)
+    out = np.empty((n, 2), dtype=np.uint64)
+    a = b = 1
+    for i in range(n):
+        out[i, 0], out[i, 1] = a, b
+        a, b = b, (a + b) % P
+    return out
 
 
 def constants(n):

@@ -31,7 +31,7 @@ def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native,nbits", [(False, 10), (True, 10), (False, 7), (True, 13)])
+@pytest.mark.parametrize("native,nbits", [(False, 10), (True, 10), (False, 7), (True, 13), (True, 19)])
 def test_a_proof_from_the_device_path_verifies(native, nbits, tmp_path):
     import mi_stark
     ctx = mi_stark.Context(0)
