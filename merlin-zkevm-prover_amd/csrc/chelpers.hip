@@ -208,10 +208,6 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
             const uint32_t *p = progw + (uint64_t)bi * (BATCH * 16);
             return {p[lane], p[64 + lane]};
         };
-        auto field = [&](const Words &w, uint32_t j, uint32_t f) -> uint32_t { // j wave-uniform
-            const uint32_t idx = j * 16 + f;
-            return (uint32_t)__builtin_amdgcn_readlane((int)(idx < 64 ? w.lo : w.hi), (int)(idx & 63));
-        };
         auto issue_prefetch = [&](const Words &w, u64 (&v)[2 * BATCH]) {
 #pragma unroll
             for (int j = 0; j < BATCH; j++) {
