@@ -3,22 +3,25 @@
 // The interpreter of chelpers.hip spends ~90 VALU + ~80 SALU instructions per field operation on fetching, decoding and
 // addressing, where the arithmetic itself is 6 (add) to 20 (multiply) instructions, and keeps every temporary in LDS.  A
 // constraint program is fixed per proving key, so -- like the reference, whose build compiles the generated chelpers C++ into
-// the prover -- the translated program can be compiled once:
-//   * the scheduled three-address program (mi_chelpers_prog::host: depth-first order, ~90 live words) is cut into CHUNKS of
-//     about 25 000 VALU instructions; every chunk becomes one straight-line HIP kernel, generated as source text and compiled
-//     with hiprtc against the very same gl_math.h the other kernels use.  Temporaries are registers; the compiler's CSE keeps a
-//     polynomial element that a chunk reads several times in a register.  Compile time is linear in the number of chunks
-//     (one 18 000-operation basic block takes LLVM 195 s, nine 2 000-operation blocks 9.5 s each); code objects are cached on
-//     disk by the hash of their source.
-//   * one row per lane, 64-lane workgroups = one TILE of 64 consecutive rows.  Values that live across a chunk boundary go
-//     through a spill area [tile][word][64 lanes] (coalesced 512-byte runs), canonical.
+// the prover -- the translated program can be compiled once.  What this file does, in the order of the code:
+//   * lower(): Horner chains over a challenge become unreduced multiply-accumulates with constants of the running proof
+//     (chelpers_acc.h), chain terms that are plain polynomial elements go to a streaming matrix-vector kernel (k_chp_linear), the
+//     scheduled three-address program (mi_chelpers_prog::host: depth-first order, ~90 live words) is cut into CHUNKS of about
+//     11 000 VALU instructions, and the values that live across a chunk boundary are found (spill lists);
+//   * Gen / generate(): every chunk becomes one straight-line HIP kernel, generated as source text and compiled with hiprtc against
+//     the very same gl_math.h the other kernels use: one row per lane, 64-lane workgroups = one TILE of 64 consecutive rows,
+//     temporaries in registers, values kept weakly reduced in [0, 2^64) and canonicalised at the stores (the generator tracks
+//     which words are canonical: add_wc / sub_wc need their second operand canonical), the instruction stream fenced into
+//     scheduling groups with the polynomial loads of the next group issued ahead, no wave-uniform "rare case" branches.
+//     Compile time is linear in the number of chunks; code objects are cached on disk by the hash of their source;
 //   * polynomial operands are read from a TILE-MAJOR copy of the sections, [tile][staged column][64 rows], which a transposing
 //     kernel (k_chp_transpose) makes per batch of rows (+ one halo tile for the shifted "prime" reads): a lane owns a row, the
 //     sections are row-major, so reading them in place would touch one 64-byte sector per lane and operand.  With the copy an
-//     operand is base + column * 512 B + lane * 8 B: a compile-time offset from a per-tile pointer.
-//   * challenges, public inputs, evaluations and ZhInv sit in one small device table read with scalar loads.
-//   * values are kept weakly reduced in [0, 2^64) (gl::mul_w / add_wc / sub_wc) and canonicalised at the stores; the generator
-//     tracks which words are canonical, because add_wc / sub_wc need their second operand canonical.
+//     operand is base + column * 512 B + lane * 8 B: a compile-time offset from a per-tile pointer;
+//   * values that cross a chunk boundary go through a spill area [tile][word][64 lanes] (coalesced 512-byte runs), canonical;
+//     challenges, public inputs, evaluations, ZhInv, chain coefficients and per-piece constants sit in one small device table
+//     read with scalar loads (fill_constants);
+//   * native_host_run(): the LOWERED program on the CPU (tests), with the same accumulator code.
 // Results are the same field elements as the interpreter's and the oracle's (exact arithmetic, canonical at the store).
 #include "chelpers_ir.h"
 #include "chelpers_acc.h"
@@ -87,7 +90,7 @@ static constexpr uint32_t LIN_COLS = MI_LIN_COLS;  // columns per staged slab
 static constexpr int LIN_MAX_SUMS = 4;
 static constexpr uint32_t LIN_MIN_TERMS = 256; // below this a pass over the sections costs more than the generated terms
 struct LinTermH { uint32_t staged_col, coef, sum; };
-struct LinTerm { uint32_t lds_off, coef; };    // device: byte offset of the column inside a staged row; word offset of the coefficient in the constants table
+struct LinTerm { uint32_t lds_off, coef; };    // byte offset of the column inside a staged row; index of the coefficient (LinTermW carries its value)
 struct LinSlabD { uint32_t section, col0, ncols, t0[LIN_MAX_SUMS + 1]; };
 struct LinSections { const u64 *ptr[MAX_SECTIONS]; uint64_t pitch[MAX_SECTIONS], row_mask[MAX_SECTIONS]; };
 
