@@ -31,9 +31,12 @@ def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("native,nbits", [(False, 10), (True, 10), (False, 7), (True, 13), (True, 19)])
-def test_a_proof_from_the_device_path_verifies(native, nbits, tmp_path):
+@pytest.mark.parametrize("native,nbits,lin", [(False, 10, False), (True, 10, False), (True, 10, True), (False, 7, False), (True, 13, True), (True, 19, False)])
+def test_a_proof_from_the_device_path_verifies(native, nbits, lin, tmp_path, monkeypatch):
+    """lin: the FRI polynomial's polynomial terms through the streaming linear kernel (forced: the AIR has too few of them)."""
     import mi_stark
+    if lin:
+        monkeypatch.setenv("MI_CHELPERS_LIN_MIN", "1")
     ctx = mi_stark.Context(0)
     proof = ms.prove(ctx, nbits, native=native, cache_dir=str(tmp_path))
     ok, why = ms.verify(proof, proof["const_root"])
