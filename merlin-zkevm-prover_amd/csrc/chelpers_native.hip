@@ -88,6 +88,7 @@ struct Piece { int32_t chain; uint32_t first, last, n_m; int32_t begin_coef = -1
 #endif
 static constexpr uint32_t LIN_COLS = MI_LIN_COLS;  // columns per staged slab
 static constexpr int LIN_MAX_SUMS = 4;
+static constexpr uint32_t LIN_TMAX = 128; // terms of a slab entry (what the kernel's LDS block holds)
 static constexpr uint32_t LIN_MIN_TERMS = 256; // below this a pass over the sections costs more than the generated terms
 struct LinTermH { uint32_t staged_col, coef, sum; };
 struct LinTerm { uint32_t lds_off, coef; };    // byte offset of the column inside a staged row; index of the coefficient (LinTermW carries its value)
@@ -389,7 +390,7 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
                 while (total) {
                     LinSlabD d = {};
                     d.section = (uint32_t)si; d.col0 = c0; d.ncols = ncols;
-                    uint32_t room = 126; // of LIN_TMAX, leaving the pair padding
+                    uint32_t room = LIN_TMAX - 2; // leaving the pair padding
                     for (int sum = 0; sum < LIN_MAX_SUMS; sum++) {
                         d.t0[sum] = (uint32_t)N->lin_dev.size();
                         while (pos[sum] < by_sum[sum].size() && room) {
@@ -400,7 +401,7 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
                         if ((N->lin_dev.size() - d.t0[sum]) & 1) { N->lin_dev.push_back({0, zero_coef}); if (room) room--; }
                     }
                     d.t0[LIN_MAX_SUMS] = (uint32_t)N->lin_dev.size();
-                    MI_REQUIRE(d.t0[LIN_MAX_SUMS] - d.t0[0] <= 128, "internal: linear slab entry over its LDS block");
+                    MI_REQUIRE(d.t0[LIN_MAX_SUMS] - d.t0[0] <= LIN_TMAX, "internal: linear slab entry over its LDS block");
                     N->lin_slabs.push_back(d);
                 }
             }
@@ -1076,7 +1077,6 @@ __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ s
 // latency-bound at three times its HBM time.  Everything of slab s + 1 is in flight during the arithmetic of slab s.
 struct LinTermW { uint32_t lds_off, pad; u64 w[3]; };
 static_assert(sizeof(LinTermW) == 32, "term must be 32 bytes");
-static constexpr uint32_t LIN_TMAX = 128; // terms per slab the LDS block holds
 
 template <int S>
 __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ slabs, uint32_t n_slabs, const LinTermW *__restrict__ terms,
