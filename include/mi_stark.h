@@ -174,6 +174,14 @@ int mi_zhinv(mi_ctx *ctx, uint64_t *out, unsigned nbits, unsigned nbits_ext);
  * a null ctx compiles for mi_dbg_host_chelpers_run only.  `step` names the opcode numbering of the tables. */
 #define MI_CHELPERS_STEP42NS 42
 #define MI_CHELPERS_STEP52NS 52 /* ZkevmSteps::step52ns_parser_first_avx (zkevm.chelpers.step52ns.parser.cpp; starks.cpp:370): the FRI polynomial f_2ns */
+/* The base-domain steps (zkevm.chelpers.step{2prev,3prev,3}.parser.cpp; starks.cpp:93,165,178): ONE opcode numbering for the three --
+ * 0-83 as step42ns (with params.pConstPols / x_n), 84-114 the forms whose result is stored into params.pols at the row or at a
+ * shifted row, 115 a fusion.  They write params.pols (pass the same device memory, it is read and written; q / zhinv are unused,
+ * const_pols = pConstPols over the N base-domain rows, nrows_ext = N) and run through the compiled kernels only:
+ * mi_chelpers_build_native before mi_chelpers_run_dev. */
+#define MI_CHELPERS_STEP2PREV 20
+#define MI_CHELPERS_STEP3PREV 30
+#define MI_CHELPERS_STEP3 31
 typedef struct mi_chelpers_prog mi_chelpers_prog;
 /* A section of the polynomial area the program reads (stark_info mapOffsets / mapSectionsN, e.g. cm1_2ns): element (row, col)
  * at pols[offset + row * ncols + col], row < nrows.  Every polynomial operand of the program must lie in a declared section:

@@ -41,6 +41,7 @@
 #include "common.h"
 #include <algorithm>
 #include <array>
+#include <set>
 #include <string.h>
 
 using gl::E3;
@@ -140,6 +141,43 @@ static const std::vector<uint64_t> *fused_step52ns(uint64_t op)
     }
     return nullptr;
 }
+
+// ---- the base-domain steps step2prev / step3prev / step3 (zkevm.chelpers.step{2prev,3prev,3}.parser.cpp, *_parser_first_avx): ONE
+// opcode numbering for the three.  Cases 0-83 are step42ns's, case for case, with params.pConstPols / params.x_n in place of
+// pConstPols2ns / x_2ns (69, the q store, is not theirs); 84-85 two more temp operations; 86-100 the result goes to a polynomial
+// at the row, &params.pols[a0 + i * a1]; 101-114 to a polynomial at a shifted row, offsets1 = a0 + ((i + a1) % a2) * a3; 91, 97,
+// 99 are "code not used" asserts; 115 (step3 only) is the fusion [0, 50].  ddim: 3 where the reference calls a Goldilocks3 form.
+struct RoleB { Cls cls; Kind dst; int ddim; Kind a, b; };
+static bool role_stepbase(uint64_t op, RoleB &r)
+{
+    if (op <= 83 && op != 69) {
+        Role q;
+        if (!role_step42ns(op, q)) return false;
+        r = {q.cls, q.dst, q.dst == K_T3 ? 3 : 1, q.a, q.b};
+        return true;
+    }
+#define R(c, d, n, x, y) r = {c, d, n, x, y}; return true
+    switch (op) {
+    case 84: R(C_ADD, K_T1, 1, K_T1, K_POLS);       case 85: R(C_MUL, K_T1, 1, K_POLS, K_NUM);
+    case 86: R(C_ADD, K_DPOL, 1, K_T1, K_T1);       case 87: R(C_ADD, K_DPOL, 1, K_T1, K_POL);      case 88: R(C_ADD, K_DPOL, 3, K_T1, K_T3);
+    case 89: R(C_ADD, K_DPOL, 3, K_POL3, K_T3);     case 90: R(C_ADD, K_DPOL, 3, K_T3, K_CHAL);     case 92: R(C_SUB, K_DPOL, 1, K_T1, K_T1);
+    case 93: R(C_SUB, K_DPOL, 1, K_NUM, K_T1);      case 94: R(C_MUL, K_DPOL, 1, K_T1, K_T1);       case 95: R(C_MUL, K_DPOL, 1, K_POL, K_T1);
+    case 96: R(C_MUL, K_DPOL, 1, K_T1, K_CONST);    case 98: R(C_MUL, K_DPOL, 3, K_T3, K_T3);       case 100: R(C_COPY, K_DPOL, 1, K_T1, K_NONE);
+    case 101: R(C_ADD, K_DPOLS, 1, K_T1, K_T1);     case 102: R(C_ADD, K_DPOLS, 1, K_T1, K_POL);    case 103: R(C_ADD, K_DPOLS, 3, K_T1, K_T3);
+    case 104: R(C_ADD, K_DPOLS, 3, K_POL3, K_T3);   case 105: R(C_ADD, K_DPOLS, 3, K_T3, K_CHAL);   case 106: R(C_SUB, K_DPOLS, 1, K_T1, K_T1);
+    case 107: R(C_SUB, K_DPOLS, 1, K_NUM, K_T1);    case 108: R(C_MUL, K_DPOLS, 1, K_T1, K_T1);     case 109: R(C_MUL, K_DPOLS, 1, K_POL, K_T1);
+    case 110: R(C_MUL, K_DPOLS, 1, K_T1, K_CONST);  case 111: R(C_MUL, K_DPOLS, 1, K_CONSTS, K_T1); case 112: R(C_MUL, K_DPOLS, 3, K_T3, K_T3);
+    case 113: R(C_COPY, K_DPOLS, 1, K_T1, K_NONE);  case 114: R(C_ADD, K_DPOLS, 1, K_T1, K_POLS);
+    }
+#undef R
+    return false;
+}
+static const std::vector<uint64_t> *fused_stepbase(uint64_t op)
+{
+    static const std::vector<uint64_t> f115 = {0, 50};
+    return op == 115 ? &f115 : nullptr;
+}
+static bool is_base_step(int step) { return step == MI_CHELPERS_STEP2PREV || step == MI_CHELPERS_STEP3PREV || step == MI_CHELPERS_STEP3; }
 
 } // namespace chp
 
@@ -294,7 +332,7 @@ __global__ __launch_bounds__(64) void k_chelpers(const GInstr *__restrict__ prog
 static int decode(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, std::vector<MicroOp> &out,
                   uint64_t &max_chal, uint64_t &max_pub, uint64_t &max_eval)
 {
-    MI_REQUIRE(step == MI_CHELPERS_STEP42NS || step == MI_CHELPERS_STEP52NS, "only the step42ns and step52ns opcode numberings are known to this build");
+    MI_REQUIRE(step == MI_CHELPERS_STEP42NS || step == MI_CHELPERS_STEP52NS || is_base_step(step), "unknown step: the opcode numberings of step2prev / step3prev / step3, step42ns and step52ns are known to this build");
     uint64_t ia = 0;
     auto take = [&](Kind k, HOpd &o) -> bool {
         o.k = k;
@@ -351,6 +389,87 @@ static int decode(int step, const uint64_t *ops, uint64_t nops, const uint64_t *
                 for (uint64_t sub : *f) MI_TRY(one52(sub));
             } else {
                 MI_TRY(one52(ops[k]));
+            }
+        }
+        if (ia != nargs) {
+            mi_set_error("mi_chelpers_compile: program consumes %llu arguments, table holds %llu", (unsigned long long)ia, (unsigned long long)nargs);
+            return MI_ERR_INVALID;
+        }
+        return MI_OK;
+    }
+    // base-domain steps: an opcode whose result goes to a polynomial becomes "fresh temp = a op b" + "store the temp" (C_STOREP, the
+    // destination in operand b); a later read of exactly that polynomial element -- same offset, stride, shift and dimension: every
+    // such read in the zkEVM programs -- is the temp, so no instruction depends on polynomial memory written by the program itself
+    uint64_t fresh = 1ull << 40;
+    std::map<std::array<uint64_t, 4>, HOpd> stored; // (offset, stride, shift, dim) -> the temp that was stored there
+    std::set<std::array<uint64_t, 3>> read_elems;   // (element offset, stride, shift) read from polynomial memory so far
+    auto forward = [&](HOpd &o) -> int {
+        if (o.k != K_POL && o.k != K_POL3 && o.k != K_POLS && o.k != K_POL3S) return MI_OK;
+        const bool sh = o.k == K_POLS || o.k == K_POL3S;
+        const uint64_t dim = (o.k == K_POL3 || o.k == K_POL3S) ? 3 : 1, stride = sh ? o.v[3] : o.v[1], shift = sh ? o.v[1] : 0;
+        auto it = stored.find({o.v[0], stride, shift, dim});
+        if (it != stored.end()) { o = it->second; return MI_OK; }
+        for (uint64_t j = 0; j < dim; j++) read_elems.insert({o.v[0] + j, stride, shift});
+        for (auto &kv : stored) // anything else that overlaps a stored element would need the stored value from memory
+            if (kv.first[1] == stride && o.v[0] < kv.first[0] + kv.first[3] && kv.first[0] < o.v[0] + dim) {
+                mi_set_error("mi_chelpers_compile: a polynomial element the program has written is read back with another shift or dimension");
+                return MI_ERR_INVALID;
+            }
+        return MI_OK;
+    };
+    auto oneb = [&](uint64_t op) -> int {
+        RoleB r;
+        if (!role_stepbase(op, r)) {
+            mi_set_error("mi_chelpers_compile: unknown opcode %llu", (unsigned long long)op);
+            return MI_ERR_INVALID;
+        }
+        MicroOp m;
+        m.cls = r.cls;
+        HOpd dst;
+        bool ok = true;
+        if (r.dst == K_T1 || r.dst == K_T3) {
+            ok = ia < nargs;
+            m.dst = r.dst;
+            m.dst_slot = ok ? args[ia++] : 0;
+        } else {
+            ok = take(r.dst, dst);
+            m.dst = r.ddim == 3 ? K_T3 : K_T1;
+            m.dst_slot = fresh++;
+        }
+        ok = ok && take(r.a, m.a);
+        if (ok && r.b != K_NONE) ok = take(r.b, m.b);
+        if (!ok) {
+            mi_set_error("mi_chelpers_compile: argument table too short");
+            return MI_ERR_INVALID;
+        }
+        MI_TRY(forward(m.a));
+        MI_TRY(forward(m.b));
+        out.push_back(m);
+        if (r.dst == K_DPOL || r.dst == K_DPOLS) {
+            MicroOp st;
+            st.cls = C_STOREP;
+            st.dst = r.dst;
+            st.dst_slot = 0;
+            st.a.k = m.dst;
+            st.a.v[0] = m.dst_slot;
+            st.b = dst;
+            out.push_back(st);
+            const bool sh = r.dst == K_DPOLS;
+            for (int j = 0; j < r.ddim; j++)
+                if (read_elems.count({dst.v[0] + (uint64_t)j, sh ? dst.v[3] : dst.v[1], sh ? dst.v[1] : 0})) {
+                    mi_set_error("mi_chelpers_compile: the program overwrites a polynomial element it has read before");
+                    return MI_ERR_INVALID;
+                }
+            stored[{dst.v[0], sh ? dst.v[3] : dst.v[1], sh ? dst.v[1] : 0, (uint64_t)r.ddim}] = st.a;
+        }
+        return MI_OK;
+    };
+    if (is_base_step(step)) {
+        for (uint64_t k = 0; k < nops; k++) {
+            if (const std::vector<uint64_t> *f = fused_stepbase(ops[k])) {
+                for (uint64_t sub : *f) MI_TRY(oneb(sub));
+            } else {
+                MI_TRY(oneb(ops[k]));
             }
         }
         if (ia != nargs) {
@@ -490,7 +609,7 @@ static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
         std::vector<uint8_t> done(n, 0);
         std::vector<std::pair<size_t, int>> stack;
         for (size_t root = 0; root < n; root++) {
-            if (prog[root].cls != C_STOREQ && prog[root].cls != C_STOREF) continue; // only stores have effects: the rest is reached from them or dead
+            if (prog[root].cls != C_STOREQ && prog[root].cls != C_STOREF && prog[root].cls != C_STOREP) continue; // only stores have effects: the rest is reached from them or dead
             stack.push_back({root, 0});
             while (!stack.empty()) {
                 auto [node, state] = stack.back();
@@ -560,11 +679,11 @@ static int translate(mi_chelpers_prog *P, std::vector<MicroOp> &prog)
             Opd &o = *ds[s];
             switch (h.k) {
             case K_T1: case K_T3: o.off = word_of((size_t)src[i][s]); break;
-            case K_POL: case K_POL3:
+            case K_POL: case K_POL3: case K_DPOL:
                 MI_REQUIRE(h.v[1] < (1ull << 32), "row stride too large");
                 o.off = h.v[0]; o.stride = (uint32_t)h.v[1];
                 break;
-            case K_POLS: case K_POL3S:
+            case K_POLS: case K_POL3S: case K_DPOLS:
                 MI_REQUIRE(h.v[3] < (1ull << 32) && h.v[1] < (1ull << 32) && h.v[2] != 0, "bad shifted-row operand");
                 o.off = h.v[0]; o.shift = (uint32_t)h.v[1]; o.mod = h.v[2]; o.stride = (uint32_t)h.v[3];
                 break;
@@ -840,8 +959,12 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
     P->staged_cols = col0;
     if (st == MI_OK) st = chp::translate(P, prog);
     // the kernel's form needs the sections; a null context without sections compiles for the host debug executor only
-    if (st == MI_OK && (c || n_sections)) st = chp::build_staged(P, 256);
-    if (st == MI_OK && c) {
+    bool stores_pols = false;
+    for (const chp::DInstr &d : P->host) stores_pols |= (d.op & 255) == chp::C_STOREP;
+    P->stores_pols = stores_pols;
+    // the base-domain steps run through the compiled kernels only (mi_chelpers_build_native): the interpreter has no store form
+    if (st == MI_OK && (c || n_sections) && !stores_pols) st = chp::build_staged(P, 256);
+    if (st == MI_OK && c && !stores_pols) {
         std::lock_guard<std::recursive_mutex> lock(c->mu);
         hipError_t e = hipSetDevice(c->device);
         // zero padding: the kernel's pipeline reads up to three batches past the end (an all-zero instruction has no destination)
@@ -962,7 +1085,7 @@ extern "C" int mi_chelpers_stats(const mi_chelpers_prog *p, uint64_t out[16])
 static int check_params(const mi_chelpers_prog *p, const mi_chelpers_params *a, uint64_t row0, uint64_t nrows)
 {
     MI_REQUIRE(p && a, "null program or parameters");
-    MI_REQUIRE(a->pols && (p->step == MI_CHELPERS_STEP52NS ? a->f != nullptr : a->q != nullptr), "null polynomial memory or output");
+    MI_REQUIRE(a->pols && (p->stores_pols || (p->step == MI_CHELPERS_STEP52NS ? a->f != nullptr : a->q != nullptr)), "null polynomial memory or output");
     MI_REQUIRE(a->n_evals >= p->max_eval && (a->evals || p->max_eval == 0), "program reads more evaluations than were given");
     MI_REQUIRE(a->n_challenges >= p->max_chal && (a->challenges || p->max_chal == 0), "program reads more challenges than were given");
     MI_REQUIRE(a->n_publics >= p->max_pub && (a->publics || p->max_pub == 0), "program reads more public inputs than were given");
@@ -979,6 +1102,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     MI_HIP_CHECK(hipSetDevice(c->device));
     MI_TRY(check_params(p, a, row0, nrows));
     if (p->native) return chp::native_run(c, p, a, row0, nrows);
+    MI_REQUIRE(!p->stores_pols, "the base-domain steps run through the compiled kernels: call mi_chelpers_build_native first");
     MI_REQUIRE(p->dev, "program was compiled without a context");
     if (nrows == 0) return MI_OK;
     MI_REQUIRE(a->n_const == p->n_const, "number of constant polynomials differs from what the program was compiled for");
@@ -1080,6 +1204,7 @@ extern "C" int mi_dbg_host_chelpers_run(const mi_chelpers_prog *p, const mi_chel
     A.zhinv = zh.data();
     A.q = (u64 *)a->q;
     A.f = (u64 *)a->f;
+    A.pols_w = (u64 *)a->pols;
     A.evals = ev.data();
     A.xd = (const u64 *)a->xdiv;
     A.xdw = (const u64 *)a->xdivw;

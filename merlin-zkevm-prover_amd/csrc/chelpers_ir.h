@@ -12,16 +12,17 @@ using gl::E3;
 namespace chp {
 
 enum Kind : uint32_t { K_NONE = 0, K_T1, K_T3, K_POL, K_POLS, K_NUM, K_CONST, K_CONSTS, K_CHAL, K_PUB, K_POL3, K_POL3S, K_X, K_ZHINV, K_Q,
-                       K_EVAL, K_XD, K_XDW }; // step52ns: params.evals[k], params.xDivXSubXi[i], params.xDivXSubWXi[i] (all dimension 3)
-enum Cls : uint32_t { C_ADD = 0, C_SUB, C_MUL, C_COPY, C_STOREQ, C_STOREF }; // STOREQ: q = zhInv * a; STOREF: f = a
+                       K_EVAL, K_XD, K_XDW, // step52ns: params.evals[k], params.xDivXSubXi[i], params.xDivXSubWXi[i] (all dimension 3)
+                       K_DPOL, K_DPOLS };   // base-domain steps: a DESTINATION pols[off + i * stride] / pols[off + ((i + shift) % n) * stride]
+enum Cls : uint32_t { C_ADD = 0, C_SUB, C_MUL, C_COPY, C_STOREQ, C_STOREF, C_STOREP }; // STOREQ: q = zhInv * a; STOREF: f = a
 
 static inline int kind_nargs(Kind k)
 {
     switch (k) {
     case K_T1: case K_T3: case K_NUM: case K_CONST: case K_CHAL: case K_PUB: case K_EVAL: return 1;
-    case K_POL: case K_POL3: return 2;   // offset, row stride
+    case K_POL: case K_POL3: case K_DPOL: return 2;   // offset, row stride
     case K_CONSTS: return 3;             // column, row shift, modulus
-    case K_POLS: case K_POL3S: return 4; // offset, row shift, modulus, row stride
+    case K_POLS: case K_POL3S: case K_DPOLS: return 4; // offset, row shift, modulus, row stride
     default: return 0;
     }
 }
@@ -39,7 +40,7 @@ static_assert(sizeof(DInstr) == 64, "instruction must be 64 bytes");
 
 struct RunArgs { // host debug executor: operands read in place
     const u64 *pols, *cpols, *x, *zhinv, *chal, *pub, *evals, *xd, *xdw;
-    u64 *q, *f;
+    u64 *q, *f, *pols_w; // pols_w: the same polynomial memory, written by the base-domain steps
     uint64_t n_const, x_stride, n_zhinv, row0, row_end;
 };
 
@@ -164,6 +165,11 @@ MI_HD void exec_instr(const DInstr &I, uint64_t r, bool active, const RunArgs &P
     } else if (active && dk == K_Q) { // (Goldilocks3::Element &)params.q_2ns[i * 3] (step42ns) / params.f_2ns[i * 3] (step52ns)
         u64 *out = cls == C_STOREF ? P.f : P.q;
         out[r * 3] = o[0]; out[r * 3 + 1] = o[1]; out[r * 3 + 2] = o[2];
+    } else if (active && (dk == K_DPOL || dk == K_DPOLS)) { // params.pols[off + row * stride]: a is the value, b describes the destination
+        const uint64_t row = dk == K_DPOLS ? ((I.b.mod & (I.b.mod - 1)) == 0 ? ((r + I.b.shift) & (I.b.mod - 1)) : ((r + I.b.shift) % I.b.mod)) : r;
+        u64 *out = P.pols_w + I.b.off + row * I.b.stride;
+        out[0] = a[0];
+        if (a3) { out[1] = a[1]; out[2] = a[2]; }
     }
 }
 
@@ -190,6 +196,7 @@ struct mi_chelpers_prog {
     uint64_t stats[8] = {0};       // ops in, micro-ops, after copy forwarding, scheduled, live words before, after, t1 slots, t3 slots
     uint64_t max_chal = 0, max_pub = 0, max_eval = 0;
     int step = 0;
+    bool stores_pols = false;      // a base-domain step: results go into polynomial memory (C_STOREP)
     struct Patch { uint32_t instr, eval, word; };
     std::vector<Patch> eval_patches; // device instructions whose a_imm is evals[eval][word] of the running proof
     chp::NativeProg *native = nullptr; // the program compiled to gfx950 code (chelpers_native.hip), when mi_chelpers_build_native was called

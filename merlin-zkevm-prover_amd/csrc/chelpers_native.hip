@@ -690,6 +690,23 @@ struct Gen {
         const uint32_t cls = d.op & 255, dk = (d.op >> 8) & 255, ak = (d.op >> 16) & 255, bk = d.op >> 24;
         V a, b;
         MI_TRY(operand(ak, d.a, a));
+        if (cls == C_STOREP) { // params.pols[off + row' * stride] = a, row' = row or (row + shift) mod n (out = the polynomial memory here)
+            body += "  if (row < row_end) { ";
+            if (dk == K_DPOLS) {
+                MI_REQUIRE(d.b.mod && (d.b.mod & (d.b.mod - 1)) == 0, "shifted-row destination: the modulus must be a power of two");
+                snprintf(buf, sizeof buf, "u64 *po = out + %lluULL + ((row + %uu) & %lluULL) * %uULL; ", (unsigned long long)d.b.off, d.b.shift,
+                         (unsigned long long)(d.b.mod - 1), d.b.stride);
+            } else {
+                snprintf(buf, sizeof buf, "u64 *po = out + %lluULL + row * %uULL; ", (unsigned long long)d.b.off, d.b.stride);
+            }
+            body += buf;
+            for (int j = 0; j < a.dim; j++) {
+                snprintf(buf, sizeof buf, "po[%d] = ", j);
+                body += buf + (a.c[j] ? a.e[j] : "gl::canon(" + a.e[j] + ")") + "; ";
+            }
+            body += "}\n";
+            return MI_OK;
+        }
         MI_TRY(operand(bk, d.b, b));
         const int rdim = (dk == K_T3 || dk == K_Q) ? 3 : 1;
         std::string o[3];
@@ -972,7 +989,7 @@ int native_host_run(const mi_chelpers_prog *P, const mi_chelpers_params *a, cons
     RunArgs A = {};
     A.pols = (const u64 *)a->pols; A.cpols = (const u64 *)a->const_pols; A.x = (const u64 *)a->x;
     A.chal = chal.data(); A.pub = pub.data(); A.zhinv = zh.data(); A.evals = ev.data();
-    A.q = (u64 *)a->q; A.f = (u64 *)a->f;
+    A.q = (u64 *)a->q; A.f = (u64 *)a->f; A.pols_w = (u64 *)a->pols;
     A.xd = (const u64 *)a->xdiv; A.xdw = (const u64 *)a->xdivw;
     A.n_const = a->n_const; A.x_stride = a->x_stride; A.n_zhinv = a->n_zhinv ? a->n_zhinv : 1;
     const u64 POISON = 0xDEADBEEFDEADBEEFull;
@@ -1240,7 +1257,7 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     // ---- batches of rows: tile-major copy (+ halo tile) and the spill
     uint64_t batch = 0;
     MI_TRY(native_reserve(c, P, nrows, &batch));
-    u64 *out = (u64 *)(P->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
+    u64 *out = P->stores_pols ? (u64 *)a->pols : (u64 *)(P->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
     uint32_t zmask = (uint32_t)(n_zh - 1);
     const uint64_t row_end = row0 + nrows;
     for (uint64_t b0 = row0; b0 < row_end; b0 += batch) {

@@ -313,6 +313,7 @@ class ChelpersParams(ctypes.Structure):
 
 MI_CHELPERS_STEP42NS = 42
 MI_CHELPERS_STEP52NS = 52
+MI_CHELPERS_STEP2PREV, MI_CHELPERS_STEP3PREV, MI_CHELPERS_STEP3 = 20, 30, 31   # the base-domain steps: results go into pols
 
 
 def default_chelpers_cache():
@@ -421,6 +422,23 @@ class ChelpersProgram:
         P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, (), None, 0, (), None, keep,
                          evals=evals, xdiv_ptr=xdiv.ctypes.data, xdivw_ptr=xdivw.ctypes.data, f_ptr=f.ctypes.data)
         _check(lib().mi_dbg_host_chelpers_run_lowered(self.h, ctypes.byref(P), _hp(rows), u64(rows.size), u64(chunk_cost)))
+
+    def run_base(self, pols, const_pols, n_const, challenges, publics, x, x_stride, row0, nrows):
+        """step2prev / step3prev / step3: pols (device) is read and written; needs build_native."""
+        keep = []
+        P = self._params(pols.data_ptr(), const_pols.data_ptr(), n_const, challenges, publics, x.data_ptr(), x_stride, (), None, keep)
+        _check(lib().mi_chelpers_run_dev(self.ctx.h, self.h, ctypes.byref(P), u64(row0), u64(nrows)))
+
+    def run_base_host(self, pols, const_pols, n_const, challenges, publics, x, x_stride, rows, lowered=False, chunk_cost=0):
+        """The same on the CPU (test hook; host numpy arrays, pols is written): the translated program, or -- lowered -- the program
+        as the native backend lowers it."""
+        keep = []
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, publics, x.ctypes.data, x_stride, (), None, keep)
+        if lowered:
+            _check(lib().mi_dbg_host_chelpers_run_lowered(self.h, ctypes.byref(P), _hp(rows), u64(rows.size), u64(chunk_cost)))
+        else:
+            _check(lib().mi_dbg_host_chelpers_run(self.h, ctypes.byref(P), _hp(rows), u64(rows.size)))
 
     def run_host(self, pols, const_pols, n_const, challenges, publics, x, x_stride, zhinv, q, rows):
         """The same translated program on the CPU (test hook): every array is a host numpy uint64 array."""

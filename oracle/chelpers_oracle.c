@@ -23,6 +23,7 @@ typedef struct {
     const uint64_t *pols, *cpols, *chal, *pub, *x, *zhinv;
     uint64_t numpols, x_stride, n_zhinv;
     uint64_t *q;
+    uint64_t *pols_w; /* the base-domain steps write params.pols */
 } chp_env;
 
 /* operand readers at row i, argument position k of the current opcode */
@@ -167,7 +168,7 @@ int glo_chelpers_step42ns(const uint64_t *ops, uint64_t nops, const uint64_t *ar
     {
         uint64_t *tmp1 = (uint64_t *)calloc(maxarg + 1, sizeof(uint64_t));
         uint64_t *tmp3 = (uint64_t *)calloc(3 * (maxarg + 1), sizeof(uint64_t));
-        chp_env e = {pols, const_pols, challenges, publics, x, zhinv, numpols, x_stride, n_zhinv, q};
+        chp_env e = {pols, const_pols, challenges, publics, x, zhinv, numpols, x_stride, n_zhinv, q, NULL};
 #pragma omp for schedule(static)
         for (uint64_t r = 0; r < nrows; r++) {
             const uint64_t i = row0 + r;
@@ -259,4 +260,86 @@ int glo_chelpers_step52ns(const uint64_t *ops, uint64_t nops, const uint64_t *ar
         }
     }
     return status;
+}
+
+
+/* ------------------------------------------------------------------ the base-domain steps: step2prev / step3prev / step3
+ * ZkevmSteps::step{2prev,3prev,3}_parser_first_avx (zkevm.chelpers.step2prev.parser.cpp:9-, step3prev.parser.cpp:9-,
+ * step3.parser.cpp:9-): one opcode numbering for the three.  Cases 0-83 are the step42ns cases above, word for word, reading
+ * params.pConstPols / params.x_n where step42ns reads pConstPols2ns / x_2ns (the caller passes those); 69 is not used by them.
+ * 84-115 below, one line per case of the reference: 86-100 store into &params.pols[a0 + i * a1] (args 0, 1), 101-114 into
+ * &params.pols[0] + offsets1, offsets1 = a0 + ((i + a1) % a2) * a3 (args 0..3); 91, 97, 99 are "code not used" asserts there;
+ * 115 (step3 only) is the fusion "0, 50".  Rows are walked in order on one thread: a row may store into the next row's cell. */
+#define DST (&e->pols_w[A(0) + i * A(1)])
+#define DSTS (&e->pols_w[A(0) + ((i + A(1)) % A(2)) * A(3)])
+static int chp_stepbase_op(uint64_t op, const uint64_t *args, uint64_t ia, uint64_t i, uint64_t *tmp1, uint64_t *tmp3, const chp_env *e)
+{
+    if (op <= 83 && op != 69) return chp_step42ns_op(op, args, ia, i, tmp1, tmp3, e);
+    switch (op) {
+    case 84: T1(0) = glo_add(T1(1), POLS(2)); return 6;
+    case 85: T1(0) = glo_mul(POLS(1), NUM(5)); return 6;
+    case 86: *DST = glo_add(T1(2), T1(3)); return 4;
+    case 87: *DST = glo_add(T1(2), POL(3)); return 5;
+    case 88: add13(DST, T1(2), T3(3)); return 4;
+    case 89: add33(DST, POLP(2), T3(4)); return 5;
+    case 90: add33(DST, T3(2), CHAL(3)); return 4;
+    case 92: *DST = glo_sub(T1(2), T1(3)); return 4;
+    case 93: *DST = glo_sub(NUM(2), T1(3)); return 4;
+    case 94: *DST = glo_mul(T1(2), T1(3)); return 4;
+    case 95: *DST = glo_mul(POL(2), T1(4)); return 5;
+    case 96: *DST = glo_mul(T1(2), CST(3)); return 4;
+    case 98: mul33(DST, T3(2), T3(3)); return 4;
+    case 100: *DST = T1(2); return 3;
+    case 101: *DSTS = glo_add(T1(4), T1(5)); return 6;
+    case 102: *DSTS = glo_add(T1(4), POL(5)); return 7;
+    case 103: add13(DSTS, T1(4), T3(5)); return 6;
+    case 104: add33(DSTS, POLP(4), T3(6)); return 7;
+    case 105: add33(DSTS, T3(4), CHAL(5)); return 6;
+    case 106: *DSTS = glo_sub(T1(4), T1(5)); return 6;
+    case 107: *DSTS = glo_sub(NUM(4), T1(5)); return 6;
+    case 108: *DSTS = glo_mul(T1(4), T1(5)); return 6;
+    case 109: *DSTS = glo_mul(POL(4), T1(6)); return 7;
+    case 110: *DSTS = glo_mul(T1(4), CST(5)); return 6;
+    case 111: *DSTS = glo_mul(CSTS(4), T1(7)); return 8;
+    case 112: mul33(DSTS, T3(4), T3(5)); return 6;
+    case 113: *DSTS = T1(4); return 5;
+    case 114: *DSTS = glo_add(T1(4), POLS(5)); return 9;
+    }
+    return -1;
+}
+#undef DST
+#undef DSTS
+
+int glo_chelpers_stepbase(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, uint64_t *pols,
+                          const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *publics,
+                          const uint64_t *x, uint64_t x_stride, const uint64_t *rows, uint64_t nrows)
+{
+    static const int G115[] = {0, 50, -1};
+    uint64_t maxarg = 0;
+    for (uint64_t k = 0; k < nargs; k++)
+        if (args[k] < (1u << 20) && args[k] > maxarg) maxarg = args[k];
+    uint64_t *tmp1 = (uint64_t *)calloc(maxarg + 1, sizeof(uint64_t));
+    uint64_t *tmp3 = (uint64_t *)calloc(3 * (maxarg + 1), sizeof(uint64_t));
+    chp_env e = {pols, const_pols, challenges, publics, x, NULL, numpols, x_stride, 1, NULL, pols};
+    int bad = 0;
+    for (uint64_t r = 0; r < nrows && !bad; r++) {
+        const uint64_t i = rows[r];
+        uint64_t ia = 0;
+        for (uint64_t kk = 0; kk < nops && !bad; kk++) {
+            const int *f = ops[kk] == 115 ? G115 : NULL;
+            if (f) {
+                for (; *f >= 0 && !bad; f++) {
+                    const int n = chp_stepbase_op((uint64_t)*f, args, ia, i, tmp1, tmp3, &e);
+                    if (n < 0) bad = -1; else ia += (uint64_t)n;
+                }
+            } else {
+                const int n = chp_stepbase_op(ops[kk], args, ia, i, tmp1, tmp3, &e);
+                if (n < 0) bad = -1; else ia += (uint64_t)n;
+            }
+        }
+        if (!bad && ia != nargs) bad = -2;
+    }
+    free(tmp1);
+    free(tmp3);
+    return bad;
 }

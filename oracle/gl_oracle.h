@@ -116,6 +116,12 @@ int glo_chelpers_step52ns(const uint64_t *ops, uint64_t nops, const uint64_t *ar
                           const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *evals,
                           const uint64_t *xdiv, const uint64_t *xdivw, uint64_t *f, uint64_t row0, uint64_t nrows);
 
+/* the base-domain steps step2prev / step3prev / step3 (zkevm.chelpers.step{2prev,3prev,3}.parser.cpp): results are written into
+ * pols; rows = the rows to evaluate, in that order (one thread) */
+int glo_chelpers_stepbase(const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, uint64_t *pols,
+                          const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *publics,
+                          const uint64_t *x, uint64_t x_stride, const uint64_t *rows, uint64_t nrows);
+
 void glo_set_num_threads(int n); /* OpenMP threads used by the parallel loops (0 = leave as is) */
 int glo_num_threads(void);
 

@@ -342,3 +342,159 @@ def synthetic_program52(rng, sections, n_const, n_evals, length=60):
     emit(8)
     emit(15)
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
+
+
+# ------------------------------------------------------------------ the base-domain steps (step2prev / step3prev / step3)
+# One opcode numbering for the three of them (zkevm.chelpers.step{2prev,3prev,3}.parser.cpp, *_parser_first_avx): cases 0-83 are
+# step42ns's with pConstPols / x_n in place of pConstPols2ns / x_2ns; 84-85 two more temp operations; 86-100 results stored into a
+# polynomial at the row; 101-114 the same stored at a shifted row; 115 (step3 only) the fusion [0, 50].
+DPOL, DPOLS = 20, 21                              # destination kinds: pols[off + i * stride], pols[off + ((i + shift) % n) * stride]
+NARGS_DST = {T1: 1, T3: 1, DPOL: 2, DPOLS: 4}
+# opcode -> (operation, destination kind, destination dimension, source a, source b); sources in argument order after the destination
+OPS_BASE_EXTRA = {
+    84: ("add", T1, 1, T1, POLS), 85: ("mul", T1, 1, POLS, NUM),
+    86: ("add", DPOL, 1, T1, T1), 87: ("add", DPOL, 1, T1, POL), 88: ("add", DPOL, 3, T1, T3), 89: ("add", DPOL, 3, POL3, T3),
+    90: ("add", DPOL, 3, T3, CHAL), 92: ("sub", DPOL, 1, T1, T1), 93: ("sub", DPOL, 1, NUM, T1), 94: ("mul", DPOL, 1, T1, T1),
+    95: ("mul", DPOL, 1, POL, T1), 96: ("mul", DPOL, 1, T1, CONST), 98: ("mul", DPOL, 3, T3, T3), 100: ("copy", DPOL, 1, T1, None),
+    101: ("add", DPOLS, 1, T1, T1), 102: ("add", DPOLS, 1, T1, POL), 103: ("add", DPOLS, 3, T1, T3), 104: ("add", DPOLS, 3, POL3, T3),
+    105: ("add", DPOLS, 3, T3, CHAL), 106: ("sub", DPOLS, 1, T1, T1), 107: ("sub", DPOLS, 1, NUM, T1), 108: ("mul", DPOLS, 1, T1, T1),
+    109: ("mul", DPOLS, 1, POL, T1), 110: ("mul", DPOLS, 1, T1, CONST), 111: ("mul", DPOLS, 1, CONSTS, T1), 112: ("mul", DPOLS, 3, T3, T3),
+    113: ("copy", DPOLS, 1, T1, None), 114: ("add", DPOLS, 1, T1, POLS),
+}
+FUSED_BASE = {115: [0, 50]}
+
+
+def _cls42(o):
+    return "add" if o <= 20 else "sub" if o <= 44 else "mul" if o <= 77 and o != 69 else "store" if o == 69 else "copy"
+
+
+def decode_base(ops, args):
+    """-> [(opcode, operation, dst kind, dst dim, dst args, [(kind, [args])])], and the number of arguments consumed."""
+    out, ia = [], 0
+    for op in ops:
+        for o in FUSED_BASE.get(int(op), [int(op)]):
+            if o in OPS_BASE_EXTRA:
+                c, dk, dd, a, b = OPS_BASE_EXTRA[o]
+            else:
+                d, a, b = OPS[o]
+                c, dk, dd = _cls42(o), d, (3 if d == T3 else 1)
+            nd = NARGS_DST[dk]
+            dargs = [int(v) for v in args[ia:ia + nd]]
+            ia += nd
+            srcs = []
+            for k in (a, b):
+                if k is None:
+                    continue
+                srcs.append((k, [int(v) for v in args[ia:ia + NARGS[k]]]))
+                ia += NARGS[k]
+            out.append((o, c, dk, dd, dargs, srcs))
+    return out, ia
+
+
+def touched_addresses_base(dec, rows, numpols):
+    """Element indices a base-domain program reads / writes in `pols`, reads in the constant polynomials, for the given rows."""
+    reads, writes, cpols = set(), set(), set()
+    for (_, _, dk, dd, dargs, srcs) in dec:
+        for r in rows:
+            if dk == DPOL:
+                writes.update(range(dargs[0] + r * dargs[1], dargs[0] + r * dargs[1] + dd))
+            elif dk == DPOLS:
+                b = dargs[0] + ((r + dargs[1]) % dargs[2]) * dargs[3]
+                writes.update(range(b, b + dd))
+            for k, a in srcs:
+                if k in (POL, POL3):
+                    b = a[0] + r * a[1]
+                elif k in (POLS, POL3S):
+                    b = a[0] + ((r + a[1]) % a[2]) * a[3]
+                elif k == CONST:
+                    cpols.add(a[0] + r * numpols); continue
+                elif k == CONSTS:
+                    cpols.add(a[0] + ((r + a[1]) % a[2]) * numpols); continue
+                else:
+                    continue
+                reads.update(range(b, b + (3 if k in (POL3, POL3S) else 1)))
+    return reads, writes, cpols
+
+
+def synthetic_program_base(rng, nrows, sections, out_section, n_const, n_chal, n_pub, n_ops=260):
+    """A random valid program in the base-domain steps' numbering: every opcode 0..115 that the three steps can use (not 69, 91, 97,
+    99) occurs; every stored result goes to its own column(s) of `out_section` = (offset, stride) -- a column is written once, with
+    one shift -- and some later operands read a stored element back (same shift and dimension: the only kind the zkEVM programs have).
+    sections: [(offset, stride)] of input polynomials."""
+    ops, args = [], []
+    def1, def3 = set(), set()
+    out_off, out_stride = out_section
+    cursor = [0]
+    stored = {POL: [], POL3: [], POLS: [], POL3S: []}
+
+    def gen_src(kind):
+        if kind == T1: return [int(rng.choice(sorted(def1)))]
+        if kind == T3: return [int(rng.choice(sorted(def3)))]
+        if kind == NUM: return [int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.5 else int(rng.integers(0, 5))]
+        if kind == CONST: return [int(rng.integers(0, n_const))]
+        if kind == CONSTS: return [int(rng.integers(0, n_const)), int(rng.integers(1, 4)), nrows]
+        if kind == CHAL: return [int(rng.integers(0, n_chal))]
+        if kind == PUB: return [int(rng.integers(0, n_pub))]
+        if kind in stored and stored[kind] and rng.random() < 0.3:
+            return list(stored[kind][int(rng.integers(0, len(stored[kind])))])
+        off, stride = sections[int(rng.integers(0, len(sections)))]
+        col = int(rng.integers(0, stride - (2 if kind in (POL3, POL3S) else 0)))
+        if kind in (POL, POL3): return [off + col, stride]
+        if kind in (POLS, POL3S): return [off + col, int(rng.integers(1, 4)), nrows, stride]
+        return []
+
+    def emit(o):
+        if o in OPS_BASE_EXTRA:
+            c, dk, dd, a, b = OPS_BASE_EXTRA[o]
+        else:
+            d, a, b = OPS[o]
+            dk, dd = d, (3 if d == T3 else 1)
+        for k in (a, b):
+            if (k == T1 and not def1) or (k == T3 and not def3):
+                return False
+        if dk in (DPOL, DPOLS):
+            if cursor[0] + dd > out_stride:
+                return False
+            col = out_off + cursor[0]
+            cursor[0] += dd
+            if dk == DPOL:
+                dargs, new_entry = [col, out_stride], (POL3 if dd == 3 else POL, (col, out_stride))
+            else:
+                sh = int(rng.integers(1, 4))
+                dargs, new_entry = [col, sh, nrows, out_stride], (POL3S if dd == 3 else POLS, (col, sh, nrows, out_stride))
+        else:
+            slot = int(rng.integers(0, 12 if dk == T1 else 6))
+            dargs, new_entry = [slot], None
+        if o == 70:
+            ar = dargs + gen_src(CHAL) + gen_src(T3)
+        else:
+            ar = dargs + gen_src(a) + (gen_src(b) if b is not None else [])
+        if new_entry is not None:                   # readable only by LATER operations
+            stored[new_entry[0]].append(new_entry[1])
+        ops.append(o); args.extend(ar)
+        if dk == T1: def1.add(dargs[0])
+        elif dk == T3: def3.add(dargs[0])
+        return True
+
+    for o in (79, 82, 81, 13, 16):          # a few temporaries to start from
+        emit(o)
+    cand = [o for o in range(0, 86) if o != 69] + [o for o in OPS_BASE_EXTRA if o >= 86]
+    pending = list(cand)
+    rng.shuffle(pending)
+    n = 0
+    while n < n_ops:
+        o = pending.pop() if pending else int(rng.choice(cand))
+        if o in FUSED_BASE:
+            continue
+        if emit(o):
+            n += 1
+    # the fused opcode, then every live temporary to a column of its own so that nothing is dead
+    if def1:
+        ar = [int(rng.integers(0, 12))] + gen_src(T1) + gen_src(T1)
+        ar += [int(rng.integers(0, 12))] + gen_src(POL) + gen_src(POL)
+        ops.append(115); args.extend(ar)
+        def1.update([ar[0], ar[3]])
+    for t in sorted(def1):
+        if cursor[0] + 1 <= out_stride:
+            ops.append(100); args.extend([out_off + cursor[0], out_stride, t]); cursor[0] += 1
+    return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)

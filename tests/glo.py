@@ -253,3 +253,17 @@ def chelpers_step52ns(ops, args, pols, const_pols, n_const, challenges, evals, x
             ctypes.c_void_p(xdivw.ctypes.data), ctypes.c_void_p(f.ctypes.data), u64(row0), u64(nrows))
     if st != 0:
         raise RuntimeError("glo_chelpers_step52ns: " + {-1: "unknown opcode", -2: "argument count mismatch"}.get(st, str(st)))
+
+
+def chelpers_stepbase(ops, args, pols, const_pols, n_const, challenges, publics, x, x_stride, rows):
+    """The reference's step2prev / step3prev / step3 interpreter restated (oracle/chelpers_oracle.c); pols (host array) is
+    read and written; rows are evaluated in the given order."""
+    ops, args, rows = A(ops), A(args), A(rows)
+    ch, pb = A(challenges).reshape(-1), A(publics).reshape(-1)
+    fn = lib().glo_chelpers_stepbase
+    fn.restype = ctypes.c_int
+    st = fn(ptr(ops), u64(ops.size), ptr(args) if args.size else None, u64(args.size), ctypes.c_void_p(pols.ctypes.data),
+            ctypes.c_void_p(const_pols.ctypes.data), u64(n_const), ptr(ch), ptr(pb), ctypes.c_void_p(x.ctypes.data), u64(x_stride),
+            ptr(rows), u64(rows.size))
+    if st != 0:
+        raise RuntimeError("glo_chelpers_stepbase: " + {-1: "unknown opcode", -2: "argument count mismatch"}.get(st, str(st)))

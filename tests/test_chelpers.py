@@ -404,3 +404,124 @@ def test_native_step52ns_matches_oracle(tmp_path, lin_min, monkeypatch):
         assert np.array_equal(ctx.to_host(f), want)
     prog.close()
     ctx.close()
+
+
+# ------------------------------------------------------------------ the base-domain steps: step2prev / step3prev / step3
+REF_BASE = {"step2prev": ("op2prev", "args2prev", 1815, 5828), "step3prev": ("op3prev", "args3prev", 5869, 18927), "step3": ("op3", "args3", 11042, 45647)}
+
+
+def _base_case(seed, nrows):
+    rng = np.random.default_rng(seed)
+    secs, out = [(0, 40), (nrows * 40, 9), (nrows * 49, 3)], (nrows * 52, 120)
+    ops, args = cp.synthetic_program_base(rng, nrows, secs, out, 7, 5, 4)
+    pols = np.zeros(nrows * (52 + 120), dtype=np.uint64)
+    pols[:nrows * 52] = glo.rand_fe(rng, nrows * 52, canonical=False)
+    return ops, args, pols, glo.rand_fe(rng, nrows * 7), glo.rand_fe(rng, 15), glo.rand_fe(rng, 4), glo.rand_fe(rng, nrows * 2), [(o, w, nrows) for o, w in secs]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_base_step_programs_match_oracle_on_the_host(seed):
+    """Every opcode of the base-domain numbering (results stored into polynomials, read back through the stored temporaries):
+    the translated program and the program as the native backend lowers it against the oracle's restatement."""
+    import mi_stark
+    nrows = 64
+    ops, args, pols, cpols, chal, pub, x, sections = _base_case(seed, nrows)
+    want, got, got2 = pols.copy(), pols.copy(), pols.copy()
+    glo.chelpers_stepbase(ops, args, want, cpols, 7, chal, pub, x, 2, np.arange(nrows))
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=sections, n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3)
+    prog.run_base_host(got, cpols, 7, chal, pub, x, 2, np.arange(nrows))
+    prog.run_base_host(got2, cpols, 7, chal, pub, x, 2, np.arange(nrows), lowered=True, chunk_cost=1200)
+    assert np.array_equal(got, want) and np.array_equal(got2, want) and want[nrows * 52:].any()
+    prog.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("step", ["step2prev", "step3prev", "step3"])
+def test_base_step_tables_agree_with_the_reference_and_its_programs_match_the_oracle(step):
+    """The three base-domain interpreters share one opcode numbering, which the product's / the oracle's / the test generator's tables
+    transcribe: argument counts against the reference's source text, the reference's own program consumed exactly, and -- over a
+    sparse address space -- every polynomial element the program writes on sampled rows equal between the oracle, the translated
+    program and the lowered program; the generated kernels of the program compile."""
+    import mi_stark
+    opn, argn, nops, nargs = REF_BASE[step]
+    src = open("/root/reference/src/starkpil/zkevm/chelpers/zkevm.chelpers.%s.parser.cpp" % step).read()
+    body = src[src.index("void ZkevmSteps::%s_parser_first_avx(" % step):]
+    body = body[:body.index("void ZkevmSteps::", 10)] if "void ZkevmSteps::" in body[10:] else body
+    cases = re.split(r"\n\s*case (\d+):", body)[1:]
+    seen = set()
+    for num, text in zip(cases[0::2], cases[1::2]):
+        o = int(num)
+        seen.add(o)
+        if o in (69, 91, 97, 99):
+            continue
+        want = sum(int(k) for k in re.findall(r"i_args \+= (\d+);", text.split("default:")[0]))
+        parts = cp.FUSED_BASE.get(o, [o])
+        got = 0
+        for q in parts:
+            if q in cp.OPS_BASE_EXTRA:
+                _, dk, _, a, b = cp.OPS_BASE_EXTRA[q]
+                got += cp.NARGS_DST[dk] + sum(cp.NARGS[k] for k in (a, b) if k is not None)
+            else:
+                got += cp.nargs_of(q)
+        assert got == want, (step, o, got, want)
+    assert set(range(115)) <= seen
+    ops, args = cp.parse_reference_tables(open("/root/reference/src/starkpil/zkevm/chelpers/zkevm.chelpers.%s.parser.hpp" % step).read(), opn, argn)
+    assert ops.size == nops and args.size == nargs
+    dec, used = cp.decode_base(ops, args)
+    assert used == args.size
+    N, numpols = 1 << 23, 360
+    secs = sorted({((a[0] // N) * N, a[1] if k in (cp.POL, cp.POL3) else a[3]) for (_, _, _, _, _, srcs) in dec for k, a in srcs if k in (cp.POL, cp.POL3, cp.POLS, cp.POL3S)})
+    rows = [0, 1, N - 2, N - 1, 4242]
+    rd, wr, ca = cp.touched_addresses_base(dec, rows, numpols)
+
+    def sparse(n_elems):
+        return np.frombuffer(mmap.mmap(-1, n_elems * 8, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | getattr(mmap, "MAP_NORESERVE", 0x4000)), dtype=np.uint64)
+    rng = np.random.default_rng(7)
+    top = max(max(rd), max(wr)) + 8
+    want, got, got2 = sparse(top), sparse(top), sparse(top)
+    idx = np.fromiter(rd, dtype=np.int64)
+    vals = glo.rand_fe(rng, idx.size)
+    for m in (want, got, got2):
+        m[idx] = vals
+    cpols = sparse(max(ca) + 8)
+    cpols[np.fromiter(ca, dtype=np.int64)] = glo.rand_fe(rng, len(ca))
+    x = sparse(N)
+    x[rows] = glo.rand_fe(rng, len(rows))
+    chal, pub = glo.rand_fe(rng, 8 * 3), glo.rand_fe(rng, 64)
+    glo.chelpers_stepbase(ops, args, want, cpols, numpols, chal, pub, x, 1, rows)
+    sid = {"step2prev": mi_stark.MI_CHELPERS_STEP2PREV, "step3prev": mi_stark.MI_CHELPERS_STEP3PREV, "step3": mi_stark.MI_CHELPERS_STEP3}[step]
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=[(o, s, N) for o, s in secs], n_const=numpols, nrows_ext=N, step=sid)
+    prog.run_base_host(got, cpols, numpols, chal, pub, x, 1, rows)
+    prog.run_base_host(got2, cpols, numpols, chal, pub, x, 1, rows, lowered=True)
+    widx = np.fromiter(wr, dtype=np.int64)
+    assert widx.size > 500 and want[widx].all()
+    assert np.array_equal(got[widx], want[widx]) and np.array_equal(got2[widx], want[widx])
+    with tempfile.TemporaryDirectory() as td:      # one share of a parallel build: the generated kernels compile
+        prog.precompile_shard(0, 8, cache_dir=td)
+        assert len([f for f in os.listdir(td) if f.endswith(".hsaco")]) >= 1
+    prog.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_base_step_program_on_gpu_matches_oracle(seed, tmp_path):
+    """The compiled kernels of a base-domain program write the same polynomial elements as the oracle, in one batch and in many;
+    the interpreter has no store form and says so."""
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 12
+    ops, args, pols, cpols, chal, pub, x, sections = _base_case(seed, nrows)
+    want = pols.copy()
+    glo.chelpers_stepbase(ops, args, want, cpols, 7, chal, pub, x, 2, np.arange(nrows))
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=sections, n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3PREV)
+    d_c, d_x = ctx.to_device(cpols), ctx.to_device(x)
+    with pytest.raises(mi_stark.MiStarkError, match="mi_chelpers_build_native first"):
+        prog.run_base(ctx.to_device(pols), d_c, 7, chal, pub, d_x, 2, 0, nrows)
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=2500)["kernels"] >= 2
+    for batch in (0, 512):
+        ctx.set_chelpers_batch_rows(batch)
+        d_pols = ctx.to_device(pols)
+        prog.run_base(d_pols, d_c, 7, chal, pub, d_x, 2, 0, nrows)
+        assert np.array_equal(ctx.to_host(d_pols), want), batch
+    prog.close()
+    ctx.close()
