@@ -157,7 +157,7 @@ def synthetic_program(rng, nrows, sections, n_const, n_chal, n_pub, passes=3, nt
     return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)
 
 
-def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_ops=17986, next_shift=2, vc=4, long_lived=70):
+def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_ops=17986, next_shift=2, vc=4, long_lived=70, base_out=None):
     """A random valid step42ns program in the SHAPE of the zkEVM one (the real tables cannot travel to the GPU box): ~2 200
     constraint values, each a short base-field expression (on average 5.6 multiplications / additions / subtractions) over
     polynomial elements, shifted ("prime") elements, constants and numbers, every one folded into the running extension
@@ -165,7 +165,10 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     multiplications); about 9 % of the constraints are extension-valued (value * challenge, an extension product, an extension
     sum or difference, folded with an extension addition).  Operand columns follow a skewed distribution (the real program reads
     1 766 distinct elements 12 525 times).  `long_lived` base values are computed up front and read throughout, so that the
-    rescheduled program keeps about as many words live as the real one (86).  Uses challenges 0..vc; ends with the q store."""
+    rescheduled program keeps about as many words live as the real one (86).  Uses challenges 0..vc; ends with the q store.
+    base_out = (offset, stride): the same shape in the BASE-DOMAIN steps' numbering (opcodes 0-83 are shared): about every other
+    constraint value is stored into a column of that section instead of being accumulated (opcode 100; the zkEVM step3 stores 430 elements) and the accumulator goes to
+    three of its columns (opcode 90) instead of q."""
     ops, args = [], []
     ACC = 0
     cls_of = lambda o: "add" if o <= 20 else "sub" if o <= 44 else "mul" if o <= 77 else "copy"
@@ -210,6 +213,7 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     def push(o, ar):
         ops.append(o); args.extend(ar)
 
+    out_cursor = [0]
     push(13, [ACC, 1, vc])                       # acc = 1 + challenge[vc]
     LL0 = 10
     for k in range(long_lived):
@@ -236,6 +240,13 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
             push(o, ar)
             prev, cur = (cur if cur is not None else dst), dst
             count += 1
+        if base_out is not None and out_cursor[0] + 4 < base_out[1] and (count // 8) % 2 == 0:
+            # this value is an output (stored, not accumulated: a value that is both keeps every such value alive until the
+            # accumulation is scheduled, which the real programs do not do)
+            push(100, [base_out[0] + out_cursor[0], base_out[1], cur])
+            out_cursor[0] += 1
+            count += 1
+            continue
         if rng.random() < 0.09:                  # extension-valued constraint
             e1, e2 = 1 + eslot % 4, 1 + (eslot + 1) % 4
             eslot += 2
@@ -247,9 +258,15 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
             push(70, [ACC, vc, ACC])
             count += 6
         else:
-            push(84, [ACC, cur, ACC, ACC, vc, ACC])                         # acc = (value + acc) * challenge[vc]
+            if base_out is not None:                                        # (84 is another opcode in the base-domain numbering)
+                push(12, [ACC, cur, ACC]); push(70, [ACC, vc, ACC])
+            else:
+                push(84, [ACC, cur, ACC, ACC, vc, ACC])                     # acc = (value + acc) * challenge[vc]
             count += 2
-    push(69, [ACC])
+    if base_out is not None:
+        push(90, [base_out[0] + out_cursor[0], base_out[1], ACC, 0])
+    else:
+        push(69, [ACC])
     return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)
 
 
@@ -425,18 +442,21 @@ def synthetic_program_base(rng, nrows, sections, out_section, n_const, n_chal, n
     def1, def3 = set(), set()
     out_off, out_stride = out_section
     cursor = [0]
+    last_dst = [0]
+    recent1, recent3 = [], []
     stored = {POL: [], POL3: [], POLS: [], POL3S: []}
 
     def gen_src(kind):
-        if kind == T1: return [int(rng.choice(sorted(def1)))]
-        if kind == T3: return [int(rng.choice(sorted(def3)))]
+        if kind == T1: return [int(rng.choice(recent1[-6:]))]      # recently defined: the live ranges stay short, as in the real programs
+        if kind == T3: return [int(rng.choice(recent3[-4:]))]
         if kind == NUM: return [int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.5 else int(rng.integers(0, 5))]
         if kind == CONST: return [int(rng.integers(0, n_const))]
         if kind == CONSTS: return [int(rng.integers(0, n_const)), int(rng.integers(1, 4)), nrows]
         if kind == CHAL: return [int(rng.integers(0, n_chal))]
         if kind == PUB: return [int(rng.integers(0, n_pub))]
-        if kind in stored and stored[kind] and rng.random() < 0.3:
-            return list(stored[kind][int(rng.integers(0, len(stored[kind])))])
+        if kind in stored and stored[kind] and rng.random() < (0.3 if n_ops < 1000 else 0.03):   # read a stored element back (a recent one)
+            recent = stored[kind][-8:]
+            return list(recent[int(rng.integers(0, len(recent)))])
         off, stride = sections[int(rng.integers(0, len(sections)))]
         col = int(rng.integers(0, stride - (2 if kind in (POL3, POL3S) else 0)))
         if kind in (POL, POL3): return [off + col, stride]
@@ -453,7 +473,7 @@ def synthetic_program_base(rng, nrows, sections, out_section, n_const, n_chal, n
             if (k == T1 and not def1) or (k == T3 and not def3):
                 return False
         if dk in (DPOL, DPOLS):
-            if cursor[0] + dd > out_stride:
+            if cursor[0] + dd > out_stride - 16:   # the last columns are kept for the accumulators and the temporaries at the end
                 return False
             col = out_off + cursor[0]
             cursor[0] += dd
@@ -472,12 +492,16 @@ def synthetic_program_base(rng, nrows, sections, out_section, n_const, n_chal, n
         if new_entry is not None:                   # readable only by LATER operations
             stored[new_entry[0]].append(new_entry[1])
         ops.append(o); args.extend(ar)
-        if dk == T1: def1.add(dargs[0])
-        elif dk == T3: def3.add(dargs[0])
+        last_dst[0] = dargs[0]
+        if dk == T1: def1.add(dargs[0]); recent1.append(dargs[0])
+        elif dk == T3: def3.add(dargs[0]); recent3.append(dargs[0])
         return True
 
     for o in (79, 82, 81, 13, 16):          # a few temporaries to start from
         emit(o)
+    ACC1, ACC3 = 12, 6                      # accumulators beyond the randomly used slots: every result is folded in, nothing is dead
+    ops.append(81); args.extend([ACC1, 1])
+    ops.append(13); args.extend([ACC3, 1, 0])
     cand = [o for o in range(0, 86) if o != 69] + [o for o in OPS_BASE_EXTRA if o >= 86]
     pending = list(cand)
     rng.shuffle(pending)
@@ -488,13 +512,20 @@ def synthetic_program_base(rng, nrows, sections, out_section, n_const, n_chal, n
             continue
         if emit(o):
             n += 1
+            dk = OPS_BASE_EXTRA[o][1] if o in OPS_BASE_EXTRA else OPS[o][0]
+            if dk == T1:
+                ops.append(12); args.extend([ACC3, last_dst[0], ACC3]); n += 1    # one accumulator chain: two would keep each other's operands alive
+            elif dk == T3:
+                ops.append(17); args.extend([ACC3, ACC3, last_dst[0]]); n += 1
     # the fused opcode, then every live temporary to a column of its own so that nothing is dead
     if def1:
         ar = [int(rng.integers(0, 12))] + gen_src(T1) + gen_src(T1)
         ar += [int(rng.integers(0, 12))] + gen_src(POL) + gen_src(POL)
         ops.append(115); args.extend(ar)
         def1.update([ar[0], ar[3]])
-    for t in sorted(def1):
-        if cursor[0] + 1 <= out_stride:
+    for t in sorted(def1)[:4]:
+        if cursor[0] + 4 <= out_stride:
             ops.append(100); args.extend([out_off + cursor[0], out_stride, t]); cursor[0] += 1
+    if cursor[0] + 3 <= out_stride:            # the extension accumulator: acc3 + challenge 1 -> three columns
+        ops.append(90); args.extend([out_off + cursor[0], out_stride, ACC3, 1]); cursor[0] += 3
     return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the constraint-evaluator backends (run on a GPU box): random step42ns / step52ns programs (every opcode,
+"""Differential fuzz of the constraint-evaluator backends (run on a GPU box): random step42ns / step52ns / base-domain programs (every opcode,
 zkEVM-shaped, Horner chains), random chunk sizes / batch sizes / row ranges, linear kernel forced on or off; the native backend
 (generated kernels + linear kernel) and the interpreter against the oracle's opcode-by-opcode restatement.  The oracle is the
 checker here, as in tests/.  Usage: chelpers_fuzz.py [count] [first seed]."""
@@ -37,8 +37,22 @@ def main():
             pols = glo.rand_fe(rng, nrows * 52, canonical=False)
             cpols = glo.rand_fe(rng, nrows * 7)
             want = np.zeros(nrows * 3, dtype=np.uint64)
-            kind = seed % 3
-            if kind == 2:
+            kind = seed % 4
+            if kind == 3:       # a base-domain step (step2prev / step3prev / step3): results stored into polynomials, compiled kernels only
+                out = (nrows * 52, 120)
+                ops, args = cp.synthetic_program_base(rng, nrows, secs, out, 7, 5, 4, n_ops=int(rng.integers(120, 400)))
+                full = np.zeros(nrows * (52 + 120), dtype=np.uint64)
+                full[:nrows * 52] = pols
+                chal, pub, x = glo.rand_fe(rng, 15), glo.rand_fe(rng, 4), glo.rand_fe(rng, nrows * 2)
+                want = full.copy()
+                glo.chelpers_stepbase(ops, args, want, cpols, 7, chal, pub, x, 2, np.arange(r0, r0 + nr))
+                prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=sections, n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3)
+                prog.build_native(cache_dir=td, chunk_cost=cc)
+                d_pols = ctx.to_device(full)
+                prog.run_base(d_pols, ctx.to_device(cpols), 7, chal, pub, ctx.to_device(x), 2, r0, nr)
+                outs = [want, ctx.to_host(d_pols)]       # no interpreter form for these
+                prog.close()
+            elif kind == 2:
                 ops, args = cp.synthetic_program52(rng, secs, 7, 6, length=int(rng.integers(20, 400)))
                 chal, evals = glo.rand_fe(rng, 21), glo.rand_fe(rng, 18)
                 xd, xdw = glo.rand_fe(rng, nrows * 3), glo.rand_fe(rng, nrows * 3)
