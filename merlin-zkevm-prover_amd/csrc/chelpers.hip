@@ -1,4 +1,6 @@
-// chelpers.hip -- the generated constraint evaluators ("chelpers") of Starks::genProof on the GPU.
+// chelpers.hip -- the generated constraint evaluators ("chelpers") of Starks::genProof on the GPU: the translator for
+// all five steps (step2prev / step3prev / step3 share one opcode numbering, see role_stepbase), the SIMT interpreter for the two
+// extended-domain steps; chelpers_native.hip compiles any of them to gfx950 kernels.
 //
 // Reference: src/starkpil/zkevm/chelpers/zkevm.chelpers.step42ns.parser.{hpp,cpp}.  The reference ships, per STARK step,
 // a PROGRAM (two generated tables: op42[NOPS_] opcodes, args42[NARGS_] operands) and an INTERPRETER
