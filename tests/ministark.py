@@ -11,6 +11,10 @@ the final polynomial).  A proof made on the GPU must verify; a tampered one must
 
 AIR (N rows, columns a, b; constant polynomials L1 = first-row selector, LLAST = last-row selector):
     (1 - LLAST) * (a' - b) = 0,   (1 - LLAST) * (b' - a - b) = 0,   L1 * (a - 1) = 0,   L1 * (b - 1) = 0        (x' = value at the next row)
+and a second stage like the reference's stage 2: after the first commitment a challenge gamma is drawn, an extension-valued column
+    z = (a + gamma) * (b + gamma)
+is computed ON THE DEVICE by a base-domain program (the step2prev / step3prev / step3 opcode numbering: results stored into polynomial
+memory), extended from device memory, committed, and bound by a fifth constraint  (a + gamma) * (b + gamma) - z = 0.
 """
 import numpy as np
 
@@ -54,7 +58,8 @@ def e3_pow(a, e):
 
 # ------------------------------------------------------------------ the AIR's programs in the reference's table formats
 def step42ns_program(n_ext, next_shift):
-    """q * Z_H = ((C1 vc + C2) vc + C3) vc + C4 with vc = challenge 0; sections: cm1_2ns (a, b) at offset 0."""
+    """q * Z_H = (((C1 vc + C2) vc + C3) vc + C4) vc + C5 with vc = challenge 0, gamma = challenge 1; sections: cm1_2ns (a, b) at
+    offset 0, cm2_2ns (z, extension-valued) at offset 2 * n_ext."""
     A_, B_, ST = 0, 1, 2                      # columns of cm1_2ns, its row stride
     L1, LLAST = 0, 1                          # constant polynomials
     ops, args = [], []
@@ -75,29 +80,44 @@ def step42ns_program(n_ext, next_shift):
     push(28, [4, B_, ST, 1])                              # t4 = b - 1
     push(49, [4, 4, L1])                                  # t4 = t4 * L1
     push(12, [0, 4, 0])                                   # acc = t4 + acc
+    push(16, [1, A_, ST, 1])                              # e1 = a + gamma            (challenge 1)
+    push(16, [2, B_, ST, 1])                              # e2 = b + gamma
+    push(71, [1, 1, 2])                                   # e1 = e1 * e2
+    push(44, [1, 1, 2 * n_ext, 3])                        # e1 = e1 - z               (z: cm2_2ns, three columns at offset 2 * n_ext)
+    push(70, [0, 0, 0])                                   # acc = vc * acc
+    push(17, [0, 1, 0])                                   # acc = e1 + acc
     push(69, [0])                                         # q = zhInv * acc
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
-EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1 = range(8)
+EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1, EV_Z = range(9)
 
 
 def step52ns_program(nrows):
     """f = ((H c5 + E_xi xDivXSubXi) c5 + E_wxi xDivXSubWXi), H = Horner_c5(a, b, q0, q1), E_* = Horner_c6(pol - eval); sections: cm1_2ns
-    (2 columns) at offset 0, cm4_2ns (two extension-valued chunks, 6 columns) at offset 2 * nrows; constants L1, LLAST."""
-    o4 = 2 * nrows
+    (2 columns) at offset 0, cm2_2ns (z, 3 columns) at offset 2 * nrows, cm4_2ns (two extension-valued chunks, 6 columns) at offset
+    5 * nrows; constants L1, LLAST."""
+    o2, o4 = 2 * nrows, 5 * nrows
     ops, args = [], []
 
     def push(o, ar):
         ops.append(o); args.extend(ar)
-    push(0, [0, 2]); push(16, [1, 2]); push(17, [o4, 6]); push(17, [o4 + 3, 6])      # H
+    push(0, [0, 2]); push(16, [1, 2]); push(17, [o2, 3]); push(17, [o4, 6]); push(17, [o4 + 3, 6])      # H
     push(3, [])                                                                       # tmp1 = H c5
     push(11, [0, 2, EV_A]); push(4, [])                                               # tmp = (a - a(xi)) c6
     push(18, [1, 2, EV_B]); push(19, [0, EV_L1]); push(19, [1, EV_LLAST])
-    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1])
+    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1]); push(20, [o2, 3, EV_Z])
     push(5, []); push(8, []); push(3, [])                                             # * xDivXSubXi; tmp = tmp1 + tmp; tmp1 = tmp c5
     push(11, [0, 2, EV_AW]); push(4, []); push(18, [1, 2, EV_BW])
     push(6, []); push(8, []); push(15, [])                                            # * xDivXSubWXi; tmp = tmp1 + tmp; f = tmp
+    return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
+
+
+def stage2_program(n):
+    """z = (a + gamma) * (b + gamma) into the three columns at offset 2 * n of the base-domain area [cm1_n (2 columns) | cm2_n (3)], in
+    the base-domain steps' numbering (gamma = challenge 1)."""
+    ops = [16, 16, 98]
+    args = [0, 0, 2, 1,   1, 1, 2, 1,   2 * n, 3, 0, 1]
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
@@ -139,21 +159,36 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     const_2ns, const_nodes = ctx.empty(NE * 2), ctx.empty((2 * NE - 1) * 4)
     ctx.lde(const_2ns, d_const_n, NE, N, 2)
     ctx.merkle_build(const_nodes, const_2ns, 2, NE)
-    area = ctx.empty(NE * (2 + 6))                       # cm1_2ns | cm4_2ns, one polynomial area
-    cm1, cm4 = area[:NE * 2], area[NE * 2:]
-    nodes1, nodes4 = ctx.empty((2 * NE - 1) * 4), ctx.empty((2 * NE - 1) * 4)
+    area = ctx.empty(NE * (2 + 3 + 6))                   # cm1_2ns | cm2_2ns | cm4_2ns, one polynomial area
+    cm1, cm2, cm4 = area[:NE * 2], area[NE * 2:NE * 5], area[NE * 5:]
+    nodes1, nodes2, nodes4 = ctx.empty((2 * NE - 1) * 4), ctx.empty((2 * NE - 1) * 4), ctx.empty((2 * NE - 1) * 4)
+    base = ctx.zeros(N * (2 + 3))                        # the base-domain area: cm1_n | cm2_n
+    base[:N * 2] = ctx.to_device(witness(N)).reshape(-1)
     tr = Transcript(ctx)
+    chal = np.zeros(7 * 3, dtype=np.uint64)
     # ---- step 1: commit the witness
-    ctx.lde(cm1, ctx.to_device(witness(N)), NE, N, 2)
+    ctx.lde(cm1, base[:N * 2], NE, N, 2)
     ctx.merkle_build(nodes1, cm1, 2, NE)
     root1 = ctx.to_host(nodes1[-4:])
     tr.put(root1)
+    chal[3:6] = tr.get_field()                           # gamma
+    # ---- step 2: the stage-2 column from a base-domain program (compiled kernels), extended from device memory, committed
+    opsb, argsb = stage2_program(N)
+    progb = mi_stark.ChelpersProgram(ctx, opsb, argsb, sections=[(0, 2, N)], n_const=2, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP2PREV)
+    progb.build_native(cache_dir=cache_dir)
+    x_n = ctx.empty(N)
+    ctx.geom_seq(x_n, N, 1, L.glo_w(nbits))
+    progb.run_base(base, d_const_n, 2, chal, np.zeros(1, dtype=np.uint64), x_n, 1, 0, N)
+    ctx.lde(cm2, base[N * 2:], NE, N, 3)
+    ctx.merkle_build(nodes2, cm2, 3, NE)
+    root2 = ctx.to_host(nodes2[-4:])
+    tr.put(root2)
     vc = tr.get_field()
     # ---- step 4: constraint polynomial q = C / Z_H on the extended domain, split, committed
     ops42, args42 = step42ns_program(NE, 2)
-    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 2, NE)], n_const=2, nrows_ext=NE)
+    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 2, NE), (2 * NE, 3, NE)], n_const=2, nrows_ext=NE)
     ops52, args52 = step52ns_program(NE)
-    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 2, NE), (2 * NE, 6, NE)], n_const=2, nrows_ext=NE, step=52)
+    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 2, NE), (2 * NE, 3, NE), (5 * NE, 6, NE)], n_const=2, nrows_ext=NE, step=52)
     if native:
         prog42.build_native(cache_dir=cache_dir)
         prog52.build_native(cache_dir=cache_dir)
@@ -161,7 +196,6 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     ctx.geom_seq(x_2ns, NE, SHIFT, L.glo_w(nbits_ext))
     zh = ctx.zhinv(nbits, nbits_ext)
     q_2ns, qq1, qq2 = ctx.empty(NE * 3), ctx.empty(NE * 3), ctx.empty(NE * 6)
-    chal = np.zeros(7 * 3, dtype=np.uint64)
     chal[0:3] = vc
     prog42.run(area, const_2ns, 2, chal, np.zeros(1, dtype=np.uint64), x_2ns, 1, zh, q_2ns, 0, NE)
     ctx.ntt(qq1, q_2ns, NE, 3, inverse=True)
@@ -181,8 +215,9 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     ctx.geom_seq3(lpev, N, wxis)
     ctx.ntt(lev, lev, N, 3, inverse=True)
     ctx.ntt(lpev, lpev, N, 3, inverse=True)
-    pols = [(cm1, 0, 1, 2), (cm1, 1, 1, 2), (cm1, 0, 1, 2), (cm1, 1, 1, 2), (const_2ns, 0, 1, 2), (const_2ns, 1, 1, 2), (cm4, 0, 3, 6), (cm4, 3, 3, 6)]
-    prime = [0, 0, 1, 1, 0, 0, 0, 0]
+    pols = [(cm1, 0, 1, 2), (cm1, 1, 1, 2), (cm1, 0, 1, 2), (cm1, 1, 1, 2), (const_2ns, 0, 1, 2), (const_2ns, 1, 1, 2), (cm4, 0, 3, 6), (cm4, 3, 3, 6),
+            (cm2, 0, 3, 3)]
+    prime = [0, 0, 1, 1, 0, 0, 0, 0, 0]
     d_evals = ctx.empty(len(pols) * 3)
     ctx.evmap(d_evals, pols, prime, lev, lpev, N, 1)
     evals = ctx.to_host(d_evals)
@@ -229,8 +264,9 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
         buf = ctx.empty(len(idx) * (width + 4 * (height - 1).bit_length()))
         ctx.merkle_group_proofs(buf, nodes, src, height, width, idx)
         return ctx.to_host(buf).reshape(len(idx), -1)
-    proof = {"nbits": nbits, "root1": root1, "root4": root4, "evals": evals, "fri_roots": fri_roots, "final_pol": final_pol,
-             "s0": {"cm1": open_tree(nodes1, cm1, NE, 2, ys), "cm4": open_tree(nodes4, cm4, NE, 6, ys), "const": open_tree(const_nodes, const_2ns, NE, 2, ys)},
+    proof = {"nbits": nbits, "root1": root1, "root2": root2, "root4": root4, "evals": evals, "fri_roots": fri_roots, "final_pol": final_pol,
+             "s0": {"cm1": open_tree(nodes1, cm1, NE, 2, ys), "cm2": open_tree(nodes2, cm2, NE, 3, ys), "cm4": open_tree(nodes4, cm4, NE, 6, ys),
+                    "const": open_tree(const_nodes, const_2ns, NE, 2, ys)},
              "fri": {}, "const_root": ctx.to_host(const_nodes[-4:])}
     y = ys.copy()
     for si in range(1, len(steps)):
@@ -239,8 +275,10 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
         proof["fri"][si] = open_tree(fri_trees[si], fri_srcs[si], 1 << steps[si], gsz, y)
     if tamper == "opening":
         proof["s0"]["cm1"][0][0] ^= np.uint64(1)
-    prog42.close()
-    prog52.close()
+    if tamper == "stage2":
+        proof["s0"]["cm2"][1][2] ^= np.uint64(1)
+    for p in (progb, prog42, prog52):
+        p.close()
     return proof
 
 
@@ -257,6 +295,8 @@ def verify(proof, const_root, n_queries=12):
     # ---- transcript replay
     tr = glo.Transcript()
     tr.put(proof["root1"])
+    gamma = e3(tr.get_field())
+    tr.put(proof["root2"])
     vc = e3(tr.get_field())
     tr.put(proof["root4"])
     xi = e3(tr.get_field())
@@ -273,14 +313,15 @@ def verify(proof, const_root, n_queries=12):
             tr.put(proof["final_pol"])
     ys = tr.get_permutations(n_queries, steps[0])
     E = lambda k: e3(ev[3 * k:3 * k + 3])
-    # ---- constraint identity at xi: ((C1 vc + C2) vc + C3) vc + C4 == Q(xi) * (xi^N - 1)
+    # ---- constraint identity at xi: (((C1 vc + C2) vc + C3) vc + C4) vc + C5 == Q(xi) * (xi^N - 1)
     one = [1, 0, 0]
     not_last = e3_sub(one, E(EV_LLAST))
     C1 = e3_mul(not_last, e3_sub(E(EV_AW), E(EV_B)))
     C2 = e3_mul(not_last, e3_sub(e3_sub(E(EV_BW), E(EV_A)), E(EV_B)))
     C3 = e3_mul(E(EV_L1), e3_sub(E(EV_A), one))
     C4 = e3_mul(E(EV_L1), e3_sub(E(EV_B), one))
-    C = e3_add(e3_mul(e3_add(e3_mul(e3_add(e3_mul(C1, vc), C2), vc), C3), vc), C4)
+    C5 = e3_sub(e3_mul(e3_add(E(EV_A), gamma), e3_add(E(EV_B), gamma)), E(EV_Z))
+    C = e3_add(e3_mul(e3_add(e3_mul(e3_add(e3_mul(e3_add(e3_mul(C1, vc), C2), vc), C3), vc), C4), vc), C5)
     xiN = e3_pow(xi, N)
     Q = e3_add(E(EV_Q0), e3_mul(xiN, E(EV_Q1)))
     if C != e3_mul(Q, e3_sub(xiN, one)):
@@ -291,11 +332,11 @@ def verify(proof, const_root, n_queries=12):
     chal[15:18], chal[18:21] = c5, c6
     wN = L.glo_w(nbits)
     wxi = [L.glo_mul(v, wN) for v in xi]
-    h1, h4, hc = proof["s0"]["cm1"], proof["s0"]["cm4"], proof["s0"]["const"]
+    h1, h2, h4, hc = proof["s0"]["cm1"], proof["s0"]["cm2"], proof["s0"]["cm4"], proof["s0"]["const"]
     y = [int(v) for v in ys]
     for q in range(n_queries):
         idx = y[q]
-        for (pr, w, root, name) in ((h1, 2, proof["root1"], "cm1"), (h4, 6, proof["root4"], "cm4"), (hc, 2, const_root, "const")):
+        for (pr, w, root, name) in ((h1, 2, proof["root1"], "cm1"), (h2, 3, proof["root2"], "cm2"), (h4, 6, proof["root4"], "cm4"), (hc, 2, const_root, "const")):
             if not glo.merkle_verify(root, pr[q][:w], pr[q][w:], idx):
                 return False, "Merkle opening of %s fails at query %d" % (name, q)
         # the FRI polynomial at x = shift * w^idx from the opened rows (the same program, over one row)
@@ -303,7 +344,7 @@ def verify(proof, const_root, n_queries=12):
         def xdiv(z):
             den = np.array([(x - z[0]) % P, (-z[1]) % P, (-z[2]) % P], dtype=np.uint64)
             return np.array(e3_mul([int(v) for v in glo.e3_inv(den)], [x, 0, 0]), dtype=np.uint64)
-        row = np.concatenate([h1[q][:2], h4[q][:6]]).astype(np.uint64)
+        row = np.concatenate([h1[q][:2], h2[q][:3], h4[q][:6]]).astype(np.uint64)
         f = np.zeros(3, dtype=np.uint64)
         glo.chelpers_step52ns(ops52, args52, row, np.ascontiguousarray(hc[q][:2]), 2, chal, ev, xdiv(xi), xdiv(wxi), f, 0, 1)
         # level by level: the value must sit in the next group, the group must fold to the value after it
