@@ -156,6 +156,20 @@ int mi_evmap_dev(mi_ctx *ctx, uint64_t *evals /* device, n_evals*3 */, uint64_t 
 /* element-wise inverse of n cubic-extension elements (Polinomial::batchInverse[Parallel],
  * polinomial.hpp:612-720); res == src allowed; inverse of 0 is 0 */
 int mi_batch_inverse3_dev(mi_ctx *ctx, uint64_t *res, const uint64_t *src, uint64_t n);
+/* plookup h1 / h2 of one lookup (Polinomial::calculateH1H2_opt1 / _opt3, polinomial.hpp:349-584; plain form :303-347; called at
+ * starks.cpp:92-128 between step2prev and the stage-2 commitment).  Device pointers to strided views as Polinomial: element i at
+ * p[i * stride .. + dim), dim 1 or 3, n rows in each of f, t, h1, h2.  Every row of t counts once plus once per row of f with the
+ * same value (credited to the last such row of t); walking t in order, each row repeated by its count, yields h1[0], h2[0],
+ * h1[1], ...  A row of f whose value is not in t fails the call like the reference does (MI_ERR_INVALID, mi_last_error():
+ * "calculateH1H2: number not included: w=<row>"); h1 / h2 are then left untouched.  The transposes the reference wraps around
+ * it (transposeH1H2Columns / Rows, starks.cpp:405-455) are not needed: the views are read in place. */
+int mi_calculate_h1h2_dev(mi_ctx *ctx, uint64_t *h1, uint64_t h1_stride, uint64_t *h2, uint64_t h2_stride, const uint64_t *f,
+                          uint64_t f_stride, const uint64_t *t, uint64_t t_stride, unsigned dim, uint64_t n);
+/* grand product (Polinomial::calculateZ, polinomial.hpp:586-607; starks.cpp:174-187 between step3prev and step3): z[0] = 1,
+ * z[i] = z[i-1] * num[i-1] / den[i-1] in the cubic extension; strided device views of dim 3.  *closes (HOST, optional) receives 1
+ * when z[n-1] * num[n-1] / den[n-1] == 1 -- the reference's zkassert -- else 0. */
+int mi_calculate_z_dev(mi_ctx *ctx, uint64_t *z, uint64_t z_stride, const uint64_t *num, uint64_t num_stride, const uint64_t *den,
+                       uint64_t den_stride, uint64_t n, int *closes);
 /* out[i] = start * ratio^i  (x_n, x_2ns: starks.hpp:149-160,176-183) */
 int mi_geom_seq_dev(mi_ctx *ctx, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio);
 /* out[k] = ratio^k in the cubic extension (LEv / LpEv: starks.cpp:311-323) */

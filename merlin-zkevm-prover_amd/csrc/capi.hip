@@ -518,6 +518,22 @@ extern "C" int mi_batch_inverse3_dev(mi_ctx *c, uint64_t *res, const uint64_t *s
     return launch_batch_inverse3(c, (u64 *)res, (const u64 *)src, n);
 }
 
+extern "C" int mi_calculate_h1h2_dev(mi_ctx *c, uint64_t *h1, uint64_t h1_stride, uint64_t *h2, uint64_t h2_stride, const uint64_t *f,
+                                     uint64_t f_stride, const uint64_t *t, uint64_t t_stride, unsigned dim, uint64_t n)
+{
+    CTX_OK(c);
+    MI_REQUIRE((h1 && h2 && f && t) || n == 0, "null buffer");
+    return launch_calculate_h1h2(c, (u64 *)h1, h1_stride, (u64 *)h2, h2_stride, (const u64 *)f, f_stride, (const u64 *)t, t_stride, dim, n);
+}
+
+extern "C" int mi_calculate_z_dev(mi_ctx *c, uint64_t *z, uint64_t z_stride, const uint64_t *num, uint64_t num_stride, const uint64_t *den,
+                                  uint64_t den_stride, uint64_t n, int *closes)
+{
+    CTX_OK(c);
+    MI_REQUIRE((z && num && den) || n == 0, "null buffer");
+    return launch_calculate_z(c, (u64 *)z, z_stride, (const u64 *)num, num_stride, (const u64 *)den, den_stride, n, closes);
+}
+
 extern "C" int mi_geom_seq_dev(mi_ctx *c, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio)
 {
     CTX_OK(c);

@@ -140,6 +140,10 @@ int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n
 int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,
                  const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev);
 int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n);
+int launch_calculate_h1h2(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uint64_t h2_stride, const u64 *f, uint64_t f_stride, const u64 *t,
+                          uint64_t t_stride, unsigned dim, uint64_t n);
+int launch_calculate_z(mi_ctx *ctx, u64 *z, uint64_t z_stride, const u64 *num, uint64_t num_stride, const u64 *den, uint64_t den_stride,
+                       uint64_t n, int *closes);
 int launch_geom_seq(mi_ctx *ctx, u64 *out, uint64_t n, u64 start, u64 ratio);
 int launch_geom_seq3(mi_ctx *ctx, u64 *out, uint64_t n, const u64 ratio[3]);
 int launch_x_div_x_sub(mi_ctx *ctx, u64 *out, const u64 *x, uint64_t n, const u64 xi[3]);

@@ -5,6 +5,7 @@
 #define POLINOMIAL
 #include <cassert>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "goldilocks_base_field.hpp"
@@ -109,5 +110,66 @@ public:
         mi_dev_free(c, d);
     }
     static void batchInverseParallel(Polinomial &res, Polinomial &src) { batchInverse(res, src); }
+
+    // polinomial.hpp:230-584 -- the plookup columns.  The reference has four bodies (map-based calculateH1H2 / calculateH1H2_, the
+    // hash-table _opt1 for dim 1 and _opt3 for dim 3) that produce the same h1 / h2; all of them run on the GPU here.  Host views in
+    // and out (packed copies cross PCIe: with the polynomials already in HBM use mi_calculate_h1h2_dev / StarksDevice instead);
+    // buffer / size_keys / size_values are the reference's hash-table scratch and are not used.  A value of f that t does not hold
+    // ends the process with "number not included: w=<row>", like the reference.
+    static void calculateH1H2(Polinomial &h1, Polinomial &h2, Polinomial &fPol, Polinomial &tPol)
+    {
+        const uint64_t n = tPol.degree(), dim = tPol.dim();
+        assert(fPol.degree() == n && h1.degree() >= n && h2.degree() >= n && fPol.dim() == dim && h1.dim() == dim && h2.dim() == dim);
+        if (!n) return;
+        mi_ctx *c = mi::ctx();
+        std::vector<uint64_t> host(4 * n * dim); // f | t | h1 | h2, packed
+        for (uint64_t i = 0; i < n; i++) {
+            std::memcpy(&host[i * dim], fPol[i], dim * 8);
+            std::memcpy(&host[(n + i) * dim], tPol[i], dim * 8);
+        }
+        uint64_t *d = (uint64_t *)mi_dev_alloc(c, host.size() * 8);
+        if (!d) mi::fail("Polinomial::calculateH1H2 (alloc)");
+        mi::check(mi_copy_h2d(c, d, host.data(), 2 * n * dim * 8), "Polinomial::calculateH1H2 (h2d)");
+        mi::check(mi_calculate_h1h2_dev(c, d + 2 * n * dim, dim, d + 3 * n * dim, dim, d, dim, d + n * dim, dim, (unsigned)dim, n),
+                  "Polinomial::calculateH1H2");
+        mi::check(mi_copy_d2h(c, &host[2 * n * dim], d + 2 * n * dim, 2 * n * dim * 8), "Polinomial::calculateH1H2 (d2h)");
+        mi_dev_free(c, d);
+        for (uint64_t i = 0; i < n; i++) {
+            std::memcpy(h1[i], &host[(2 * n + i) * dim], dim * 8);
+            std::memcpy(h2[i], &host[(3 * n + i) * dim], dim * 8);
+        }
+    }
+    static void calculateH1H2_(Polinomial &h1, Polinomial &h2, Polinomial &fPol, Polinomial &tPol, uint64_t) { calculateH1H2(h1, h2, fPol, tPol); }
+    static void calculateH1H2_opt1(Polinomial &h1, Polinomial &h2, Polinomial &fPol, Polinomial &tPol, uint64_t, uint64_t *, uint64_t, uint64_t)
+    {
+        calculateH1H2(h1, h2, fPol, tPol);
+    }
+    static void calculateH1H2_opt3(Polinomial &h1, Polinomial &h2, Polinomial &fPol, Polinomial &tPol, uint64_t, uint64_t *, uint64_t, uint64_t)
+    {
+        calculateH1H2(h1, h2, fPol, tPol);
+    }
+    // polinomial.hpp:586-607 -- the grand product z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1], on the GPU (host views, packed copies)
+    static void calculateZ(Polinomial &z, Polinomial &num, Polinomial &den)
+    {
+        const uint64_t n = num.degree();
+        assert(num.dim() == 3 && den.dim() == 3 && z.dim() == 3 && den.degree() == n && z.degree() >= n);
+        if (!n) return;
+        mi_ctx *c = mi::ctx();
+        std::vector<uint64_t> host(3 * n * 3); // num | den | z
+        for (uint64_t i = 0; i < n; i++) {
+            std::memcpy(&host[i * 3], num[i], 24);
+            std::memcpy(&host[(n + i) * 3], den[i], 24);
+        }
+        uint64_t *d = (uint64_t *)mi_dev_alloc(c, host.size() * 8);
+        if (!d) mi::fail("Polinomial::calculateZ (alloc)");
+        mi::check(mi_copy_h2d(c, d, host.data(), 2 * n * 3 * 8), "Polinomial::calculateZ (h2d)");
+        int closes = 0;
+        mi::check(mi_calculate_z_dev(c, d + 6 * n, 3, d, 3, d + 3 * n, 3, n, &closes), "Polinomial::calculateZ");
+        mi::check(mi_copy_d2h(c, &host[6 * n], d + 6 * n, n * 3 * 8), "Polinomial::calculateZ (d2h)");
+        mi_dev_free(c, d);
+        for (uint64_t i = 0; i < n; i++) std::memcpy(z[i], &host[(6 * n) + i * 3], 24);
+        assert(closes); // zkassert(Goldilocks3::isOne(checkVal)) at :606
+        (void)closes;
+    }
 };
 #endif

@@ -13,12 +13,21 @@
 //   starks.cpp:261-292  INTT(qq1, q_2ns) / split / NTT(cm4_2ns, qq2) / treesGL[3]->merkelize()    -> commitQ(root)
 //   friProve.cpp:219-250 treesGL[t]->getGroupProof(..)                                            -> getGroupProofs(t, ..)
 //
+// and, with enableBaseDomain(), the base-domain half of stages 2 and 3 as well (cm1_n .. cm3_n, tmpExp_n resident: nothing but
+// challenges and roots crosses PCIe between the upload of the witness and the openings):
+//
+//   starks.cpp:66-90, 150-170, 190-210  steps->step2prev / step3prev / step3_parser_first_avx      -> setBaseProgram + stepBase
+//   starks.cpp:92-128   transposeH1H2Columns / calculateH1H2_opt1,3 / transposeH1H2Rows            -> calculateH1H2
+//   starks.cpp:174-187  transposeZColumns / calculateZ / transposeZRows                            -> calculateZ
+//   starks.cpp:133-140, 214-221  extendPol(p_cm2_2ns, p_cm2_n ..) + merkelize                       -> commitStageResident(1 / 2, root)
+//
 // One polynomial area in HBM holds the sections in the reference's order and row-major layout (element (row, col) of
 // section s at area[offset_s + row * cols_s + col], stark_info.cpp:473-482), so that the constraint program's offsets --
 // which are relative to the start of cm1_2ns here -- address it directly.  The host trace of a stage is streamed up in
 // column chunks behind the kernels (mi_lde_merkle_host).  Errors follow the reference: log + exit.
 #ifndef STARKS_DEVICE_HPP
 #define STARKS_DEVICE_HPP
+#include <utility>
 #include <vector>
 #include "goldilocks_base_field.hpp"
 #include "goldilocks_cubic_extension.hpp"
@@ -32,6 +41,10 @@ class StarksDevice
     uint64_t *d_area = nullptr;
     std::vector<uint64_t *> d_nodes;
     mi_chelpers_prog *prog42 = nullptr, *prog52 = nullptr;
+    std::vector<std::pair<int, mi_chelpers_prog *>> progBase; // (step, program): step2prev, step3prev, step3
+    std::vector<uint64_t> colsN, offsetN;                     // base-domain sections cm1_n, cm2_n, cm3_n, tmpExp_n
+    uint64_t *d_baseArea = nullptr, *d_constN = nullptr, *d_xn = nullptr;
+    uint64_t nConstN = 0;
     uint64_t nConst = 0;
     uint64_t *d_const = nullptr, *d_x2ns = nullptr, *d_xdiv = nullptr, *d_xdivw = nullptr, *d_f2ns = nullptr;
 
@@ -63,6 +76,8 @@ public:
         mi_ctx *c = mi::ctx();
         if (prog42) mi_chelpers_free(c, prog42);
         if (prog52) mi_chelpers_free(c, prog52);
+        for (auto &pb : progBase) mi_chelpers_free(c, pb.second);
+        mi_dev_free(c, d_baseArea); mi_dev_free(c, d_constN); mi_dev_free(c, d_xn);
         mi_dev_free(c, d_xdiv); mi_dev_free(c, d_xdivw); mi_dev_free(c, d_f2ns);
         for (uint64_t *p : d_nodes) mi_dev_free(c, p);
         mi_dev_free(c, d_area); mi_dev_free(c, d_const); mi_dev_free(c, d_x2ns);
@@ -158,6 +173,79 @@ public:
         mi::check(mi_merkle_build_dev(c, d_nodes[3], section(3), qDim * qDeg, qDim * qDeg, NExtended), "StarksDevice::commitQ (merkelize)");
         mi_dev_free(c, qq1); mi_dev_free(c, qq2);
         getRoot(3, root);
+    }
+    // ---- stages 2 and 3 with the base domain in HBM.  Sections 0..2 = cm1_n .. cm3_n (the columns given to the constructor), 3 =
+    // tmpExp_n; one area in that order, row-major (stark_info.cpp:473-482), offsets relative to cm1_n -- the offsets the base-domain
+    // programs' arguments use.  pConstPolsN: the constant polynomials over the N base-domain rows (host, N x nConstN).
+    void enableBaseDomain(uint64_t tmpExpCols, const Goldilocks::Element *pConstPolsN, uint64_t _nConstN)
+    {
+        mi_ctx *c = mi::ctx();
+        colsN = {cols[0], cols[1], cols[2], tmpExpCols};
+        uint64_t o = 0;
+        offsetN.clear();
+        for (uint64_t w : colsN) { offsetN.push_back(o); o += N * w; }
+        d_baseArea = alloc(o, "StarksDevice (base-domain polynomial area)");
+        nConstN = _nConstN;
+        if (nConstN) {
+            d_constN = alloc(N * nConstN, "StarksDevice (constant polynomials, base domain)");
+            mi::check(mi_copy_h2d(c, d_constN, pConstPolsN, N * nConstN * 8), "StarksDevice (constant polynomials, base domain, h2d)");
+        }
+        d_xn = alloc(N, "StarksDevice (x_n)");
+        mi::check(mi_geom_seq_dev(c, d_xn, N, 1, Goldilocks::toU64(Goldilocks::w(nBits))), "StarksDevice (x_n)"); // starks.hpp:149-160
+    }
+    uint64_t *baseSection(unsigned s) { return d_baseArea + offsetN[s]; }
+    uint64_t baseOffset(unsigned s) const { return offsetN[s]; }
+    // the witness (or any base-domain section a host step produced) into HBM
+    void loadStage(unsigned s, const Goldilocks::Element *p_cm_n)
+    {
+        mi::check(mi_copy_h2d(mi::ctx(), baseSection(s), p_cm_n, N * colsN[s] * 8), "StarksDevice::loadStage");
+    }
+    // starks.cpp:52-59 / 133-140 / 214-221 with the base-domain section already in HBM
+    void commitStageResident(unsigned s, Goldilocks::Element *root)
+    {
+        mi_ctx *c = mi::ctx();
+        mi::check(mi_lde_dev(c, section(s), cols[s], baseSection(s), colsN[s], NExtended, N, cols[s]), "StarksDevice::commitStageResident (extendPol)");
+        mi::check(mi_merkle_build_dev(c, d_nodes[s], section(s), cols[s], cols[s], NExtended), "StarksDevice::commitStageResident (merkelize)");
+        getRoot(s, root);
+    }
+    // step = MI_CHELPERS_STEP2PREV / STEP3PREV / STEP3 with the tables of zkevm.chelpers.step{2prev,3prev,3}.parser.hpp; these
+    // programs store into the polynomial area and exist as compiled kernels only, so the build (hiprtc, cached in cacheDir) is here
+    void setBaseProgram(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, const char *cacheDir = nullptr)
+    {
+        std::vector<mi_chelpers_section> secs;
+        for (unsigned s = 0; s < 4; s++) secs.push_back({offsetN[s], colsN[s], N});
+        mi_chelpers_prog *p = nullptr;
+        mi::check(mi_chelpers_compile(mi::ctx(), &p, step, ops, nops, args, nargs, secs.data(), secs.size(), nConstN, N), "StarksDevice::setBaseProgram");
+        mi::check(mi_chelpers_build_native(p, cacheDir, 0), "StarksDevice::setBaseProgram (build)");
+        progBase.push_back({step, p});
+    }
+    void stepBase(int step, const Goldilocks::Element *challenges, uint64_t nChallenges, const Goldilocks::Element *publicInputs, uint64_t nPublics)
+    {
+        for (auto &pb : progBase)
+            if (pb.first == step) {
+                mi_chelpers_params p = {d_baseArea, d_constN, nConstN, (const uint64_t *)challenges, nChallenges, (const uint64_t *)publicInputs,
+                                        nPublics, d_xn, 1, nullptr, 0, nullptr};
+                mi::check(mi_chelpers_run_dev(mi::ctx(), pb.second, &p, 0, N), "StarksDevice::stepBase");
+                return;
+            }
+        mi::fail("StarksDevice::stepBase: no program set for this step");
+    }
+    // One plookup (starks.cpp:106-126): offsets of the four polynomials in the base-domain area and their row strides, as
+    // starkInfo.getPolinomial gives them (h1, h2 = cm_n[numCommited + 2 i], [.. + 1]; f, t = exp2pol of puCtx[i].fExpId / tExpId).
+    // A value of f that t does not hold ends the process like the reference (log + exit).
+    void calculateH1H2(uint64_t h1Off, uint64_t h1Stride, uint64_t h2Off, uint64_t h2Stride, uint64_t fOff, uint64_t fStride, uint64_t tOff,
+                       uint64_t tStride, uint64_t dim)
+    {
+        mi::check(mi_calculate_h1h2_dev(mi::ctx(), d_baseArea + h1Off, h1Stride, d_baseArea + h2Off, h2Stride, d_baseArea + fOff, fStride,
+                                        d_baseArea + tOff, tStride, (unsigned)dim, N), "StarksDevice::calculateH1H2");
+    }
+    // One grand product (starks.cpp:179-185); returns whether it closes (the reference zkasserts that)
+    bool calculateZ(uint64_t zOff, uint64_t zStride, uint64_t numOff, uint64_t numStride, uint64_t denOff, uint64_t denStride)
+    {
+        int closes = 0;
+        mi::check(mi_calculate_z_dev(mi::ctx(), d_baseArea + zOff, zStride, d_baseArea + numOff, numStride, d_baseArea + denOff, denStride, N,
+                                     &closes), "StarksDevice::calculateZ");
+        return closes != 0;
     }
     // friProve.cpp:219-250: proofs[q] = row idx[q] of tree t (cols[t] values) followed by nBitsExt x 4 siblings
     void getGroupProofs(unsigned t, Goldilocks::Element *proofs, const uint64_t *idx, uint64_t nq)

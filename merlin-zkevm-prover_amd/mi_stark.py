@@ -50,7 +50,7 @@ EXPORTS = [
     "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
     "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
     "mi_merkle_group_proofs_dev",
-    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev",
+    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
@@ -255,6 +255,19 @@ class Context:
 
     def batch_inverse3(self, res, src, n):
         _check(lib().mi_batch_inverse3_dev(self.h, _dp(res), _dp(src), u64(n)))
+
+    def calculate_h1h2(self, h1, h1_stride, h2, h2_stride, f, f_stride, t, t_stride, dim, n):
+        """Polinomial::calculateH1H2 (polinomial.hpp:303-584) on strided device views (tensors whose first element is row 0 of the
+        polynomial); raises MiStarkError ("number not included: w=<row>") when a row of f is not in t."""
+        _check(lib().mi_calculate_h1h2_dev(self.h, _dp(h1), u64(h1_stride), _dp(h2), u64(h2_stride), _dp(f), u64(f_stride), _dp(t),
+                                           u64(t_stride), ctypes.c_uint(dim), u64(n)))
+
+    def calculate_z(self, z, z_stride, num, num_stride, den, den_stride, n):
+        """Polinomial::calculateZ (polinomial.hpp:586-607) on strided device views; returns whether the product closes (== 1)."""
+        closes = ctypes.c_int(0)
+        _check(lib().mi_calculate_z_dev(self.h, _dp(z), u64(z_stride), _dp(num), u64(num_stride), _dp(den), u64(den_stride), u64(n),
+                                        ctypes.byref(closes)))
+        return bool(closes.value)
 
     def geom_seq(self, out, n, start, ratio):
         _check(lib().mi_geom_seq_dev(self.h, _dp(out), u64(n), u64(start), u64(ratio)))

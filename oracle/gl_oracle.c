@@ -549,6 +549,69 @@ void glo_batch_inverse3(uint64_t *res, const uint64_t *src, uint64_t n)
     }
 }
 
+/* ---- plookup h1 / h2 (polinomial.hpp:303-347): the reference's std::map from the value of a row of t to its (last) index is a
+ * sorted array here */
+typedef struct { uint64_t k[3]; uint64_t idx; } h1h2_key;
+static int h1h2_cmp(const void *a, const void *b)
+{
+    const h1h2_key *x = a, *y = b;
+    for (int j = 0; j < 3; j++)
+        if (x->k[j] != y->k[j]) return x->k[j] < y->k[j] ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+int64_t glo_calculate_h1h2(uint64_t *h1, uint64_t h1_stride, uint64_t *h2, uint64_t h2_stride, const uint64_t *f, uint64_t f_stride,
+                           const uint64_t *t, uint64_t t_stride, unsigned dim, uint64_t n)
+{
+    if (!n) return 0;
+    h1h2_key *keys = malloc(n * sizeof *keys);
+    uint64_t *counter = malloc(n * sizeof *counter);
+    for (uint64_t i = 0; i < n; i++) {
+        for (unsigned j = 0; j < 3; j++) keys[i].k[j] = j < dim ? t[i * t_stride + j] : 0;
+        keys[i].idx = i;
+        counter[i] = 1; /* :309 vector<int> counter(tPol.degree(), 1) */
+    }
+    qsort(keys, n, sizeof *keys, h1h2_cmp);
+    int64_t bad = 0;
+    for (uint64_t i = 0; i < n && !bad; i++) {
+        h1h2_key q = {{0, 0, 0}, UINT64_MAX};
+        for (unsigned j = 0; j < dim; j++) q.k[j] = f[i * f_stride + j];
+        uint64_t lo = 0, hi = n; /* the last entry that sorts below (value, infinity): idx_t[key] = i + 1 keeps the last row (:314) */
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) / 2;
+            if (h1h2_cmp(&keys[mid], &q) < 0) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0 || memcmp(keys[lo - 1].k, q.k, sizeof q.k)) { bad = (int64_t)i + 1; break; } /* :321-325 */
+        counter[keys[lo - 1].idx]++;
+    }
+    if (!bad) {
+        uint64_t id = 0; /* :330-346 */
+        for (uint64_t i = 0; i < n; i++) {
+            if (counter[id] == 0) ++id;
+            counter[id] -= 1;
+            memcpy(h1 + i * h1_stride, t + id * t_stride, dim * 8);
+            if (counter[id] == 0) ++id;
+            counter[id] -= 1;
+            memcpy(h2 + i * h2_stride, t + id * t_stride, dim * 8);
+        }
+    }
+    free(keys); free(counter);
+    return bad;
+}
+
+int glo_calculate_z(uint64_t *z, uint64_t z_stride, const uint64_t *num, uint64_t num_stride, const uint64_t *den, uint64_t den_stride,
+                    uint64_t n)
+{
+    if (!n) return 1;
+    uint64_t cur[3] = {1, 0, 0}, di[3], tmp[3]; /* polinomial.hpp:592-593 */
+    for (uint64_t i = 0; i < n; i++) {
+        memcpy(z + i * z_stride, cur, sizeof cur);
+        glo3_inv(di, den + i * den_stride);          /* :595 batchInverse(denI, den): the same values one at a time */
+        glo3_mul(tmp, num + i * num_stride, di);     /* :599 */
+        glo3_mul(cur, cur, tmp);                     /* :600 */
+    }
+    return cur[0] == 1 && cur[1] == 0 && cur[2] == 0; /* :603-606 */
+}
+
 void glo_geom_seq(uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio)
 {
     uint64_t x = glo_canon(start); /* starks.hpp:149-160 */

@@ -122,6 +122,19 @@ int glo_chelpers_stepbase(const uint64_t *ops, uint64_t nops, const uint64_t *ar
                           const uint64_t *const_pols, uint64_t numpols, const uint64_t *challenges, const uint64_t *publics,
                           const uint64_t *x, uint64_t x_stride, const uint64_t *rows, uint64_t nrows);
 
+/* ---- between the base-domain steps (starks.cpp:92-128, 174-187).  Strided views as the reference's Polinomial: element i of a
+ *      polynomial at p[i * stride .. + dim).
+ * plookup (polinomial.hpp:303-347 calculateH1H2_; _opt1 / _opt3 at :349-584 compute the same thing with a hash table): every row
+ * of t counts once plus once per row of f equal to it (rows of f go to the LAST row of t holding that value); walking t in order
+ * and repeating each row by its count gives 2n values, alternately h1[i], h2[i].  Returns 0, or 1 + the first row of f whose
+ * value is not in t (the reference logs "Number not included" and exits). */
+int64_t glo_calculate_h1h2(uint64_t *h1, uint64_t h1_stride, uint64_t *h2, uint64_t h2_stride, const uint64_t *f, uint64_t f_stride,
+                           const uint64_t *t, uint64_t t_stride, unsigned dim, uint64_t n);
+/* grand product (polinomial.hpp:586-607 calculateZ): z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1] in F_p^3; returns 1 when the
+ * product closes (z[n-1] * num[n-1] / den[n-1] == 1: the reference's zkassert), else 0 */
+int glo_calculate_z(uint64_t *z, uint64_t z_stride, const uint64_t *num, uint64_t num_stride, const uint64_t *den, uint64_t den_stride,
+                    uint64_t n);
+
 void glo_set_num_threads(int n); /* OpenMP threads used by the parallel loops (0 = leave as is) */
 int glo_num_threads(void);
 

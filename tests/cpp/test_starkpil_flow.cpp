@@ -181,6 +181,111 @@ int main()
         EXPECT(same(gf.data(), wf.data(), gf.size()), "StarksDevice::step52ns after buildNative (compiled kernels) == oracle interpreter");
     }
 
+    // ---- stages 2 and 3 with the base domain resident (starks.cpp:66-221): witness up once; step2prev-numbered program -> compressed
+    // lookup columns in tmpExp_n; plookup h1 / h2 into cm2_n; commit; step3prev program -> num / den; grand product z into cm3_n;
+    // step3 program; commit.  The oracle does the same on a host copy of the area.
+    {
+        const uint64_t c1 = 4, c2 = 8, c3 = 3, cT = 15, nConstN = 2;
+        StarksDevice sd(nBits, nBitsExt, {c1, c2, c3});
+        std::vector<Goldilocks::Element> constN(N * nConstN), w1(N * c1), chal(4 * 3), pub(1);
+        for (uint64_t i = 0; i < constN.size(); i++) constN[i] = Goldilocks::fromU64(splitmix(31, i));
+        for (uint64_t i = 0; i < chal.size(); i++) chal[i] = Goldilocks::fromU64(splitmix(32, i));
+        pub[0] = Goldilocks::fromU64(9);
+        for (uint64_t i = 0; i < N; i++) { // column 0: a table with repeated rows; 1: a permutation of it; 2: lookups with repetition; 3: noise
+            w1[i * c1] = Goldilocks::fromU64(splitmix(33, i >> 2));
+            w1[i * c1 + 3] = Goldilocks::fromU64(splitmix(34, i));
+        }
+        for (uint64_t i = 0; i < N; i++) {
+            w1[i * c1 + 1] = w1[((i * 5 + 3) & (N - 1)) * c1];
+            w1[i * c1 + 2] = w1[((i * i + 7) & (N - 1)) * c1];
+        }
+        sd.enableBaseDomain(cT, constN.data(), nConstN);
+        sd.loadStage(0, w1.data());
+        const uint64_t o1 = sd.baseOffset(0), o2 = sd.baseOffset(1), o3 = sd.baseOffset(2), oT = sd.baseOffset(3);
+        // step2prev: f' = cm1[1] * u + defVal -> tmpExp[0..2];  t' = cm1[0] * u + defVal -> tmpExp[3..5]      (challenges 0, 1)
+        const uint64_t ops2[] = {62, 90, 62, 90};
+        const uint64_t args2[] = {0, o1 + 1, c1, 0,   oT + 0, cT, 0, 1,   1, o1 + 0, c1, 0,   oT + 3, cT, 1, 1};
+        // step3prev: num = (f' + gamma) + beta -> tmpExp[6..8];  den = (t' + gamma) + beta -> tmpExp[9..11]   (challenges 2, 3)
+        const uint64_t ops3p[] = {20, 90, 20, 90};
+        const uint64_t args3p[] = {0, oT + 0, cT, 2,   oT + 6, cT, 0, 3,   1, oT + 3, cT, 2,   oT + 9, cT, 1, 3};
+        // step3: (z * z) * (z * z) -> tmpExp[12..14]
+        const uint64_t ops3[] = {72, 98};
+        const uint64_t args3[] = {0, o3, c3, o3, c3,   oT + 12, cT, 0, 0};
+        sd.setBaseProgram(MI_CHELPERS_STEP2PREV, ops2, sizeof(ops2) / 8, args2, sizeof(args2) / 8);
+        sd.setBaseProgram(MI_CHELPERS_STEP3PREV, ops3p, sizeof(ops3p) / 8, args3p, sizeof(args3p) / 8);
+        sd.setBaseProgram(MI_CHELPERS_STEP3, ops3, sizeof(ops3) / 8, args3, sizeof(args3) / 8);
+        Goldilocks::Element r1[HASH_SIZE], r2[HASH_SIZE], r3[HASH_SIZE];
+        sd.commitStageResident(0, r1);
+        sd.stepBase(MI_CHELPERS_STEP2PREV, chal.data(), 4, pub.data(), 1);
+        sd.calculateH1H2(o2 + 0, c2, o2 + 3, c2, oT + 0, cT, oT + 3, cT, 3);          // the compressed lookup, dim 3
+        sd.calculateH1H2(o2 + 6, c2, o2 + 7, c2, o1 + 2, c1, o1 + 0, c1, 1);          // a lookup straight on witness columns, dim 1
+        sd.commitStageResident(1, r2);
+        sd.stepBase(MI_CHELPERS_STEP3PREV, chal.data(), 4, pub.data(), 1);
+        const bool closes = sd.calculateZ(o3, c3, oT + 6, cT, oT + 9, cT);
+        sd.stepBase(MI_CHELPERS_STEP3, chal.data(), 4, pub.data(), 1);
+        sd.commitStageResident(2, r3);
+        // oracle
+        std::vector<uint64_t> area(oT + N * cT, 0), xn(N), rows(N);
+        std::memcpy(&area[o1], w1.data(), w1.size() * 8);
+        glo_geom_seq(xn.data(), N, 1, glo_w((unsigned)nBits));
+        for (uint64_t i = 0; i < N; i++) rows[i] = i;
+        auto run = [&](const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs) {
+            return glo_chelpers_stepbase(ops, nops, args, nargs, area.data(), (const uint64_t *)constN.data(), nConstN, (const uint64_t *)chal.data(),
+                                         (const uint64_t *)pub.data(), xn.data(), 1, rows.data(), N);
+        };
+        int st = run(ops2, sizeof(ops2) / 8, args2, sizeof(args2) / 8);
+        int64_t bad = glo_calculate_h1h2(&area[o2], c2, &area[o2 + 3], c2, &area[oT], cT, &area[oT + 3], cT, 3, N);
+        bad |= glo_calculate_h1h2(&area[o2 + 6], c2, &area[o2 + 7], c2, &area[o1 + 2], c1, &area[o1], c1, 1, N);
+        st |= run(ops3p, sizeof(ops3p) / 8, args3p, sizeof(args3p) / 8);
+        const int wcloses = glo_calculate_z(&area[o3], c3, &area[oT + 6], cT, &area[oT + 9], cT, N);
+        st |= run(ops3, sizeof(ops3) / 8, args3, sizeof(args3) / 8);
+        std::vector<uint64_t> got(area.size()); // every column of the four sections is written by the flow
+        mi::check(mi_copy_d2h(mi::ctx(), got.data(), sd.baseSection(0), got.size() * 8), "d2h");
+        EXPECT(st == 0 && bad == 0 && same(got.data(), area.data(), area.size()), "StarksDevice: step2prev -> calculateH1H2 (dim 3, dim 1) -> step3prev -> calculateZ -> step3 on the device == oracle");
+        EXPECT(closes == (wcloses != 0) && closes, "StarksDevice::calculateZ closes (the lookup columns are permutations of each other)");
+        // the stage-2 / stage-3 roots: the device extended what it computed itself
+        std::vector<uint64_t> e2(NExtended * c2), t2((2 * NExtended - 1) * 4), e3(NExtended * c3), t3((2 * NExtended - 1) * 4);
+        glo_extend_pol(e2.data(), &area[o2], NExtended, N, c2);
+        glo_merkletree(t2.data(), e2.data(), c2, NExtended);
+        glo_extend_pol(e3.data(), &area[o3], NExtended, N, c3);
+        glo_merkletree(t3.data(), e3.data(), c3, NExtended);
+        EXPECT(same(r2, &t2[t2.size() - 4], 4) && same(r3, &t3[t3.size() - 4], 4), "StarksDevice::commitStageResident(1), (2) roots == oracle");
+    }
+
+    // ---- the same two operations through the Polinomial shim, the way starks.cpp:106-126,179-185 calls them (host views)
+    {
+        const uint64_t cw = 11; // host area a, columns: t (0..2), f (3..5), h1 (6..8), t1 (9), f1 (10); h2 and the dim-1 outputs go to area b
+        std::vector<Goldilocks::Element> a(N * cw), b(N * 6), wa, wb;
+        for (uint64_t i = 0; i < a.size(); i++) a[i] = Goldilocks::fromU64(splitmix(41, i));
+        for (uint64_t i = 0; i < N; i++)
+            for (int d = 0; d < 3; d++) a[i * cw + 3 + d] = a[((i * 9 + 1) & (N - 1)) / 3 * 3 * cw + d]; // f = rows of t (every third row, repeated)
+        wa = a; wb = b;
+        Polinomial t(&a[0], N, 3, cw), f(&a[3], N, 3, cw), h1(&a[6], N, 3, cw), h2(&b[1], N, 3, 6);
+        Polinomial::calculateH1H2_opt3(h1, h2, f, t, 0, NULL, 0, 0);
+        int64_t bad = glo_calculate_h1h2((uint64_t *)&wa[6], cw, (uint64_t *)&wb[1], 6, (const uint64_t *)&wa[3], cw, (const uint64_t *)&wa[0], cw, 3, N);
+        EXPECT(bad == 0 && same(a.data(), wa.data(), a.size()) && same(b.data(), wb.data(), b.size()), "Polinomial::calculateH1H2_opt3 (strided host views) == oracle");
+        Polinomial t1(&a[9], N, 1, cw), f1(&a[10], N, 1, cw), g1(&b[0], N, 1, 6), g2(&b[4], N, 1, 6);
+        for (uint64_t i = 0; i < N; i++) { a[i * cw + 9] = Goldilocks::fromU64(i & 63); a[i * cw + 10] = Goldilocks::fromU64((i * 7) & 63); }
+        wa = a;
+        Polinomial::calculateH1H2_opt1(g1, g2, f1, t1, 1, NULL, 0, 0);
+        bad = glo_calculate_h1h2((uint64_t *)&wb[0], 6, (uint64_t *)&wb[4], 6, (const uint64_t *)&wa[10], cw, (const uint64_t *)&wa[9], cw, 1, N);
+        EXPECT(bad == 0 && same(b.data(), wb.data(), b.size()), "Polinomial::calculateH1H2_opt1 (dim 1) == oracle");
+        // grand products that close (the shim asserts the check value like the reference's zkassert): t / t, then a permutation
+        Polinomial z(&b[1], N, 3, 6);
+        Polinomial::calculateZ(z, t, t);
+        bool ones = true;
+        for (uint64_t i = 0; i < N && ones; i++) ones = Goldilocks::toU64(b[i * 6 + 1]) == 1 && Goldilocks::toU64(b[i * 6 + 2]) == 0 && Goldilocks::toU64(b[i * 6 + 3]) == 0;
+        EXPECT(ones, "Polinomial::calculateZ(z, t, t) == 1 everywhere");
+        std::vector<Goldilocks::Element> pn(N * 3), pd(N * 3), pz(N * 3);
+        std::vector<uint64_t> wz(N * 3);
+        for (uint64_t i = 0; i < N * 3; i++) pn[i] = Goldilocks::fromU64(splitmix(42, i));
+        for (uint64_t i = 0; i < N; i++) std::memcpy(&pd[i * 3], &pn[((i * 5 + 1) & (N - 1)) * 3], 24);
+        Polinomial num(pn.data(), N, 3, 3), den(pd.data(), N, 3, 3), zz(pz.data(), N, 3, 3);
+        Polinomial::calculateZ(zz, num, den);
+        int closes = glo_calculate_z(wz.data(), 3, (const uint64_t *)pn.data(), 3, (const uint64_t *)pd.data(), 3, N);
+        EXPECT(closes == 1 && same(pz.data(), wz.data(), wz.size()), "Polinomial::calculateZ == oracle (and the product closes)");
+    }
+
     // ---- STEP 4 shapes (starks.cpp:261,284): INTT with the positional (NULL, 2, 1) hints, NTT over 6 columns
     std::vector<Goldilocks::Element> q_2ns(NExtended * 3), qq1(NExtended * 3), wq(NExtended * 3);
     for (uint64_t i = 0; i < q_2ns.size(); i++) q_2ns[i] = Goldilocks::fromU64(splitmix(2, i));

@@ -267,3 +267,25 @@ def chelpers_stepbase(ops, args, pols, const_pols, n_const, challenges, publics,
             ptr(rows), u64(rows.size))
     if st != 0:
         raise RuntimeError("glo_chelpers_stepbase: " + {-1: "unknown opcode", -2: "argument count mismatch"}.get(st, str(st)))
+
+
+def calculate_h1h2(area, h1_off, h1_stride, h2_off, h2_stride, f_off, f_stride, t_off, t_stride, dim, n):
+    """polinomial.hpp:303-347 over strided views of one host array (offsets in elements); h1 / h2 are written into `area`.  Returns 0
+    or 1 + the first row of f that is not in t."""
+    assert area.dtype == np.uint64 and area.flags.c_contiguous
+    fn = lib().glo_calculate_h1h2
+    fn.restype = ctypes.c_int64
+    base = area.ctypes.data
+    P = lambda off: ctypes.c_void_p(base + 8 * off)
+    return int(fn(P(h1_off), u64(h1_stride), P(h2_off), u64(h2_stride), P(f_off), u64(f_stride), P(t_off), u64(t_stride), ctypes.c_uint(dim),
+                  u64(n)))
+
+
+def calculate_z(area, z_off, z_stride, num_off, num_stride, den_off, den_stride, n):
+    """polinomial.hpp:586-607 over strided views of one host array; returns whether the product closes."""
+    assert area.dtype == np.uint64 and area.flags.c_contiguous
+    fn = lib().glo_calculate_z
+    fn.restype = ctypes.c_int
+    base = area.ctypes.data
+    P = lambda off: ctypes.c_void_p(base + 8 * off)
+    return int(fn(P(z_off), u64(z_stride), P(num_off), u64(num_stride), P(den_off), u64(den_stride), u64(n)))
