@@ -9,12 +9,17 @@ and an independent VERIFIER on the oracle's arithmetic (pil-stark's stark_verify
 challenge point, Merkle openings, the FRI polynomial recomputed at the query points from the opened rows, fold consistency, degree of
 the final polynomial).  A proof made on the GPU must verify; a tampered one must not.
 
-AIR (N rows, columns a, b; constant polynomials L1 = first-row selector, LLAST = last-row selector):
+AIR (N rows, columns a, b, c, d; constant polynomials L1 = first-row selector, LLAST = last-row selector):
     (1 - LLAST) * (a' - b) = 0,   (1 - LLAST) * (b' - a - b) = 0,   L1 * (a - 1) = 0,   L1 * (b - 1) = 0        (x' = value at the next row)
 and a second stage like the reference's stage 2: after the first commitment a challenge gamma is drawn, an extension-valued column
     z = (a + gamma) * (b + gamma)
 is computed ON THE DEVICE by a base-domain program (the step2prev / step3prev / step3 opcode numbering: results stored into polynomial
-memory), extended from device memory, committed, and bound by a fifth constraint  (a + gamma) * (b + gamma) - z = 0.
+memory), extended from device memory, committed, and bound by a fifth constraint  (a + gamma) * (b + gamma) - z = 0;
+and a third stage like the reference's stage 3 -- a permutation argument: d is a permutation of c; after the second commitment beta is
+drawn, a base-domain program writes c + beta and d + beta into tmpExp_n, the grand product
+    p[0] = 1,  p[i+1] = p[i] * (c[i] + beta) / (d[i] + beta)
+is computed ON THE DEVICE (mi_calculate_z_dev = Polinomial::calculateZ), extended, committed, and bound by
+    p' * (d + beta) - p * (c + beta) = 0   (every row: the wrap-around row holds because the product closes),    L1 * (p - 1) = 0.
 """
 import numpy as np
 
@@ -58,9 +63,10 @@ def e3_pow(a, e):
 
 # ------------------------------------------------------------------ the AIR's programs in the reference's table formats
 def step42ns_program(n_ext, next_shift):
-    """q * Z_H = (((C1 vc + C2) vc + C3) vc + C4) vc + C5 with vc = challenge 0, gamma = challenge 1; sections: cm1_2ns (a, b) at
-    offset 0, cm2_2ns (z, extension-valued) at offset 2 * n_ext."""
-    A_, B_, ST = 0, 1, 2                      # columns of cm1_2ns, its row stride
+    """q * Z_H = Horner_vc(C1 .. C7) with vc = challenge 0, gamma = challenge 1, beta = challenge 2; sections: cm1_2ns (a, b, c, d) at
+    offset 0, cm2_2ns (z, extension-valued) at 4 * n_ext, cm3_2ns (p, extension-valued) at 7 * n_ext."""
+    A_, B_, C_, D_, ST = 0, 1, 2, 3, 4        # columns of cm1_2ns, its row stride
+    o2, o3 = 4 * n_ext, 7 * n_ext
     L1, LLAST = 0, 1                          # constant polynomials
     ops, args = [], []
 
@@ -83,50 +89,78 @@ def step42ns_program(n_ext, next_shift):
     push(16, [1, A_, ST, 1])                              # e1 = a + gamma            (challenge 1)
     push(16, [2, B_, ST, 1])                              # e2 = b + gamma
     push(71, [1, 1, 2])                                   # e1 = e1 * e2
-    push(44, [1, 1, 2 * n_ext, 3])                        # e1 = e1 - z               (z: cm2_2ns, three columns at offset 2 * n_ext)
+    push(44, [1, 1, o2, 3])                               # e1 = e1 - z               (z: cm2_2ns, three columns)
     push(70, [0, 0, 0])                                   # acc = vc * acc
     push(17, [0, 1, 0])                                   # acc = e1 + acc
+    push(16, [1, D_, ST, 2])                              # e1 = d + beta             (challenge 2)
+    push(74, [1, o3, next_shift, n_ext, 3, 1])            # e1 = p' * e1              (p: cm3_2ns, at the next row)
+    push(16, [2, C_, ST, 2])                              # e2 = c + beta
+    push(75, [2, o3, 3, 2])                               # e2 = p * e2
+    push(42, [1, 1, 2])                                   # e1 = e1 - e2
+    push(70, [0, 0, 0])
+    push(17, [0, 1, 0])                                   # acc = vc * acc + e1
+    push(41, [1, o3, 3, 1])                               # e1 = p - 1
+    push(60, [1, L1, 1])                                  # e1 = L1 * e1
+    push(70, [0, 0, 0])
+    push(17, [0, 1, 0])                                   # acc = vc * acc + e1
     push(69, [0])                                         # q = zhInv * acc
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
-EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1, EV_Z = range(9)
+EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1, EV_Z, EV_C, EV_D, EV_GP, EV_GPW = range(13)
 
 
 def step52ns_program(nrows):
-    """f = ((H c5 + E_xi xDivXSubXi) c5 + E_wxi xDivXSubWXi), H = Horner_c5(a, b, q0, q1), E_* = Horner_c6(pol - eval); sections: cm1_2ns
-    (2 columns) at offset 0, cm2_2ns (z, 3 columns) at offset 2 * nrows, cm4_2ns (two extension-valued chunks, 6 columns) at offset
-    5 * nrows; constants L1, LLAST."""
-    o2, o4 = 2 * nrows, 5 * nrows
+    """f = ((H c5 + E_xi xDivXSubXi) c5 + E_wxi xDivXSubWXi), H = Horner_c5(every committed column), E_* = Horner_c6(pol - eval);
+    sections: cm1_2ns (4 columns) at offset 0, cm2_2ns (z, 3 columns) at 4 * nrows, cm3_2ns (p, 3 columns) at 7 * nrows, cm4_2ns (two
+    extension-valued chunks, 6 columns) at 10 * nrows; constants L1, LLAST."""
+    o2, o3, o4 = 4 * nrows, 7 * nrows, 10 * nrows
     ops, args = [], []
 
     def push(o, ar):
         ops.append(o); args.extend(ar)
-    push(0, [0, 2]); push(16, [1, 2]); push(17, [o2, 3]); push(17, [o4, 6]); push(17, [o4 + 3, 6])      # H
+    push(0, [0, 4]); push(16, [1, 4]); push(16, [2, 4]); push(16, [3, 4])             # H
+    push(17, [o2, 3]); push(17, [o3, 3]); push(17, [o4, 6]); push(17, [o4 + 3, 6])
     push(3, [])                                                                       # tmp1 = H c5
-    push(11, [0, 2, EV_A]); push(4, [])                                               # tmp = (a - a(xi)) c6
-    push(18, [1, 2, EV_B]); push(19, [0, EV_L1]); push(19, [1, EV_LLAST])
-    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1]); push(20, [o2, 3, EV_Z])
+    push(11, [0, 4, EV_A]); push(4, [])                                               # tmp = (a - a(xi)) c6
+    push(18, [1, 4, EV_B]); push(18, [2, 4, EV_C]); push(18, [3, 4, EV_D]); push(19, [0, EV_L1]); push(19, [1, EV_LLAST])
+    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1]); push(20, [o2, 3, EV_Z]); push(20, [o3, 3, EV_GP])
     push(5, []); push(8, []); push(3, [])                                             # * xDivXSubXi; tmp = tmp1 + tmp; tmp1 = tmp c5
-    push(11, [0, 2, EV_AW]); push(4, []); push(18, [1, 2, EV_BW])
+    push(11, [0, 4, EV_AW]); push(4, []); push(18, [1, 4, EV_BW]); push(20, [o3, 3, EV_GPW])
     push(6, []); push(8, []); push(15, [])                                            # * xDivXSubWXi; tmp = tmp1 + tmp; f = tmp
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
 def stage2_program(n):
-    """z = (a + gamma) * (b + gamma) into the three columns at offset 2 * n of the base-domain area [cm1_n (2 columns) | cm2_n (3)], in
+    """z = (a + gamma) * (b + gamma) into cm2_n of the base-domain area [cm1_n (4 columns) | cm2_n (3) | cm3_n (3) | tmpExp_n (6)], in
     the base-domain steps' numbering (gamma = challenge 1)."""
     ops = [16, 16, 98]
-    args = [0, 0, 2, 1,   1, 1, 2, 1,   2 * n, 3, 0, 1]
+    args = [0, 0, 4, 1,   1, 1, 4, 1,   4 * n, 3, 0, 1]
+    return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
+
+
+BASE_SECTIONS = lambda n: [(0, 4, n), (4 * n, 3, n), (7 * n, 3, n), (10 * n, 6, n)]
+
+
+def stage3_program(n):
+    """The grand product's numerators c + beta and denominators d + beta into tmpExp_n (columns 0..2 and 3..5), beta = challenge 2."""
+    oT = 10 * n
+    ops = [13, 79, 88, 79, 88]
+    args = [0, 0, 2,                  # e0 = 0 + beta
+            0, 2, 4,   oT, 6, 0, 0,   # t0 = c;  tmpExp[0..2] = t0 + e0
+            1, 3, 4,   oT + 3, 6, 1, 0]
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
 def witness(n):
-    out = np.empty((n, 2), dtype=np.uint64)
+    out = np.empty((n, 4), dtype=np.uint64)
     a = b = 1
     for i in range(n):
         out[i, 0], out[i, 1] = a, b
         a, b = b, (a + b) % P
+    rng = np.random.default_rng(n)
+    out[:, 2] = glo.rand_fe(rng, (n,))
+    out[:, 3] = out[rng.permutation(n), 2]            # d: a permutation of c
     return out
 
 
@@ -159,36 +193,52 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     const_2ns, const_nodes = ctx.empty(NE * 2), ctx.empty((2 * NE - 1) * 4)
     ctx.lde(const_2ns, d_const_n, NE, N, 2)
     ctx.merkle_build(const_nodes, const_2ns, 2, NE)
-    area = ctx.empty(NE * (2 + 3 + 6))                   # cm1_2ns | cm2_2ns | cm4_2ns, one polynomial area
-    cm1, cm2, cm4 = area[:NE * 2], area[NE * 2:NE * 5], area[NE * 5:]
-    nodes1, nodes2, nodes4 = ctx.empty((2 * NE - 1) * 4), ctx.empty((2 * NE - 1) * 4), ctx.empty((2 * NE - 1) * 4)
-    base = ctx.zeros(N * (2 + 3))                        # the base-domain area: cm1_n | cm2_n
-    base[:N * 2] = ctx.to_device(witness(N)).reshape(-1)
+    area = ctx.empty(NE * (4 + 3 + 3 + 6))               # cm1_2ns | cm2_2ns | cm3_2ns | cm4_2ns, one polynomial area
+    cm1, cm2, cm3, cm4 = area[:NE * 4], area[NE * 4:NE * 7], area[NE * 7:NE * 10], area[NE * 10:]
+    nodes1, nodes2, nodes3, nodes4 = (ctx.empty((2 * NE - 1) * 4) for _ in range(4))
+    base = ctx.zeros(N * (4 + 3 + 3 + 6))                # the base-domain area: cm1_n | cm2_n | cm3_n | tmpExp_n
+    w = witness(N)
+    if tamper == "perm":                                 # d is no longer a permutation of c: the grand product does not close
+        w[N // 2, 3] = (int(w[N // 2, 3]) + 1) % P
+    base[:N * 4] = ctx.to_device(w).reshape(-1)
     tr = Transcript(ctx)
     chal = np.zeros(7 * 3, dtype=np.uint64)
     # ---- step 1: commit the witness
-    ctx.lde(cm1, base[:N * 2], NE, N, 2)
-    ctx.merkle_build(nodes1, cm1, 2, NE)
+    ctx.lde(cm1, base[:N * 4], NE, N, 4)
+    ctx.merkle_build(nodes1, cm1, 4, NE)
     root1 = ctx.to_host(nodes1[-4:])
     tr.put(root1)
     chal[3:6] = tr.get_field()                           # gamma
     # ---- step 2: the stage-2 column from a base-domain program (compiled kernels), extended from device memory, committed
     opsb, argsb = stage2_program(N)
-    progb = mi_stark.ChelpersProgram(ctx, opsb, argsb, sections=[(0, 2, N)], n_const=2, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP2PREV)
+    progb = mi_stark.ChelpersProgram(ctx, opsb, argsb, sections=BASE_SECTIONS(N), n_const=2, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP2PREV)
     progb.build_native(cache_dir=cache_dir)
     x_n = ctx.empty(N)
     ctx.geom_seq(x_n, N, 1, L.glo_w(nbits))
     progb.run_base(base, d_const_n, 2, chal, np.zeros(1, dtype=np.uint64), x_n, 1, 0, N)
-    ctx.lde(cm2, base[N * 2:], NE, N, 3)
+    ctx.lde(cm2, base[N * 4:], NE, N, 3)
     ctx.merkle_build(nodes2, cm2, 3, NE)
     root2 = ctx.to_host(nodes2[-4:])
     tr.put(root2)
+    chal[6:9] = tr.get_field()                           # beta
+    # ---- step 3: numerators / denominators from a base-domain program, the grand product on the device, extended, committed
+    opsc, argsc = stage3_program(N)
+    progc = mi_stark.ChelpersProgram(ctx, opsc, argsc, sections=BASE_SECTIONS(N), n_const=2, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP3PREV)
+    progc.build_native(cache_dir=cache_dir)
+    progc.run_base(base, d_const_n, 2, chal, np.zeros(1, dtype=np.uint64), x_n, 1, 0, N)
+    closes = ctx.calculate_z(base[N * 7:], 3, base[N * 10:], 6, base[N * 10 + 3:], 6, N)
+    assert closes == (tamper != "perm")                  # (the reference zkasserts this; a cheating prover goes on)
+    ctx.lde(cm3, base[N * 7:], NE, N, 3)
+    ctx.merkle_build(nodes3, cm3, 3, NE)
+    root3 = ctx.to_host(nodes3[-4:])
+    tr.put(root3)
     vc = tr.get_field()
     # ---- step 4: constraint polynomial q = C / Z_H on the extended domain, split, committed
     ops42, args42 = step42ns_program(NE, 2)
-    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 2, NE), (2 * NE, 3, NE)], n_const=2, nrows_ext=NE)
+    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 4, NE), (4 * NE, 3, NE), (7 * NE, 3, NE)], n_const=2, nrows_ext=NE)
     ops52, args52 = step52ns_program(NE)
-    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 2, NE), (2 * NE, 3, NE), (5 * NE, 6, NE)], n_const=2, nrows_ext=NE, step=52)
+    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 4, NE), (4 * NE, 3, NE), (7 * NE, 3, NE), (10 * NE, 6, NE)], n_const=2,
+                                      nrows_ext=NE, step=52)
     if native:
         prog42.build_native(cache_dir=cache_dir)
         prog52.build_native(cache_dir=cache_dir)
@@ -215,9 +265,9 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     ctx.geom_seq3(lpev, N, wxis)
     ctx.ntt(lev, lev, N, 3, inverse=True)
     ctx.ntt(lpev, lpev, N, 3, inverse=True)
-    pols = [(cm1, 0, 1, 2), (cm1, 1, 1, 2), (cm1, 0, 1, 2), (cm1, 1, 1, 2), (const_2ns, 0, 1, 2), (const_2ns, 1, 1, 2), (cm4, 0, 3, 6), (cm4, 3, 3, 6),
-            (cm2, 0, 3, 3)]
-    prime = [0, 0, 1, 1, 0, 0, 0, 0, 0]
+    pols = [(cm1, 0, 1, 4), (cm1, 1, 1, 4), (cm1, 0, 1, 4), (cm1, 1, 1, 4), (const_2ns, 0, 1, 2), (const_2ns, 1, 1, 2), (cm4, 0, 3, 6), (cm4, 3, 3, 6),
+            (cm2, 0, 3, 3), (cm1, 2, 1, 4), (cm1, 3, 1, 4), (cm3, 0, 3, 3), (cm3, 0, 3, 3)]
+    prime = [0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1]
     d_evals = ctx.empty(len(pols) * 3)
     ctx.evmap(d_evals, pols, prime, lev, lpev, N, 1)
     evals = ctx.to_host(d_evals)
@@ -264,9 +314,10 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
         buf = ctx.empty(len(idx) * (width + 4 * (height - 1).bit_length()))
         ctx.merkle_group_proofs(buf, nodes, src, height, width, idx)
         return ctx.to_host(buf).reshape(len(idx), -1)
-    proof = {"nbits": nbits, "root1": root1, "root2": root2, "root4": root4, "evals": evals, "fri_roots": fri_roots, "final_pol": final_pol,
-             "s0": {"cm1": open_tree(nodes1, cm1, NE, 2, ys), "cm2": open_tree(nodes2, cm2, NE, 3, ys), "cm4": open_tree(nodes4, cm4, NE, 6, ys),
-                    "const": open_tree(const_nodes, const_2ns, NE, 2, ys)},
+    proof = {"nbits": nbits, "root1": root1, "root2": root2, "root3": root3, "root4": root4, "evals": evals, "fri_roots": fri_roots,
+             "final_pol": final_pol,
+             "s0": {"cm1": open_tree(nodes1, cm1, NE, 4, ys), "cm2": open_tree(nodes2, cm2, NE, 3, ys), "cm3": open_tree(nodes3, cm3, NE, 3, ys),
+                    "cm4": open_tree(nodes4, cm4, NE, 6, ys), "const": open_tree(const_nodes, const_2ns, NE, 2, ys)},
              "fri": {}, "const_root": ctx.to_host(const_nodes[-4:])}
     y = ys.copy()
     for si in range(1, len(steps)):
@@ -277,7 +328,9 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
         proof["s0"]["cm1"][0][0] ^= np.uint64(1)
     if tamper == "stage2":
         proof["s0"]["cm2"][1][2] ^= np.uint64(1)
-    for p in (progb, prog42, prog52):
+    if tamper == "stage3":
+        proof["s0"]["cm3"][2][1] ^= np.uint64(1)
+    for p in (progb, progc, prog42, prog52):
         p.close()
     return proof
 
@@ -297,6 +350,8 @@ def verify(proof, const_root, n_queries=12):
     tr.put(proof["root1"])
     gamma = e3(tr.get_field())
     tr.put(proof["root2"])
+    beta = e3(tr.get_field())
+    tr.put(proof["root3"])
     vc = e3(tr.get_field())
     tr.put(proof["root4"])
     xi = e3(tr.get_field())
@@ -313,7 +368,7 @@ def verify(proof, const_root, n_queries=12):
             tr.put(proof["final_pol"])
     ys = tr.get_permutations(n_queries, steps[0])
     E = lambda k: e3(ev[3 * k:3 * k + 3])
-    # ---- constraint identity at xi: (((C1 vc + C2) vc + C3) vc + C4) vc + C5 == Q(xi) * (xi^N - 1)
+    # ---- constraint identity at xi: Horner_vc(C1 .. C7) == Q(xi) * (xi^N - 1)
     one = [1, 0, 0]
     not_last = e3_sub(one, E(EV_LLAST))
     C1 = e3_mul(not_last, e3_sub(E(EV_AW), E(EV_B)))
@@ -321,7 +376,11 @@ def verify(proof, const_root, n_queries=12):
     C3 = e3_mul(E(EV_L1), e3_sub(E(EV_A), one))
     C4 = e3_mul(E(EV_L1), e3_sub(E(EV_B), one))
     C5 = e3_sub(e3_mul(e3_add(E(EV_A), gamma), e3_add(E(EV_B), gamma)), E(EV_Z))
-    C = e3_add(e3_mul(e3_add(e3_mul(e3_add(e3_mul(e3_add(e3_mul(C1, vc), C2), vc), C3), vc), C4), vc), C5)
+    C6 = e3_sub(e3_mul(E(EV_GPW), e3_add(E(EV_D), beta)), e3_mul(E(EV_GP), e3_add(E(EV_C), beta)))
+    C7 = e3_mul(E(EV_L1), e3_sub(E(EV_GP), one))
+    C = [0, 0, 0]
+    for Ck in (C1, C2, C3, C4, C5, C6, C7):
+        C = e3_add(e3_mul(C, vc), Ck)
     xiN = e3_pow(xi, N)
     Q = e3_add(E(EV_Q0), e3_mul(xiN, E(EV_Q1)))
     if C != e3_mul(Q, e3_sub(xiN, one)):
@@ -332,11 +391,12 @@ def verify(proof, const_root, n_queries=12):
     chal[15:18], chal[18:21] = c5, c6
     wN = L.glo_w(nbits)
     wxi = [L.glo_mul(v, wN) for v in xi]
-    h1, h2, h4, hc = proof["s0"]["cm1"], proof["s0"]["cm2"], proof["s0"]["cm4"], proof["s0"]["const"]
+    h1, h2, h3, h4, hc = proof["s0"]["cm1"], proof["s0"]["cm2"], proof["s0"]["cm3"], proof["s0"]["cm4"], proof["s0"]["const"]
     y = [int(v) for v in ys]
     for q in range(n_queries):
         idx = y[q]
-        for (pr, w, root, name) in ((h1, 2, proof["root1"], "cm1"), (h2, 3, proof["root2"], "cm2"), (h4, 6, proof["root4"], "cm4"), (hc, 2, const_root, "const")):
+        for (pr, w, root, name) in ((h1, 4, proof["root1"], "cm1"), (h2, 3, proof["root2"], "cm2"), (h3, 3, proof["root3"], "cm3"),
+                                    (h4, 6, proof["root4"], "cm4"), (hc, 2, const_root, "const")):
             if not glo.merkle_verify(root, pr[q][:w], pr[q][w:], idx):
                 return False, "Merkle opening of %s fails at query %d" % (name, q)
         # the FRI polynomial at x = shift * w^idx from the opened rows (the same program, over one row)
@@ -344,7 +404,7 @@ def verify(proof, const_root, n_queries=12):
         def xdiv(z):
             den = np.array([(x - z[0]) % P, (-z[1]) % P, (-z[2]) % P], dtype=np.uint64)
             return np.array(e3_mul([int(v) for v in glo.e3_inv(den)], [x, 0, 0]), dtype=np.uint64)
-        row = np.concatenate([h1[q][:2], h2[q][:3], h4[q][:6]]).astype(np.uint64)
+        row = np.concatenate([h1[q][:4], h2[q][:3], h3[q][:3], h4[q][:6]]).astype(np.uint64)
         f = np.zeros(3, dtype=np.uint64)
         glo.chelpers_step52ns(ops52, args52, row, np.ascontiguousarray(hc[q][:2]), 2, chal, ev, xdiv(xi), xdiv(wxi), f, 0, 1)
         # level by level: the value must sit in the next group, the group must fold to the value after it

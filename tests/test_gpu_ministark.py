@@ -28,8 +28,8 @@ def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
     assert cp.decode(ops, args)[1] == args.size
     ops, args = ms.step52ns_program(2 * n)
     assert sum(cp.nargs52_of(int(o)) for o in ops) == args.size
-    ops, args = ms.stage2_program(n)
-    assert cp.decode_base(ops, args)[1] == args.size
+    for ops, args in (ms.stage2_program(n), ms.stage3_program(n)):
+        assert cp.decode_base(ops, args)[1] == args.size
 
 
 @pytest.mark.gpu
@@ -50,7 +50,7 @@ def test_a_proof_from_the_device_path_verifies(native, nbits, lin, tmp_path, mon
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tamper,expect", [("eval", "constraint identity"), ("opening", "Merkle opening of cm1"), ("stage2", "Merkle opening of cm2"),
+@pytest.mark.parametrize("tamper,expect", [("eval", "constraint identity"), ("opening", "Merkle opening of cm1"), ("stage2", "Merkle opening of cm2"), ("stage3", "Merkle opening of cm3"), ("perm", "constraint identity"),
                                            ("final", "final polynomial"), ("f", "")])
 def test_a_tampered_proof_is_rejected(tamper, expect):
     import mi_stark
