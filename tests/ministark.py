@@ -9,7 +9,7 @@ and an independent VERIFIER on the oracle's arithmetic (pil-stark's stark_verify
 challenge point, Merkle openings, the FRI polynomial recomputed at the query points from the opened rows, fold consistency, degree of
 the final polynomial).  A proof made on the GPU must verify; a tampered one must not.
 
-AIR (N rows, columns a, b, c, d; constant polynomials L1 = first-row selector, LLAST = last-row selector):
+AIR (N rows, columns a, b, c, d, f; constant polynomials L1 = first-row selector, LLAST = last-row selector, T = a lookup table):
     (1 - LLAST) * (a' - b) = 0,   (1 - LLAST) * (b' - a - b) = 0,   L1 * (a - 1) = 0,   L1 * (b - 1) = 0        (x' = value at the next row)
 and a second stage like the reference's stage 2: after the first commitment a challenge gamma is drawn, an extension-valued column
     z = (a + gamma) * (b + gamma)
@@ -19,7 +19,13 @@ and a third stage like the reference's stage 3 -- a permutation argument: d is a
 drawn, a base-domain program writes c + beta and d + beta into tmpExp_n, the grand product
     p[0] = 1,  p[i+1] = p[i] * (c[i] + beta) / (d[i] + beta)
 is computed ON THE DEVICE (mi_calculate_z_dev = Polinomial::calculateZ), extended, committed, and bound by
-    p' * (d + beta) - p * (c + beta) = 0   (every row: the wrap-around row holds because the product closes),    L1 * (p - 1) = 0.
+    p' * (d + beta) - p * (c + beta) = 0   (every row: the wrap-around row holds because the product closes),    L1 * (p - 1) = 0;
+and a lookup (plookup, as pil-stark arithmetises it): every f[i] is a row of T.  In stage 2 the sorted columns h1, h2 are computed ON
+THE DEVICE (mi_calculate_h1h2_dev = Polinomial::calculateH1H2*) and committed beside z; after that commitment gamma2, beta2 are drawn
+and stage 3 carries a second grand product p2 of
+    num = (1 + beta2) (gamma2 + f) (gamma2 (1 + beta2) + T + beta2 T'),    den = (gamma2 (1 + beta2) + h1 + beta2 h2) (gamma2 (1 + beta2) + h2 + beta2 h1'),
+bound by  p2' * den - p2 * num = 0  and  L1 * (p2 - 1) = 0.  The product closes only if (h1[0], h2[0], h1[1], ...) is f u T sorted
+along T -- which is exactly what calculateH1H2 has to deliver, so a verifying proof pins its output convention.
 """
 import numpy as np
 
@@ -63,11 +69,12 @@ def e3_pow(a, e):
 
 # ------------------------------------------------------------------ the AIR's programs in the reference's table formats
 def step42ns_program(n_ext, next_shift):
-    """q * Z_H = Horner_vc(C1 .. C7) with vc = challenge 0, gamma = challenge 1, beta = challenge 2; sections: cm1_2ns (a, b, c, d) at
-    offset 0, cm2_2ns (z, extension-valued) at 4 * n_ext, cm3_2ns (p, extension-valued) at 7 * n_ext."""
-    A_, B_, C_, D_, ST = 0, 1, 2, 3, 4        # columns of cm1_2ns, its row stride
-    o2, o3 = 4 * n_ext, 7 * n_ext
-    L1, LLAST = 0, 1                          # constant polynomials
+    """q * Z_H = Horner_vc(C1 .. C9) with vc = challenge 0, gamma = 1, beta = 2, gamma2 = 3, beta2 = 4; sections: cm1_2ns (a, b, c, d, f)
+    at offset 0, cm2_2ns (z extension-valued, h1, h2) at 5 * n_ext, cm3_2ns (p, p2 extension-valued) at 10 * n_ext."""
+    A_, B_, C_, D_, F_, ST = 0, 1, 2, 3, 4, 5 # columns of cm1_2ns, its row stride
+    o2, o3 = 5 * n_ext, 10 * n_ext
+    H1_, H2_, ST2, ST3 = o2 + 3, o2 + 4, 5, 6
+    L1, LLAST, T_ = 0, 1, 2                   # constant polynomials
     ops, args = [], []
 
     def push(o, ar):
@@ -89,17 +96,44 @@ def step42ns_program(n_ext, next_shift):
     push(16, [1, A_, ST, 1])                              # e1 = a + gamma            (challenge 1)
     push(16, [2, B_, ST, 1])                              # e2 = b + gamma
     push(71, [1, 1, 2])                                   # e1 = e1 * e2
-    push(44, [1, 1, o2, 3])                               # e1 = e1 - z               (z: cm2_2ns, three columns)
+    push(44, [1, 1, o2, ST2])                             # e1 = e1 - z               (z: cm2_2ns, three columns)
     push(70, [0, 0, 0])                                   # acc = vc * acc
     push(17, [0, 1, 0])                                   # acc = e1 + acc
     push(16, [1, D_, ST, 2])                              # e1 = d + beta             (challenge 2)
-    push(74, [1, o3, next_shift, n_ext, 3, 1])            # e1 = p' * e1              (p: cm3_2ns, at the next row)
+    push(74, [1, o3, next_shift, n_ext, ST3, 1])          # e1 = p' * e1              (p: cm3_2ns, at the next row)
     push(16, [2, C_, ST, 2])                              # e2 = c + beta
-    push(75, [2, o3, 3, 2])                               # e2 = p * e2
+    push(75, [2, o3, ST3, 2])                             # e2 = p * e2
     push(42, [1, 1, 2])                                   # e1 = e1 - e2
     push(70, [0, 0, 0])
     push(17, [0, 1, 0])                                   # acc = vc * acc + e1
-    push(41, [1, o3, 3, 1])                               # e1 = p - 1
+    push(41, [1, o3, ST3, 1])                             # e1 = p - 1
+    push(60, [1, L1, 1])                                  # e1 = L1 * e1
+    push(70, [0, 0, 0])
+    push(17, [0, 1, 0])                                   # acc = vc * acc + e1
+    # the lookup's grand product p2 (cm3_2ns columns 3..5): p2' * den - p2 * num
+    push(13, [3, 1, 4])                                   # e3 = 1 + beta2
+    push(70, [4, 3, 3])                                   # e4 = gamma2 * e3
+    push(82, [5, T_])                                     # t5 = T
+    push(83, [6, T_, next_shift, n_ext])                  # t6 = T'
+    push(59, [1, 6, 4])                                   # e1 = t6 * beta2
+    push(12, [1, 5, 1])                                   # e1 = t5 + e1
+    push(17, [1, 1, 4])                                   # e1 = e1 + e4
+    push(16, [2, F_, ST, 3])                              # e2 = f + gamma2
+    push(71, [2, 2, 3])                                   # e2 = e2 * e3
+    push(71, [2, 2, 1])                                   # e2 = e2 * e1              = num
+    push(75, [2, o3 + 3, ST3, 2])                         # e2 = p2 * e2
+    push(62, [1, H2_, ST2, 4])                            # e1 = h2 * beta2
+    push(15, [1, H1_, ST2, 1])                            # e1 = h1 + e1
+    push(17, [1, 1, 4])                                   # e1 = e1 + e4
+    push(63, [5, H1_, next_shift, n_ext, ST2, 4])         # e5 = h1' * beta2
+    push(15, [5, H2_, ST2, 5])                            # e5 = h2 + e5
+    push(17, [5, 5, 4])                                   # e5 = e5 + e4
+    push(71, [1, 1, 5])                                   # e1 = e1 * e5              = den
+    push(74, [1, o3 + 3, next_shift, n_ext, ST3, 1])      # e1 = p2' * e1
+    push(42, [1, 1, 2])                                   # e1 = e1 - e2
+    push(70, [0, 0, 0])
+    push(17, [0, 1, 0])                                   # acc = vc * acc + e1
+    push(41, [1, o3 + 3, ST3, 1])                         # e1 = p2 - 1
     push(60, [1, L1, 1])                                  # e1 = L1 * e1
     push(70, [0, 0, 0])
     push(17, [0, 1, 0])                                   # acc = vc * acc + e1
@@ -107,53 +141,70 @@ def step42ns_program(n_ext, next_shift):
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
-EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1, EV_Z, EV_C, EV_D, EV_GP, EV_GPW = range(13)
+EV_A, EV_B, EV_AW, EV_BW, EV_L1, EV_LLAST, EV_Q0, EV_Q1, EV_Z, EV_C, EV_D, EV_GP, EV_GPW, EV_F, EV_T, EV_TW, EV_H1, EV_H2, EV_H1W, EV_P2, EV_P2W = range(21)
 
 
 def step52ns_program(nrows):
     """f = ((H c5 + E_xi xDivXSubXi) c5 + E_wxi xDivXSubWXi), H = Horner_c5(every committed column), E_* = Horner_c6(pol - eval);
-    sections: cm1_2ns (4 columns) at offset 0, cm2_2ns (z, 3 columns) at 4 * nrows, cm3_2ns (p, 3 columns) at 7 * nrows, cm4_2ns (two
-    extension-valued chunks, 6 columns) at 10 * nrows; constants L1, LLAST."""
-    o2, o3, o4 = 4 * nrows, 7 * nrows, 10 * nrows
+    sections: cm1_2ns (5 columns) at offset 0, cm2_2ns (z, h1, h2: 5 columns) at 5 * nrows, cm3_2ns (p, p2: 6 columns) at 10 * nrows,
+    cm4_2ns (two extension-valued chunks, 6 columns) at 16 * nrows; constants L1, LLAST, T."""
+    o2, o3, o4 = 5 * nrows, 10 * nrows, 16 * nrows
     ops, args = [], []
 
     def push(o, ar):
         ops.append(o); args.extend(ar)
-    push(0, [0, 4]); push(16, [1, 4]); push(16, [2, 4]); push(16, [3, 4])             # H
-    push(17, [o2, 3]); push(17, [o3, 3]); push(17, [o4, 6]); push(17, [o4 + 3, 6])
+    push(0, [0, 5]); push(16, [1, 5]); push(16, [2, 5]); push(16, [3, 5]); push(16, [4, 5])            # H
+    push(17, [o2, 5]); push(16, [o2 + 3, 5]); push(16, [o2 + 4, 5]); push(17, [o3, 6]); push(17, [o3 + 3, 6])
+    push(17, [o4, 6]); push(17, [o4 + 3, 6])
     push(3, [])                                                                       # tmp1 = H c5
-    push(11, [0, 4, EV_A]); push(4, [])                                               # tmp = (a - a(xi)) c6
-    push(18, [1, 4, EV_B]); push(18, [2, 4, EV_C]); push(18, [3, 4, EV_D]); push(19, [0, EV_L1]); push(19, [1, EV_LLAST])
-    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1]); push(20, [o2, 3, EV_Z]); push(20, [o3, 3, EV_GP])
+    push(11, [0, 5, EV_A]); push(4, [])                                               # tmp = (a - a(xi)) c6
+    push(18, [1, 5, EV_B]); push(18, [2, 5, EV_C]); push(18, [3, 5, EV_D]); push(18, [4, 5, EV_F])
+    push(19, [0, EV_L1]); push(19, [1, EV_LLAST]); push(19, [2, EV_T])
+    push(20, [o4, 6, EV_Q0]); push(20, [o4 + 3, 6, EV_Q1]); push(20, [o2, 5, EV_Z]); push(18, [o2 + 3, 5, EV_H1]); push(18, [o2 + 4, 5, EV_H2])
+    push(20, [o3, 6, EV_GP]); push(20, [o3 + 3, 6, EV_P2])
     push(5, []); push(8, []); push(3, [])                                             # * xDivXSubXi; tmp = tmp1 + tmp; tmp1 = tmp c5
-    push(11, [0, 4, EV_AW]); push(4, []); push(18, [1, 4, EV_BW]); push(20, [o3, 3, EV_GPW])
+    push(11, [0, 5, EV_AW]); push(4, []); push(18, [1, 5, EV_BW]); push(20, [o3, 6, EV_GPW])
+    push(19, [2, EV_TW]); push(18, [o2 + 3, 5, EV_H1W]); push(20, [o3 + 3, 6, EV_P2W])
     push(6, []); push(8, []); push(15, [])                                            # * xDivXSubWXi; tmp = tmp1 + tmp; f = tmp
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
 def stage2_program(n):
-    """z = (a + gamma) * (b + gamma) into cm2_n of the base-domain area [cm1_n (4 columns) | cm2_n (3) | cm3_n (3) | tmpExp_n (6)], in
-    the base-domain steps' numbering (gamma = challenge 1)."""
+    """z = (a + gamma) * (b + gamma) into cm2_n of the base-domain area [cm1_n (5 columns) | cm2_n (5: z, h1, h2) | cm3_n (6: p, p2) |
+    tmpExp_n (12)], in the base-domain steps' numbering (gamma = challenge 1)."""
     ops = [16, 16, 98]
-    args = [0, 0, 4, 1,   1, 1, 4, 1,   4 * n, 3, 0, 1]
+    args = [0, 0, 5, 1,   1, 1, 5, 1,   5 * n, 5, 0, 1]
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
-BASE_SECTIONS = lambda n: [(0, 4, n), (4 * n, 3, n), (7 * n, 3, n), (10 * n, 6, n)]
+BASE_SECTIONS = lambda n: [(0, 5, n), (5 * n, 5, n), (10 * n, 6, n), (16 * n, 12, n)]
 
 
 def stage3_program(n):
-    """The grand product's numerators c + beta and denominators d + beta into tmpExp_n (columns 0..2 and 3..5), beta = challenge 2."""
-    oT = 10 * n
-    ops = [13, 79, 88, 79, 88]
-    args = [0, 0, 2,                  # e0 = 0 + beta
-            0, 2, 4,   oT, 6, 0, 0,   # t0 = c;  tmpExp[0..2] = t0 + e0
-            1, 3, 4,   oT + 3, 6, 1, 0]
+    """Numerators / denominators of the two grand products into tmpExp_n: c + beta (columns 0..2), d + beta (3..5), the lookup's num
+    (6..8) and den (9..11); beta = challenge 2, gamma2 = 3, beta2 = 4; T = constant polynomial 2; h1, h2 = columns 3, 4 of cm2_n."""
+    o2, oT, STT = 5 * n, 16 * n, 12
+    ops, args = [], []
+
+    def push(o, ar):
+        ops.append(o); args.extend(ar)
+    push(13, [0, 0, 2])                                   # e0 = 0 + beta
+    push(79, [0, 2, 5]); push(88, [oT, STT, 0, 0])        # t0 = c;  tmpExp[0..2] = t0 + e0
+    push(79, [1, 3, 5]); push(88, [oT + 3, STT, 1, 0])    # t1 = d;  tmpExp[3..5] = t1 + e0
+    push(13, [3, 1, 4])                                   # e3 = 1 + beta2
+    push(70, [4, 3, 3])                                   # e4 = gamma2 * e3
+    push(82, [5, 2]); push(83, [6, 2, 1, n])              # t5 = T;  t6 = T'
+    push(59, [1, 6, 4]); push(12, [1, 5, 1]); push(17, [1, 1, 4])        # e1 = T + beta2 T' + e4
+    push(16, [2, 4, 5, 3]); push(71, [2, 2, 3])           # e2 = (f + gamma2) * e3
+    push(98, [oT + 6, STT, 2, 1])                         # tmpExp[6..8] = e2 * e1
+    push(62, [1, o2 + 4, 5, 4]); push(15, [1, o2 + 3, 5, 1]); push(17, [1, 1, 4])          # e1 = h1 + beta2 h2 + e4
+    push(63, [5, o2 + 3, 1, n, 5, 4]); push(15, [5, o2 + 4, 5, 5]); push(17, [5, 5, 4])    # e5 = h2 + beta2 h1' + e4
+    push(98, [oT + 9, STT, 1, 5])                         # tmpExp[9..11] = e1 * e5
     return np.array(ops, dtype=np.uint64), np.array(args, dtype=np.uint64)
 
 
 def witness(n):
-    out = np.empty((n, 4), dtype=np.uint64)
+    out = np.empty((n, 5), dtype=np.uint64)
     a = b = 1
     for i in range(n):
         out[i, 0], out[i, 1] = a, b
@@ -161,13 +212,18 @@ def witness(n):
     rng = np.random.default_rng(n)
     out[:, 2] = glo.rand_fe(rng, (n,))
     out[:, 3] = out[rng.permutation(n), 2]            # d: a permutation of c
+    idx = rng.integers(0, n, size=n)
+    idx[: n // 3] = idx[0]                            # (one row of the table takes a third of the lookups)
+    out[:, 4] = constants(n)[idx, 2]                  # f: rows of the table T
     return out
 
 
 def constants(n):
-    c = np.zeros((n, 2), dtype=np.uint64)
+    c = np.zeros((n, 3), dtype=np.uint64)
     c[0, 0] = 1
     c[n - 1, 1] = 1
+    i = np.arange(n, dtype=np.uint64)
+    c[:, 2] = (i * i) % np.uint64(97) + (i >> np.uint64(3)) * np.uint64(1000)   # the table T: repeated values, adjacent and not
     return c
 
 
@@ -190,54 +246,68 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     steps = fri_steps(nbits_ext)
     # constant polynomials: extended and committed once (the verification key is their root)
     d_const_n = ctx.to_device(constants(N))
-    const_2ns, const_nodes = ctx.empty(NE * 2), ctx.empty((2 * NE - 1) * 4)
-    ctx.lde(const_2ns, d_const_n, NE, N, 2)
-    ctx.merkle_build(const_nodes, const_2ns, 2, NE)
-    area = ctx.empty(NE * (4 + 3 + 3 + 6))               # cm1_2ns | cm2_2ns | cm3_2ns | cm4_2ns, one polynomial area
-    cm1, cm2, cm3, cm4 = area[:NE * 4], area[NE * 4:NE * 7], area[NE * 7:NE * 10], area[NE * 10:]
+    NC = 3
+    const_2ns, const_nodes = ctx.empty(NE * NC), ctx.empty((2 * NE - 1) * 4)
+    ctx.lde(const_2ns, d_const_n, NE, N, NC)
+    ctx.merkle_build(const_nodes, const_2ns, NC, NE)
+    area = ctx.empty(NE * (5 + 5 + 6 + 6))               # cm1_2ns | cm2_2ns | cm3_2ns | cm4_2ns, one polynomial area
+    cm1, cm2, cm3, cm4 = area[:NE * 5], area[NE * 5:NE * 10], area[NE * 10:NE * 16], area[NE * 16:]
     nodes1, nodes2, nodes3, nodes4 = (ctx.empty((2 * NE - 1) * 4) for _ in range(4))
-    base = ctx.zeros(N * (4 + 3 + 3 + 6))                # the base-domain area: cm1_n | cm2_n | cm3_n | tmpExp_n
+    base = ctx.zeros(N * (5 + 5 + 6 + 12))               # the base-domain area: cm1_n | cm2_n | cm3_n | tmpExp_n
     w = witness(N)
     if tamper == "perm":                                 # d is no longer a permutation of c: the grand product does not close
         w[N // 2, 3] = (int(w[N // 2, 3]) + 1) % P
-    base[:N * 4] = ctx.to_device(w).reshape(-1)
+    if tamper == "lookup":                               # a value the table does not hold
+        w[N // 2, 4] = 5
+    base[:N * 5] = ctx.to_device(w).reshape(-1)
+    zero_pub = np.zeros(1, dtype=np.uint64)
     tr = Transcript(ctx)
     chal = np.zeros(7 * 3, dtype=np.uint64)
     # ---- step 1: commit the witness
-    ctx.lde(cm1, base[:N * 4], NE, N, 4)
-    ctx.merkle_build(nodes1, cm1, 4, NE)
+    ctx.lde(cm1, base[:N * 5], NE, N, 5)
+    ctx.merkle_build(nodes1, cm1, 5, NE)
     root1 = ctx.to_host(nodes1[-4:])
     tr.put(root1)
     chal[3:6] = tr.get_field()                           # gamma
     # ---- step 2: the stage-2 column from a base-domain program (compiled kernels), extended from device memory, committed
     opsb, argsb = stage2_program(N)
-    progb = mi_stark.ChelpersProgram(ctx, opsb, argsb, sections=BASE_SECTIONS(N), n_const=2, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP2PREV)
+    progb = mi_stark.ChelpersProgram(ctx, opsb, argsb, sections=BASE_SECTIONS(N), n_const=NC, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP2PREV)
     progb.build_native(cache_dir=cache_dir)
     x_n = ctx.empty(N)
     ctx.geom_seq(x_n, N, 1, L.glo_w(nbits))
-    progb.run_base(base, d_const_n, 2, chal, np.zeros(1, dtype=np.uint64), x_n, 1, 0, N)
-    ctx.lde(cm2, base[N * 4:], NE, N, 3)
-    ctx.merkle_build(nodes2, cm2, 3, NE)
+    progb.run_base(base, d_const_n, NC, chal, zero_pub, x_n, 1, 0, N)
+    # the lookup's sorted columns (starks.cpp:92-128): h1, h2 = columns 3, 4 of cm2_n from f = column 4 of cm1_n and T = constant 2
+    ctx.calculate_h1h2(base[N * 5 + 3:], 5, base[N * 5 + 4:], 5, base[4:], 5, d_const_n.reshape(-1)[2:], NC, 1, N)
+    if tamper == "h1h2":                                 # two neighbours of the sorted sequence swapped
+        hb = ctx.to_host(base[N * 5:N * 10]).reshape(N, 5)
+        k = next(i for i in range(N) if hb[i, 3] != hb[i, 4])
+        hb[k, 3], hb[k, 4] = hb[k, 4], hb[k, 3]
+        base[N * 5:N * 10] = ctx.to_device(hb.reshape(-1))
+    ctx.lde(cm2, base[N * 5:], NE, N, 5)
+    ctx.merkle_build(nodes2, cm2, 5, NE)
     root2 = ctx.to_host(nodes2[-4:])
     tr.put(root2)
     chal[6:9] = tr.get_field()                           # beta
+    chal[9:12] = tr.get_field()                          # gamma2
+    chal[12:15] = tr.get_field()                         # beta2
     # ---- step 3: numerators / denominators from a base-domain program, the grand product on the device, extended, committed
     opsc, argsc = stage3_program(N)
-    progc = mi_stark.ChelpersProgram(ctx, opsc, argsc, sections=BASE_SECTIONS(N), n_const=2, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP3PREV)
+    progc = mi_stark.ChelpersProgram(ctx, opsc, argsc, sections=BASE_SECTIONS(N), n_const=NC, nrows_ext=N, step=mi_stark.MI_CHELPERS_STEP3PREV)
     progc.build_native(cache_dir=cache_dir)
-    progc.run_base(base, d_const_n, 2, chal, np.zeros(1, dtype=np.uint64), x_n, 1, 0, N)
-    closes = ctx.calculate_z(base[N * 7:], 3, base[N * 10:], 6, base[N * 10 + 3:], 6, N)
-    assert closes == (tamper != "perm")                  # (the reference zkasserts this; a cheating prover goes on)
-    ctx.lde(cm3, base[N * 7:], NE, N, 3)
-    ctx.merkle_build(nodes3, cm3, 3, NE)
+    progc.run_base(base, d_const_n, NC, chal, zero_pub, x_n, 1, 0, N)
+    closes = ctx.calculate_z(base[N * 10:], 6, base[N * 16:], 12, base[N * 16 + 3:], 12, N)
+    closes2 = ctx.calculate_z(base[N * 10 + 3:], 6, base[N * 16 + 6:], 12, base[N * 16 + 9:], 12, N)
+    assert closes == (tamper != "perm") and closes2 == (tamper != "h1h2")   # (the reference zkasserts this; a cheating prover goes on)
+    ctx.lde(cm3, base[N * 10:], NE, N, 6)
+    ctx.merkle_build(nodes3, cm3, 6, NE)
     root3 = ctx.to_host(nodes3[-4:])
     tr.put(root3)
     vc = tr.get_field()
     # ---- step 4: constraint polynomial q = C / Z_H on the extended domain, split, committed
     ops42, args42 = step42ns_program(NE, 2)
-    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 4, NE), (4 * NE, 3, NE), (7 * NE, 3, NE)], n_const=2, nrows_ext=NE)
+    prog42 = mi_stark.ChelpersProgram(ctx, ops42, args42, sections=[(0, 5, NE), (5 * NE, 5, NE), (10 * NE, 6, NE)], n_const=NC, nrows_ext=NE)
     ops52, args52 = step52ns_program(NE)
-    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 4, NE), (4 * NE, 3, NE), (7 * NE, 3, NE), (10 * NE, 6, NE)], n_const=2,
+    prog52 = mi_stark.ChelpersProgram(ctx, ops52, args52, sections=[(0, 5, NE), (5 * NE, 5, NE), (10 * NE, 6, NE), (16 * NE, 6, NE)], n_const=NC,
                                       nrows_ext=NE, step=52)
     if native:
         prog42.build_native(cache_dir=cache_dir)
@@ -247,7 +317,7 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     zh = ctx.zhinv(nbits, nbits_ext)
     q_2ns, qq1, qq2 = ctx.empty(NE * 3), ctx.empty(NE * 3), ctx.empty(NE * 6)
     chal[0:3] = vc
-    prog42.run(area, const_2ns, 2, chal, np.zeros(1, dtype=np.uint64), x_2ns, 1, zh, q_2ns, 0, NE)
+    prog42.run(area, const_2ns, NC, chal, zero_pub, x_2ns, 1, zh, q_2ns, 0, NE)
     ctx.ntt(qq1, q_2ns, NE, 3, inverse=True)
     ctx.q_split(qq2, qq1, N, NE, 2)
     ctx.ntt(cm4, qq2, NE, 6)
@@ -265,9 +335,10 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     ctx.geom_seq3(lpev, N, wxis)
     ctx.ntt(lev, lev, N, 3, inverse=True)
     ctx.ntt(lpev, lpev, N, 3, inverse=True)
-    pols = [(cm1, 0, 1, 4), (cm1, 1, 1, 4), (cm1, 0, 1, 4), (cm1, 1, 1, 4), (const_2ns, 0, 1, 2), (const_2ns, 1, 1, 2), (cm4, 0, 3, 6), (cm4, 3, 3, 6),
-            (cm2, 0, 3, 3), (cm1, 2, 1, 4), (cm1, 3, 1, 4), (cm3, 0, 3, 3), (cm3, 0, 3, 3)]
-    prime = [0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+    pols = [(cm1, 0, 1, 5), (cm1, 1, 1, 5), (cm1, 0, 1, 5), (cm1, 1, 1, 5), (const_2ns, 0, 1, NC), (const_2ns, 1, 1, NC), (cm4, 0, 3, 6), (cm4, 3, 3, 6),
+            (cm2, 0, 3, 5), (cm1, 2, 1, 5), (cm1, 3, 1, 5), (cm3, 0, 3, 6), (cm3, 0, 3, 6),
+            (cm1, 4, 1, 5), (const_2ns, 2, 1, NC), (const_2ns, 2, 1, NC), (cm2, 3, 1, 5), (cm2, 4, 1, 5), (cm2, 3, 1, 5), (cm3, 3, 3, 6), (cm3, 3, 3, 6)]
+    prime = [0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1,   0, 0, 1, 0, 0, 1, 0, 1]
     d_evals = ctx.empty(len(pols) * 3)
     ctx.evmap(d_evals, pols, prime, lev, lpev, N, 1)
     evals = ctx.to_host(d_evals)
@@ -279,7 +350,7 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     xd, xdw, f_2ns = ctx.empty(NE * 3), ctx.empty(NE * 3), ctx.empty(NE * 3)
     ctx.x_div_x_sub(xd, x_2ns, NE, xi)
     ctx.x_div_x_sub(xdw, x_2ns, NE, wxi)
-    prog52.run52(area, const_2ns, 2, chal, evals, xd, xdw, f_2ns, 0, NE)
+    prog52.run52(area, const_2ns, NC, chal, evals, xd, xdw, f_2ns, 0, NE)
     if tamper == "f":                                   # a value that is not on the low-degree polynomial
         h = ctx.to_host(f_2ns)
         h[3 * 5] ^= np.uint64(1)
@@ -316,8 +387,8 @@ def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
         return ctx.to_host(buf).reshape(len(idx), -1)
     proof = {"nbits": nbits, "root1": root1, "root2": root2, "root3": root3, "root4": root4, "evals": evals, "fri_roots": fri_roots,
              "final_pol": final_pol,
-             "s0": {"cm1": open_tree(nodes1, cm1, NE, 4, ys), "cm2": open_tree(nodes2, cm2, NE, 3, ys), "cm3": open_tree(nodes3, cm3, NE, 3, ys),
-                    "cm4": open_tree(nodes4, cm4, NE, 6, ys), "const": open_tree(const_nodes, const_2ns, NE, 2, ys)},
+             "s0": {"cm1": open_tree(nodes1, cm1, NE, 5, ys), "cm2": open_tree(nodes2, cm2, NE, 5, ys), "cm3": open_tree(nodes3, cm3, NE, 6, ys),
+                    "cm4": open_tree(nodes4, cm4, NE, 6, ys), "const": open_tree(const_nodes, const_2ns, NE, NC, ys)},
              "fri": {}, "const_root": ctx.to_host(const_nodes[-4:])}
     y = ys.copy()
     for si in range(1, len(steps)):
@@ -351,6 +422,8 @@ def verify(proof, const_root, n_queries=12):
     gamma = e3(tr.get_field())
     tr.put(proof["root2"])
     beta = e3(tr.get_field())
+    gamma2 = e3(tr.get_field())
+    beta2 = e3(tr.get_field())
     tr.put(proof["root3"])
     vc = e3(tr.get_field())
     tr.put(proof["root4"])
@@ -368,7 +441,7 @@ def verify(proof, const_root, n_queries=12):
             tr.put(proof["final_pol"])
     ys = tr.get_permutations(n_queries, steps[0])
     E = lambda k: e3(ev[3 * k:3 * k + 3])
-    # ---- constraint identity at xi: Horner_vc(C1 .. C7) == Q(xi) * (xi^N - 1)
+    # ---- constraint identity at xi: Horner_vc(C1 .. C9) == Q(xi) * (xi^N - 1)
     one = [1, 0, 0]
     not_last = e3_sub(one, E(EV_LLAST))
     C1 = e3_mul(not_last, e3_sub(E(EV_AW), E(EV_B)))
@@ -379,7 +452,13 @@ def verify(proof, const_root, n_queries=12):
     C6 = e3_sub(e3_mul(E(EV_GPW), e3_add(E(EV_D), beta)), e3_mul(E(EV_GP), e3_add(E(EV_C), beta)))
     C7 = e3_mul(E(EV_L1), e3_sub(E(EV_GP), one))
     C = [0, 0, 0]
-    for Ck in (C1, C2, C3, C4, C5, C6, C7):
+    g1 = e3_add(one, beta2)                                                  # the lookup: p2' den - p2 num, L1 (p2 - 1)
+    gg = e3_mul(gamma2, g1)
+    num = e3_mul(e3_mul(e3_add(E(EV_F), gamma2), g1), e3_add(e3_add(E(EV_T), e3_mul(beta2, E(EV_TW))), gg))
+    den = e3_mul(e3_add(e3_add(E(EV_H1), e3_mul(beta2, E(EV_H2))), gg), e3_add(e3_add(E(EV_H2), e3_mul(beta2, E(EV_H1W))), gg))
+    C8 = e3_sub(e3_mul(E(EV_P2W), den), e3_mul(E(EV_P2), num))
+    C9 = e3_mul(E(EV_L1), e3_sub(E(EV_P2), one))
+    for Ck in (C1, C2, C3, C4, C5, C6, C7, C8, C9):
         C = e3_add(e3_mul(C, vc), Ck)
     xiN = e3_pow(xi, N)
     Q = e3_add(E(EV_Q0), e3_mul(xiN, E(EV_Q1)))
@@ -395,8 +474,8 @@ def verify(proof, const_root, n_queries=12):
     y = [int(v) for v in ys]
     for q in range(n_queries):
         idx = y[q]
-        for (pr, w, root, name) in ((h1, 4, proof["root1"], "cm1"), (h2, 3, proof["root2"], "cm2"), (h3, 3, proof["root3"], "cm3"),
-                                    (h4, 6, proof["root4"], "cm4"), (hc, 2, const_root, "const")):
+        for (pr, w, root, name) in ((h1, 5, proof["root1"], "cm1"), (h2, 5, proof["root2"], "cm2"), (h3, 6, proof["root3"], "cm3"),
+                                    (h4, 6, proof["root4"], "cm4"), (hc, 3, const_root, "const")):
             if not glo.merkle_verify(root, pr[q][:w], pr[q][w:], idx):
                 return False, "Merkle opening of %s fails at query %d" % (name, q)
         # the FRI polynomial at x = shift * w^idx from the opened rows (the same program, over one row)
@@ -404,9 +483,9 @@ def verify(proof, const_root, n_queries=12):
         def xdiv(z):
             den = np.array([(x - z[0]) % P, (-z[1]) % P, (-z[2]) % P], dtype=np.uint64)
             return np.array(e3_mul([int(v) for v in glo.e3_inv(den)], [x, 0, 0]), dtype=np.uint64)
-        row = np.concatenate([h1[q][:4], h2[q][:3], h3[q][:3], h4[q][:6]]).astype(np.uint64)
+        row = np.concatenate([h1[q][:5], h2[q][:5], h3[q][:6], h4[q][:6]]).astype(np.uint64)
         f = np.zeros(3, dtype=np.uint64)
-        glo.chelpers_step52ns(ops52, args52, row, np.ascontiguousarray(hc[q][:2]), 2, chal, ev, xdiv(xi), xdiv(wxi), f, 0, 1)
+        glo.chelpers_step52ns(ops52, args52, row, np.ascontiguousarray(hc[q][:3]), 3, chal, ev, xdiv(xi), xdiv(wxi), f, 0, 1)
         # level by level: the value must sit in the next group, the group must fold to the value after it
         val, g = f, idx
         for si in range(1, len(steps)):

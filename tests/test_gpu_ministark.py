@@ -15,7 +15,8 @@ import ministark as ms
 
 
 def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
-    """CPU: the witness satisfies the four constraints on every row, and the two programs are well-formed tables."""
+    """CPU: the witness satisfies the row constraints, d is a permutation of c, every f is in the table, and the programs are
+    well-formed tables."""
     import chelpers_programs as cp
     n = 1 << 6
     w, c = ms.witness(n).astype(object), ms.constants(n).astype(object)
@@ -24,6 +25,7 @@ def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
         a, b, an, bn = w[i][0], w[i][1], w[(i + 1) % n][0], w[(i + 1) % n][1]
         l1, ll = c[i][0], c[i][1]
         assert ((1 - ll) * (an - b)) % P == 0 and ((1 - ll) * (bn - a - b)) % P == 0 and (l1 * (a - 1)) % P == 0 and (l1 * (b - 1)) % P == 0
+    assert sorted(w[:, 2]) == sorted(w[:, 3]) and set(w[:, 4]) <= set(c[:, 2]) and len(set(c[:, 2])) < n
     ops, args = ms.step42ns_program(2 * n, 2)
     assert cp.decode(ops, args)[1] == args.size
     ops, args = ms.step52ns_program(2 * n)
@@ -51,6 +53,7 @@ def test_a_proof_from_the_device_path_verifies(native, nbits, lin, tmp_path, mon
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tamper,expect", [("eval", "constraint identity"), ("opening", "Merkle opening of cm1"), ("stage2", "Merkle opening of cm2"), ("stage3", "Merkle opening of cm3"), ("perm", "constraint identity"),
+                                           ("h1h2", "constraint identity"),
                                            ("final", "final polynomial"), ("f", "")])
 def test_a_tampered_proof_is_rejected(tamper, expect):
     import mi_stark
@@ -58,4 +61,14 @@ def test_a_tampered_proof_is_rejected(tamper, expect):
     proof = ms.prove(ctx, 10, n_queries=32, tamper=tamper)
     ok, why = ms.verify(proof, proof["const_root"], n_queries=32)
     assert not ok and expect in why, why
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_a_lookup_of_a_value_outside_the_table_stops_the_prover():
+    """Like the reference (polinomial.hpp:321-325, "Number not included"): calculateH1H2 fails, naming the row."""
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    with pytest.raises(mi_stark.MiStarkError, match="number not included: w=512"):
+        ms.prove(ctx, 10, tamper="lookup")
     ctx.close()
