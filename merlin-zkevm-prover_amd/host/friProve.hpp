@@ -20,13 +20,28 @@ public:
     static void prove(FRIProof &fproof, MerkleTreeGL **treesGL, Transcript transcript, Polinomial &friPol, uint64_t polBits, StarkInfo starkInfo,
                       uint64_t nTrees = 5)
     {
+        proveImpl(fproof, treesGL, transcript, &friPol, nullptr, polBits, starkInfo, nTrees);
+    }
+    // the same with the FRI polynomial already in HBM (f_2ns as StarksDevice::step52ns leaves it: 2^polBits x 3, read only): no
+    // upload, and nothing is written back but the proof
+    static void prove(FRIProof &fproof, MerkleTreeGL **treesGL, Transcript transcript, const uint64_t *d_friPol, uint64_t polBits, StarkInfo starkInfo,
+                      uint64_t nTrees = 5)
+    {
+        proveImpl(fproof, treesGL, transcript, nullptr, d_friPol, polBits, starkInfo, nTrees);
+    }
+
+private:
+    static void proveImpl(FRIProof &fproof, MerkleTreeGL **treesGL, Transcript &transcript, Polinomial *friPol, const uint64_t *d_friPol, uint64_t polBits,
+                          StarkInfo &starkInfo, uint64_t nTrees)
+    {
         mi_ctx *c = mi::ctx();
         const std::vector<StepStruct> &steps = starkInfo.starkStruct.steps;
         const uint64_t nBitsExt = polBits;
         uint64_t *d_pol = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8), *d_next = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8);
         uint64_t *d_aux = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8);
         if (!d_pol || !d_next || !d_aux) mi::fail("FRIProve::prove (alloc)");
-        mi::check(mi_copy_h2d(c, d_pol, friPol.address(), (3ULL << polBits) * 8), "FRIProve::prove (h2d)");
+        if (friPol) mi::check(mi_copy_h2d(c, d_pol, friPol->address(), (3ULL << polBits) * 8), "FRIProve::prove (h2d)");
+        else mi::check(mi_copy_2d_dev(c, d_pol, 3, d_friPol, 3, 1ULL << polBits, 3), "FRIProve::prove (device copy)");
         std::vector<MerkleTreeGL *> treesFRIGL(steps.size(), nullptr);
         std::vector<uint64_t *> owned_sources; // device leaves of the step trees, released after the query phase
         uint64_t pol2N = 0;
@@ -59,7 +74,7 @@ public:
                 fproof.proofs.fri.setPol(last.data());
                 // the reference copies every step's folded polynomial over the head of friPol (friProve.cpp:136-140); a
                 // caller can only observe the final state, of which the head -- the last polynomial -- is reproduced
-                std::memcpy(friPol.address(), last.data(), pol2N * 3 * 8);
+                if (friPol) std::memcpy(friPol->address(), last.data(), pol2N * 3 * 8);
             }
             std::swap(d_pol, d_next);
             polBits = curBits;

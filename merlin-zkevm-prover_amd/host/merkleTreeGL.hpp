@@ -18,13 +18,13 @@
 class MerkleTreeGL
 {
     uint64_t *d_source = nullptr, *d_nodes = nullptr; // HBM copies
-    bool d_source_borrowed = false;
+    bool d_source_borrowed = false, d_nodes_borrowed = false;
     void releaseDevice()
     {
         if (d_source && !d_source_borrowed) mi_dev_free(mi::ctx(), d_source);
-        if (d_nodes) mi_dev_free(mi::ctx(), d_nodes);
+        if (d_nodes && !d_nodes_borrowed) mi_dev_free(mi::ctx(), d_nodes);
         d_source = d_nodes = nullptr;
-        d_source_borrowed = false;
+        d_source_borrowed = d_nodes_borrowed = false;
     }
 
 public:
@@ -66,6 +66,13 @@ public:
         releaseDevice();
         d_source = dev_source;
         d_source_borrowed = true;
+    }
+    // a tree that was built in HBM by someone else (StarksDevice): leaves and nodes borrowed, ready for getRoot / getGroupProofs
+    void setDeviceTree(uint64_t *dev_source, uint64_t *dev_nodes)
+    {
+        releaseDevice();
+        d_source = dev_source; d_nodes = dev_nodes;
+        d_source_borrowed = d_nodes_borrowed = true;
     }
     uint64_t *deviceNodes() { return d_nodes; }
     uint64_t *deviceSource() { return d_source; }

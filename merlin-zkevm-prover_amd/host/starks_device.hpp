@@ -11,6 +11,8 @@
 //   starks.cpp:237-248  steps->step42ns_parser_first_avx(params, NExtended, nrowsStepBatch)       -> setStep42nsProgram + step42ns
 //   starks.cpp:350-380  xDivXSubXi / xDivXSubWXi, steps->step52ns_parser_first_avx(params, ...)     -> setStep52nsProgram + step52ns
 //   starks.cpp:261-292  INTT(qq1, q_2ns) / split / NTT(cm4_2ns, qq2) / treesGL[3]->merkelize()    -> commitQ(root)
+//   starks.cpp:300-332  LEv / LpEv, evmap(pAddress, evals, LEv, LpEv)                              -> calculateEvals(evMap, xi, evals)
+//   starks.cpp:393-394  FRIProve::prove(proof, treesGL, transcript, friPol, nBitsExt, starkInfo)   -> friProve(proof, transcript, starkInfo, constTree)
 //   friProve.cpp:219-250 treesGL[t]->getGroupProof(..)                                            -> getGroupProofs(t, ..)
 //
 // and, with enableBaseDomain(), the base-domain half of stages 2 and 3 as well (cm1_n .. cm3_n, tmpExp_n resident: nothing but
@@ -33,6 +35,9 @@
 #include "goldilocks_cubic_extension.hpp"
 #include "merklehash_goldilocks.hpp"
 #include "mi_runtime.hpp"
+#include "merkleTreeGL.hpp"
+#include "transcript.hpp"
+#include "friProve.hpp"
 
 class StarksDevice
 {
@@ -246,6 +251,54 @@ public:
         mi::check(mi_calculate_z_dev(mi::ctx(), d_baseArea + zOff, zStride, d_baseArea + numOff, numStride, d_baseArea + denOff, denStride, N,
                                      &closes), "StarksDevice::calculateZ");
         return closes != 0;
+    }
+    // ---- step 5: evaluations (starks.cpp:300-332).  One entry per starkInfo.evMap element: where the polynomial lives (a section of
+    // the extended area, or the extended constant polynomials), its column, its dimension, and whether it is evaluated at w * xi.
+    struct EvMapEntry { bool isConst; unsigned section; uint64_t column; uint64_t dim; bool prime; };
+    void calculateEvals(const std::vector<EvMapEntry> &evMap, const Goldilocks::Element *xi, Goldilocks::Element *evals /* host, evMap.size() x 3 */)
+    {
+        mi_ctx *c = mi::ctx();
+        Goldilocks::Element sinv = Goldilocks::inv(Goldilocks::shift()), wN = Goldilocks::w(nBits), xis[3], wxis[3];
+        for (int d = 0; d < 3; d++) { xis[d] = xi[d] * sinv; wxis[d] = xi[d] * wN * sinv; } // :314-316
+        uint64_t *lev = alloc(2 * N * 3, "StarksDevice::calculateEvals (LEv)"), *lpev = lev + N * 3;
+        mi::check(mi_geom_seq3_dev(c, lev, N, (const uint64_t *)xis), "StarksDevice::calculateEvals (LEv)");     // :318-322
+        mi::check(mi_geom_seq3_dev(c, lpev, N, (const uint64_t *)wxis), "StarksDevice::calculateEvals (LpEv)");
+        mi::check(mi_ntt_dev(c, lev, 3, lev, 3, N, 3, 1), "StarksDevice::calculateEvals (INTT LEv)");             // :323-324
+        mi::check(mi_ntt_dev(c, lpev, 3, lpev, 3, N, 3, 1), "StarksDevice::calculateEvals (INTT LpEv)");
+        const uint64_t n = evMap.size();
+        std::vector<const uint64_t *> ptr(n);
+        std::vector<uint32_t> dim(n);
+        std::vector<uint64_t> stride(n);
+        std::vector<uint8_t> prime(n);
+        for (uint64_t i = 0; i < n; i++) {
+            const EvMapEntry &e = evMap[i];
+            ptr[i] = e.isConst ? d_const + e.column : section(e.section) + e.column;
+            stride[i] = e.isConst ? nConst : cols[e.section];
+            dim[i] = (uint32_t)e.dim;
+            prime[i] = e.prime ? 1 : 0;
+        }
+        uint64_t *d_evals = alloc(n * 3 + 1, "StarksDevice::calculateEvals (evals)");
+        mi::check(mi_evmap_dev(c, d_evals, n, N, (unsigned)(nBitsExt - nBits), ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev),
+                  "StarksDevice::calculateEvals (evmap)");
+        mi::check(mi_copy_d2h(c, evals, d_evals, n * 3 * 8), "StarksDevice::calculateEvals (d2h)");
+        mi_dev_free(c, d_evals); mi_dev_free(c, lev);
+    }
+    // ---- FRI over the resident f_2ns (starks.cpp:393-394): the four resident trees are lent to FRIProve as MerkleTreeGL views, the
+    // fifth is the caller's constant tree (as treesGL[4] in the reference); transcript by value like there
+    void friProve(FRIProof &proof, Transcript transcript, StarkInfo starkInfo, MerkleTreeGL *constTree)
+    {
+        if (!d_f2ns) mi::fail("StarksDevice::friProve: step52ns has not run");
+        std::vector<MerkleTreeGL *> views;
+        MerkleTreeGL *trees[5] = {nullptr, nullptr, nullptr, nullptr, constTree};
+        for (unsigned t = 0; t < 4; t++) {
+            MerkleTreeGL *v = new MerkleTreeGL();
+            v->height = NExtended; v->width = cols[t];
+            v->setDeviceTree(section(t), d_nodes[t]);
+            trees[t] = v;
+            views.push_back(v);
+        }
+        FRIProve::prove(proof, trees, transcript, d_f2ns, nBitsExt, starkInfo);
+        for (MerkleTreeGL *v : views) delete v;
     }
     // friProve.cpp:219-250: proofs[q] = row idx[q] of tree t (cols[t] values) followed by nBitsExt x 4 siblings
     void getGroupProofs(unsigned t, Goldilocks::Element *proofs, const uint64_t *idx, uint64_t nq)

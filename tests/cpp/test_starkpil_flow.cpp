@@ -179,6 +179,56 @@ int main()
         std::fill(gf.begin(), gf.end(), 0);
         mi::check(mi_copy_d2h(mi::ctx(), gf.data(), d_f, gf.size() * 8), "d2h");
         EXPECT(same(gf.data(), wf.data(), gf.size()), "StarksDevice::step52ns after buildNative (compiled kernels) == oracle interpreter");
+        // step 5, evaluations (starks.cpp:300-332) from the resident sections
+        {
+            std::vector<StarksDevice::EvMapEntry> evMap = {{false, 0, 3, 1, false}, {false, 1, 1, 1, true}, {false, 2, 0, 3, false}, {false, 3, 3, 3, true},
+                                                           {true, 0, 2, 1, false}, {false, 0, 36, 1, true}, {true, 0, 4, 1, true}};
+            std::vector<Goldilocks::Element> ev(evMap.size() * 3);
+            sd.calculateEvals(evMap, xi.data(), ev.data());
+            uint64_t xis_[3], wxis_[3];
+            const uint64_t sinv = glo_inv(49), wN = glo_w((unsigned)nBits);
+            for (int d = 0; d < 3; d++) { xis_[d] = glo_mul(Goldilocks::toU64(xi[d]), sinv); wxis_[d] = glo_mul(glo_mul(Goldilocks::toU64(xi[d]), wN), sinv); }
+            std::vector<uint64_t> l0(N * 3), l1(N * 3), lev(N * 3), lpev(N * 3), wev(evMap.size() * 3);
+            glo_geom_seq3(l0.data(), N, xis_); glo_geom_seq3(l1.data(), N, wxis_);
+            glo_ntt(lev.data(), l0.data(), N, 3, 1); glo_ntt(lpev.data(), l1.data(), N, 3, 1);
+            const uint64_t soff[4] = {o1, o2, o3, o4}, sw[4] = {nCols, c2, 3, 6};
+            std::vector<const uint64_t *> pp; std::vector<uint32_t> pd; std::vector<uint64_t> ps; std::vector<uint8_t> pr;
+            for (auto &e : evMap) {
+                pp.push_back(e.isConst ? (const uint64_t *)cpols.data() + e.column : &area52[soff[e.section] + e.column]);
+                pd.push_back((uint32_t)e.dim); ps.push_back(e.isConst ? nConst : sw[e.section]); pr.push_back(e.prime);
+            }
+            glo_evmap(wev.data(), evMap.size(), N, 1, pp.data(), pd.data(), ps.data(), pr.data(), lev.data(), lpev.data());
+            EXPECT(same(ev.data(), wev.data(), wev.size()), "StarksDevice::calculateEvals (LEv, LpEv, evmap over resident sections) == oracle");
+        }
+        // FRI over the resident f_2ns with the resident trees lent as MerkleTreeGL views == FRIProve::prove over host copies
+        {
+            StarkInfo si;
+            si.starkStruct.nBits = nBits; si.starkStruct.nBitsExt = nBitsExt; si.starkStruct.nQueries = 7;
+            for (uint64_t bts : {13, 8, 4}) si.starkStruct.steps.push_back(StepStruct{bts});
+            Transcript tr;
+            tr.put(r, HASH_SIZE);
+            MerkleTreeGL constTree(NExtended, nConst, cpols.data());
+            constTree.merkelize();
+            FRIProof pa(1ULL << 4, FIELD_EXTENSION, si.starkStruct.steps.size(), 5, 3), pb(1ULL << 4, FIELD_EXTENSION, si.starkStruct.steps.size(), 5, 3);
+            sd.friProve(pa, tr, si, &constTree);
+            // host-side twin: trees from host copies of the same sections (area52), the FRI polynomial from the host copy gf
+            std::vector<std::vector<Goldilocks::Element>> hs(4);
+            MerkleTreeGL *tw[5] = {nullptr, nullptr, nullptr, nullptr, &constTree};
+            const uint64_t soff[4] = {o1, o2, o3, o4}, sw[4] = {nCols, c2, 3, 6};
+            for (int t = 0; t < 4; t++) {
+                hs[t].resize(NExtended * sw[t]);
+                std::memcpy(hs[t].data(), &area52[soff[t]], hs[t].size() * 8);
+                tw[t] = new MerkleTreeGL(NExtended, sw[t], hs[t].data());
+                tw[t]->merkelize();
+            }
+            std::vector<Goldilocks::Element> fh(gf.size());
+            std::memcpy(fh.data(), gf.data(), gf.size() * 8);
+            Polinomial friPolH(fh.data(), NExtended, 3, 3, "friPol");
+            FRIProve::prove(pb, tw, tr, friPolH, nBitsExt, si);
+            const std::string ja = pa.proofs.proof2json(), jb = pb.proofs.proof2json();
+            EXPECT(ja == jb && ja.size() > 1000, "StarksDevice::friProve (resident f_2ns, resident trees) == FRIProve::prove over host copies");
+            for (int t = 0; t < 4; t++) delete tw[t];
+        }
     }
 
     // ---- stages 2 and 3 with the base domain resident (starks.cpp:66-221): witness up once; step2prev-numbered program -> compressed
