@@ -99,7 +99,13 @@ __global__ __launch_bounds__(256) void k_h1h2_insert(uint32_t *__restrict__ tabl
         h = (h + 1) & mask;
     }
     // (the loop is divergent; the merge below runs with the whole wave converged again)
-    wave_merge<true>(found, h, i, [&](uint32_t slot, uint32_t row) { if (table[slot] < row) atomicMax(&table[slot], row); });
+    // The plain read only saves atomics: the vector L1 is not coherent within a launch, so it may return an older value -- a smaller
+    // row (the atomic then runs, harmlessly) or still EMPTY although the compare-and-swap above has seen the slot taken (EMPTY is the
+    // largest 32-bit value: it must not be mistaken for "already larger").
+    wave_merge<true>(found, h, i, [&](uint32_t slot, uint32_t row) {
+        const uint32_t seen = table[slot];
+        if (seen == EMPTY || seen < row) atomicMax(&table[slot], row);
+    });
 }
 
 template <int DIM>
