@@ -239,3 +239,11 @@ def test_full_size_properties(ctx):
     for k in range(rows.size):
         num, den, z0, z1 = a[0][k][0:3], a[0][k][3:6], a[0][k][6:9], a[1][k][6:9]
         assert e3_mul(z1, den) == e3_mul(z0, num), rows[k]
+
+
+@pytest.mark.gpu
+def test_zero_rows_are_a_no_op(ctx):
+    d = ctx.to_device(np.arange(12, dtype=np.uint64))
+    ctx.calculate_h1h2(d[2:], 4, d[3:], 4, d[1:], 4, d, 4, 1, 0)
+    assert ctx.calculate_z(d[6:], 9, d, 9, d[3:], 9, 0) is True
+    assert np.array_equal(ctx.to_host(d), np.arange(12, dtype=np.uint64))

@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, "merlin-zkevm-prover_amd"); sys.path.insert(0, "tests")
+"""Times mi_calculate_h1h2_dev and mi_calculate_z_dev at 2^23 rows (the zkEVM's N) on random and run-heavy inputs."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "merlin-zkevm-prover_amd"))
 import torch, mi_stark
 ctx = mi_stark.Context(0)
 n = 1 << 23
