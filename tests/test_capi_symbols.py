@@ -74,3 +74,11 @@ def test_device_register_dft_on_host_matches_oracle(log_size):
         if inverse:                                         # dft_reg is unscaled
             want = np.array([int(v) * n % P for v in want], dtype=np.uint64)
         assert np.array_equal(got, want)
+
+
+def test_header_is_plain_c():
+    """The drop-in boundary is a C ABI: include/mi_stark.h must compile as C99 (what cgo / JNI / ctypes-style bindings consume)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                           os.path.join(root, "include", "mi_stark.h")])
