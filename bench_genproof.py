@@ -102,6 +102,9 @@ def arg_parser():
     ap.add_argument("--chelpers-batch-rows", type=int, default=0, help="native backend: rows per tile-major operand copy (0 = about 8 GiB worth)")
     ap.add_argument("--chelpers-backend", choices=("native", "interpreter"), default="native",
                     help="native: the programs compiled to gfx950 kernels (chelpers_native.hip); interpreter: the SIMT interpreter (chelpers.hip)")
+    ap.add_argument("--fri-detail", action="store_true", help="synchronise and time every part of the FRI phase (adds its parts to the JSON)")
+    ap.add_argument("--n-lookups", type=int, default=21, help="plookups of stage 2 (h1 / h2 of dimension 3: 128 columns of cm2_n / 6)")
+    ap.add_argument("--n-products", type=int, default=40, help="grand products of stage 3 (plookups + permutations + connections)")
     return ap
 
 
@@ -196,6 +199,19 @@ def main():
     # resident prover's buffers have been long before its second proof
     pols_area.zero_()
     big.zero_()
+    # stage 2 / 3 host routines of the reference, on the device: one lookup's f, t, h1, h2 (dimension 3) and one product's num, den, z,
+    # base domain; the same two small areas serve every lookup / product of the flow
+    g = torch.Generator(device=ctx.device)
+    g.manual_seed(7)
+    lk = torch.randint(0, 1 << 62, (N * 12,), generator=g, device=ctx.device, dtype=torch.int64)
+    lkv = lk.view(N, 12)
+    lkv[:, 0:3] = lkv[(torch.arange(N, device=ctx.device) >> 4) << 4][:, 0:3]                 # t: runs of 16 equal rows (a padded table)
+    lkv[:, 3:6] = lkv[torch.randint(0, N, (N,), generator=g, device=ctx.device)][:, 0:3]      # f: rows of t
+    zq = torch.randint(0, 1 << 62, (N * 9,), generator=g, device=ctx.device, dtype=torch.int64)
+    # FRI: the folded polynomials' ping-pong buffers, every step tree's transposed leaves and nodes
+    fri_nxt, fri_spare = ctx.zeros(NE * 3), ctx.zeros(NE * 3)
+    fri_src = [ctx.zeros((1 << cur) * 3) for cur in steps[:-1]]
+    fri_nodes = [ctx.zeros((2 * (1 << nb) - 1) * 4) for nb in steps[1:]]
     torch.cuda.synchronize()
     # warm-up, untimed: NTT plans (twiddle tables) of both domain sizes and the Poseidon constants, as a resident prover has them
     ctx.lde(pols_area[:NE], trace[:N], NE, N, 1)
@@ -204,11 +220,23 @@ def main():
     if args.chelpers_backend == "native":
         prog.reserve(NE)
         prog52.reserve(NE)
+    if args.n_lookups:                       # ... and the lookups' device scratch (grow-only, kept by the context)
+        ctx.calculate_h1h2(lk[6:], 12, lk[9:], 12, lk[3:], 12, lk, 12, 3, N)
     torch.cuda.synchronize()
+    # The host side of this flow is Python; a generation-2 collection of the interpreter's garbage collector walks the constraint
+    # programs' argument lists (hundreds of thousands of objects) and was seen to stall one launch by 35-55 ms, in whichever phase the
+    # allocation counter happened to trip it.  Collect now, and keep the collector out of the timed flow.
+    import gc
+    gc.collect()
+    gc.disable()
     t_start = time.perf_counter()
     # ---- steps 1..3
     for i, w in enumerate((w1, w2, w3)):
         ctx.fill_synthetic(trace, N * w, 0x5EED0100 + i)      # stands in for the executor / chelpers output (not timed)
+        if i == 1:      # starks.cpp:92-128 (the transposes around it are not needed: strided views)
+            timed("STARK_STEP_2_CALCULATEH1H2", lambda: [ctx.calculate_h1h2(lk[6:], 12, lk[9:], 12, lk[3:], 12, lk, 12, 3, N) for _ in range(args.n_lookups)])
+        if i == 2:      # starks.cpp:174-187
+            timed("STARK_STEP_3_CALCULATE_Z", lambda: [ctx.calculate_z(zq[6:], 9, zq, 9, zq[3:], 9, N) for _ in range(args.n_products)])
         timed(f"STARK_STEP_{i + 1}_LDE", lambda: ctx.lde(ext[i], trace, NE, N, w))
         timed(f"STARK_STEP_{i + 1}_MERKLETREE", lambda: ctx.merkle_build(trees[i], ext[i], w, NE))
         root = ctx.to_host(trees[i][-4:])
@@ -284,28 +312,41 @@ def main():
     pol_h0 = None
     fri_roots, fri_trees, fri_srcs, challenges = [], {}, {}, []
 
+    fri_marks = []
+
+    def mark(name):
+        if args.fri_detail:
+            torch.cuda.synchronize()
+            fri_marks.append((name, time.perf_counter()))
+
     def fri_phase():
         nonlocal pol_h0
-        pol, nxt, aux = f_2ns, ctx.empty(NE * 3), ctx.empty(NE * 3)
+        pol, nxt = f_2ns, fri_nxt
         pol_bits = nbits_ext
+        mark("start")
         for si, cur in enumerate(steps):
             x = tr.get_field()
             challenges.append(x)
+            mark("challenge")
             ctx.fri_fold(nxt, pol, pol_bits, cur, nbits_ext, x)
+            mark("fold%d" % si)
             if si < len(steps) - 1:
                 nb = steps[si + 1]
                 groups, gsz = 1 << nb, (1 << (cur - nb)) * 3
-                src = ctx.empty((1 << cur) * 3)
+                src, nodes = fri_src[si], fri_nodes[si]
                 ctx.fri_transpose(src, nxt, 1 << cur, nb)
-                nodes = ctx.empty((2 * groups - 1) * 4)
+                mark("transpose%d" % si)
                 ctx.merkle_build(nodes, src, gsz, groups)
+                mark("tree%d" % si)
                 root = ctx.to_host(nodes[-4:])
                 tr.put(root)
+                mark("root%d" % si)
                 fri_roots.append(root)
                 fri_trees[si + 1], fri_srcs[si + 1] = nodes, src
             else:
                 tr.put(ctx.to_host(nxt[:(1 << cur) * 3]))
-            pol, nxt = nxt, (pol if pol is not f_2ns else ctx.empty(NE * 3))
+                mark("final")
+            pol, nxt = nxt, (pol if pol is not f_2ns else fri_spare)
             pol_bits = cur
         return pol
     final_pol = timed("STARK_STEP_FRI_FOLD_AND_TREES", fri_phase)
@@ -333,6 +374,7 @@ def main():
     timed("STARK_STEP_FRI_QUERIES", query_phase)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_start
+    gc.enable()
 
     # ---- size-independent checks (oracle = checker only)
     checks = {}
@@ -415,14 +457,37 @@ def main():
                 acc[d] = (acc[d] + int(h_l[k][d]) * int(col[k])) % P
         checks["evmap_spot_check"] = [int(v) for v in h_evals[:3]] == acc
 
+    # stage 2 / 3 routines: h1 u h2 is f u t as a multiset and follows t's order (the table is runs of 16 rows: the run index along
+    # (h1[0], h2[0], h1[1], ...) never decreases); the grand product satisfies its recurrence on sampled rows (oracle arithmetic)
+    if args.n_lookups:
+        key = lambda v: (v[:, 0] * -7046029254386353131 + v[:, 1] * 0x3C6EF372FE94F82B + v[:, 2])     # 64-bit mix of a row (int64 arithmetic wraps)
+        sq = torch.stack([lkv[:, 6:9], lkv[:, 9:12]], dim=1).reshape(2 * N, 3)
+        both = torch.cat([lkv[:, 3:6], lkv[:, 0:3]])
+        ok = torch.equal(torch.sort(key(sq)).values, torch.sort(key(both)).values)
+        tk = key(lkv[::16, 0:3])
+        order = torch.argsort(tk)
+        pos = order[torch.searchsorted(tk[order], key(sq)).clamp(max=tk.numel() - 1)]
+        checks["h1h2_is_f_u_t_sorted_along_t"] = bool(ok) and bool((pos[1:] >= pos[:-1]).all())
+    if args.n_products:
+        rows_z = np.unique(np.concatenate([[0, 1, N - 2], np.random.default_rng(5).integers(0, N - 1, size=64)]))
+        idx = torch.from_numpy(rows_z).to(ctx.device)
+        zv = zq.view(N, 9)
+        r0, r1 = ctx.to_host(zv[idx]), ctx.to_host(zv[idx + 1])
+        ok = [int(v) for v in ctx.to_host(zq[6:9])] == [1, 0, 0]
+        for k in range(rows_z.size):
+            ok = ok and np.array_equal(glo.e3_mul(r1[k][6:9], r0[k][3:6]), glo.e3_mul(r0[k][6:9], r0[k][0:3]))
+        checks["grand_product_recurrence_on_sampled_rows"] = bool(ok)
+
     total_cols = w1 + w2 + w3
     out = {
         "metric": "genproof_shaped_device_phases_wall_time", "value": wall, "unit": "s", "higher_is_better": False,
         "n_gpus": 1, "data": "synthetic", "dtype": "u64 (Goldilocks)",
         "config": {"workload": "Starks::genProof-shaped pass (BASELINE config 4 substitute; step42ns and step52ns by the chelpers interpreter on synthetic programs of the real size, the witness-side chelpers outputs replaced by synthetic fills)",
                    "rows": N, "rows_ext": NE, "committed_widths": [w1, w2, w3, qdim * qdeg], "n_evals": len(pols),
-                   "fri_steps_bits": steps, "n_queries": args.n_queries},
+                   "fri_steps_bits": steps, "n_queries": args.n_queries,
+                   "stage2_lookups": args.n_lookups, "stage3_grand_products": args.n_products},
         "field_elements_per_s_lde_merkle_fri": N * total_cols / sum(phases.values()) * 1e3,
+        "fri_detail_ms": [(n, round((b - a) * 1e3, 3)) for (n, b), (_, a) in zip(fri_marks[1:], fri_marks[:-1])] or None,
         "phase_ms": phases, "device_phase_ms_total": sum(phases.values()), "checks": checks,
         "chelpers_backend": args.chelpers_backend, "chelpers_translate_and_build_s": t_prog,
         "chelpers_step42ns": {"program": "synthetic, every opcode, sized like the zkEVM program", "translator_stats": chelpers_stats,

@@ -36,6 +36,25 @@ extern "C" int mi_device_count(void)
     std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);       \
     MI_HIP_CHECK(hipSetDevice((ctx)->device))
 
+int mi_scratch(mi_ctx *c, uint64_t bytes, void **p)
+{
+    if (c->scratch_bytes < bytes) {
+        MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // earlier users are done with the old buffer
+        if (c->scratch) MI_HIP_CHECK(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+        const uint64_t want = (bytes + (1ull << 20) - 1) & ~((1ull << 20) - 1);
+        hipError_t e = hipMalloc((void **)&c->scratch, want);
+        if (e != hipSuccess) {
+            mi_set_error("cannot allocate %llu bytes of device scratch: %s", (unsigned long long)want, hipGetErrorString(e));
+            return MI_ERR_NOMEM;
+        }
+        c->scratch_bytes = want;
+    }
+    *p = c->scratch;
+    return MI_OK;
+}
+
 extern "C" void mi_ctx_destroy(mi_ctx *c);
 
 static int ctx_init(mi_ctx *c, int device)
@@ -48,6 +67,7 @@ static int ctx_init(mi_ctx *c, int device)
     c->stream = nullptr; // the device's default stream until the caller hands one over
     c->own_stream = false;
     MI_HIP_CHECK(hipMalloc((void **)&c->small, 4096));
+    MI_HIP_CHECK(hipHostMalloc((void **)&c->pinned, 4096, hipHostMallocDefault));
     for (int i = 0; i < mi_ctx::N_TIMERS; i++) {
         MI_HIP_CHECK(hipEventCreate(&c->ev_start[i]));
         MI_HIP_CHECK(hipEventCreate(&c->ev_stop[i]));
@@ -87,6 +107,8 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->workspace) (void)hipFree(c->workspace);
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
     if (c->chelpers_stage) (void)hipFree(c->chelpers_stage);
     if (c->chelpers_cst) (void)hipFree(c->chelpers_cst);
@@ -260,10 +282,12 @@ extern "C" int mi_poseidon_hash_full_result(mi_ctx *c, uint64_t out[12], const u
 {
     CTX_OK(c);
     MI_REQUIRE(out && in, "null buffer");
-    MI_HIP_CHECK(hipMemcpyAsync(c->small, in, 96, hipMemcpyHostToDevice, c->stream));
+    memcpy(c->pinned, in, 96);
+    MI_HIP_CHECK(hipMemcpyAsync(c->small, c->pinned, 96, hipMemcpyHostToDevice, c->stream));
     MI_TRY(launch_permute(c, c->small + 16, c->small, 1));
-    MI_HIP_CHECK(hipMemcpyAsync(out, c->small + 16, 96, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipMemcpyAsync(c->pinned + 16, c->small + 16, 96, hipMemcpyDeviceToHost, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->pinned + 16, 96);
     return MI_OK;
 }
 
@@ -302,8 +326,9 @@ extern "C" int mi_poseidon_linear_hash(mi_ctx *c, uint64_t out[4], const uint64_
     MI_TRY(d.alloc(size * 8 + 32));
     if (size) MI_HIP_CHECK(hipMemcpyAsync((char *)d.p + 32, in, size * 8, hipMemcpyHostToDevice, c->stream));
     MI_TRY(launch_linear_hash_rows(c, (u64 *)d.p, (const u64 *)d.p + 4, size, size, 1));
-    MI_HIP_CHECK(hipMemcpyAsync(out, d.p, 32, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipMemcpyAsync(c->pinned, d.p, 32, hipMemcpyDeviceToHost, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->pinned, 32);
     return MI_OK;
 }
 

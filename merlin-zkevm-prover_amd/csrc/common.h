@@ -80,6 +80,14 @@ struct mi_ctx {
     uint64_t workspace_bytes = 0;
     u64 *w256 = nullptr; // w_256^j, j < 256
     u64 *small = nullptr; // 4 KiB device scratch for host-pointer single hashes
+    u64 *pinned = nullptr; // 4 KiB of page-locked host memory: the few words an entry point hands back (a hash, a flag) are copied
+                           // through it -- pageable async copies go through the runtime's staging pool, whose housekeeping after a
+                           // few dozen of them stalled a later launch by ~40 ms (seen in bench_genproof.py's FRI phase)
+    // grow-only device scratch of the entry points that need a few hundred MB per call (plookup tables, evaluation partials): kept
+    // for the life of the context -- memory that goes back to the driver, also through the stream-ordered pool, is wiped in the
+    // background and slows down whatever runs next ("released and fresh device memory")
+    char *scratch = nullptr;
+    uint64_t scratch_bytes = 0;
     std::map<uint32_t, NttPlan> plans;
     std::vector<void *> owned; // tables to free
     static constexpr int N_TIMERS = 64;
@@ -109,6 +117,7 @@ struct mi_ctx {
 };
 
 int mi_ensure_workspace(mi_ctx *ctx, uint64_t bytes);
+int mi_scratch(mi_ctx *ctx, uint64_t bytes, void **p); // *p = ctx->scratch, at least `bytes` long; stream-ordered use only
 int mi_get_plan(mi_ctx *ctx, uint32_t log_n, NttPlan **plan);
 int mi_make_pow_table(mi_ctx *ctx, PowTable *t, uint64_t count_log, u64 s0, u64 g);
 

@@ -226,7 +226,7 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned
     const uint64_t rows_per_slice = (n + n_slices - 1) / n_slices;
     const uint64_t desc_bytes = n_evals * sizeof(EvDesc), part_bytes = (uint64_t)n_slices * n_evals * 3 * 8;
     char *scratch = nullptr;
-    MI_HIP_CHECK(hipMallocAsync((void **)&scratch, desc_bytes + part_bytes + 64, ctx->stream));
+    MI_TRY(mi_scratch(ctx, desc_bytes + part_bytes + 64, (void **)&scratch));
     EvDesc *ddesc = (EvDesc *)scratch;
     u64 *partial = (u64 *)(scratch + ((desc_bytes + 63) & ~63ull));
     MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -236,7 +236,6 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned
                        (uint32_t)ext_bits, rows_per_slice, lev, lpev);
     hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, partial, ddesc, (uint32_t)n_evals, n_slices);
     MI_HIP_CHECK(hipGetLastError());
-    MI_HIP_CHECK(hipFreeAsync(scratch, ctx->stream));
     return MI_OK;
 }
 

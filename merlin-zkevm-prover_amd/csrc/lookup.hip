@@ -299,7 +299,7 @@ int h1h2_impl(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uint64_t h2_str
     const uint32_t nb_scan = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK, nb = (n + 255) / 256;
     const uint64_t words = (uint64_t)slots + 2 * (uint64_t)n + nb_scan + 4;
     uint32_t *scratch = nullptr;
-    MI_HIP_CHECK(hipMallocAsync((void **)&scratch, words * 4, ctx->stream));
+    MI_TRY(mi_scratch(ctx, words * 4, (void **)&scratch));
     uint32_t *table = scratch, *counter = table + slots, *start = counter + n, *sums = start + n;
     unsigned long long *bad = (unsigned long long *)(scratch + ((words - 2) & ~1ull));
     hipLaunchKernelGGL(k_fill_u32, dim3(mi_grid_256(slots)), dim3(256), 0, ctx->stream, table, (uint64_t)slots, EMPTY);
@@ -307,11 +307,10 @@ int h1h2_impl(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uint64_t h2_str
     hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(256), 0, ctx->stream, (uint32_t *)bad, (uint64_t)2, EMPTY);
     hipLaunchKernelGGL(k_h1h2_insert<DIM>, dim3(nb), dim3(256), 0, ctx->stream, table, slots - 1, t, t_stride, n);
     hipLaunchKernelGGL(k_h1h2_count<DIM>, dim3(nb), dim3(256), 0, ctx->stream, counter, table, slots - 1, f, f_stride, t, t_stride, n, bad);
-    unsigned long long bad_host = 0;
-    hipError_t e = hipMemcpyAsync(&bad_host, bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(ctx->pinned, bad, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    const unsigned long long bad_host = ctx->pinned[0];
     if (e != hipSuccess || bad_host != ~0ull) {
-        (void)hipFreeAsync(scratch, ctx->stream);
         if (e != hipSuccess) { mi_set_error("calculateH1H2 failed: %s", hipGetErrorString(e)); return MI_ERR_HIP; }
         mi_set_error("calculateH1H2: number not included: w=%llu", bad_host);
         return MI_ERR_INVALID;
@@ -321,7 +320,6 @@ int h1h2_impl(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uint64_t h2_str
     hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(256), 0, ctx->stream, start, counter, sums, n);
     hipLaunchKernelGGL(k_h1h2_expand<DIM>, dim3(nb), dim3(256), 0, ctx->stream, h1, h1_stride, h2, h2_stride, t, t_stride, start, n);
     MI_HIP_CHECK(hipGetLastError());
-    MI_HIP_CHECK(hipFreeAsync(scratch, ctx->stream));
     return MI_OK;
 }
 
@@ -346,18 +344,17 @@ int launch_calculate_z(mi_ctx *ctx, u64 *z, uint64_t z_stride, const u64 *num, u
     MI_REQUIRE(z_stride >= 3 && num_stride >= 3 && den_stride >= 3, "stride smaller than dim");
     const uint32_t nb = (uint32_t)((n + Z_PER_BLOCK - 1) / Z_PER_BLOCK);
     u64 *prods = nullptr;
-    MI_HIP_CHECK(hipMallocAsync((void **)&prods, ((uint64_t)nb + 1) * 24, ctx->stream));
+    MI_TRY(mi_scratch(ctx, ((uint64_t)nb + 1) * 24, (void **)&prods));
     u64 *total = prods + (uint64_t)nb * 3;
     hipLaunchKernelGGL(k_z_blocks<false>, dim3(nb), dim3(256), 0, ctx->stream, z, z_stride, num, num_stride, den, den_stride, n, prods);
     hipLaunchKernelGGL(k_z_scan_top, dim3(1), dim3(256), 0, ctx->stream, prods, nb, total);
     hipLaunchKernelGGL(k_z_blocks<true>, dim3(nb), dim3(256), 0, ctx->stream, z, z_stride, num, num_stride, den, den_stride, n, prods);
     MI_HIP_CHECK(hipGetLastError());
     if (closes) { // polinomial.hpp:603-606 (a zkassert there): does the product return to one?
-        u64 tot[3];
-        MI_HIP_CHECK(hipMemcpyAsync(tot, total, 24, hipMemcpyDeviceToHost, ctx->stream));
+        const u64 *tot = ctx->pinned;
+        MI_HIP_CHECK(hipMemcpyAsync(ctx->pinned, total, 24, hipMemcpyDeviceToHost, ctx->stream));
         MI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *closes = tot[0] == 1 && tot[1] == 0 && tot[2] == 0;
     }
-    MI_HIP_CHECK(hipFreeAsync(prods, ctx->stream));
     return MI_OK;
 }
