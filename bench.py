@@ -265,6 +265,9 @@ def main():
     root = None
     for _ in range(args.warmup):
         root = lde_merkle_sharded(plan, Ops, dist, trace, bufs, always_exchange=exchange)
+    import gc
+    gc.collect()
+    gc.disable()     # no collector pauses inside the timed region (bench_genproof.py met a 35-55 ms one)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -281,6 +284,7 @@ def main():
         t_lvls += ctx.timer_ms(2)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
