@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--poseidon-variant", type=int, default=2)
     ap.add_argument("--cpu-log-n", type=int, default=18, help="log2 rows of the CPU-baseline sample")
     ap.add_argument("--pcie-steps", type=int, default=2, help="N = 1: steps of the PCIe-inclusive leg (host trace streamed in by mi_lde_merkle_host); 0 = skip")
+    ap.add_argument("--pack-threads", type=int, default=-1,
+                    help="PCIe-inclusive leg: host threads packing column chunks into page-locked staging (0 = strided 2-D copies; "
+                         "-1 = the library's default, min(16, hardware threads))")
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size oracle verification after the timed region (N = 1)")
     ap.add_argument("--ntt-log-b", type=int, default=5)
     ap.add_argument("--lde-fuse", type=int, default=1, help="0 = separate last-INTT / first-NTT passes (A/B only)")
@@ -314,6 +317,8 @@ def main():
             host_trace.copy_(trace)
             torch.cuda.synchronize()
             t_c = time.perf_counter()
+            pack_threads = args.pack_threads if args.pack_threads >= 0 else min(16, os.cpu_count() or 1)     # the library's default
+            ctx.set_host_pack_threads(args.pack_threads)
             ctx.lde_merkle_host(bufs["nodes"], bufs["ext"], host_trace.data_ptr(), n, n_ext, ncols)     # warm-up (staging buffers)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -329,8 +334,12 @@ def main():
                     "host_memory": "page-locked (hipHostMalloc), %.1f GB, allocated in %.1f s; D2H fill %.1f GB/s" % (n * ncols * 8 / 1e9, t_b - t_a, n * ncols * 8 / 1e9 / (t_c - t_b)),
                     "h2d_bytes_per_step": n * ncols * 8, "h2d_floor_ms_at_55GBps": 1e3 * n * ncols * 8 / 55e9,
                     "root_matches": [int(v) for v in root_p] == root_host,
-                    "path": "mi_lde_merkle_host: column chunks of 32, 64, 64 ... columns, H2D of chunk k+1 (two copy streams) || LDE + leaf absorption of chunk k; extension + tree stay in HBM",
-                    "h2d_note": "the chunks are 2-D copies out of the row-major host trace: 49 GB/s at 64 columns against 55 GB/s for whole rows; the bare upload of all chunks takes 0.91 s (profiles/r02_pcie_chunk_sweep.json)"}
+                    "host_pack_threads": pack_threads,
+                    "path": ("mi_lde_merkle_host: 32-column chunks packed by %d host threads into page-locked staging, one contiguous H2D copy each, "
+                             "|| LDE + leaf absorption of the chunk before; extension + tree stay in HBM" % pack_threads) if pack_threads else
+                            "mi_lde_merkle_host: column chunks of 32, 64, 64 ... columns, H2D of chunk k+1 (two copy streams) || LDE + leaf absorption of chunk k; extension + tree stay in HBM",
+                    "h2d_note": "strided 2-D copies out of the row-major host trace run at 39 / 49 / 53 GB/s for 32 / 64 / 128 columns against 57 GB/s contiguous "
+                                "(profiles/r02_pcie_chunk_sweep.json): hence the host-side packing"}
             del host_trace
         except Exception as e:  # a box without enough page-lockable host memory must not lose the headline number
             pcie = {"error": repr(e)}

@@ -2,6 +2,8 @@
 // reference interfaces each one replaces).  No CPU fallback exists: without a HIP device every compute
 // call returns MI_ERR_NO_DEVICE.
 #include "common.h"
+#include <thread>
+#include <emmintrin.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -116,6 +118,10 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     if (c->chelpers_spill) (void)hipFree(c->chelpers_spill);
     if (c->chelpers_lin) (void)hipFree(c->chelpers_lin);
     if (c->stage) (void)hipFree(c->stage);
+    for (int i = 0; i < 3; i++) {
+        if (c->pack_stage[i]) (void)hipHostFree(c->pack_stage[i]);
+        if (c->ev_pack_sent[i]) (void)hipEventDestroy(c->ev_pack_sent[i]);
+    }
     for (int s = 0; s < 2; s++)
         if (c->copy_stream[s]) (void)hipStreamSynchronize(c->copy_stream[s]);
     for (int i = 0; i < 2; i++) {
@@ -386,7 +392,9 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
 // Starks::genProof step 1 (starks.cpp:48-59) with the callers unchanged hands over a HOST trace (p_cm1_n, 44.6 GB) and wants
 // the extended trace and its tree.  Done call by call (extendPol, then merkelize) that is 44.6 GB up, 89 GB down, 89 GB up
 // again.  Here the trace is streamed up in COLUMN CHUNKS on a copy stream while the GPU works on the chunks that have
-// arrived: chunk k+1 uploads (a strided 2-D copy out of the row-major host matrix into a compact staging buffer) while
+// arrived: chunk k+1 uploads (packed by host threads into page-locked staging and sent as one contiguous copy -- or, with
+// mi_set_host_pack_threads(ctx, 0), as a strided 2-D copy out of the row-major host matrix, which the DMA engines move at
+// 39-53 GB/s instead of 57) while
 // chunk k is extended into its columns of the resident extended trace and chunk k-1's columns are absorbed into the
 // running leaf sponges (the streaming form of linear_hash: the capacity is carried in the digest buffer).  The PCIe
 // time (0.78 s at 57 GB/s) and the kernel time (0.77 s) overlap instead of adding; the extended trace and the nodes stay
@@ -406,13 +414,29 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     // 52.7 at 128, 55 for whole rows) -- but nothing can run before the first chunk is up, and a chunk's kernels (0.91 x its
     // upload time) only hide behind the NEXT upload, so wide chunks leave a long tail after the last one.  Measured optimum
     // for the 665-column trace: a 32-column first chunk, then 64 (1.00 s per step against 0.91 s for the bare upload).
+    // With pack_threads > 0 (mi_set_host_pack_threads) a chunk is first packed by host threads into page-locked staging and sent
+    // as ONE contiguous copy at the full rate whatever its width, so the chunks can be narrow (a short head before the first kernel
+    // and a short tail after the last upload): 32 columns each, the remainder split so that the last chunk is the smallest.
+    const int pack_threads = c->pack_threads >= 0 ? c->pack_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const bool packed = pack_threads > 0;
     std::vector<uint64_t> c0s, cws;
-    for (uint64_t c0 = 0, k = 0; c0 < ncols; k++) {
-        uint64_t w = k == 0 ? 32 : k == 1 ? 96 : chunk_cols;
-        w = std::min(std::min(w, chunk_cols), ncols - c0);
-        c0s.push_back(c0);
-        cws.push_back(w);
-        c0 += w;
+    if (packed) {
+        const uint64_t pw = std::min<uint64_t>(32, chunk_cols);
+        for (uint64_t c0 = 0; c0 < ncols;) {
+            uint64_t w = std::min(pw, ncols - c0);
+            if (ncols - c0 > pw && ncols - c0 < 2 * pw) w = ((ncols - c0 + 1) / 2 + 7) & ~7ull; // two near-equal last chunks
+            c0s.push_back(c0);
+            cws.push_back(w);
+            c0 += w;
+        }
+    } else {
+        for (uint64_t c0 = 0, k = 0; c0 < ncols; k++) {
+            uint64_t w = k == 0 ? 32 : k == 1 ? 96 : chunk_cols;
+            w = std::min(std::min(w, chunk_cols), ncols - c0);
+            c0s.push_back(c0);
+            cws.push_back(w);
+            c0 += w;
+        }
     }
     const uint64_t n_chunks = c0s.size();
     if (!c->copy_stream[0]) {
@@ -440,7 +464,57 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     // the copy streams must not overtake work already queued on the compute stream that still reads the staging buffers
     MI_HIP_CHECK(hipEventRecord(c->ev_consumed[0], c->stream));
     MI_HIP_CHECK(hipEventRecord(c->ev_consumed[1], c->stream));
+    if (packed) {
+        const uint64_t need = n * std::min<uint64_t>(32, chunk_cols) * 8;
+        if (c->pack_stage_bytes < need) {
+            MI_HIP_CHECK(hipStreamSynchronize(c->copy_stream[0]));
+            for (int i = 0; i < 3; i++) {
+                if (c->pack_stage[i]) MI_HIP_CHECK(hipHostFree(c->pack_stage[i]));
+                c->pack_stage[i] = nullptr;
+                MI_HIP_CHECK(hipHostMalloc((void **)&c->pack_stage[i], need, hipHostMallocDefault));
+                if (!c->ev_pack_sent[i]) MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pack_sent[i], hipEventDisableTiming));
+            }
+            c->pack_stage_bytes = need;
+        }
+    }
+    auto upload_packed = [&](uint64_t k) -> int {
+        const uint64_t cw = cws[k], slot = k % 3;
+        u64 *hs = c->pack_stage[slot];
+        MI_HIP_CHECK(hipEventSynchronize(c->ev_pack_sent[slot])); // the copy that last read this staging buffer (three chunks ago, or in
+                                                                   // an earlier call) is done; a never-recorded event is complete
+        const int T = pack_threads;
+        std::vector<std::thread> th;
+        const uint64_t rows_per = (n + T - 1) / T;
+        for (int t = 0; t < T; t++) {
+            const uint64_t r0 = (uint64_t)t * rows_per, r1 = std::min(n, r0 + rows_per);
+            if (r0 >= r1) break;
+            th.emplace_back([=]() {
+                const uint64_t *src = trace_host + r0 * ncols + c0s[k];
+                u64 *dst = hs + r0 * cw;
+                if (cw % 8 == 0) { // 64-byte groups: unaligned loads, streaming stores (the staging is read next by the DMA engine, not by
+                                   // this core: no write-allocate, no cache pollution)
+                    for (uint64_t r = r0; r < r1; r++, src += ncols, dst += cw)
+                        for (uint64_t j = 0; j < cw; j += 8) {
+                            const __m128i v0 = _mm_loadu_si128((const __m128i *)(src + j)), v1 = _mm_loadu_si128((const __m128i *)(src + j + 2));
+                            const __m128i v2 = _mm_loadu_si128((const __m128i *)(src + j + 4)), v3 = _mm_loadu_si128((const __m128i *)(src + j + 6));
+                            _mm_stream_si128((__m128i *)(dst + j), v0); _mm_stream_si128((__m128i *)(dst + j + 2), v1);
+                            _mm_stream_si128((__m128i *)(dst + j + 4), v2); _mm_stream_si128((__m128i *)(dst + j + 6), v3);
+                        }
+                    _mm_sfence();
+                } else {
+                    for (uint64_t r = r0; r < r1; r++, src += ncols, dst += cw) memcpy(dst, src, cw * 8);
+                }
+            });
+        }
+        for (auto &t : th) t.join();
+        MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[0], c->ev_consumed[k & 1], 0)); // the LDE that read this device buffer is done
+        MI_HIP_CHECK(hipMemcpyAsync(st[k & 1], hs, n * cw * 8, hipMemcpyHostToDevice, c->copy_stream[0]));
+        MI_HIP_CHECK(hipEventRecord(c->ev_pack_sent[slot], c->copy_stream[0]));
+        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k & 1][s], c->copy_stream[0]));
+        return MI_OK;
+    };
     auto upload = [&](uint64_t k) -> int { // the chunk's upper and lower rows on two copy streams (two DMA engines)
+        if (packed) return upload_packed(k);
         const uint64_t cw = cws[k], half = n / 2 ? n / 2 : n;
         for (int s = 0; s < 2; s++) {
             const uint64_t r0 = s * half, nr = s == 0 ? half : n - half;
@@ -473,6 +547,14 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
         if (k + 1 < n_chunks) MI_TRY(upload(k + 1));
     }
     return launch_merkle_levels(c, (u64 *)nodes, n_ext);
+}
+
+extern "C" int mi_set_host_pack_threads(mi_ctx *c, int threads)
+{
+    CTX_OK(c);
+    MI_REQUIRE(threads >= -1 && threads <= 256, "thread count out of range");
+    c->pack_threads = threads;
+    return MI_OK;
 }
 
 extern "C" int mi_host_register(mi_ctx *c, void *p, uint64_t bytes)

@@ -439,11 +439,14 @@ def test_lde_column_chunks_and_pitches(ctx):
 
 @pytest.mark.parametrize("n,n_ext,ncols,chunk,pinned", [(1 << 10, 1 << 11, 70, 32, True), (1 << 10, 1 << 11, 70, 8, False), (1 << 12, 1 << 13, 100, 0, True),
                                                      (1 << 9, 1 << 11, 33, 16, True), (1 << 8, 1 << 9, 5, 8, False), (1 << 11, 1 << 12, 64, 32, True)])
-def test_stage_driver_streams_a_host_trace(ctx, n, n_ext, ncols, chunk, pinned):
+@pytest.mark.parametrize("pack", [0, 3])
+def test_stage_driver_streams_a_host_trace(ctx, n, n_ext, ncols, chunk, pinned, pack):
     """mi_lde_merkle_host: host trace in column chunks on a copy stream, LDE + streaming leaf absorption behind it; the
     resident extension and the whole node array equal the oracle's, with pinned and pageable host memory, ragged last chunk,
-    one chunk only, a pitched output, and when called twice in a row (buffers and events are reused)."""
+    one chunk only, a pitched output, and when called twice in a row (buffers and events are reused).  pack: the chunks as strided
+    2-D copies (0) or packed by that many host threads into page-locked staging and sent as contiguous copies."""
     import torch
+    ctx.set_host_pack_threads(pack)
     rng = np.random.default_rng(n + ncols + chunk)
     trace = glo.rand_fe(rng, (n, ncols))
     want_ext = glo.extend_pol(trace, n_ext, n, ncols)
@@ -461,6 +464,7 @@ def test_stage_driver_streams_a_host_trace(ctx, n, n_ext, ncols, chunk, pinned):
         assert np.array_equal(got[:, :ncols], want_ext)
         assert np.all(got[:, ncols:] == 0x5151)
         assert np.array_equal(ctx.to_host(nodes), want_nodes)
+    ctx.set_host_pack_threads(0)
 
 
 def test_config3_shape_at_2pow18_rows_bit_exact():
