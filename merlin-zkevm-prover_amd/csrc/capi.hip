@@ -421,10 +421,19 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     const bool packed = pack_threads > 0;
     std::vector<uint64_t> c0s, cws;
     if (packed) {
-        const uint64_t pw = std::min<uint64_t>(32, chunk_cols);
-        for (uint64_t c0 = 0; c0 < ncols;) {
-            uint64_t w = std::min(pw, ncols - c0);
-            if (ncols - c0 > pw && ncols - c0 < 2 * pw) w = ((ncols - c0 + 1) / 2 + 7) & ~7ull; // two near-equal last chunks
+        // nothing runs before the first chunk is up and only the last chunk's kernels run after the last upload: a narrow first
+        // chunk (8 columns, then 24), 32-column chunks, and a tapering end (... 32, 16, the rest)
+        uint64_t pw = std::min<uint64_t>(32, chunk_cols);
+        if (const char *e = getenv("MI_PACK_COLS")) pw = std::min<uint64_t>((uint64_t)atoi(e) & ~7ull, chunk_cols); // experiments
+        const bool taper = pw >= 32 && ncols > 3 * pw && !getenv("MI_PACK_NO_TAPER");
+        for (uint64_t c0 = 0, k = 0; c0 < ncols; k++) {
+            const uint64_t rem = ncols - c0;
+            uint64_t w = std::min(pw, rem);
+            if (taper) {
+                if (k == 0) w = 8;
+                else if (k == 1) w = 24;
+                else if (rem <= 32 && rem > 16) w = 16;
+            }
             c0s.push_back(c0);
             cws.push_back(w);
             c0 += w;
@@ -465,7 +474,7 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     MI_HIP_CHECK(hipEventRecord(c->ev_consumed[0], c->stream));
     MI_HIP_CHECK(hipEventRecord(c->ev_consumed[1], c->stream));
     if (packed) {
-        const uint64_t need = n * std::min<uint64_t>(32, chunk_cols) * 8;
+        const uint64_t need = n * *std::max_element(cws.begin(), cws.end()) * 8;
         if (c->pack_stage_bytes < need) {
             MI_HIP_CHECK(hipStreamSynchronize(c->copy_stream[0]));
             for (int i = 0; i < 3; i++) {
