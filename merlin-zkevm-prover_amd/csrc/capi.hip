@@ -124,7 +124,7 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     }
     for (int s = 0; s < 2; s++)
         if (c->copy_stream[s]) (void)hipStreamSynchronize(c->copy_stream[s]);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < mi_ctx::N_STAGE; i++) {
         for (int s = 0; s < 2; s++)
             if (c->ev_uploaded[i][s]) (void)hipEventDestroy(c->ev_uploaded[i][s]);
         if (c->ev_consumed[i]) (void)hipEventDestroy(c->ev_consumed[i]);
@@ -450,13 +450,15 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     const uint64_t n_chunks = c0s.size();
     if (!c->copy_stream[0]) {
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream[s], hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < mi_ctx::N_STAGE; i++) {
             for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_uploaded[i][s], hipEventDisableTiming));
             MI_HIP_CHECK(hipEventCreateWithFlags(&c->ev_consumed[i], hipEventDisableTiming));
         }
     }
-    // two compact staging buffers [n x chunk]
-    const uint64_t stage_bytes = 2 * n * chunk_cols * 8;
+    // compact staging buffers [n x chunk]
+    constexpr int NS = mi_ctx::N_STAGE;
+    const uint64_t max_cw = *std::max_element(cws.begin(), cws.end()); // widest chunk of the schedule
+    const uint64_t stage_bytes = NS * n * max_cw * 8;
     if (c->stage_bytes < stage_bytes) {
         MI_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (c->stage) MI_HIP_CHECK(hipFree(c->stage));
@@ -469,12 +471,11 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
         }
         c->stage_bytes = stage_bytes;
     }
-    u64 *const st[2] = {c->stage, c->stage + n * chunk_cols};
+    u64 *const st[NS] = {c->stage, c->stage + n * max_cw, c->stage + 2 * n * max_cw};
     // the copy streams must not overtake work already queued on the compute stream that still reads the staging buffers
-    MI_HIP_CHECK(hipEventRecord(c->ev_consumed[0], c->stream));
-    MI_HIP_CHECK(hipEventRecord(c->ev_consumed[1], c->stream));
+    for (int i = 0; i < NS; i++) MI_HIP_CHECK(hipEventRecord(c->ev_consumed[i], c->stream));
     if (packed) {
-        const uint64_t need = n * *std::max_element(cws.begin(), cws.end()) * 8;
+        const uint64_t need = n * max_cw * 8;
         if (c->pack_stage_bytes < need) {
             MI_HIP_CHECK(hipStreamSynchronize(c->copy_stream[0]));
             for (int i = 0; i < 3; i++) {
@@ -516,10 +517,10 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
             });
         }
         for (auto &t : th) t.join();
-        MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[0], c->ev_consumed[k & 1], 0)); // the LDE that read this device buffer is done
-        MI_HIP_CHECK(hipMemcpyAsync(st[k & 1], hs, n * cw * 8, hipMemcpyHostToDevice, c->copy_stream[0]));
+        MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[0], c->ev_consumed[k % NS], 0)); // the LDE that read this device buffer is done
+        MI_HIP_CHECK(hipMemcpyAsync(st[k % NS], hs, n * cw * 8, hipMemcpyHostToDevice, c->copy_stream[0]));
         MI_HIP_CHECK(hipEventRecord(c->ev_pack_sent[slot], c->copy_stream[0]));
-        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k & 1][s], c->copy_stream[0]));
+        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k % NS][s], c->copy_stream[0]));
         return MI_OK;
     };
     auto upload = [&](uint64_t k) -> int { // the chunk's upper and lower rows on two copy streams (two DMA engines)
@@ -527,11 +528,11 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
         const uint64_t cw = cws[k], half = n / 2 ? n / 2 : n;
         for (int s = 0; s < 2; s++) {
             const uint64_t r0 = s * half, nr = s == 0 ? half : n - half;
-            MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[s], c->ev_consumed[k & 1], 0)); // the LDE that read this buffer is done
+            MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[s], c->ev_consumed[k % NS], 0)); // the LDE that read this buffer is done
             if (nr)
-                MI_HIP_CHECK(hipMemcpy2DAsync(st[k & 1] + r0 * cw, cw * 8, trace_host + r0 * ncols + c0s[k], ncols * 8, cw * 8, nr,
+                MI_HIP_CHECK(hipMemcpy2DAsync(st[k % NS] + r0 * cw, cw * 8, trace_host + r0 * ncols + c0s[k], ncols * 8, cw * 8, nr,
                                               hipMemcpyHostToDevice, c->copy_stream[s]));
-            MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k & 1][s], c->copy_stream[s]));
+            MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k % NS][s], c->copy_stream[s]));
         }
         return MI_OK;
     };
@@ -547,9 +548,9 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     // is left after the last upload is the extension and absorption of the last -- short -- chunk.
     MI_TRY(upload(0));
     for (uint64_t k = 0; k < n_chunks; k++) {
-        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k & 1][s], 0));
-        MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k & 1], cws[k], n_ext, n, cws[k]));
-        MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k & 1], c->stream));
+        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k % NS][s], 0));
+        MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k % NS], cws[k], n_ext, n, cws[k]));
+        MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k % NS], c->stream));
         MI_TRY(absorb(k));
         // enqueued after this chunk's kernels (the copy call may block the host), but its only dependency -- the LDE of chunk
         // k - 1 -- is long done: it starts as soon as chunk k's upload ends and runs beside the kernels above

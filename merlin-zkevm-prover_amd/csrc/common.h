@@ -102,7 +102,8 @@ struct mi_ctx {
     hipStream_t copy_stream[2] = {};
     u64 *stage = nullptr;
     uint64_t stage_bytes = 0;
-    hipEvent_t ev_uploaded[2][2] = {}, ev_consumed[2] = {}; // [staging buffer][copy stream], [staging buffer]
+    static constexpr int N_STAGE = 3; // device staging buffers of the upload: the copy of chunk k + 2 must not wait for the kernels of chunk k
+    hipEvent_t ev_uploaded[N_STAGE][2] = {}, ev_consumed[N_STAGE] = {}; // [staging buffer][copy stream], [staging buffer]
     // ... second form of the upload: host threads pack a column chunk into page-locked staging (1-D), which then moves at the full
     // PCIe rate instead of the 2-D copies' 39-53 GB/s (the default); 0 threads = 2-D copies
     int pack_threads = -1; // -1: min(16, hardware threads)
