@@ -120,7 +120,8 @@ int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *no
 /* mi_lde_merkle_host, how a column chunk crosses PCIe: `threads` host threads pack it out of the row-major host trace into
  * page-locked staging (streaming stores), which then moves as one contiguous copy at the full rate -- a strided 2-D copy of a
  * 32- / 64- / 128-column chunk runs at 39 / 49 / 53 GB/s against 57 -- in 32-column chunks.  -1 (default) = min(16, hardware
- * threads); 0 = strided 2-D copies on two copy streams, no host threads (measured: 1.00 s per zkEVM stage-1 step against 0.87 s). */
+ * threads) when the host has at least 8 of them, else 0; 0 = strided 2-D copies on two copy streams, no host threads
+ * (measured per zkEVM stage-1 step: 0.86 s packed by 12 or more threads, 0.91 s by 8, 1.00 s with 2-D copies). */
 int mi_set_host_pack_threads(mi_ctx *ctx, int threads);
 /* ------------------------------------------------------------------ stage driver (host trace in, resident result out)
  * Starks::genProof step 1 (starks.cpp:48-59: extendPol of p_cm1_n, then treesGL[0]->merkelize()) for a caller that holds
