@@ -495,13 +495,13 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
         u64 *hs = c->pack_stage[slot];
         MI_HIP_CHECK(hipEventSynchronize(c->ev_pack_sent[slot])); // the copy that last read this staging buffer (three chunks ago, or in
                                                                    // an earlier call) is done; a never-recorded event is complete
-        const int T = pack_threads;
+        const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pack_threads, (n * cw * 8) >> 22)); // at least 4 MiB per thread
         std::vector<std::thread> th;
         const uint64_t rows_per = (n + T - 1) / T;
         for (int t = 0; t < T; t++) {
             const uint64_t r0 = (uint64_t)t * rows_per, r1 = std::min(n, r0 + rows_per);
             if (r0 >= r1) break;
-            th.emplace_back([=]() {
+            auto work = [=]() {
                 const uint64_t *src = trace_host + r0 * ncols + c0s[k];
                 u64 *dst = hs + r0 * cw;
                 if (cw % 8 == 0) { // 64-byte groups: unaligned loads, streaming stores (the staging is read next by the DMA engine, not by
@@ -517,7 +517,9 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
                 } else {
                     for (uint64_t r = r0; r < r1; r++, src += ncols, dst += cw) memcpy(dst, src, cw * 8);
                 }
-            });
+            };
+            if (T == 1) work(); // a small chunk: not worth a thread
+            else th.emplace_back(work);
         }
         for (auto &t : th) t.join();
         MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[0], c->ev_consumed[k % NS], 0)); // the LDE that read this device buffer is done

@@ -438,7 +438,8 @@ def test_lde_column_chunks_and_pitches(ctx):
 
 
 @pytest.mark.parametrize("n,n_ext,ncols,chunk,pinned", [(1 << 10, 1 << 11, 70, 32, True), (1 << 10, 1 << 11, 70, 8, False), (1 << 12, 1 << 13, 100, 0, True),
-                                                     (1 << 9, 1 << 11, 33, 16, True), (1 << 8, 1 << 9, 5, 8, False), (1 << 11, 1 << 12, 64, 32, True)])
+                                                     (1 << 9, 1 << 11, 33, 16, True), (1 << 8, 1 << 9, 5, 8, False), (1 << 11, 1 << 12, 64, 32, True),
+                                                     (1 << 16, 1 << 17, 70, 32, False)])   # (16 MiB chunks: the packing really runs on several threads)
 @pytest.mark.parametrize("pack", [0, 3])
 def test_stage_driver_streams_a_host_trace(ctx, n, n_ext, ncols, chunk, pinned, pack):
     """mi_lde_merkle_host: host trace in column chunks on a copy stream, LDE + streaming leaf absorption behind it; the
