@@ -35,6 +35,7 @@ struct NttPass {
     uint32_t log_n, log_K;
     uint32_t apply_scale;
     uint32_t unit_tw; // last pass of an unscaled transform: every inter-pass twiddle is 1, outputs are only canonicalised
+    uint32_t weak_out; // not the last pass: the next pass accepts any encoding of a value, so the store skips the canonical form
     uint32_t tj_log, tcp_log; // TJ = beta rows per tile, TCP = padded columns per tile; TJ*TCP = B, or less when the
                               // transform has fewer than B/TCP beta rows: the surplus lanes of a tile row then own nothing
     uint32_t n_col_tiles;
@@ -261,7 +262,11 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
             for (int kb = 0; kb < RB; kb++) x[kb] = gl::canon(x[kb]);
         } else {
 #pragma unroll
-            for (int kb = 0; kb < RB; kb++) x[kb] = gl::mul(x[kb], t[kb * tstride]);
+            for (int kb = 0; kb < RB; kb++) x[kb] = gl::mul_w(x[kb], t[kb * tstride]);
+            if (!a.weak_out) { // wave-uniform
+#pragma unroll
+                for (int kb = 0; kb < RB; kb++) x[kb] = gl::canon(x[kb]);
+            }
         }
         if (WIDE && RB >= 2) {
             const bool odd = b & 1;
@@ -287,6 +292,7 @@ struct LdeMid {
     u64 *dst;
     uint64_t src_pitch, dst_pitch;
     uint32_t ncols, log_n1, log_n2;
+    uint32_t weak_out; // the NTT has further passes: they accept any encoding, the store skips the canonical form
     uint32_t tj_log, tcp_log, n_col_tiles;
     uint64_t n_tiles;
     const u64 *sc_lo, *sc_hi; // shift^k / N over k < N
@@ -406,7 +412,11 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
         u64 x[T2::RB];
         tile_step_b<LOG_R2, false, LOG_B>(tile, kap, b, x);
 #pragma unroll
-        for (int kb = 0; kb < T2::RB; kb++) x[kb] = gl::mul(x[kb], tw2[((kap + T2::RA * kb) << a.tj_log) + tj]);
+        for (int kb = 0; kb < T2::RB; kb++) x[kb] = gl::mul_w(x[kb], tw2[((kap + T2::RA * kb) << a.tj_log) + tj]);
+        if (!a.weak_out) { // a one-pass NTT: this is the result
+#pragma unroll
+            for (int kb = 0; kb < T2::RB; kb++) x[kb] = gl::canon(x[kb]);
+        }
         const bool odd = b & 1;
         const uint32_t col_e = col & ~1u;
         u64 *q = a.dst + col_e + (((kappa0 + tj) << LOG_R2) + kap) * a.dst_pitch;
@@ -562,6 +572,7 @@ static int run_passes(mi_ctx *ctx, NttPlan *plan, const std::vector<Buf> &bufs, 
         a.tw_lo_bits = plan->tw.lo_bits;
         a.apply_scale = (ps == P - 1 && scale) ? 1 : 0;
         a.unit_tw = (ps == P - 1 && !scale) ? 1 : 0; // ip = 0 in every tile of the last pass: exponent 0
+        a.weak_out = ps == P - 1 ? 0 : 1;
         if (a.apply_scale) {
             a.sc_lo = scale->lo;
             a.sc_hi = scale->hi;
@@ -621,6 +632,7 @@ static int launch_lde_mid(mi_ctx *ctx, NttPlan *p1, NttPlan *p2, const Buf &src,
     a.ncols = (uint32_t)ncols;
     a.log_n1 = L1;
     a.log_n2 = L2;
+    a.weak_out = num_passes(L2) > 1 ? 1 : 0;
     uint32_t tcp_log = 0;
     while ((1u << tcp_log) < a.ncols && tcp_log < 5) tcp_log++;
     uint32_t tj_log = 5 - tcp_log;
