@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--pack-threads", type=int, default=-1,
                     help="PCIe-inclusive leg: host threads packing column chunks into page-locked staging (0 = strided 2-D copies; "
                          "-1 = the library's default, min(16, hardware threads))")
+    ap.add_argument("--pcie-pageable", action="store_true", help="PCIe-inclusive leg: the host trace in pageable memory (as a mapped file would be)")
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size oracle verification after the timed region (N = 1)")
     ap.add_argument("--ntt-log-b", type=int, default=5)
     ap.add_argument("--lde-fuse", type=int, default=1, help="0 = separate last-INTT / first-NTT passes (A/B only)")
@@ -312,7 +313,7 @@ def main():
     if world == 1 and not exchange and args.pcie_steps > 0:
         try:
             t_a = time.perf_counter()
-            host_trace = torch.empty(n * ncols, dtype=torch.int64, pin_memory=True)
+            host_trace = torch.empty(n * ncols, dtype=torch.int64, pin_memory=not args.pcie_pageable)
             t_b = time.perf_counter()
             host_trace.copy_(trace)
             torch.cuda.synchronize()
@@ -331,7 +332,7 @@ def main():
             import ctypes as _ct
             pcie = {"ms_per_step": 1e3 * dt, "value": n * ncols / dt, "unit": "field-elements/s", "steps": args.pcie_steps,
                     "ratio_to_device_resident_step": dt / (elapsed / max(args.steps, 1)),
-                    "host_memory": "page-locked (hipHostMalloc), %.1f GB, allocated in %.1f s; D2H fill %.1f GB/s" % (n * ncols * 8 / 1e9, t_b - t_a, n * ncols * 8 / 1e9 / (t_c - t_b)),
+                    "host_memory": "%s, %.1f GB, allocated in %.1f s; D2H fill %.1f GB/s" % ("pageable" if args.pcie_pageable else "page-locked (hipHostMalloc)", n * ncols * 8 / 1e9, t_b - t_a, n * ncols * 8 / 1e9 / (t_c - t_b)),
                     "h2d_bytes_per_step": n * ncols * 8, "h2d_floor_ms_at_55GBps": 1e3 * n * ncols * 8 / 55e9,
                     "root_matches": [int(v) for v in root_p] == root_host,
                     "host_pack_threads": pack_threads,
