@@ -25,6 +25,15 @@
 #include "common.h"
 #include "ntt_math.h"
 
+// MI_NTT_NO_ARITH: A/B diagnosis build -- the passes move the same bytes through the same LDS round trips and barriers, the
+// field arithmetic (butterflies in ntt_math.h, twiddle multiplies, canonical form) is replaced by an xor that keeps the data flow
+#ifdef MI_NTT_NO_ARITH
+#define NTT_MULW(x, t) ((x) ^ (t))
+#define NTT_CANON(x) (x)
+#else
+#define NTT_MULW(x, t) gl::mul_w((x), (t))
+#define NTT_CANON(x) gl::canon(x)
+#endif
 
 struct NttPass {
     const u64 *src;
@@ -90,7 +99,7 @@ __device__ __forceinline__ void tile_step_a(u64 *tile, const u64 *w256, uint32_t
             for (int ka = 1; ka < T::RA; ka++) {
                 uint32_t idx = (pp * ka) << (8 - LOG_R);
                 if (INV) idx = (256 - idx) & 255;
-                x[ka] = gl::mul_w(x[ka], w256[idx]);
+                x[ka] = NTT_MULW(x[ka], w256[idx]);
             }
 #pragma unroll
             for (int ka = 0; ka < T::RA; ka++) tile[(ka * T::RB + pp) * B + b] = x[ka];
@@ -259,13 +268,13 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
         const uint32_t tstride = (uint32_t)RA << a.tj_log;
         if (a.unit_tw) {
 #pragma unroll
-            for (int kb = 0; kb < RB; kb++) x[kb] = gl::canon(x[kb]);
+            for (int kb = 0; kb < RB; kb++) x[kb] = NTT_CANON(x[kb]);
         } else {
 #pragma unroll
-            for (int kb = 0; kb < RB; kb++) x[kb] = gl::mul_w(x[kb], t[kb * tstride]);
+            for (int kb = 0; kb < RB; kb++) x[kb] = NTT_MULW(x[kb], t[kb * tstride]);
             if (!a.weak_out) { // wave-uniform
 #pragma unroll
-                for (int kb = 0; kb < RB; kb++) x[kb] = gl::canon(x[kb]);
+                for (int kb = 0; kb < RB; kb++) x[kb] = NTT_CANON(x[kb]);
             }
         }
         if (WIDE && RB >= 2) {
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
         if (has_item) {
             tile_step_b<LOG_R1, true, LOG_B>(tile, kap, b, x);
 #pragma unroll
-            for (int kb = 0; kb < T1::RB; kb++) x[kb] = gl::mul_w(x[kb], tw1[((kap + T1::RA * kb) << a.tj_log) + tj]);
+            for (int kb = 0; kb < T1::RB; kb++) x[kb] = NTT_MULW(x[kb], tw1[((kap + T1::RA * kb) << a.tj_log) + tj]);
         }
         __syncthreads(); // every read of the INTT input rows is done
         if (has_item) {
@@ -412,10 +421,10 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
         u64 x[T2::RB];
         tile_step_b<LOG_R2, false, LOG_B>(tile, kap, b, x);
 #pragma unroll
-        for (int kb = 0; kb < T2::RB; kb++) x[kb] = gl::mul_w(x[kb], tw2[((kap + T2::RA * kb) << a.tj_log) + tj]);
+        for (int kb = 0; kb < T2::RB; kb++) x[kb] = NTT_MULW(x[kb], tw2[((kap + T2::RA * kb) << a.tj_log) + tj]);
         if (!a.weak_out) { // a one-pass NTT: this is the result
 #pragma unroll
-            for (int kb = 0; kb < T2::RB; kb++) x[kb] = gl::canon(x[kb]);
+            for (int kb = 0; kb < T2::RB; kb++) x[kb] = NTT_CANON(x[kb]);
         }
         const bool odd = b & 1;
         const uint32_t col_e = col & ~1u;

@@ -58,6 +58,9 @@ template <int Q, bool INV>
 MI_HD void dft_reg(u64 (&x)[1 << Q])
 {
     constexpr int N = 1 << Q;
+#ifdef MI_NTT_NO_ARITH // diagnosis build (profiles/r03_pmc_ntt.txt): every load, LDS round trip and store, no butterflies
+    return;
+#endif
     static_for<0, Q>([&](auto L) {
         constexpr int len = N >> decltype(L)::value;
         constexpr int half = len / 2;
