@@ -56,6 +56,13 @@ int mi_ctx_sync(mi_ctx *ctx);
 /* Scratch HBM the library may allocate lazily for NTT/LDE ping-pong buffers (default 32 GiB,
  * clamped to what the problem needs).  Wide LDEs are processed in column chunks that fit it. */
 int mi_ctx_set_workspace_limit(mi_ctx *ctx, uint64_t bytes);
+/* The `buf` argument of NTT_Goldilocks::extendPol / NTT (starks.cpp:52 lends p_cm2_2ns, :133,214 pBuffer): device scratch the
+ * CALLER owns -- e.g. a section of its polynomial area that is not live yet.  While a buffer is lent (16-byte aligned, >= 1 MiB)
+ * every transform sizes its column chunks to it and allocates nothing; its contents are undefined afterwards.  ptr = NULL
+ * returns to the context's own workspace.  Synchronises the stream. */
+int mi_ctx_lend_workspace(mi_ctx *ctx, void *ptr, uint64_t bytes);
+/* hipMemGetInfo of the context's device (the HBM plan of host/starks.hpp is checked against it) */
+int mi_dev_mem_info(mi_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 const char *mi_last_error(void);
 const char *mi_version(void);
 int mi_device_count(void);
@@ -123,6 +130,7 @@ int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *no
  * threads) when the host has at least 8 of them, else 0; 0 = strided 2-D copies on two copy streams, no host threads
  * (measured per zkEVM stage-1 step: 0.86 s packed by 12 or more threads, 0.91 s by 8, 1.00 s with 2-D copies). */
 int mi_set_host_pack_threads(mi_ctx *ctx, int threads);
+int mi_get_host_pack_threads(mi_ctx *ctx); /* the count in effect (the default resolved against this host's threads) */
 /* ------------------------------------------------------------------ stage driver (host trace in, resident result out)
  * Starks::genProof step 1 (starks.cpp:48-59: extendPol of p_cm1_n, then treesGL[0]->merkelize()) for a caller that holds
  * the trace in HOST memory and wants the extension and the tree to STAY on the device: the n x ncols row-major host trace is
@@ -133,6 +141,10 @@ int mi_set_host_pack_threads(mi_ctx *ctx, int threads);
  * page-locked (mi_host_register once per buffer, or hipHostMalloc). */
 int mi_lde_merkle_host(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, const uint64_t *trace_host,
                        uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
+/* The same, and the uploaded base-domain section stays in HBM as well: base (device, n x ncols at row pitch base_pitch) receives
+ * the trace itself (canonical) -- what the base-domain steps of stages 2 and 3 read (starks.cpp:66-90,150-210 over p_cm1_n). */
+int mi_lde_merkle_host_keep(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base, uint64_t base_pitch,
+                            const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
 int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister: page-lock a host range for DMA */
 int mi_host_unregister(mi_ctx *ctx, void *p);
 
@@ -208,7 +220,8 @@ typedef struct mi_chelpers_prog mi_chelpers_prog;
  * the kernel stages the sections, 64 rows at a time, in column-major order so that its per-row reads are coalesced. */
 typedef struct { uint64_t offset, ncols, nrows; } mi_chelpers_section;
 typedef struct {
-    const uint64_t *pols;       /* device: params.pols, the base every polynomial offset of the program is relative to */
+    uint64_t *pols;             /* device: params.pols, the base every polynomial offset of the program is relative to; the base-domain
+                                 * steps (STEP2PREV / 3PREV / 3) also WRITE their results into it */
     const uint64_t *const_pols; /* device: params.pConstPols2ns, element (col, row) at const_pols[col + row * n_const] */
     uint64_t n_const;           /* pConstPols2ns->numPols() */
     const uint64_t *challenges; /* HOST: params.challenges, n_challenges x 3 */
@@ -227,7 +240,7 @@ typedef struct {
     const uint64_t *xdivw;      /* device: params.xDivXSubWXi, rows x 3 */
     uint64_t *f;                /* device: params.f_2ns, row i at f[3 i .. 3 i + 3) (step52ns output) */
 } mi_chelpers_params;
-/* sections: the n_sections (<= 6) sections of params.pols the program reads; n_const = pConstPols2ns->numPols();
+/* sections: the n_sections (<= 4) sections of params.pols the program reads; n_const = pConstPols2ns->numPols();
  * nrows_ext = rows of the extended domain (the constant polynomials and x_2ns have that many rows). */
 int mi_chelpers_compile(mi_ctx *ctx, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops,
                         const uint64_t *args, uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections,

@@ -106,7 +106,8 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
-    if (c->workspace) (void)hipFree(c->workspace);
+    if (c->workspace_lent) { if (c->own_workspace) (void)hipFree(c->own_workspace); } // the lent buffer is the caller's
+    else if (c->workspace) (void)hipFree(c->workspace);
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -165,9 +166,48 @@ extern "C" int mi_ctx_set_workspace_limit(mi_ctx *c, uint64_t bytes)
     return MI_OK;
 }
 
+// The reference's `buf` argument of extendPol / NTT (starks.cpp:52 lends p_cm2_2ns, :133,214 pBuffer): scratch the CALLER owns.
+// While lent, transforms size their column chunks to it and allocate nothing.
+extern "C" int mi_ctx_lend_workspace(mi_ctx *c, void *ptr, uint64_t bytes)
+{
+    CTX_OK(c);
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // queued transforms still use the current scratch
+    if (c->workspace_lent) {
+        c->workspace = c->own_workspace;
+        c->workspace_bytes = c->own_workspace_bytes;
+        c->workspace_limit = c->own_workspace_limit;
+        c->own_workspace = nullptr;
+        c->workspace_lent = false;
+    }
+    if (!ptr) return MI_OK;
+    MI_REQUIRE(bytes >= (1ull << 20) && ((uintptr_t)ptr & 15) == 0, "a lent workspace must be 16-byte aligned and at least 1 MiB");
+    c->own_workspace = c->workspace;
+    c->own_workspace_bytes = c->workspace_bytes;
+    c->own_workspace_limit = c->workspace_limit;
+    c->workspace = (u64 *)ptr;
+    c->workspace_bytes = c->workspace_limit = bytes;
+    c->workspace_lent = true;
+    return MI_OK;
+}
+
+extern "C" int mi_dev_mem_info(mi_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    CTX_OK(c);
+    size_t f = 0, t = 0;
+    MI_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return MI_OK;
+}
+
 int mi_ensure_workspace(mi_ctx *c, uint64_t bytes)
 {
     if (bytes <= c->workspace_bytes) return MI_OK;
+    if (c->workspace_lent) {
+        mi_set_error("the lent NTT workspace (%llu bytes) is too small: one column chunk of this transform needs %llu",
+                     (unsigned long long)c->workspace_bytes, (unsigned long long)bytes);
+        return MI_ERR_NOMEM;
+    }
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->workspace) MI_HIP_CHECK(hipFree(c->workspace));
     c->workspace = nullptr;
@@ -399,12 +439,24 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
 // running leaf sponges (the streaming form of linear_hash: the capacity is carried in the digest buffer).  The PCIe
 // time (0.78 s at 57 GB/s) and the kernel time (0.77 s) overlap instead of adding; the extended trace and the nodes stay
 // in HBM for the later steps and only the root is read back by the caller.
-extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, const uint64_t *trace_host,
-                                  uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+static int effective_pack_threads(const mi_ctx *c)
 {
-    CTX_OK(c);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return c->pack_threads >= 0 ? c->pack_threads : (hw >= 8 ? (int)std::min(16u, hw) : 0);
+}
+
+extern "C" int mi_get_host_pack_threads(mi_ctx *c)
+{
+    if (!c) return -1;
+    return effective_pack_threads(c);
+}
+
+static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base, uint64_t base_pitch,
+                                const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+{
     if (n == 0 || ncols == 0) return MI_OK;
     MI_REQUIRE(nodes && ext && trace_host, "null buffer");
+    MI_REQUIRE(!base || base_pitch >= ncols, "pitch smaller than ncols");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
     MI_REQUIRE(ext_pitch >= ncols, "pitch smaller than ncols");
     if (chunk_cols == 0) chunk_cols = 64;
@@ -419,15 +471,17 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     // and a short tail after the last upload): 32 columns each, the remainder split so that the last chunk is the smallest.
     // default: up to 16 packing threads; a host with fewer than 8 hardware threads packs slower than the strided 2-D copies run
     // (measured: 6 threads 1.10 s, 8 threads 0.91 s, 2-D copies 1.00 s per zkEVM step)
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int pack_threads = c->pack_threads >= 0 ? c->pack_threads : (hw >= 8 ? (int)std::min(16u, hw) : 0);
+    const int pack_threads = effective_pack_threads(c);
     const bool packed = pack_threads > 0;
     std::vector<uint64_t> c0s, cws;
     if (packed) {
         // nothing runs before the first chunk is up and only the last chunk's kernels run after the last upload: a narrow first
         // chunk (8 columns, then 24), 32-column chunks, and a tapering end (... 32, 16, the rest)
         uint64_t pw = std::min<uint64_t>(32, chunk_cols);
-        if (const char *e = getenv("MI_PACK_COLS")) pw = std::min<uint64_t>((uint64_t)atoi(e) & ~7ull, chunk_cols); // experiments
+        if (const char *e = getenv("MI_PACK_COLS")) { // experiments; anything that is not a multiple of 8 >= 8 is ignored
+            const uint64_t v = (uint64_t)std::max(0, atoi(e)) & ~7ull;
+            if (v >= 8) pw = std::min<uint64_t>(v, chunk_cols);
+        }
         const bool taper = pw >= 32 && ncols > 3 * pw && !getenv("MI_PACK_NO_TAPER");
         for (uint64_t c0 = 0, k = 0; c0 < ncols; k++) {
             const uint64_t rem = ncols - c0;
@@ -555,13 +609,32 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
     for (uint64_t k = 0; k < n_chunks; k++) {
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k % NS][s], 0));
         MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k % NS], cws[k], n_ext, n, cws[k]));
+        if (base) MI_TRY(launch_copy_2d(c, (u64 *)base + c0s[k], base_pitch, st[k % NS], cws[k], n, cws[k])); // the base-domain section stays too
         MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k % NS], c->stream));
         MI_TRY(absorb(k));
         // enqueued after this chunk's kernels (the copy call may block the host), but its only dependency -- the LDE of chunk
         // k - 1 -- is long done: it starts as soon as chunk k's upload ends and runs beside the kernels above
         if (k + 1 < n_chunks) MI_TRY(upload(k + 1));
     }
+    // the strided form reads trace_host from the copy engines: nothing of it may still be queued when the caller gets its trace back
+    if (!packed)
+        for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamSynchronize(c->copy_stream[s]));
     return launch_merkle_levels(c, (u64 *)nodes, n_ext);
+}
+
+extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, const uint64_t *trace_host,
+                                  uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+{
+    CTX_OK(c);
+    return lde_merkle_host_impl(c, nodes, ext, ext_pitch, nullptr, 0, trace_host, n, n_ext, ncols, chunk_cols);
+}
+
+extern "C" int mi_lde_merkle_host_keep(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base, uint64_t base_pitch,
+                                       const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+{
+    CTX_OK(c);
+    MI_REQUIRE(base, "null buffer");
+    return lde_merkle_host_impl(c, nodes, ext, ext_pitch, base, base_pitch, trace_host, n, n_ext, ncols, chunk_cols);
 }
 
 extern "C" int mi_set_host_pack_threads(mi_ctx *c, int threads)

@@ -781,7 +781,9 @@ static int compile_source(const std::string &src, const std::string &cache_dir, 
             code.resize(n > 0 ? (size_t)n : 0);
             const bool ok = n > 0 && fread(code.data(), 1, (size_t)n, f) == (size_t)n;
             fclose(f);
-            if (ok) { N.cache_hits++; return MI_OK; }
+            // a code object is an ELF image; anything else at this path (a truncated or foreign file) is dropped and rebuilt
+            if (ok && n > 64 && memcmp(code.data(), "\x7f" "ELF", 4) == 0) { N.cache_hits++; return MI_OK; }
+            remove(path.c_str());
         }
     }
     if (const char *dump = getenv("MI_CHELPERS_DUMP_SRC")) { // debugging: the generated source, for experiments with hipcc
@@ -1226,8 +1228,17 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     if (N->loaded_device != c->device) {
         MI_REQUIRE(N->loaded_device < 0, "program is loaded on another device");
         for (Chunk &C : N->chunks) {
-            MI_HIP_CHECK(hipModuleLoadData(&C.mod, C.code.data()));
-            MI_HIP_CHECK(hipModuleGetFunction(&C.fn, C.mod, "chelpers_chunk"));
+            hipError_t e = hipModuleLoadData(&C.mod, C.code.data());
+            if (e == hipSuccess) e = hipModuleGetFunction(&C.fn, C.mod, "chelpers_chunk");
+            if (e != hipSuccess) { // leave nothing half-loaded behind: the next run starts from scratch
+                for (Chunk &D : N->chunks) {
+                    if (D.mod) (void)hipModuleUnload(D.mod);
+                    D.mod = nullptr;
+                    D.fn = nullptr;
+                }
+                mi_set_error("mi_chelpers_run_dev: cannot load a compiled kernel (%s); if it came from the code-object cache, clear the cache directory", hipGetErrorString(e));
+                return MI_ERR_HIP;
+            }
         }
         if (!N->lin_dev.empty()) { // the linear kernel's tables, coefficient indices turned into word offsets of the constants table
             MI_HIP_CHECK(hipMalloc((void **)&N->d_lin_terms, (N->lin_dev.size() + 64) * sizeof(LinTermW)));

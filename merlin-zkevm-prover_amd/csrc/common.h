@@ -78,6 +78,11 @@ struct mi_ctx {
     uint64_t workspace_limit = 32ULL << 30;
     u64 *workspace = nullptr;
     uint64_t workspace_bytes = 0;
+    // mi_ctx_lend_workspace: while a caller's buffer is lent, `workspace` / `workspace_bytes` / `workspace_limit` describe IT and
+    // the context's own allocation waits here
+    bool workspace_lent = false;
+    u64 *own_workspace = nullptr;
+    uint64_t own_workspace_bytes = 0, own_workspace_limit = 0;
     u64 *w256 = nullptr; // w_256^j, j < 256
     u64 *small = nullptr; // 4 KiB device scratch for host-pointer single hashes
     u64 *pinned = nullptr; // 4 KiB of page-locked host memory: the few words an entry point hands back (a hash, a flag) are copied

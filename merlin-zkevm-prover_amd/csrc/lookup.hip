@@ -34,7 +34,7 @@ template <int DIM> __device__ __forceinline__ Key<DIM> load_key(const u64 *p)
 {
     Key<DIM> r;
 #pragma unroll
-    for (int j = 0; j < DIM; j++) r.k[j] = p[j];
+    for (int j = 0; j < DIM; j++) r.k[j] = gl::canon_sel(p[j]); // keys are field VALUES: x and x + p are the same key (polinomial.hpp CompareFe)
     return r;
 }
 template <int DIM> __device__ __forceinline__ bool same(const Key<DIM> &a, const Key<DIM> &b)

@@ -1,0 +1,119 @@
+// chelpers_steps.hpp -- what stands behind Steps::step*_parser_first_avx when the polynomial area lives in HBM.
+//
+// In the reference a Steps object evaluates a constraint program over HOST memory: ZkevmSteps::step42ns_parser_first_avx
+// (zkevm.chelpers.step42ns.parser.cpp:10-760) interprets the generated tables op42[] / args42[] over params.pols, four rows per
+// AVX2 batch.  Here Starks::genProof (host/starks.hpp) keeps a device image of params.pols (a StarkMirror, registered for the
+// duration of the proof), and the batched Steps entry points hand their TABLES to the library (mi_chelpers_*): translated once
+// per proving key, compiled to gfx950 kernels, run over the image.  MI_DEFINE_PARSER_STEP writes such an entry point.
+//
+// Reference interfaces: steps.hpp:4-59 (StepsParams, Steps), zkevmSteps.hpp:10-57, call sites starks.cpp:66-90,150-210,237-258,
+// 367-388.
+#ifndef MI_CHELPERS_STEPS_HPP
+#define MI_CHELPERS_STEPS_HPP
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+#include "goldilocks_base_field.hpp"
+#include "mi_runtime.hpp"
+#include "steps.hpp"
+
+namespace mi {
+// Device image of one Starks' polynomial area while its genProof runs: section offsets are StarkInfo::mapOffsets, i.e. element e of
+// the host area (params.pols[e]) is d_mem[e].
+struct StarkMirror
+{
+    const void *hostPols = nullptr; // the pAddress this image mirrors (StepsParams::pols)
+    uint64_t *d_mem = nullptr;
+    uint64_t N = 0, NExtended = 0, nBits = 0, nBitsExt = 0, nPublics = 0, nEvals = 0;
+    struct Sec { uint64_t offset, cols; };
+    Sec cmN[4] = {}, cm2ns[4] = {}; // cm1_n cm2_n cm3_n tmpExp_n / cm1_2ns .. cm4_2ns
+    uint64_t qOffset = 0, fOffset = 0;
+    uint64_t *d_constN = nullptr, *d_const2ns = nullptr, nConst = 0;
+    uint64_t *d_xn = nullptr, *d_x2ns = nullptr, *d_xdiv = nullptr, *d_xdivw = nullptr;
+    std::vector<uint64_t> zhinv;
+    // programs of this proving key, by (step, address of the opcode table): translated and compiled on first use, kept by the Starks
+    std::map<std::pair<int, const void *>, mi_chelpers_prog *> *progs = nullptr;
+    std::string cacheDir;
+};
+// one proof in flight per process (prover.cpp:187-260): the image of the running genProof
+inline StarkMirror *&currentMirror()
+{
+    static StarkMirror *m = nullptr;
+    return m;
+}
+
+inline bool isBaseStep(int step) { return step == MI_CHELPERS_STEP2PREV || step == MI_CHELPERS_STEP3PREV || step == MI_CHELPERS_STEP3; }
+
+// One constraint program over rows [0, nrows) of its domain, on the device image of params.pols.
+inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, StepsParams &params, uint64_t nrows)
+{
+    StarkMirror *m = currentMirror();
+    if (!m || m->hostPols != (const void *)params.pols) {
+        // no silent host fallback: the interpreter this replaces does not exist here
+        std::fprintf(stderr, "mi_stark: step*_parser_first_avx called on a polynomial area that has no device image "
+                             "(these entry points run inside Starks::genProof of host/starks.hpp)\n");
+        std::exit(-1);
+    }
+    mi_ctx *c = ctx();
+    const bool base = isBaseStep(step);
+    mi_chelpers_prog *&prog = (*m->progs)[{step, (const void *)ops}];
+    if (!prog) {
+        std::vector<mi_chelpers_section> secs;
+        const unsigned nsec = base ? 4 : step == MI_CHELPERS_STEP52NS ? 4 : 3;
+        for (unsigned s = 0; s < nsec; s++) {
+            const StarkMirror::Sec &S = base ? m->cmN[s] : m->cm2ns[s];
+            if (S.cols) secs.push_back({S.offset, S.cols, base ? m->N : m->NExtended});
+        }
+        check(mi_chelpers_compile(c, &prog, step, ops, nops, args, nargs, secs.data(), secs.size(), m->nConst, base ? m->N : m->NExtended),
+              "Steps::step*_parser_first_avx (translate the program)");
+        const char *backend = std::getenv("MI_CHELPERS_BACKEND"); // "interpreter": the extended-domain steps through the SIMT interpreter (A/B)
+        if (base || !backend || std::string(backend) != "interpreter")
+            check(mi_chelpers_build_native(prog, m->cacheDir.empty() ? nullptr : m->cacheDir.c_str(), 0), "Steps::step*_parser_first_avx (compile the program)");
+    }
+    mi_chelpers_params p = {};
+    p.pols = m->d_mem;
+    p.const_pols = base ? m->d_constN : m->d_const2ns;
+    p.n_const = m->nConst;
+    p.challenges = (const uint64_t *)params.challenges.address();
+    p.n_challenges = params.challenges.degree();
+    p.publics = (const uint64_t *)params.publicInputs;
+    p.n_publics = m->nPublics;
+    p.x = base ? m->d_xn : m->d_x2ns;
+    p.x_stride = 1;
+    p.zhinv = m->zhinv.data();
+    p.n_zhinv = m->zhinv.size();
+    p.q = m->d_mem + m->qOffset;
+    if (step == MI_CHELPERS_STEP52NS) {
+        p.x = nullptr; p.x_stride = 0; p.zhinv = nullptr; p.n_zhinv = 0; p.publics = nullptr; p.n_publics = 0; p.q = nullptr;
+        p.evals = (const uint64_t *)params.evals.address();
+        p.n_evals = m->nEvals;
+        p.xdiv = m->d_xdiv;
+        p.xdivw = m->d_xdivw;
+        p.f = m->d_mem + m->fOffset;
+    }
+    if (base) { p.zhinv = nullptr; p.n_zhinv = 0; p.q = nullptr; }
+    check(mi_chelpers_run_dev(c, prog, &p, 0, nrows), "Steps::step*_parser_first_avx");
+}
+} // namespace mi
+
+// The batched entry points of a Steps class over its generated tables.  In the translation unit that replaces the class's
+// *.parser.cpp files:
+//     #include "zkevmSteps.hpp"
+//     #include "chelpers_steps.hpp"
+//     #include "zkevm.chelpers.step42ns.parser.hpp"                       // op42[NOPS_], args42[NARGS_]
+//     MI_DEFINE_PARSER_STEP(ZkevmSteps, step42ns, _avx, MI_CHELPERS_STEP42NS, op42, NOPS_, args42, NARGS_)
+//     MI_FORWARD_PARSER_STEP(ZkevmSteps, step42ns, , _avx)                // step42ns_parser_first -> the same program
+// nrowsBatch (4 = AVX2 lanes, 8 = AVX-512) has no meaning on the device: a lane owns a row.
+#define MI_DEFINE_PARSER_STEP(Class, step, flavour, STEP_ID, ops, nops, args, nargs)                              \
+    void Class::step##_parser_first##flavour(StepsParams &params, uint64_t nrows, uint64_t /*nrowsBatch*/)        \
+    {                                                                                                              \
+        mi::runChelpersStep(STEP_ID, ops, nops, args, nargs, params, nrows);                                       \
+    }
+#define MI_FORWARD_PARSER_STEP(Class, step, flavour, to)                                                           \
+    void Class::step##_parser_first##flavour(StepsParams &params, uint64_t nrows, uint64_t nrowsBatch)             \
+    {                                                                                                              \
+        step##_parser_first##to(params, nrows, nrowsBatch);                                                        \
+    }
+#endif

@@ -37,9 +37,8 @@ private:
         mi_ctx *c = mi::ctx();
         const std::vector<StepStruct> &steps = starkInfo.starkStruct.steps;
         const uint64_t nBitsExt = polBits;
-        uint64_t *d_pol = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8), *d_next = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8);
-        uint64_t *d_aux = (uint64_t *)mi_dev_alloc(c, (3ULL << polBits) * 8);
-        if (!d_pol || !d_next || !d_aux) mi::fail("FRIProve::prove (alloc)");
+        uint64_t *d_pol = mi::devAlloc(3ULL << polBits, "FRIProve::prove (alloc)"), *d_next = mi::devAlloc(3ULL << polBits, "FRIProve::prove (alloc)");
+        uint64_t *d_aux = mi::devAlloc(3ULL << polBits, "FRIProve::prove (alloc)");
         if (friPol) mi::check(mi_copy_h2d(c, d_pol, friPol->address(), (3ULL << polBits) * 8), "FRIProve::prove (h2d)");
         else mi::check(mi_copy_2d_dev(c, d_pol, 3, d_friPol, 3, 1ULL << polBits, 3), "FRIProve::prove (device copy)");
         std::vector<MerkleTreeGL *> treesFRIGL(steps.size(), nullptr);
@@ -56,8 +55,7 @@ private:
                 const uint64_t nGroups = 1ULL << steps[si + 1].nBits, groupSize = pol2N / nGroups;
                 mi::check(mi_fri_transpose_dev(c, d_aux, d_next, pol2N, (unsigned)steps[si + 1].nBits), "FRIProve::prove (transpose)");
                 MerkleTreeGL *t = new MerkleTreeGL(nGroups, groupSize * FIELD_EXTENSION, NULL);
-                uint64_t *d_src = (uint64_t *)mi_dev_alloc(c, pol2N * 3 * 8); // the tree keeps its own leaves for the query phase
-                if (!d_src) mi::fail("FRIProve::prove (alloc tree source)");
+                uint64_t *d_src = mi::devAlloc(pol2N * 3, "FRIProve::prove (alloc tree source)"); // the tree keeps its own leaves for the query phase
                 mi::check(mi_copy_2d_dev(c, d_src, groupSize * 3, d_aux, groupSize * 3, nGroups, groupSize * 3), "FRIProve::prove (copySource)");
                 t->setDeviceSource(d_src);
                 t->merkelize();
@@ -115,8 +113,8 @@ private:
                 for (uint64_t i = 0; i < ys.size(); i++) ys[i] = ys[i] % (1ULL << steps[si + 1].nBits);
         }
         for (MerkleTreeGL *t : treesFRIGL) delete t;
-        for (uint64_t *p : owned_sources) mi_dev_free(c, p);
-        mi_dev_free(c, d_pol); mi_dev_free(c, d_next); mi_dev_free(c, d_aux);
+        for (uint64_t *p : owned_sources) mi::devFree(p);
+        mi::devFree(d_pol); mi::devFree(d_next); mi::devFree(d_aux);
     }
 };
 #endif

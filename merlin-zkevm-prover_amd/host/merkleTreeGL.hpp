@@ -21,8 +21,8 @@ class MerkleTreeGL
     bool d_source_borrowed = false, d_nodes_borrowed = false;
     void releaseDevice()
     {
-        if (d_source && !d_source_borrowed) mi_dev_free(mi::ctx(), d_source);
-        if (d_nodes && !d_nodes_borrowed) mi_dev_free(mi::ctx(), d_nodes);
+        if (d_source && !d_source_borrowed) mi::devFree(d_source);
+        if (d_nodes && !d_nodes_borrowed) mi::devFree(d_nodes);
         d_source = d_nodes = nullptr;
         d_source_borrowed = d_nodes_borrowed = false;
     }
@@ -81,13 +81,11 @@ public:
     {
         mi_ctx *c = mi::ctx();
         if (!d_source) {
-            d_source = (uint64_t *)mi_dev_alloc(c, height * width * 8);
-            if (!d_source) mi::fail("MerkleTreeGL::merkelize (alloc source)");
+            d_source = mi::devAlloc(height * width, "MerkleTreeGL::merkelize (alloc source)");
         }
         if (!d_source_borrowed) mi::check(mi_copy_h2d(c, d_source, source, height * width * 8), "MerkleTreeGL::merkelize (h2d)");
         if (!d_nodes) {
-            d_nodes = (uint64_t *)mi_dev_alloc(c, getTreeNumElements() * 8);
-            if (!d_nodes) mi::fail("MerkleTreeGL::merkelize (alloc nodes)");
+            d_nodes = mi::devAlloc(getTreeNumElements(), "MerkleTreeGL::merkelize (alloc nodes)");
         }
         mi::check(mi_merkle_build_dev(c, d_nodes, d_source, width, width, height), "MerkleTreeGL::merkelize");
     }
@@ -113,11 +111,10 @@ public:
         const uint64_t stride = width + MerkleProofSize() * HASH_SIZE;
         if (d_nodes && d_source) {
             mi_ctx *c = mi::ctx();
-            uint64_t *d_out = (uint64_t *)mi_dev_alloc(c, nq * stride * 8);
-            if (!d_out) mi::fail("MerkleTreeGL::getGroupProofs (alloc)");
+            uint64_t *d_out = mi::devAlloc(nq * stride, "MerkleTreeGL::getGroupProofs (alloc)");
             mi::check(mi_merkle_group_proofs_dev(c, d_out, d_nodes, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs");
             mi::check(mi_copy_d2h(c, proofs, d_out, nq * stride * 8), "MerkleTreeGL::getGroupProofs (d2h)");
-            mi_dev_free(c, d_out);
+            mi::devFree(d_out);
             return;
         }
         for (uint64_t q = 0; q < nq; q++) { // tree loaded from a file (constant tree): plain copies, no arithmetic

@@ -31,5 +31,35 @@ inline void check(int status, const char *where)
 {
     if (status != MI_OK) fail(where);
 }
+// Device scratch of the host classes (FRI polynomials, step-tree leaves and nodes, opening buffers).  A caller that owns a plan of
+// the HBM (host/starks.hpp) lends a region and the classes carve it in order; without one every request is a device allocation.
+// Memory handed back to the driver is wiped in the background on the GPU's own bandwidth, so a proof that
+// allocates nothing while it runs is also a faster proof.
+struct Bump { uint64_t *base = nullptr; uint64_t cap = 0, used = 0; };
+inline Bump &bump()
+{
+    static Bump b;
+    return b;
+}
+inline void lendScratch(uint64_t *base, uint64_t elems) { bump() = Bump{base, elems, 0}; }
+inline uint64_t *devAlloc(uint64_t elems, const char *what)
+{
+    Bump &b = bump();
+    const uint64_t e = (elems + 15) & ~15ULL; // 128-byte granules
+    if (b.base && b.used + e <= b.cap) {
+        uint64_t *p = b.base + b.used;
+        b.used += e;
+        return p;
+    }
+    uint64_t *p = (uint64_t *)mi_dev_alloc(ctx(), (elems ? elems : 1) * 8);
+    if (!p) fail(what);
+    return p;
+}
+inline void devFree(uint64_t *p)
+{
+    Bump &b = bump();
+    if (!p || (b.base && p >= b.base && p < b.base + b.cap)) return; // part of a lent region: its owner reuses it
+    mi_dev_free(ctx(), p);
+}
 } // namespace mi
 #endif

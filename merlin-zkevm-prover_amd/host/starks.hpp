@@ -1,0 +1,507 @@
+// starks.hpp -- class Starks with the reference's interface (src/starkpil/starks.hpp:19-232, starks.cpp:9-403), on a device image
+// of the polynomial area.
+//
+//     Starks(const Config &, StarkFiles, void *pAddress)                      starks.hpp:74     (prover.cpp:128-132)
+//     void genProof(FRIProof &, Goldilocks::Element *publicInputs, Steps *)   starks.hpp:225    (prover.cpp:541-544)
+//     public: config, starkInfo, nrowsStepBatch
+//
+// The caller is unchanged: it fills the witness (cm1_n) at pAddress, constructs the Steps object of its STARK and calls genProof.
+// What changes is where the work happens.  The reference keeps every section of StarkInfo's memory map in the host area behind
+// pAddress (zkEVM: 254 GB + a 50 GB buffer) and walks it with OpenMP loops; here genProof keeps a DEVICE IMAGE of that area --
+// same offsets, so the generated constraint programs address it as they address pAddress -- and strings the library's entry points
+// together in the reference's order.  pAddress is read (the witness) and never written; roots, evaluations and the query
+// openings are what returns.
+//
+// HBM plan (one arena per process, carved per proof; zkEVM sizes in GB, N = 2^23):
+//     image of pAddress[0, mapTotalN)     254.1   cm1_n 44.6 | cm2_n 8.6 | cm3_n 24.9 | cm4_n 0.4 | tmpExp_n 17.8 | cm1_2ns 89.3 | cm2_2ns 17.2 |
+//                                                 cm3_2ns 49.8 | cm4_2ns 0.8 | q_2ns 0.4 | f_2ns 0.4
+//     four Merkle trees                     4.3
+//     constant polynomials, base domain    24.2   (persistent per Starks: uploaded once, not per proof)
+//   and nothing else of size: like the reference (starks.cpp:52 lends p_cm2_2ns, :102-104 reuses cm3_2ns) sections that are not live
+//   yet, or no longer, serve as scratch --
+//     stage 1 LDE scratch  = the cm2_2ns | cm3_2ns regions         stage 3 LDE scratch = cm1_n | cm2_n (their last reader, step3, has run)
+//     stage 2 LDE scratch  = the cm3_2ns region                    stages 4, 5, FRI    = the whole base-domain part [0, cm1_2ns): the extended
+//   constant polynomials are RE-EXTENDED there from the resident base-domain ones (an LDE of nConstants columns, ~0.1 s at zkEVM size,
+//   instead of 48 GB over PCIe per proof; the constant TREE is only opened at the query points, from the mapped file), next to
+//   x_2ns, the quotient's coefficient buffers, LEv / LpEv, xDivXSubXi / xDivXSubWXi and the FRI polynomials.
+//   A STARK whose base-domain part is smaller than that (the recursive ones) gets the difference as extra arena.
+//
+// Steps: with nrowsStepBatch 4 or 8 (the zkEVM: prover.cpp:129) the batched entry points step*_parser_first_avx[512] run on the image
+// (host/chelpers_steps.hpp).  With nrowsStepBatch 1 (c12a, recursive1/2: generated per-row C++, starks.cpp:84-88 ...) the Steps
+// callbacks are the CALLER'S host code and need host memory: the sections they read are copied down into pAddress, the loop runs
+// on the host cores as in the reference, and what it wrote is copied back up ("host steps"; everything else stays on the device).
+#ifndef STARKS_HPP
+#define STARKS_HPP
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+#include "config.hpp"
+#include "utils.hpp"
+#include "timer.hpp"
+#include "zklog.hpp"
+#include "exit_process.hpp"
+#include "zkassert.hpp"
+#include "constant_pols_starks.hpp"
+#include "stark_info.hpp"
+#include "friProof.hpp"
+#include "friProve.hpp"
+#include "transcript.hpp"
+#include "zhInv.hpp"
+#include "steps.hpp"
+#include "merkleTreeGL.hpp"
+#include "ntt_goldilocks.hpp"
+#include "chelpers_steps.hpp"
+
+#define STARK_C12_A_NUM_TREES 5
+#define NUM_CHALLENGES 8
+
+struct StarkFiles
+{
+    std::string zkevmConstPols;
+    bool mapConstPolsFile;
+    std::string zkevmConstantsTree;
+    std::string zkevmStarkInfo;
+};
+
+namespace mi {
+// The process's HBM arena: grown (never shrunk) to the largest plan asked for, so that consecutive proofs -- zkEVM, c12a,
+// recursive1, ... share pAddress in the reference and share this here -- allocate nothing.
+struct Arena
+{
+    uint64_t *base = nullptr;
+    uint64_t elems = 0;
+    uint64_t *reserve(uint64_t want)
+    {
+        if (want <= elems) return base;
+        mi_ctx *c = ctx();
+        if (base) mi_dev_free(c, base);
+        base = (uint64_t *)mi_dev_alloc(c, want * 8);
+        if (!base) {
+            uint64_t fr = 0, tot = 0;
+            mi_dev_mem_info(c, &fr, &tot);
+            std::fprintf(stderr, "mi_stark: the proof's HBM plan needs %.1f GB, the device has %.1f GB free of %.1f\n", want * 8 / 1e9, fr / 1e9, tot / 1e9);
+            fail("Starks (HBM arena)");
+        }
+        elems = want;
+        return base;
+    }
+};
+inline Arena &arena()
+{
+    static Arena a;
+    return a;
+}
+} // namespace mi
+
+class Starks
+{
+public:
+    const Config &config;
+    StarkInfo starkInfo;
+    uint64_t nrowsStepBatch;
+
+private:
+    void *pConstPolsAddress = NULL;
+    void *pConstTreeAddress = NULL;
+    ConstantPolsStarks *pConstPols = NULL;
+    ConstantPolsStarks *pConstPols2ns = NULL; // a view of the constant-tree file's polynomials (the reference copies them out: starks.hpp:141-143)
+    StarkFiles starkFiles;
+    ZhInv zi;
+    uint64_t N, NExtended;
+    uint64_t constPolsSize = 0;
+    MerkleTreeGL *treesGL[STARK_C12_A_NUM_TREES] = {};
+    Goldilocks::Element *mem = NULL;
+    void *pAddress;
+    // device side
+    uint64_t *d_constN = nullptr; // constant polynomials over the base domain: resident for the life of this object
+    uint64_t treeElems = 0, scratchElems = 0;
+    std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
+
+    uint64_t off(eSection s) const { return starkInfo.mapOffsets.section[s]; }
+    uint64_t cols(eSection s) const { return starkInfo.mapSectionsN.section[s]; }
+    struct PolRef { uint64_t offset, stride, dim; };
+    PolRef polRef(uint64_t idPol) const // stark_info.cpp:473-482 without the host pointer
+    {
+        const VarPolMap &p = starkInfo.varPolMap[idPol];
+        return {starkInfo.mapOffsets.section[p.section] + p.sectionPos, starkInfo.mapSectionsN.section[p.section], p.dim};
+    }
+    uint64_t exp2pol(uint64_t expId)
+    {
+        auto it = starkInfo.exp2pol.find(std::to_string(expId));
+        if (it == starkInfo.exp2pol.end()) { zklog.error("Starks: expression " + std::to_string(expId) + " has no polynomial (exp2pol)"); exitProcess(); }
+        return it->second;
+    }
+    // stage-4+ buffers: elements beyond what the dead base-domain part of the image offers
+    uint64_t lateNeed() const
+    {
+        const uint64_t qd = starkInfo.qDim, qg = starkInfo.qDeg;
+        uint64_t need = starkInfo.nConstants * NExtended + NExtended + 64;                       // const_2ns, x_2ns
+        need += NExtended * qd + NExtended * qd * qg + 6 * N + 6 * NExtended;                    // qq1, qq2, LEv | LpEv, xDivXSubXi | xDivXSubWXi
+        need += 9 * NExtended + 3 * NExtended + 4 * (2 * NExtended) + starkInfo.evMap.size() * 3 + 4096; // FRI: 3 polynomials, step-tree leaves and nodes, openings
+        need += starkInfo.starkStruct.nQueries * (cols(cm1_n) + cols(cm2_n) + cols(cm3_n) + cols(cm4_2ns) + 4 * starkInfo.starkStruct.nBitsExt * 4 + 64);
+        need += std::min<uint64_t>(64, std::max<uint64_t>(starkInfo.nConstants, 8)) * 2 * (N + NExtended); // room for an LDE's column chunk
+        return need;
+    }
+
+public:
+    Starks(const Config &config, StarkFiles starkFiles, void *_pAddress)
+        : config(config), starkInfo(config, starkFiles.zkevmStarkInfo), starkFiles(starkFiles),
+          zi(config.generateProof() ? starkInfo.starkStruct.nBits : 0, config.generateProof() ? starkInfo.starkStruct.nBitsExt : 0),
+          N(config.generateProof() ? 1ULL << starkInfo.starkStruct.nBits : 0), NExtended(config.generateProof() ? 1ULL << starkInfo.starkStruct.nBitsExt : 0),
+          pAddress(_pAddress)
+    {
+        nrowsStepBatch = 1;
+        if (!config.generateProof()) return; // starks.hpp:90-91
+        if (starkFiles.zkevmConstPols.size() == 0) { zklog.error("Starks::Starks() received an empty config.zkevmConstPols"); exitProcess(); }
+        if (starkFiles.zkevmConstantsTree.size() == 0) { zklog.error("Starks::Starks() received an empty config.zkevmConstantsTree"); exitProcess(); }
+        TimerStart(LOAD_CONST_POLS_TO_MEMORY);
+        constPolsSize = starkInfo.nConstants * sizeof(Goldilocks::Element) * N;
+        pConstPolsAddress = starkFiles.mapConstPolsFile ? mapFile(starkFiles.zkevmConstPols, constPolsSize, false) : copyFile(starkFiles.zkevmConstPols, constPolsSize);
+        pConstPols = new ConstantPolsStarks(pConstPolsAddress, constPolsSize, starkInfo.nConstants);
+        TimerStopAndLog(LOAD_CONST_POLS_TO_MEMORY);
+        TimerStart(LOAD_CONST_TREE_TO_MEMORY);
+        const uint64_t treeBytes = starkInfo.getConstTreeSizeInBytes();
+        pConstTreeAddress = config.mapConstantsTreeFile ? mapFile(starkFiles.zkevmConstantsTree, treeBytes, false) : copyFile(starkFiles.zkevmConstantsTree, treeBytes);
+        pConstPols2ns = new ConstantPolsStarks((uint8_t *)pConstTreeAddress + MERKLEHASHGOLDILOCKS_HEADER_SIZE * sizeof(Goldilocks::Element), NExtended, starkInfo.nConstants);
+        TimerStopAndLog(LOAD_CONST_TREE_TO_MEMORY);
+        mem = (Goldilocks::Element *)pAddress;
+        treesGL[4] = new MerkleTreeGL((Goldilocks::Element *)pConstTreeAddress); // opened at the query points from the file (merkleTreeGL.hpp:24-32)
+        treeElems = MerklehashGoldilocks::getTreeNumElements(NExtended);
+        // everything of stages 4, 5 and FRI fits the dead base-domain part of the image (the zkEVM: 51 of 96 GB), or gets an area of its own
+        scratchElems = lateNeed() > off(cm1_2ns) ? lateNeed() : 0;
+        if (starkInfo.nConstants) {
+            d_constN = (uint64_t *)mi_dev_alloc(mi::ctx(), starkInfo.nConstants * N * 8);
+            if (!d_constN) mi::fail("Starks::Starks (constant polynomials)");
+            mi::check(mi_copy_h2d(mi::ctx(), d_constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (constant polynomials h2d)");
+        }
+    }
+    Starks(const Starks &) = delete;
+    Starks &operator=(const Starks &) = delete;
+    ~Starks()
+    {
+        if (!config.generateProof()) return;
+        for (auto &p : progs) if (p.second) mi_chelpers_free(mi::ctx(), p.second);
+        if (d_constN) mi_dev_free(mi::ctx(), d_constN);
+        delete pConstPols;
+        delete pConstPols2ns;
+        if (starkFiles.mapConstPolsFile) unmapFile(pConstPolsAddress, constPolsSize); else free(pConstPolsAddress);
+        if (config.mapConstantsTreeFile) unmapFile(pConstTreeAddress, starkInfo.getConstTreeSizeInBytes()); else free(pConstTreeAddress);
+        for (unsigned i = 0; i < STARK_C12_A_NUM_TREES; i++) delete treesGL[i];
+    }
+    // bytes of HBM a genProof of this STARK plans for (image + trees + late scratch) plus the resident constant polynomials
+    uint64_t hbmPlanBytes() const { return (starkInfo.mapTotalN + 4 * treeElems + scratchElems + starkInfo.nConstants * N) * 8; }
+
+    void genProof(FRIProof &proof, Goldilocks::Element *publicInputs, Steps *steps);
+
+private:
+    void hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
+};
+
+// Host steps (nrowsStepBatch == 1): the caller's per-row code over pAddress, as starks.cpp:84-88,166-170,204-208,252-256,382-386 run
+// it; sections it may read come down first, sections it may write go back up.  which: 0 step2prev, 1 step3prev, 2 step3, 3 step42ns,
+// 4 step52ns.
+inline void Starks::hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which)
+{
+    mi_ctx *c = mi::ctx();
+    auto down = [&](uint64_t o, uint64_t n) { if (n) mi::check(mi_copy_d2h(c, mem + o, m.d_mem + o, n * 8), "Starks::genProof (host steps, d2h)"); };
+    auto up = [&](uint64_t o, uint64_t n) { if (n) mi::check(mi_copy_h2d(c, m.d_mem + o, mem + o, n * 8), "Starks::genProof (host steps, h2d)"); };
+    const uint64_t baseBegin = off(cm2_n), baseEnd = off(cm1_2ns);
+    if (which <= 2) {
+        down(baseBegin, baseEnd - baseBegin); // cm2_n .. tmpExp_n as the device left them (cm1_n is the caller's witness: already there)
+#pragma omp parallel for
+        for (uint64_t i = 0; i < N; i++) {
+            if (which == 0) steps->step2prev_first(params, i);
+            else if (which == 1) steps->step3prev_first(params, i);
+            else steps->step3_first(params, i);
+        }
+        up(baseBegin, baseEnd - baseBegin);
+    } else if (which == 3) {
+        down(off(cm1_2ns), off(cm4_2ns) - off(cm1_2ns));
+#pragma omp parallel for
+        for (uint64_t i = 0; i < NExtended; i++) steps->step42ns_first(params, i);
+        up(off(q_2ns), NExtended * starkInfo.qDim);
+    } else {
+        down(off(cm4_2ns), NExtended * cols(cm4_2ns)); // cm1..3_2ns came down for step42ns and have not changed
+        mi::check(mi_copy_d2h(c, params.xDivXSubXi.address(), m.d_xdiv, NExtended * 3 * 8), "Starks::genProof (host steps, xDivXSubXi)");
+        mi::check(mi_copy_d2h(c, params.xDivXSubWXi.address(), m.d_xdivw, NExtended * 3 * 8), "Starks::genProof (host steps, xDivXSubWXi)");
+#pragma omp parallel for
+        for (uint64_t i = 0; i < NExtended; i++) steps->step52ns_first(params, i);
+        up(off(f_2ns), NExtended * 3);
+    }
+}
+
+inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs, Steps *steps)
+{
+    TimerStart(STARK_INITIALIZATION);
+    mi_ctx *c = mi::ctx();
+    const bool deviceSteps = nrowsStepBatch == 4 || nrowsStepBatch == 8; // starks.cpp:69-90: the batched ("parser") forms
+    const uint64_t nBits = starkInfo.starkStruct.nBits, nBitsExt = starkInfo.starkStruct.nBitsExt, extendBits = nBitsExt - nBits;
+    const uint64_t nEvals = starkInfo.evMap.size();
+    Transcript transcript;
+    Polinomial evals(std::max<uint64_t>(nEvals, 1), FIELD_EXTENSION);
+    Polinomial challenges(NUM_CHALLENGES, FIELD_EXTENSION);
+    // host tables only the host steps read (starks.hpp:149-160; starks.cpp:17-18): empty with device steps
+    Polinomial x_n(deviceSteps ? 0 : N, 1), x_2ns(deviceSteps ? 0 : NExtended, 1);
+    Polinomial xDivXSubXi(deviceSteps ? 0 : NExtended, FIELD_EXTENSION), xDivXSubWXi(deviceSteps ? 0 : NExtended, FIELD_EXTENSION);
+    Polinomial root0(HASH_SIZE, 1), root1(HASH_SIZE, 1), root2(HASH_SIZE, 1), root3(HASH_SIZE, 1);
+
+    // ---- the HBM plan: image | trees | late scratch
+    const uint64_t imageElems = starkInfo.mapTotalN;
+    uint64_t *d_mem = mi::arena().reserve(imageElems + 4 * treeElems + scratchElems);
+    uint64_t *d_nodes[4];
+    for (int t = 0; t < 4; t++) d_nodes[t] = d_mem + imageElems + t * treeElems;
+    uint64_t *d_late = d_mem + imageElems + 4 * treeElems;
+    auto sec = [&](eSection s) { return d_mem + off(s); };
+    auto lend = [&](uint64_t *p, uint64_t elems) { // LDE / NTT scratch out of a region that is not live
+        const uint64_t atLeast = 16 * 2 * (N + NExtended);
+        mi::check(mi_ctx_lend_workspace(c, elems >= atLeast ? p : nullptr, elems * 8), "Starks::genProof (lend workspace)");
+    };
+    mi::StarkMirror m;
+    m.hostPols = mem; m.d_mem = d_mem; m.N = N; m.NExtended = NExtended; m.nBits = nBits; m.nBitsExt = nBitsExt;
+    m.nPublics = starkInfo.nPublics; m.nEvals = nEvals;
+    const eSection sN[4] = {cm1_n, cm2_n, cm3_n, tmpExp_n}, s2[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
+    for (int i = 0; i < 4; i++) { m.cmN[i] = {off(sN[i]), cols(sN[i])}; m.cm2ns[i] = {off(s2[i]), cols(s2[i])}; }
+    m.qOffset = off(q_2ns); m.fOffset = off(f_2ns);
+    m.d_constN = d_constN; m.nConst = starkInfo.nConstants;
+    m.zhinv.resize(1ULL << extendBits);
+    for (uint64_t i = 0; i < m.zhinv.size(); i++) m.zhinv[i] = Goldilocks::toU64(zi.zhInv(i));
+    m.progs = &progs;
+    if (const char *e = std::getenv("MI_CHELPERS_CACHE")) m.cacheDir = e;
+    mi::currentMirror() = &m;
+
+    transcript.put(&publicInputs[0], starkInfo.nPublics);
+    ConstantPolsStarks *cp = pConstPols, *cp2 = pConstPols2ns;
+    StepsParams params = {mem, cp, cp2, challenges, x_n, x_2ns, zi, evals, xDivXSubXi, xDivXSubWXi, publicInputs, mem + off(q_2ns), mem + off(f_2ns)};
+    // x_n (starks.hpp:149-154), N elements read by the base-domain steps only: it borrows the head of the q_2ns section, whose first
+    // writer (step42ns) runs after the last of them
+    m.d_xn = sec(q_2ns);
+    mi::check(mi_geom_seq_dev(c, m.d_xn, N, 1, Goldilocks::toU64(Goldilocks::w(nBits))), "Starks::genProof (x_n)");
+    if (!deviceSteps) mi::check(mi_copy_d2h(c, x_n.address(), m.d_xn, N * 8), "Starks::genProof (x_n d2h)");
+    TimerStopAndLog(STARK_INITIALIZATION);
+
+    //--------------------------------
+    // 1.- Calculate p_cm1_2ns  (starks.cpp:48-61): the witness streams up in column chunks behind the kernels and stays, its
+    //     extension and tree are built as the chunks arrive
+    //--------------------------------
+    TimerStart(STARK_STEP_1);
+    TimerStart(STARK_STEP_1_LDE_AND_MERKLETREE);
+    lend(sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns));
+    mi::check(mi_lde_merkle_host_keep(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
+                                      cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
+    mi::check(mi_copy_d2h(c, root0.address(), d_nodes[0] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 1)");
+    transcript.put(root0.address(), HASH_SIZE);
+    TimerStopAndLog(STARK_STEP_1_LDE_AND_MERKLETREE);
+    TimerStopAndLog(STARK_STEP_1);
+
+    //--------------------------------
+    // 2.- Caluculate plookups h1 and h2  (starks.cpp:66-143)
+    //--------------------------------
+    TimerStart(STARK_STEP_2);
+    transcript.getField(challenges[0]); // u
+    transcript.getField(challenges[1]); // defVal
+    TimerStart(STARK_STEP_2_CALCULATE_EXPS);
+    if (nrowsStepBatch == 4) steps->step2prev_parser_first_avx(params, N, nrowsStepBatch);
+    else if (nrowsStepBatch == 8) steps->step2prev_parser_first_avx512(params, N, nrowsStepBatch);
+    else hostStep(m, steps, params, 0);
+    TimerStopAndLog(STARK_STEP_2_CALCULATE_EXPS);
+    TimerStart(STARK_STEP_2_CALCULATEH1H2);
+    uint64_t numCommited = starkInfo.nCm1;
+    for (uint64_t i = 0; i < starkInfo.puCtx.size(); i++) { // starks.cpp:106-124 with the transposes of :92,:128 gone: strided views in place
+        const PolRef f = polRef(exp2pol(starkInfo.puCtx[i].fExpId)), t = polRef(exp2pol(starkInfo.puCtx[i].tExpId));
+        const PolRef h1 = polRef(starkInfo.cm_n[numCommited + i * 2]), h2 = polRef(starkInfo.cm_n[numCommited + i * 2 + 1]);
+        if (f.dim != t.dim || h1.dim != t.dim || h2.dim != t.dim) mi::fail("Starks::genProof (plookup polynomials of different dimensions)");
+        mi::check(mi_calculate_h1h2_dev(c, d_mem + h1.offset, h1.stride, d_mem + h2.offset, h2.stride, d_mem + f.offset, f.stride, d_mem + t.offset, t.stride,
+                                        (unsigned)t.dim, N), "Starks::genProof (calculateH1H2)");
+    }
+    numCommited += starkInfo.puCtx.size() * 2;
+    TimerStopAndLog(STARK_STEP_2_CALCULATEH1H2);
+    TimerStart(STARK_STEP_2_LDE_AND_MERKLETREE);
+    lend(sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns));
+    mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
+    mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
+    mi::check(mi_copy_d2h(c, root1.address(), d_nodes[1] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 2)");
+    transcript.put(root1.address(), HASH_SIZE);
+    TimerStopAndLog(STARK_STEP_2_LDE_AND_MERKLETREE);
+    TimerStopAndLog(STARK_STEP_2);
+
+    //--------------------------------
+    // 3.- Compute Z polynomials  (starks.cpp:148-223)
+    //--------------------------------
+    TimerStart(STARK_STEP_3);
+    transcript.getField(challenges[2]); // gamma
+    transcript.getField(challenges[3]); // betta
+    TimerStart(STARK_STEP_3_CALCULATE_EXPS);
+    if (nrowsStepBatch == 4) steps->step3prev_parser_first_avx(params, N, nrowsStepBatch);
+    else if (nrowsStepBatch == 8) steps->step3prev_parser_first_avx512(params, N, nrowsStepBatch);
+    else hostStep(m, steps, params, 1);
+    TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS);
+    TimerStart(STARK_STEP_3_CALCULATE_Z);
+    {
+        struct ND { uint64_t numId, denId; };
+        std::vector<ND> gp; // the order of starks.cpp:473-536: lookups, permutations, connections
+        for (auto &x : starkInfo.puCtx) gp.push_back({x.numId, x.denId});
+        for (auto &x : starkInfo.peCtx) gp.push_back({x.numId, x.denId});
+        for (auto &x : starkInfo.ciCtx) gp.push_back({x.numId, x.denId});
+        for (uint64_t i = 0; i < gp.size(); i++) {
+            const PolRef num = polRef(exp2pol(gp[i].numId)), den = polRef(exp2pol(gp[i].denId)), z = polRef(starkInfo.cm_n[numCommited + i]);
+            int closes = 0;
+            mi::check(mi_calculate_z_dev(c, d_mem + z.offset, z.stride, d_mem + num.offset, num.stride, d_mem + den.offset, den.stride, N, &closes),
+                      "Starks::genProof (calculateZ)");
+            zkassert(closes); // polinomial.hpp:606
+            (void)closes;
+        }
+    }
+    TimerStopAndLog(STARK_STEP_3_CALCULATE_Z);
+    TimerStart(STARK_STEP_3_CALCULATE_EXPS_2);
+    if (nrowsStepBatch == 4) steps->step3_parser_first_avx(params, N, nrowsStepBatch);
+    else if (nrowsStepBatch == 8) steps->step3_parser_first_avx512(params, N, nrowsStepBatch);
+    else hostStep(m, steps, params, 2);
+    TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS_2);
+    TimerStart(STARK_STEP_3_LDE_AND_MERKLETREE);
+    lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run
+    mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
+    mi::check(mi_merkle_build_dev(c, d_nodes[2], sec(cm3_2ns), cols(cm3_n), cols(cm3_n), NExtended), "Starks::genProof (stage 3: merkelize)");
+    mi::check(mi_copy_d2h(c, root2.address(), d_nodes[2] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 3)");
+    transcript.put(root2.address(), HASH_SIZE);
+    TimerStopAndLog(STARK_STEP_3_LDE_AND_MERKLETREE);
+    TimerStopAndLog(STARK_STEP_3);
+
+    //--------------------------------
+    // 4. Compute C Polynomial  (starks.cpp:228-295).  The base-domain part of the image is dead from here on: it is re-planned as
+    //    [const_2ns | x_2ns | qq1 | qq2 | LEv LpEv | xDivXSubXi xDivXSubWXi | FRI scratch ...], continuing in the late scratch
+    //--------------------------------
+    TimerStart(STARK_STEP_4);
+    TimerStart(STARK_STEP_4_INIT);
+    const uint64_t poolElems = off(cm1_2ns);
+    uint64_t poolUsed = 0, lateUsed = 0;
+    auto take = [&](uint64_t elems) -> uint64_t * { // the dead base-domain part first, then the late scratch (128-byte granules)
+        const uint64_t e = (elems + 15) & ~15ULL;
+        uint64_t *p = nullptr;
+        if (!scratchElems && poolUsed + e <= poolElems) { p = d_mem + poolUsed; poolUsed += e; }
+        else if (lateUsed + e <= scratchElems) { p = d_late + lateUsed; lateUsed += e; }
+        else mi::fail("Starks::genProof (stage-4 scratch exhausted: plan error)");
+        return p;
+    };
+    const uint64_t qDim = starkInfo.qDim, qDeg = starkInfo.qDeg, nConst = starkInfo.nConstants;
+    m.d_const2ns = take(nConst * NExtended);
+    m.d_x2ns = take(NExtended);
+    uint64_t *qq1 = take(NExtended * qDim), *qq2 = take(NExtended * qDim * qDeg);
+    uint64_t *lev = take(6 * N), *lpev = lev + 3 * N;
+    m.d_xdiv = take(3 * NExtended);
+    m.d_xdivw = take(3 * NExtended);
+    uint64_t *d_evals = take(nEvals * 3 + 16);
+    // what is left serves the transforms of stages 4 and 5, then FRI
+    uint64_t *rest = scratchElems ? d_late + lateUsed : d_mem + poolUsed;
+    const uint64_t restElems = scratchElems ? scratchElems - lateUsed : poolElems - poolUsed;
+    lend(rest, restElems);
+    if (nConst) mi::check(mi_lde_dev(c, m.d_const2ns, nConst, d_constN, nConst, NExtended, N, nConst), "Starks::genProof (constant polynomials, extended)");
+    mi::check(mi_geom_seq_dev(c, m.d_x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))),
+              "Starks::genProof (x_2ns)"); // starks.hpp:155-160
+    transcript.getField(challenges[4]); // gamma
+    TimerStopAndLog(STARK_STEP_4_INIT);
+    TimerStart(STARK_STEP_4_CALCULATE_EXPS_2NS);
+    if (!deviceSteps) mi::check(mi_copy_d2h(c, x_2ns.address(), m.d_x2ns, NExtended * 8), "Starks::genProof (x_2ns d2h)");
+    if (nrowsStepBatch == 4) steps->step42ns_parser_first_avx(params, NExtended, nrowsStepBatch);
+    else if (nrowsStepBatch == 8) steps->step42ns_parser_first_avx512(params, NExtended, nrowsStepBatch);
+    else hostStep(m, steps, params, 3);
+    TimerStopAndLog(STARK_STEP_4_CALCULATE_EXPS_2NS);
+    TimerStart(STARK_STEP_4_CALCULATE_EXPS_2NS_INTT);
+    mi::check(mi_ntt_dev(c, qq1, qDim, sec(q_2ns), qDim, NExtended, qDim, 1), "Starks::genProof (INTT of q)");
+    TimerStopAndLog(STARK_STEP_4_CALCULATE_EXPS_2NS_INTT);
+    TimerStart(STARK_STEP_4_CALCULATE_EXPS_2NS_MUL);
+    if (qDim != FIELD_EXTENSION) mi::fail("Starks::genProof (qDim != 3)");
+    mi::check(mi_q_split_dev(c, qq2, qq1, N, NExtended, (unsigned)qDeg), "Starks::genProof (split of q)"); // starks.cpp:265-280
+    TimerStopAndLog(STARK_STEP_4_CALCULATE_EXPS_2NS_MUL);
+    TimerStart(STARK_STEP_4_CALCULATE_EXPS_2NS_NTT);
+    mi::check(mi_ntt_dev(c, sec(cm4_2ns), qDim * qDeg, qq2, qDim * qDeg, NExtended, qDim * qDeg, 0), "Starks::genProof (NTT of the q chunks)");
+    TimerStopAndLog(STARK_STEP_4_CALCULATE_EXPS_2NS_NTT);
+    TimerStart(STARK_STEP_4_MERKLETREE);
+    mi::check(mi_merkle_build_dev(c, d_nodes[3], sec(cm4_2ns), cols(cm4_2ns), cols(cm4_2ns), NExtended), "Starks::genProof (stage 4: merkelize)");
+    mi::check(mi_copy_d2h(c, root3.address(), d_nodes[3] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 4)");
+    transcript.put(root3.address(), HASH_SIZE);
+    TimerStopAndLog(STARK_STEP_4_MERKLETREE);
+    TimerStopAndLog(STARK_STEP_4);
+
+    //--------------------------------
+    // 5. Compute FRI Polynomial  (starks.cpp:300-390)
+    //--------------------------------
+    TimerStart(STARK_STEP_5);
+    TimerStart(STARK_STEP_5_LEv_LpEv);
+    transcript.getField(challenges[7]); // xi
+    Goldilocks::Element xi[3], wxi[3], xis[3], wxis[3];
+    {
+        const Goldilocks::Element sinv = Goldilocks::inv(Goldilocks::shift()), wN = Goldilocks::w(nBits);
+        for (int d = 0; d < 3; d++) { // starks.cpp:316-318, 347-348
+            xi[d] = challenges[7][d];
+            wxi[d] = xi[d] * wN;
+            xis[d] = xi[d] * sinv;
+            wxis[d] = wxi[d] * sinv;
+        }
+    }
+    mi::check(mi_geom_seq3_dev(c, lev, N, (const uint64_t *)xis), "Starks::genProof (LEv)");   // :320-324
+    mi::check(mi_geom_seq3_dev(c, lpev, N, (const uint64_t *)wxis), "Starks::genProof (LpEv)");
+    mi::check(mi_ntt_dev(c, lev, 3, lev, 3, N, 3, 1), "Starks::genProof (INTT LEv)");            // :325-326
+    mi::check(mi_ntt_dev(c, lpev, 3, lpev, 3, N, 3, 1), "Starks::genProof (INTT LpEv)");
+    TimerStopAndLog(STARK_STEP_5_LEv_LpEv);
+    TimerStart(STARK_STEP_5_EVMAP);
+    if (nEvals) { // starks.cpp:555-668
+        std::vector<const uint64_t *> ptr(nEvals);
+        std::vector<uint32_t> dim(nEvals);
+        std::vector<uint64_t> stride(nEvals);
+        std::vector<uint8_t> prime(nEvals);
+        for (uint64_t i = 0; i < nEvals; i++) {
+            const EvMap &ev = starkInfo.evMap[i];
+            if (ev.type == EvMap::eType::_const) { ptr[i] = m.d_const2ns + ev.id; stride[i] = nConst; dim[i] = 1; }
+            else {
+                const PolRef p = polRef(ev.type == EvMap::eType::cm ? starkInfo.cm_2ns[ev.id] : starkInfo.qs[ev.id]);
+                ptr[i] = d_mem + p.offset; stride[i] = p.stride; dim[i] = (uint32_t)p.dim;
+            }
+            prime[i] = ev.prime ? 1 : 0;
+        }
+        mi::check(mi_evmap_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev), "Starks::genProof (evmap)");
+        mi::check(mi_copy_d2h(c, evals.address(), d_evals, nEvals * 3 * 8), "Starks::genProof (evals d2h)");
+    }
+    TimerStopAndLog(STARK_STEP_5_EVMAP);
+    TimerStart(STARK_STEP_5_XDIVXSUB);
+    for (uint64_t i = 0; i < nEvals; i++) transcript.put(evals[i], 3);
+    transcript.getField(challenges[5]); // v1
+    transcript.getField(challenges[6]); // v2
+    mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, NExtended, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");    // :350-365
+    mi::check(mi_x_div_x_sub_dev(c, m.d_xdivw, m.d_x2ns, NExtended, (const uint64_t *)wxi), "Starks::genProof (xDivXSubWXi)");
+    TimerStopAndLog(STARK_STEP_5_XDIVXSUB);
+    TimerStart(STARK_STEP_5_CALCULATE_EXPS);
+    if (nrowsStepBatch == 4) steps->step52ns_parser_first_avx(params, NExtended, nrowsStepBatch);
+    else if (nrowsStepBatch == 8) steps->step52ns_parser_first_avx512(params, NExtended, nrowsStepBatch);
+    else hostStep(m, steps, params, 4);
+    TimerStopAndLog(STARK_STEP_5_CALCULATE_EXPS);
+    TimerStopAndLog(STARK_STEP_5);
+
+    //--------------------------------
+    // FRI over the resident f_2ns (starks.cpp:391-402): the four trees are lent to FRIProve as views, the fifth is the constant tree
+    //--------------------------------
+    TimerStart(STARK_STEP_FRI);
+    {
+        MerkleTreeGL views[4];
+        MerkleTreeGL *trees[STARK_C12_A_NUM_TREES] = {&views[0], &views[1], &views[2], &views[3], treesGL[4]};
+        for (int t = 0; t < 4; t++) {
+            views[t].height = NExtended;
+            views[t].width = cols(s2[t]);
+            views[t].setDeviceTree(sec(s2[t]), d_nodes[t]);
+        }
+        // FRI's polynomials, step trees and opening buffers come out of the same remainder (the fold transforms in registers: no
+        // NTT scratch is in use any more)
+        mi::check(mi_ctx_lend_workspace(c, nullptr, 0), "Starks::genProof (return the workspace)");
+        mi::lendScratch(rest, restElems);
+        FRIProve::prove(proof, trees, transcript, sec(f_2ns), nBitsExt, starkInfo);
+        mi::lendScratch(nullptr, 0);
+    }
+    proof.proofs.setEvals(evals.address());
+    std::memcpy(&proof.proofs.root1[0], root0.address(), HASH_SIZE * sizeof(Goldilocks::Element));
+    std::memcpy(&proof.proofs.root2[0], root1.address(), HASH_SIZE * sizeof(Goldilocks::Element));
+    std::memcpy(&proof.proofs.root3[0], root2.address(), HASH_SIZE * sizeof(Goldilocks::Element));
+    std::memcpy(&proof.proofs.root4[0], root3.address(), HASH_SIZE * sizeof(Goldilocks::Element));
+    mi::currentMirror() = nullptr;
+    TimerStopAndLog(STARK_STEP_FRI);
+}
+#endif

@@ -11,7 +11,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "test_starkpil_flow")
 
 def build_exe():
     glo.build()
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"), SRC, "-o", EXE,
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"), "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host", "standalone"), SRC, "-o", EXE,
            "-L", os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-lmi_stark", "-L", os.path.join(ROOT, "oracle"), "-lgl_oracle",
            "-Wl,-rpath," + os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
@@ -28,7 +28,7 @@ def test_starkstruct_json_top_level_keys_only(tmp_path):
     """host/build_const_tree.hpp reads nBits / nBitsExt / verificationHashType of the OUTER object even when "steps" (with
     its own nBits entries) comes first; CPU only, nothing of libmi_stark is called."""
     exe = str(tmp_path / "test_host_json")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"), "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host", "standalone"),
                            os.path.join(ROOT, "tests", "cpp", "test_host_json.cpp"), "-o", exe,
                            "-L", os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-lmi_stark", "-Wl,-rpath," + os.path.join(ROOT, "merlin-zkevm-prover_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
@@ -74,7 +74,7 @@ def test_zkin_serialisation_is_byte_identical_to_reference_produced_files(tmp_pa
     blob += U(z["finalPol"]) + U(z["publics"])
     np.array(blob, dtype=np.uint64).tofile(tmp_path / "blob.bin")
     exe = str(tmp_path / "test_zkin_format")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host"), "-I", os.path.join(ROOT, "merlin-zkevm-prover_amd", "host", "standalone"),
                            os.path.join(ROOT, "tests", "cpp", "test_zkin_format.cpp"), "-o", exe])
     subprocess.check_call([exe, str(tmp_path / "blob.bin"), str(tmp_path / "out.json")])
     assert open(tmp_path / "out.json").read() == raw.strip()

@@ -26,12 +26,16 @@ def test_the_air_is_satisfied_by_its_witness_and_its_programs_decode():
         l1, ll = c[i][0], c[i][1]
         assert ((1 - ll) * (an - b)) % P == 0 and ((1 - ll) * (bn - a - b)) % P == 0 and (l1 * (a - 1)) % P == 0 and (l1 * (b - 1)) % P == 0
     assert sorted(w[:, 2]) == sorted(w[:, 3]) and set(w[:, 4]) <= set(c[:, 2]) and len(set(c[:, 2])) < n
-    ops, args = ms.step42ns_program(2 * n, 2)
+    lay = ms.Layout(n, 2 * n)
+    ops, args = ms.step42ns_program(lay, 2)
     assert cp.decode(ops, args)[1] == args.size
-    ops, args = ms.step52ns_program(2 * n)
+    ops, args = ms.step52ns_program(lay)
     assert sum(cp.nargs52_of(int(o)) for o in ops) == args.size
-    for ops, args in (ms.stage2_program(n), ms.stage3_program(n)):
+    for ops, args in (ms.stage2_program(lay), ms.stage3_program(lay), ms.step3_program(lay)):
         assert cp.decode_base(ops, args)[1] == args.size
+    # the starkinfo description agrees with the layout the programs were written against
+    si = ms.starkinfo(6)
+    assert si["mapTotalN"] == lay.total and si["mapOffsets"]["tmpExp_n"] == lay.off["tmpExp_n"] and len(si["evMap"]) == 21
 
 
 @pytest.mark.gpu
