@@ -318,8 +318,8 @@ def main():
             host_trace.copy_(trace)
             torch.cuda.synchronize()
             t_c = time.perf_counter()
-            pack_threads = args.pack_threads if args.pack_threads >= 0 else min(16, os.cpu_count() or 1)     # the library's default
             ctx.set_host_pack_threads(args.pack_threads)
+            pack_threads = ctx.host_pack_threads()                # the count in effect (the default resolves against this host's threads)
             ctx.lde_merkle_host(bufs["nodes"], bufs["ext"], host_trace.data_ptr(), n, n_ext, ncols)     # warm-up (staging buffers)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -361,7 +361,7 @@ def main():
         out = {
             "metric": "goldilocks_field_elements_per_s_lde_merkleize_2^%d_rows" % args.log_n,
             "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "none",
             "vs_baseline": None, "dtype": "u64 (Goldilocks mod 2^64-2^32+1, 32-bit integer VALU)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: 2^%d-row x %d-col trace -> LDE blow-up 2 -> Poseidon Merkle tree"
                                    % (args.log_n, ncols),

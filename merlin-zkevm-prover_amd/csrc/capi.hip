@@ -516,19 +516,34 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
     constexpr int NS = mi_ctx::N_STAGE;
     const uint64_t max_cw = *std::max_element(cws.begin(), cws.end()); // widest chunk of the schedule
     const uint64_t stage_bytes = NS * n * max_cw * 8;
-    if (c->stage_bytes < stage_bytes) {
-        MI_HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (c->stage) MI_HIP_CHECK(hipFree(c->stage));
-        c->stage = nullptr;
-        c->stage_bytes = 0;
-        hipError_t e = hipMalloc((void **)&c->stage, stage_bytes);
-        if (e != hipSuccess) {
-            mi_set_error("cannot allocate %llu bytes of upload staging: %s", (unsigned long long)stage_bytes, hipGetErrorString(e));
-            return MI_ERR_NOMEM;
+    // With a lent workspace (a caller that plans its HBM: host/starks.hpp) the staging comes out of the lent buffer's tail and nothing
+    // is allocated; the transforms of this call see the rest.  Later work on the stream is ordered behind this call's kernels, which
+    // wait for the last upload, so the tail is free again when the call's work is done.
+    struct WorkspaceCarve {
+        mi_ctx *c; uint64_t saved = 0;
+        ~WorkspaceCarve() { if (saved) c->workspace_bytes = c->workspace_limit = saved; }
+    } carve{c};
+    u64 *stage_base = nullptr;
+    if (c->workspace_lent && c->workspace_bytes >= stage_bytes + (2ull << 30)) {
+        carve.saved = c->workspace_bytes;
+        c->workspace_bytes = c->workspace_limit = (carve.saved - stage_bytes) & ~(uint64_t)255;
+        stage_base = c->workspace + c->workspace_bytes / 8;
+    } else {
+        if (c->stage_bytes < stage_bytes) {
+            MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->stage) MI_HIP_CHECK(hipFree(c->stage));
+            c->stage = nullptr;
+            c->stage_bytes = 0;
+            hipError_t e = hipMalloc((void **)&c->stage, stage_bytes);
+            if (e != hipSuccess) {
+                mi_set_error("cannot allocate %llu bytes of upload staging: %s", (unsigned long long)stage_bytes, hipGetErrorString(e));
+                return MI_ERR_NOMEM;
+            }
+            c->stage_bytes = stage_bytes;
         }
-        c->stage_bytes = stage_bytes;
+        stage_base = c->stage;
     }
-    u64 *const st[NS] = {c->stage, c->stage + n * max_cw, c->stage + 2 * n * max_cw};
+    u64 *const st[NS] = {stage_base, stage_base + n * max_cw, stage_base + 2 * n * max_cw};
     // the copy streams must not overtake work already queued on the compute stream that still reads the staging buffers
     for (int i = 0; i < NS; i++) MI_HIP_CHECK(hipEventRecord(c->ev_consumed[i], c->stream));
     if (packed) {

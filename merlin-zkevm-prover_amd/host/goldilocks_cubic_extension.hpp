@@ -24,6 +24,14 @@ public:
         r[0] = r0; r[1] = r1; r[2] = r2;
     }
     static inline void mul(Element &r, const Element &a, const Goldilocks::Element &b) { for (int i = 0; i < 3; i++) r[i] = a[i] * b; }
+    // mixed forms (a base-field operand stands for (a, 0, 0)): what the generated per-row chelpers of the recursive STARKs call, e.g.
+    // Goldilocks3::mul(tmp, params.x_n[i], challenge), Goldilocks3::add(tmp, pols[..], tmp3) (recursive1.chelpers.step3prev.cpp:11-19)
+    static inline void mul(Element &r, const Goldilocks::Element &a, const Element &b) { for (int i = 0; i < 3; i++) r[i] = a * b[i]; }
+    static inline void add(Element &r, const Goldilocks::Element &a, const Element &b) { r[0] = a + b[0]; r[1] = b[1]; r[2] = b[2]; }
+    static inline void add(Element &r, const Element &a, const Goldilocks::Element &b) { r[0] = a[0] + b; r[1] = a[1]; r[2] = a[2]; }
+    static inline void sub(Element &r, const Goldilocks::Element &a, const Element &b) { r[0] = a - b[0]; r[1] = Goldilocks::neg(b[1]); r[2] = Goldilocks::neg(b[2]); }
+    static inline void sub(Element &r, const Element &a, const Goldilocks::Element &b) { r[0] = a[0] - b; r[1] = a[1]; r[2] = a[2]; }
+    static inline void copy(Element &dst, const Goldilocks::Element &src) { dst[0] = src; dst[1] = dst[2] = Goldilocks::zero(); }
     static inline void inv(Element *r, const Element *a) { inv(*r, *a); }
     static inline void inv(Element &r, const Element &a)
     {

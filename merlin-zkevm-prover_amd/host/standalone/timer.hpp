@@ -11,6 +11,7 @@
 namespace mi {
 struct PhaseTimer {
     std::vector<std::pair<std::string, int>> slots; // phase name -> event slot
+    uint64_t minFree = ~0ULL;                       // low-water mark of free HBM, sampled at every phase end
     bool enabled = std::getenv("MI_STARK_PHASE_TIMES") != nullptr; // off by default: an event pair per phase
     int slotOf(const char *name)
     {
@@ -21,7 +22,14 @@ struct PhaseTimer {
 };
 inline PhaseTimer &phaseTimer() { static PhaseTimer t; return t; }
 inline void timerStart(const char *name) { PhaseTimer &t = phaseTimer(); if (t.enabled && t.slots.size() < 60) mi_timer_start(ctx(), t.slotOf(name)); }
-inline void timerStop(const char *name) { PhaseTimer &t = phaseTimer(); if (t.enabled) for (auto &s : t.slots) if (s.first == name) mi_timer_stop(ctx(), s.second); }
+inline void timerStop(const char *name)
+{
+    PhaseTimer &t = phaseTimer();
+    if (!t.enabled) return;
+    for (auto &s : t.slots) if (s.first == name) mi_timer_stop(ctx(), s.second);
+    uint64_t fr = 0, tot = 0;
+    if (mi_dev_mem_info(ctx(), &fr, &tot) == MI_OK && fr < t.minFree) t.minFree = fr;
+}
 // (phase, milliseconds) in first-start order; synchronises on each stop event
 inline std::vector<std::pair<std::string, float>> phaseTimes()
 {

@@ -158,13 +158,58 @@ public:
         TimerStart(LOAD_CONST_POLS_TO_MEMORY);
         constPolsSize = starkInfo.nConstants * sizeof(Goldilocks::Element) * N;
         pConstPolsAddress = starkFiles.mapConstPolsFile ? mapFile(starkFiles.zkevmConstPols, constPolsSize, false) : copyFile(starkFiles.zkevmConstPols, constPolsSize);
-        pConstPols = new ConstantPolsStarks(pConstPolsAddress, constPolsSize, starkInfo.nConstants);
         TimerStopAndLog(LOAD_CONST_POLS_TO_MEMORY);
         TimerStart(LOAD_CONST_TREE_TO_MEMORY);
         const uint64_t treeBytes = starkInfo.getConstTreeSizeInBytes();
         pConstTreeAddress = config.mapConstantsTreeFile ? mapFile(starkFiles.zkevmConstantsTree, treeBytes, false) : copyFile(starkFiles.zkevmConstantsTree, treeBytes);
-        pConstPols2ns = new ConstantPolsStarks((uint8_t *)pConstTreeAddress + MERKLEHASHGOLDILOCKS_HEADER_SIZE * sizeof(Goldilocks::Element), NExtended, starkInfo.nConstants);
         TimerStopAndLog(LOAD_CONST_TREE_TO_MEMORY);
+        ownsConstants = true;
+        init();
+    }
+    // Not in the reference: the same object over constants that are already in memory (embedding, benchmarks).  constPols: N x
+    // nConstants; constTree: the image of the constant-tree file [nPols, nExt, pols, nodes] -- of which only the rows and paths the
+    // queries open are ever read.  Both stay the caller's.
+    Starks(const Config &config, const StarkInfo &info, void *constPols, void *constTree, void *_pAddress)
+        : config(config), starkInfo(info), zi(info.starkStruct.nBits, info.starkStruct.nBitsExt), N(1ULL << info.starkStruct.nBits),
+          NExtended(1ULL << info.starkStruct.nBitsExt), pAddress(_pAddress)
+    {
+        nrowsStepBatch = 1;
+        constPolsSize = starkInfo.nConstants * sizeof(Goldilocks::Element) * N;
+        pConstPolsAddress = constPols;
+        pConstTreeAddress = constTree;
+        init();
+    }
+    Starks(const Starks &) = delete;
+    Starks &operator=(const Starks &) = delete;
+    ~Starks()
+    {
+        if (!pConstPols) return; // nothing was set up (config.generateProof() false)
+        for (auto &p : progs) if (p.second) mi_chelpers_free(mi::ctx(), p.second);
+        if (d_constN) mi_dev_free(mi::ctx(), d_constN);
+        delete pConstPols;
+        delete pConstPols2ns;
+        if (ownsConstants) {
+            if (starkFiles.mapConstPolsFile) unmapFile(pConstPolsAddress, constPolsSize); else free(pConstPolsAddress);
+            if (config.mapConstantsTreeFile) unmapFile(pConstTreeAddress, starkInfo.getConstTreeSizeInBytes()); else free(pConstTreeAddress);
+        }
+        for (unsigned i = 0; i < STARK_C12_A_NUM_TREES; i++) delete treesGL[i];
+    }
+    // bytes of HBM a genProof of this STARK plans for (image + trees + late scratch) plus the resident constant polynomials
+    uint64_t hbmPlanBytes() const { return (starkInfo.mapTotalN + 4 * treeElems + scratchElems + starkInfo.nConstants * N) * 8; }
+
+    void genProof(FRIProof &proof, Goldilocks::Element *publicInputs, Steps *steps);
+
+    // device image of the last proof's polynomial area (valid until the next genProof of any Starks): for checks after the fact.
+    // lateOffsets: where the stage-4 re-plan put the extended constant polynomials, xDivXSubXi and xDivXSubWXi (elements from the image's start)
+    const uint64_t *deviceImage() const { return mi::arena().base; }
+    uint64_t lateOffsets[3] = {0, 0, 0};
+
+private:
+    bool ownsConstants = false;
+    void init()
+    {
+        pConstPols = new ConstantPolsStarks(pConstPolsAddress, constPolsSize, starkInfo.nConstants);
+        pConstPols2ns = new ConstantPolsStarks((uint8_t *)pConstTreeAddress + MERKLEHASHGOLDILOCKS_HEADER_SIZE * sizeof(Goldilocks::Element), NExtended, starkInfo.nConstants);
         mem = (Goldilocks::Element *)pAddress;
         treesGL[4] = new MerkleTreeGL((Goldilocks::Element *)pConstTreeAddress); // opened at the query points from the file (merkleTreeGL.hpp:24-32)
         treeElems = MerklehashGoldilocks::getTreeNumElements(NExtended);
@@ -176,25 +221,6 @@ public:
             mi::check(mi_copy_h2d(mi::ctx(), d_constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (constant polynomials h2d)");
         }
     }
-    Starks(const Starks &) = delete;
-    Starks &operator=(const Starks &) = delete;
-    ~Starks()
-    {
-        if (!config.generateProof()) return;
-        for (auto &p : progs) if (p.second) mi_chelpers_free(mi::ctx(), p.second);
-        if (d_constN) mi_dev_free(mi::ctx(), d_constN);
-        delete pConstPols;
-        delete pConstPols2ns;
-        if (starkFiles.mapConstPolsFile) unmapFile(pConstPolsAddress, constPolsSize); else free(pConstPolsAddress);
-        if (config.mapConstantsTreeFile) unmapFile(pConstTreeAddress, starkInfo.getConstTreeSizeInBytes()); else free(pConstTreeAddress);
-        for (unsigned i = 0; i < STARK_C12_A_NUM_TREES; i++) delete treesGL[i];
-    }
-    // bytes of HBM a genProof of this STARK plans for (image + trees + late scratch) plus the resident constant polynomials
-    uint64_t hbmPlanBytes() const { return (starkInfo.mapTotalN + 4 * treeElems + scratchElems + starkInfo.nConstants * N) * 8; }
-
-    void genProof(FRIProof &proof, Goldilocks::Element *publicInputs, Steps *steps);
-
-private:
     void hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
 };
 
@@ -391,6 +417,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     m.d_xdiv = take(3 * NExtended);
     m.d_xdivw = take(3 * NExtended);
     uint64_t *d_evals = take(nEvals * 3 + 16);
+    lateOffsets[0] = m.d_const2ns - d_mem; lateOffsets[1] = m.d_xdiv - d_mem; lateOffsets[2] = m.d_xdivw - d_mem;
     // what is left serves the transforms of stages 4 and 5, then FRI
     uint64_t *rest = scratchElems ? d_late + lateUsed : d_mem + poolUsed;
     const uint64_t restElems = scratchElems ? scratchElems - lateUsed : poolElems - poolUsed;

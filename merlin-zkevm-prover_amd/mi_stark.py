@@ -56,6 +56,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
+    "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_get_host_pack_threads",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
 ]
 
@@ -180,6 +181,26 @@ class Context:
         """host_trace_ptr: address of the row-major n x ncols host trace (e.g. a pinned torch tensor's data_ptr())."""
         _check(lib().mi_lde_merkle_host(self.h, _dp(nodes), _dp(ext), u64(ext_pitch or ncols), ctypes.c_void_p(host_trace_ptr),
                                         u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
+
+    def lde_merkle_host_keep(self, nodes, ext, base, host_trace_ptr, n, n_ext, ncols, ext_pitch=None, base_pitch=None, chunk_cols=0):
+        """lde_merkle_host, and the uploaded base-domain section stays in `base` (device, n x ncols) as well."""
+        _check(lib().mi_lde_merkle_host_keep(self.h, _dp(nodes), _dp(ext), u64(ext_pitch or ncols), _dp(base), u64(base_pitch or ncols),
+                                             ctypes.c_void_p(host_trace_ptr), u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
+
+    def lend_workspace(self, buf):
+        """NTT / LDE scratch out of a caller-owned device tensor (None: back to the context's own workspace)."""
+        if buf is None:
+            _check(lib().mi_ctx_lend_workspace(self.h, ctypes.c_void_p(0), u64(0)))
+        else:
+            _check(lib().mi_ctx_lend_workspace(self.h, _dp(buf), u64(buf.numel() * 8)))
+
+    def mem_info(self):
+        f, t = u64(0), u64(0)
+        _check(lib().mi_dev_mem_info(self.h, ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    def host_pack_threads(self):
+        return int(lib().mi_get_host_pack_threads(self.h))
 
     def host_register(self, ptr, nbytes):
         _check(lib().mi_host_register(self.h, ctypes.c_void_p(ptr), u64(nbytes)))

@@ -166,7 +166,7 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     sum or difference, folded with an extension addition).  Operand columns follow a skewed distribution (the real program reads
     1 766 distinct elements 12 525 times).  `long_lived` base values are computed up front and read throughout, so that the
     rescheduled program keeps about as many words live as the real one (86).  Uses challenges 0..vc; ends with the q store.
-    base_out = (offset, stride): the same shape in the BASE-DOMAIN steps' numbering (opcodes 0-83 are shared): about every other
+    sections: [(offset, stride[, readable columns])].  base_out = (offset, stride[, columns]): the same shape in the BASE-DOMAIN steps' numbering (opcodes 0-83 are shared): about every other
     constraint value is stored into a column of that section instead of being accumulated (opcode 100; the zkEVM step3 stores 430 elements) and the accumulator goes to
     three of its columns (opcode 90) instead of q."""
     ops, args = [], []
@@ -187,8 +187,9 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
         return pool[int(rng.choice(len(pool), p=w / w.sum()))]
 
     def rand_col(three=False):
-        off, stride = sections[int(rng.integers(0, len(sections)))]
-        return off + int(rng.integers(0, stride - (2 if three else 0))), stride
+        sec = sections[int(rng.integers(0, len(sections)))]          # (offset, stride[, readable columns])
+        off, stride = sec[0], sec[1]
+        return off + int(rng.integers(0, (sec[2] if len(sec) > 2 else stride) - (2 if three else 0))), stride
     shared = {"pol": [rand_col() for _ in range(12)], "pols": [rand_col() for _ in range(4)], "const": [int(rng.integers(0, n_const)) for _ in range(4)]}
 
     def new_run():
@@ -240,7 +241,7 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
             push(o, ar)
             prev, cur = (cur if cur is not None else dst), dst
             count += 1
-        if base_out is not None and out_cursor[0] + 4 < base_out[1] and (count // 8) % 2 == 0:
+        if base_out is not None and out_cursor[0] + 4 < (base_out[2] if len(base_out) > 2 else base_out[1]) and (count // 8) % 2 == 0:
             # this value is an output (stored, not accumulated: a value that is both keeps every such value alive until the
             # accumulation is scheduled, which the real programs do not do)
             push(100, [base_out[0] + out_cursor[0], base_out[1], cur])

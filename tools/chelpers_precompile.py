@@ -21,6 +21,28 @@ CONFIGS = [
 ]
 
 
+# bench_starks.py (class Starks end to end): the default zkEVM-shaped STARK and the small one the GPU test runs
+STARKS_CONFIGS = [
+    [],
+    ["--log-n", "12", "--widths", "37", "20", "40", "--tmpexp", "60", "--n-const", "11", "--n-evals", "24", "--n-queries", "16", "--n-lookups", "2", "2",
+     "--n-products", "6", "--field-ops", "200", "300", "400", "1500", "700"],
+]
+
+
+def precompile_starks(jobs, only):
+    import bench_starks
+    for ci, argv in enumerate(STARKS_CONFIGS):
+        if only >= 0 and ci != only:
+            continue
+        t0 = time.time()
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench_starks.py")] + argv + ["--precompile", str(s), str(jobs)]) for s in range(jobs)]
+        if any(p.wait() for p in procs):
+            raise SystemExit("a precompile shard of bench_starks.py failed")
+        st = bench_starks.compiled_programs(bench_starks.arg_parser().parse_args(argv))
+        print("precompiled bench_starks", argv or "(default)", {k: (v["kernels"], v["cache_hits"], v["code_bytes"]) for k, v in st.items()},
+              "%.1f s" % (time.time() - t0), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=min(8, os.cpu_count() or 1))
@@ -28,7 +50,11 @@ def main():
     ap.add_argument("--config", type=int, default=-1)
     ap.add_argument("--only", type=int, default=-1, help="precompile only this configuration")
     ap.add_argument("--extra", nargs=argparse.REMAINDER, default=[], help="further bench_genproof.py arguments for every configuration")
+    ap.add_argument("--starks-only", type=int, default=None, help="only the bench_starks.py configuration with this index (-1: all of them)")
     a = ap.parse_args()
+    if a.starks_only is not None:
+        precompile_starks(a.jobs, a.starks_only)
+        return
     for c in CONFIGS:
         c.extend(a.extra)
     import bench_genproof
@@ -52,6 +78,8 @@ def main():
               "%.1f s" % (time.time() - t0), flush=True)
         prog.close()
         prog52.close()
+    if a.shard < 0 and a.only < 0:
+        precompile_starks(a.jobs, -1)
 
 
 if __name__ == "__main__":
