@@ -77,49 +77,73 @@ def cpu_model():
 
 
 def cpu_baseline(log_n, ncols):
-    """CPU baseline = this repo's C restatement of the path (oracle/gl_oracle.c built -O3 -mavx2 with OpenMP as
-    oracle/libgl_oracle_avx2.so; "restatement, not upstream": the reference's src/goldilocks is absent) on a bounded
-    sample of the same workload: LDE + Merkle tree of a 2^log_n x ncols trace on all host cores of this process's share,
-    plus a 1-thread figure on a smaller sample.  Phase names mirror the reference's timers (starks.cpp:50-57)."""
-    # threads = this process's CPU share (the GPU box gives 16 cores per GPU).  libgomp is already loaded (torch), so
-    # the environment variable would come too late: set the count through the oracle itself.
+    """CPU baseline on this node's host cores, on a bounded sample of the same workload (LDE + Merkle tree of a 2^log_n x ncols trace).
+    The reference's CPU path (src/goldilocks: AVX2 + OpenMP) is an absent submodule, so what is timed is this repo's restatement of
+    it, labelled as such:
+      value           oracle/cpu_baseline_avx2.c -- hand-vectorised (4 sponges per __m256i, MDS as 32-bit multiply-adds, vector butterflies on
+                      cache-sized column blocks), OpenMP; itself checked bit for bit against the checker (tests/test_cpu_baseline.py);
+      naive           oracle/gl_oracle.c built -O3 -mavx2 -- the CHECKER's scalar code (30 x 144 128-bit multiply-adds per permutation, a
+                      layer-by-layer NTT over the whole matrix), on a sample 4x smaller: kept for continuity with rounds 1-2, not a baseline
+                      anyone should quote.
+    Phase names mirror the reference's timers (starks.cpp:50-57)."""
     share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
     import glo
-    L = glo.lib("avx2")
-    L.glo_set_num_threads(max(1, min(share, 64)))
-    cores = int(L.glo_num_threads())
-    n, n_ext = 1 << log_n, 2 << log_n
-    trace = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
-    t0 = time.perf_counter()
-    ext = glo.extend_pol(trace, n_ext, n, ncols, flavour="avx2")
-    t1 = time.perf_counter()
-    nodes = glo.merkletree(ext, ncols, n_ext, flavour="avx2")
-    t2 = time.perf_counter()
-    # 1 thread: LDE of 32 of the columns at the same row count, tree over 2^13 of the extended rows
-    L.glo_set_num_threads(1)
-    c1, h1 = min(32, ncols), min(n_ext, 1 << 13)
-    sub = np.ascontiguousarray(trace[:, :c1])
-    u0 = time.perf_counter()
-    glo.extend_pol(sub, n_ext, n, c1, flavour="avx2")
-    u1 = time.perf_counter()
-    glo.merkletree(np.ascontiguousarray(ext[:h1]), ncols, h1, flavour="avx2")
-    u2 = time.perf_counter()
-    L.glo_set_num_threads(cores)
-    lde_1t = n * c1 / (u1 - u0)                       # trace elements/s through the LDE
-    mrk_1t = (h1 / 2) * ncols / (u2 - u1)             # trace elements/s through the tree (2 extended rows per trace row)
-    return {
-        "value": n * ncols / (t2 - t0), "unit": "field-elements/s", "cores": cores, "kind": "port",
-        "label": "restatement, not upstream (oracle/gl_oracle.c, gcc -O3 -mavx2 -fopenmp; the reference's src/goldilocks AVX2 library is absent)",
-        "cpu_model": cpu_model(), "nproc": os.cpu_count(), "omp_threads": cores,
-        "sample": f"2^{log_n} rows x {ncols} cols -> LDE 2^{log_n + 1} + Poseidon Merkle tree, {cores} threads; "
-                  f"STARK_STEP_1_LDE {t1 - t0:.2f} s, STARK_STEP_1_MERKLETREE {t2 - t1:.2f} s",
-        "phase_s": {"STARK_STEP_1_LDE": t1 - t0, "STARK_STEP_1_MERKLETREE": t2 - t1},
-        "one_thread": {"value": 1.0 / (1.0 / lde_1t + 1.0 / mrk_1t), "unit": "field-elements/s",
-                       "lde_elements_per_s": lde_1t, "merkle_elements_per_s": mrk_1t,
-                       "sample": f"LDE 2^{log_n} x {c1} cols ({u1 - u0:.2f} s); tree over 2^{h1.bit_length() - 1} x {ncols} extended rows ({u2 - u1:.2f} s)"},
-        "root": [int(v) for v in nodes[-4:]],
-    }
+    u64 = ctypes.c_uint64
+    threads = max(1, min(share, 64))
+
+    def run(L, extend, tree, n, label):
+        n_ext = 2 * n
+        trace = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
+        L.glo_set_num_threads(threads)
+        cores = int(L.glo_num_threads())
+        t0 = time.perf_counter()
+        ext = extend(trace, n_ext, n)
+        t1 = time.perf_counter()
+        nodes = tree(ext, n_ext)
+        t2 = time.perf_counter()
+        L.glo_set_num_threads(1)                           # 1 thread: 32 of the columns at the same row count, tree over 2^13 extended rows
+        c1, h1 = min(32, ncols), min(n_ext, 1 << 13)
+        sub = np.ascontiguousarray(trace[:, :c1])
+        u0 = time.perf_counter()
+        extend(sub, n_ext, n)
+        u1 = time.perf_counter()
+        tree(np.ascontiguousarray(ext[:h1]), h1)
+        u2 = time.perf_counter()
+        L.glo_set_num_threads(cores)
+        lde_1t, mrk_1t = n * c1 / (u1 - u0), (h1 / 2) * ncols / (u2 - u1)
+        perms = n_ext * ((ncols + 7) // 8) + n_ext - 1
+        return {"value": n * ncols / (t2 - t0), "unit": "field-elements/s", "cores": cores, "kind": "port", "label": label,
+                "sample": f"2^{n.bit_length() - 1} rows x {ncols} cols -> LDE 2^{n.bit_length()} + Poseidon Merkle tree, {cores} threads; "
+                          f"STARK_STEP_1_LDE {t1 - t0:.2f} s, STARK_STEP_1_MERKLETREE {t2 - t1:.2f} s",
+                "phase_s": {"STARK_STEP_1_LDE": t1 - t0, "STARK_STEP_1_MERKLETREE": t2 - t1},
+                "permutations_per_s_per_thread": perms / (t2 - t1) / cores,
+                "one_thread": {"value": 1.0 / (1.0 / lde_1t + 1.0 / mrk_1t), "unit": "field-elements/s", "lde_elements_per_s": lde_1t,
+                               "merkle_elements_per_s": mrk_1t, "permutations_per_s": (h1 * ((ncols + 7) // 8) + h1 - 1) / (u2 - u1)},
+                "root": [int(v) for v in nodes[-4:]]}
+
+    Lb = glo.lib("baseline")
+
+    def extend_fast(trace, n_ext, n):
+        c = trace.shape[1]
+        out = np.empty(n_ext * c, dtype=np.uint64)
+        Lb.glb_extend_pol(glo.ptr(out), glo.ptr(np.ascontiguousarray(trace).reshape(-1)), u64(n_ext), u64(n), u64(c))
+        return out.reshape(n_ext, c)
+
+    def tree_fast(ext, rows):
+        nodes = np.zeros((2 * rows - 1) * 4, dtype=np.uint64)
+        Lb.glb_merkletree(glo.ptr(nodes), glo.ptr(np.ascontiguousarray(ext).reshape(-1)), u64(ext.shape[1]), u64(rows))
+        return nodes
+
+    out = run(Lb, extend_fast, tree_fast, 1 << log_n,
+              "restatement, not upstream (oracle/cpu_baseline_avx2.c: hand-vectorised AVX2 + OpenMP; the reference's src/goldilocks library is absent)")
+    out["cpu_model"], out["nproc"], out["omp_threads"] = cpu_model(), os.cpu_count(), out["cores"]
+    Ln = glo.lib("avx2")
+    out["naive"] = run(Ln, lambda t, ne, n: glo.extend_pol(t, ne, n, t.shape[1], flavour="avx2"),
+                       lambda e, rows: glo.merkletree(e, e.shape[1], rows, flavour="avx2"), 1 << max(log_n - 2, 8),
+                       "the CHECKER's scalar restatement (oracle/gl_oracle.c, gcc -O3 -mavx2 -fopenmp): not an optimised CPU path")
+    return out
 
 
 def launch_ranks(args):
@@ -152,13 +176,16 @@ def main():
     ap.add_argument("--cols", type=int, default=665, help="committed columns (BASELINE: 665)")
     ap.add_argument("--workspace-gib", type=float, default=32.0)
     ap.add_argument("--poseidon-variant", type=int, default=2)
-    ap.add_argument("--cpu-log-n", type=int, default=18, help="log2 rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 rows of the CPU-baseline sample (the checker's scalar code runs on a quarter of it)")
     ap.add_argument("--pcie-steps", type=int, default=2, help="N = 1: steps of the PCIe-inclusive leg (host trace streamed in by mi_lde_merkle_host); 0 = skip")
     ap.add_argument("--pack-threads", type=int, default=-1,
                     help="PCIe-inclusive leg: host threads packing column chunks into page-locked staging (0 = strided 2-D copies; "
                          "-1 = the library's default, min(16, hardware threads))")
     ap.add_argument("--pcie-pageable", action="store_true", help="PCIe-inclusive leg: the host trace in pageable memory (as a mapped file would be)")
     ap.add_argument("--no-verify", action="store_true", help="skip the full-size oracle verification after the timed region (N = 1)")
+    ap.add_argument("--verify-sharded", action="store_true",
+                    help="tile-by-tile / N > 1 path: gather the row-sharded extension and leaf digests on rank 0 and verify them against the oracle "
+                         "(for sizes one GPU holds whole, e.g. --log-n 18: about half a minute of CPU)")
     ap.add_argument("--ntt-log-b", type=int, default=5)
     ap.add_argument("--lde-fuse", type=int, default=1, help="0 = separate last-INTT / first-NTT passes (A/B only)")
     ap.add_argument("--leaf-mode", type=int, default=1, help="1 = line-aligned leaf fetch (default), 0 = per-block loads")
@@ -247,6 +274,20 @@ def main():
             ctx.linear_hash_absorb(digests, windows, nrows, first, final)
             ctx.timer_stop(ABSORB_SLOT0 + chunk)
 
+        wait_events = []
+
+        @staticmethod
+        def wait_begin(k):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            OpsTimed.wait_events.append([e, None])
+
+        @staticmethod
+        def wait_end(k):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            OpsTimed.wait_events[-1][1] = e
+
         @staticmethod
         def merkle_levels(nodes, nleaves):
             if nleaves == plan.rows_per_rank:        # my subtree (the top levels over the G roots are not timed apart)
@@ -259,7 +300,7 @@ def main():
     lde_rounds = [k for k in range(plan.n_rounds) if plan.width(k, rank)] if exchange else []
     absorb_rounds = list(range(plan.n_rounds)) if exchange else []
 
-    t_lde = t_leaf = t_lvls = 0.0
+    t_lde = t_leaf = t_lvls = t_wait = 0.0
 
     def barrier():
         if dist is not None:
@@ -286,6 +327,10 @@ def main():
             t_lde += ctx.timer_ms(0)
             t_leaf += ctx.timer_ms(1)
         t_lvls += ctx.timer_ms(2)
+        if exchange:
+            torch.cuda.synchronize()
+            t_wait += sum(a.elapsed_time(b) for a, b in OpsTimed.wait_events if b is not None)
+            OpsTimed.wait_events.clear()
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -294,6 +339,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     root_host = [int(v) for v in ctx.to_host(root)]
+
+    # ---- per-rank breakdown (every N): a first run on real hardware must be able to say WHERE it went wrong or slow
+    from shard import exchange_bytes_to_peers, gather_sharded_result
+    K_ = max(args.steps, 1)
+    mine = [t_lde / K_, t_leaf / K_, t_lvls / K_, t_wait / K_] + [float(b) for b in (exchange_bytes_to_peers(plan) if exchange else [0] * world)]
+    per_rank = None
+    if dist is not None and world > 1:
+        tt = torch.tensor(mine, dtype=torch.float64, device=ctx.device)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        rows_ = [[float(v) for v in t_.cpu()] for t_ in allt]
+    else:
+        rows_ = [mine]
+    per_rank = [{"rank": r, "lde_ms": v[0], "absorb_ms": v[1], "levels_ms": v[2], "exchange_wait_ms": v[3], "bytes_sent_to_peer": [int(b) for b in v[4:]]}
+                for r, v in enumerate(rows_)]
+    sharded_verify = None
+    if exchange and args.verify_sharded:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from verify_full import verify_gathered
+        ext_full, dig_full = gather_sharded_result(plan, OpsTimed, dist if world > 1 else None, bufs)
+        if rank == 0:
+            sharded_verify = verify_gathered(ctx, ext_full, dig_full, root_host, n, n_ext, ncols, seed=0x5EED0003,
+                                             log=lambda m: print(m, file=sys.stderr, flush=True))
 
     verify = None
     if world == 1 and not args.no_verify:
@@ -369,9 +437,10 @@ def main():
                        "poseidon_variant": args.poseidon_variant},
             "root": root_host,
             "root_verified_against_oracle": bool(verify and verify.get("tree_levels_match_oracle") and verify.get("all_columns_all_rows_lincomb")),
+            "leaf_rows_checked": (verify or {}).get("leaf_rows_checked", 0),
             "verify": verify,
             "root_matches_regression_constant": (root_host == ROOT_2P23_X665) if (args.log_n == 23 and ncols == 665) else None,
-            "comm": comm,
+            "comm": comm, "per_rank": per_rank, "sharded_verify": sharded_verify,
             "pcie_inclusive": pcie,
             "value_pcie_inclusive": (pcie or {}).get("value"),
             "roofline": {"kernel": "k_linear_hash_rows_lines" if args.leaf_mode else "k_linear_hash_rows", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -196,6 +196,18 @@ def phase_top(plan: ShardPlan, ops, bufs):
     return bufs["roots"][(2 * plan.world - 2) * 4:(2 * plan.world - 1) * 4]
 
 
+def _wait_all(ops, pending):
+    """The compute stream waits for a round's transfers; ops may bracket the wait (wait_begin / wait_end: stream-side timers that
+    show how long the kernels stood still for the links)."""
+    k, works = pending
+    if hasattr(ops, "wait_begin"):
+        ops.wait_begin(k)
+    for w in works:
+        w.wait()
+    if hasattr(ops, "wait_end"):
+        ops.wait_end(k)
+
+
 def lde_merkle_sharded(plan: ShardPlan, ops, dist, trace_shard, bufs, always_exchange=False):
     """Runs steps 1-4.  `ops` provides lde / absorb / merkle_build / merkle_levels on the device the tensors live on;
     `dist` is torch.distributed (or None when world == 1).  always_exchange: take the pipelined path even for
@@ -213,18 +225,46 @@ def lde_merkle_sharded(plan: ShardPlan, ops, dist, trace_shard, bufs, always_exc
         phase_lde(p, ops, trace_shard, bufs, k)
         works = phase_exchange(p, dist, bufs, k) if p.world > 1 else []
         if pending is not None:          # round k-1 has arrived (its transfers ran beside this round's LDE)
-            for w in pending[1]:
-                w.wait()
+            _wait_all(ops, pending)
             phase_absorb(p, ops, bufs, pending[0])
         pending = (k, works)
-    for w in pending[1]:
-        w.wait()
+    _wait_all(ops, pending)
     phase_absorb(p, ops, bufs, pending[0])
     my_root = phase_subtree(p, ops, bufs)
     if p.world == 1:
         return my_root
     dist.all_gather_into_tensor(bufs["roots"][:p.world * 4], my_root.contiguous())
     return phase_top(p, ops, bufs)
+
+
+# ------------------------------------------------------------------ diagnostics for a first run on real hardware
+def exchange_bytes_to_peers(plan: ShardPlan):
+    """Bytes this rank sends to every peer per step (its own entry is 0): what the exchange should show on each xGMI link."""
+    out = [0] * plan.world
+    for k in range(plan.n_rounds):
+        for msgs in exchange_messages(plan, k):
+            for (peer, _s_off, s_cnt, _r_off, _r_cnt) in msgs:
+                out[peer] += 8 * s_cnt
+    return out
+
+
+def gather_sharded_result(plan: ShardPlan, ops, dist, bufs):
+    """The row-sharded extension and leaf digests assembled on rank 0 (None elsewhere): ext [n_ext, ncols], digests [n_ext, 4].
+    For verification against the oracle at sizes where one GPU / host holds the whole result; every rank calls it."""
+    p = plan
+    wins = [(bufs[name], off, w, pitch) for (name, off, w, pitch) in p.row_windows()]
+    mine = ops.gather_rows(wins, list(range(p.rows_per_rank))).contiguous()            # [rows_per_rank, ncols]
+    dig = bufs["nodes"][:4 * p.rows_per_rank].reshape(p.rows_per_rank, 4).contiguous()
+    if p.world == 1:
+        return mine, dig
+    ext_all = [ops.zeros(p.rows_per_rank * p.ncols).view(p.rows_per_rank, p.ncols) for _ in range(p.world)] if p.rank == 0 else None
+    dig_all = [ops.zeros(p.rows_per_rank * 4).view(p.rows_per_rank, 4) for _ in range(p.world)] if p.rank == 0 else None
+    dist.gather(mine, ext_all, dst=0)
+    dist.gather(dig, dig_all, dst=0)
+    if p.rank != 0:
+        return None, None
+    import torch
+    return torch.cat(ext_all, dim=0), torch.cat(dig_all, dim=0)
 
 
 # ------------------------------------------------------------------ query openings over the row-sharded tree

@@ -10,8 +10,10 @@ _p64 = ctypes.POINTER(u64)
 
 
 def build(flavour=""):
-    so = os.path.join(ROOT, "oracle", "libgl_oracle%s.so" % ("_" + flavour if flavour else ""))
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("gl_oracle.c", "chelpers_oracle.c", "gl_oracle.h", "poseidon_constants.h", "Makefile")]
+    """flavour "baseline": oracle/libgl_baseline_avx2.so (cpu_baseline_avx2.c: the hand-vectorised CPU-baseline leg, plus the oracle's
+    symbols it is checked against)."""
+    so = os.path.join(ROOT, "oracle", "libgl_baseline_avx2.so" if flavour == "baseline" else "libgl_oracle%s.so" % ("_" + flavour if flavour else ""))
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("gl_oracle.c", "chelpers_oracle.c", "gl_oracle.h", "poseidon_constants.h", "Makefile", "cpu_baseline_avx2.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return so

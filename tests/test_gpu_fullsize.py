@@ -59,6 +59,10 @@ def test_verification_harness_on_a_small_case_and_that_it_catches_a_wrong_value(
     bad[5000 * ncols + 17] += 1
     with pytest.raises(AssertionError, match="combination"):
         verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(bad, 0, ncols, ncols)], None, n, n_ext, ncols, cols=[0, 69])
+    nodes3 = nodes.clone()
+    nodes3[4 * 1234 + 1] ^= 1                                             # one wrong leaf digest, at a row the old 64-row sample never visited
+    with pytest.raises(AssertionError, match="leaf digest"):
+        verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(ext, 0, ncols, ncols)], nodes3, n, n_ext, ncols, cols=[0])   # default: 2^16 >= all rows
     nodes2 = nodes.clone()
     nodes2[(n_ext + 100) * 4] ^= 1                                        # a corrupted level-1 node
     with pytest.raises(AssertionError, match="tree levels"):
@@ -117,7 +121,7 @@ def test_config3_full_size_tile_by_tile_path_vs_oracle(ctx, state):
     # columns at tile edges of THIS layout; the tree above the digests was verified in the test before, so equality of the
     # level-0 digests and of the root with that run closes the loop without a second 30-second oracle tree
     s = verify_lde_merkle(ctx, [(trace, 0, NCOLS, NCOLS)], ext_windows, bufs["nodes"], n, n_ext, NCOLS,
-                          cols=[0, 31, 32, 63, 639, 640, 664], n_rows=24, check_tree=False)
+                          cols=[0, 31, 32, 63, 639, 640, 664], n_rows=1 << 14, check_tree=False)
     assert s["all_columns_all_rows_lincomb"]
     if "leaf_digests" in state:
         assert np.array_equal(ctx.to_host(bufs["nodes"][:4 * n_ext]), state["leaf_digests"])
@@ -138,6 +142,6 @@ def test_stage_widths_full_size_lde_and_tree_vs_oracle(ctx, ncols):
     ctx.merkle_build(nodes, ext, ncols, n_ext)
     torch.cuda.synchronize()
     s = verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(ext, 0, ncols, ncols)], nodes, n, n_ext, ncols,
-                          cols=[0, 1, 2, 31, 32, 95, 96, ncols - 2, ncols - 1], n_rows=32, check_tree=(ncols == 128))
+                          cols=[0, 1, 2, 31, 32, 95, 96, ncols - 2, ncols - 1], n_rows=1 << 12, check_tree=(ncols == 128))
     assert s["all_columns_all_rows_lincomb"]
     _free(trace, ext, nodes)

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import glo
-from shard import ShardPlan, lde_merkle_sharded, group_proofs_sharded, fri_commit_sharded, merkle_levels_of
+from shard import ShardPlan, lde_merkle_sharded, group_proofs_sharded, fri_commit_sharded, merkle_levels_of, exchange_bytes_to_peers, gather_sharded_result
 
 
 def test_tile_dealing_and_buffer_layouts():
@@ -174,7 +174,11 @@ def _worker(rank, world, port, n, ncols, q):
     tr.put(root.numpy().view(np.uint64))
     final, trees, chal = fri_commit_sharded(world, rank, OracleOps, dist, tr, pol, [fb, fb - 3, fb - 5, fb - 7], fb, min_per_rank=8)
     fri = (final.numpy().view(np.uint64)[:3 << (fb - 7)].copy(), [t[0].numpy().view(np.uint64)[-4:].copy() for t in trees], tr.get_fields1())
-    q.put((rank, root.numpy().view(np.uint64).copy(), bufs["nodes"].numpy().view(np.uint64)[:plan.rows_per_rank * 4].copy(), idx, proofs, fri))
+    # the diagnostics bench.py prints for N > 1: what this rank sends each peer per step, and the whole result gathered on rank 0
+    sent = exchange_bytes_to_peers(plan)
+    ext_full, dig_full = gather_sharded_result(plan, OracleOps, dist, bufs)
+    gathered = None if rank else (ext_full.numpy().view(np.uint64).copy(), dig_full.numpy().view(np.uint64).copy())
+    q.put((rank, root.numpy().view(np.uint64).copy(), bufs["nodes"].numpy().view(np.uint64)[:plan.rows_per_rank * 4].copy(), idx, proofs, fri, sent, gathered))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -211,7 +215,15 @@ def test_sharded_path_reproduces_single_process_tree(world, ncols):
     pol = torch.from_numpy(glo.splitmix64(0xF00D, 3 << fb).view(np.int64).copy())
     want_final, want_trees, _ = fri_commit_sharded(1, 0, OracleOps, None, tr, pol, [fb, fb - 3, fb - 5, fb - 7], fb)
     want_fri = (want_final.numpy().view(np.uint64)[:3 << (fb - 7)], [t[0].numpy().view(np.uint64)[-4:] for t in want_trees], tr.get_fields1())
-    for rank, root, leaves, idx, proofs, fri in res:
+    sent_matrix = [r[6] for r in res]
+    for a in range(world):                                                   # what a sends b is b's slice of a's columns, and nothing to itself
+        assert sent_matrix[a][a] == 0
+        pa = ShardPlan(n=n, n_ext=2 * n, ncols=ncols, world=world, rank=a, tile=8)
+        assert all(sent_matrix[a][b] == 8 * rows * pa.my_cols for b in range(world) if b != a)
+    g_ext, g_dig = res[0][7]
+    assert np.array_equal(g_ext, ext) and np.array_equal(g_dig.reshape(-1), nodes[:2 * n * 4])     # rank 0 holds the whole extension and level 0
+    assert all(r[7] is None for r in res[1:])
+    for rank, root, leaves, idx, proofs, fri, _sent, _g in res:
         assert np.array_equal(root, nodes[-4:]), rank                       # every rank ends with the global root
         assert np.array_equal(leaves, nodes[rank * rows * 4:(rank + 1) * rows * 4])   # and owns its slice of level 0
         for j, i in enumerate(idx):                                         # every rank holds every opening = the single-process one

@@ -10,14 +10,17 @@ and what together pins every value of the device result to the oracle:
       column sum_c r_c trace[:, c] must equal sum_c r_c ext[:, c] at all rows (a wrong value anywhere in ext survives with
       probability 2^-64).  The two combinations are formed on the device by mi_dbg_lincomb_cols_dev, which is itself
       checked against Python integers on sampled rows of both matrices;
-  (c) leaves: for sampled rows (first, last, around n, random) the oracle's linear_hash of the device's extended row must
-      equal the device's level-0 digest;
+  (c) leaves: for 2^16 rows (default) -- every 256th row at a scrambled offset, so that all 16 wave residue classes (row & 15),
+      all 64 lane positions and all slab phases of the line-ring leaf kernel are hit equally often, from the first row to the
+      element offsets above 2^33, plus the first / last rows and the rows around n -- the oracle's linear_hash of the device's
+      extended row must equal the device's level-0 digest.  The rows are gathered on the device (the query-opening kernel) and
+      hashed by the oracle on all host threads;
   (d) tree: the oracle rebuilds every level above the device's level-0 digests; the whole node array must match, so the
       device root is the oracle's root of those digests.
 
-(a)+(b) pin the extension, (c) ties digests to rows on a sample and (d) pins the tree above the digests; (c) is a sample
-because each leaf costs the oracle 84 permutations -- the kernel that hashes all rows is the same one the small-size tests
-compare in full.
+(a)+(b) pin the extension, (c) ties digests to rows on a stratified sample and (d) pins the tree above the digests; (c) is a
+sample because each leaf costs the oracle 84 permutations (2^16 rows: a few seconds on the GPU box's host cores) -- the kernel
+that hashes all rows is the same one the small-size tests compare in full.
 """
 import time
 
@@ -57,7 +60,34 @@ def lincomb(ctx, windows, nrows, coef_dev):
     return ctx.to_host(out)
 
 
-def verify_lde_merkle(ctx, trace_windows, ext_windows, nodes, n, n_ext, ncols, cols=None, n_rows=64, seed=2024,
+def leaf_sample_rows(n, n_ext, n_rows, rng):
+    """Stratified sample: one row out of every n_ext / n_rows consecutive ones at an offset that walks through all residues, plus
+    the edge rows."""
+    edge = {0, 1, 2, n - 1, n, n + 1, n_ext - 2, n_ext - 1} & set(range(n_ext))
+    if n_rows >= n_ext:
+        return sorted(range(n_ext))
+    stride = n_ext // n_rows
+    k = np.arange(n_rows, dtype=np.uint64)
+    # offset inside the stride: an odd multiplier mod stride visits every residue of the low bits equally often; the added k // stride
+    # term decorrelates it from the stride index
+    offs = (k * np.uint64(0x9E3779B1) + k // np.uint64(max(stride, 1))) % np.uint64(stride)
+    rows = set(int(v) for v in (k * np.uint64(stride) + offs))
+    return sorted(rows | edge | {int(v) for v in rng.integers(0, n_ext, 8)})
+
+
+def gather_rows(ctx, windows, nodes, n_ext, rows):
+    """rows x ncols host matrix of the listed rows of a matrix given as column windows, gathered on the device."""
+    idx = np.array(rows, dtype=np.uint64)
+    levels = (n_ext - 1).bit_length()
+    parts = []
+    for (t, off, w, pitch) in windows:
+        buf = ctx.empty(len(rows) * (w + 4 * levels))
+        ctx.merkle_group_proofs(buf, nodes, t[off:], n_ext, w, idx, pitch=pitch)
+        parts.append(ctx.to_host(buf).reshape(len(rows), w + 4 * levels)[:, :w])
+    return np.ascontiguousarray(np.concatenate(parts, axis=1))
+
+
+def verify_lde_merkle(ctx, trace_windows, ext_windows, nodes, n, n_ext, ncols, cols=None, n_rows=1 << 16, seed=2024,
                       check_tree=True, log=lambda *_: None):
     """trace_windows / ext_windows: the n x ncols trace and the n_ext x ncols extension as column windows in column
     order, [(device tensor, element offset, width, pitch)] (a plain matrix is one window).  nodes: device node array
@@ -99,12 +129,22 @@ def verify_lde_merkle(ctx, trace_windows, ext_windows, nodes, n, n_ext, ncols, c
         f"({time.perf_counter() - t0:.1f} s)")
 
     if nodes is not None:
-        # ---- (c) sampled leaves
-        rows = sorted({0, 1, 2, n - 1, n, n + 1, n_ext - 2, n_ext - 1} | {int(v) for v in rng.integers(0, n_ext, max(0, n_rows - 8))})
-        for r in rows:
-            row = pull_row(ctx, ext_windows, r)
-            assert np.array_equal(glo.linear_hash(row), ctx.to_host(nodes[4 * r: 4 * r + 4])), ("leaf digest", r)
+        # ---- (c) sampled leaves: rows gathered on the device, leaf digests by the oracle (all host threads), compared with the
+        # device's level-0 digests of those rows
+        rows = leaf_sample_rows(n, n_ext, n_rows, rng)
+        t_c = time.perf_counter()
+        mat = gather_rows(ctx, ext_windows, nodes, n_ext, rows)
+        got = ctx.to_host(nodes[:4 * n_ext]).reshape(n_ext, 4)[np.array(rows, dtype=np.int64)]
+        # the oracle's merkletree hashes every row (OpenMP over rows) before it builds levels: its first 4 * rows words are the leaf
+        # digests; pad to a power of two with copies of the first row
+        npad = 1 << max(len(rows) - 1, 0).bit_length()
+        padded = np.concatenate([mat, np.repeat(mat[:1], npad - len(rows), axis=0)]) if npad > len(rows) else mat
+        want = glo.merkletree(padded, ncols, npad)[:4 * len(rows)].reshape(len(rows), 4)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, ("leaf digest", rows[int(bad[0])], bad.size)
         summary["leaf_rows_checked"] = len(rows)
+        summary["leaf_rows_residues"] = sorted({r & 15 for r in rows})
+        summary["leaf_seconds"] = time.perf_counter() - t_c
         # ---- (d) the tree above the device's level-0 digests (linear_hash of 4 values is a copy: merkletree over
         # the digests as a 4-column source rebuilds exactly the upper levels)
         if check_tree:
@@ -116,4 +156,23 @@ def verify_lde_merkle(ctx, trace_windows, ext_windows, nodes, n, n_ext, ncols, c
         log(f"verify: {len(rows)} leaf digests" + (" + every upper tree level" if check_tree else "") +
             f" match the oracle ({time.perf_counter() - t0:.1f} s)")
     summary["seconds"] = time.perf_counter() - t0
+    return summary
+
+
+def verify_gathered(ctx, ext_full, dig_full, root, n, n_ext, ncols, seed, n_rows=1 << 12, log=lambda *_: None):
+    """The result of the SHARDED path, gathered on one rank (shard.gather_sharded_result): the extension of the synthetic trace
+    `seed` against the oracle through verify_lde_merkle's (a) + (b), sampled leaf digests against the oracle's linear_hash, and the
+    sharded root against the oracle's tree over the gathered digests.  Returns a summary (raises on the first mismatch)."""
+    trace = ctx.empty(n * ncols)
+    ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, seed)
+    ext = ext_full.contiguous().view(-1)
+    summary = verify_lde_merkle(ctx, [(trace, 0, ncols, ncols)], [(ext, 0, ncols, ncols)], None, n, n_ext, ncols, log=log)
+    rng = np.random.default_rng(seed)
+    rows = leaf_sample_rows(n, n_ext, min(n_rows, n_ext), rng)
+    dig = ctx.to_host(dig_full.contiguous().view(-1)).reshape(n_ext, 4)
+    for r in rows[:: max(1, len(rows) // 256)]:
+        assert np.array_equal(glo.linear_hash(ctx.to_host(ext[r * ncols:(r + 1) * ncols])), dig[r]), ("leaf digest of the sharded path", r)
+    want_root = glo.merkletree(dig, 4, n_ext)[-4:]
+    assert [int(v) for v in want_root] == [int(v) for v in root], "the sharded root is not the oracle's root over the gathered leaf digests"
+    summary.update({"leaf_rows_checked": len(rows[:: max(1, len(rows) // 256)]), "root_matches_oracle_tree_over_gathered_digests": True})
     return summary
