@@ -43,6 +43,12 @@ def arg_parser():
     ap.add_argument("--n-products", type=int, default=30, help="grand products (lookups + permutations + connections)")
     ap.add_argument("--field-ops", type=int, nargs=5, default=[1815, 5869, 13158, 17986, 7101],
                     help="field operations per row of the step2prev, step3prev, step3, step42ns, step52ns programs")
+    ap.add_argument("--ext-bits", type=int, default=1, help="log2 of the blow-up factor (zkEVM 1; c12a / recursive1 / recursive2: 3)")
+    ap.add_argument("--qdeg", type=int, default=2, help="chunks of the quotient polynomial: cm4 has 3 * qdeg columns (recursive STARKs: 7)")
+    ap.add_argument("--fri-steps", type=int, nargs="*", default=None, help="FRI layer sizes in bits (default: nBitsExt, then -5, -5, -4, -4)")
+    ap.add_argument("--shape", choices=("zkevm", "recursive1"), default="zkevm",
+                    help="recursive1: the shape the golden proofs testvectors/aggregatedProof/recursive1.zkin.proof_*.json imply (2^17 rows, blow-up 8, "
+                         "18 / 0 / 39 / 21 columns, 52 constants, 118 evaluations, 43 queries, FRI 20/16/12/9/6); sets every size argument")
     ap.add_argument("--proofs", type=int, default=2, help="genProof runs; the last one is reported (the first pays first-touch / code loading)")
     ap.add_argument("--check-rows", type=int, default=6)
     ap.add_argument("--chelpers-batch-rows", type=int, default=0)
@@ -50,7 +56,23 @@ def arg_parser():
     return ap
 
 
-def fri_steps(nbits_ext):
+RECURSIVE1 = ["--log-n", "17", "--ext-bits", "3", "--qdeg", "7", "--widths", "18", "0", "39", "--tmpexp", "90", "--n-const", "52", "--n-evals", "118",
+              "--n-queries", "43", "--n-lookups", "0", "0", "--n-products", "13", "--fri-steps", "20", "16", "12", "9", "6",
+              "--field-ops", "0", "600", "5000", "5500", "1500"]
+
+
+def parse(argv=None):
+    ap = arg_parser()
+    args = ap.parse_args(argv)
+    if args.shape == "recursive1":
+        args = ap.parse_args(RECURSIVE1 + (list(argv) if argv is not None else sys.argv[1:]))
+    return args
+
+
+def fri_steps(nbits_ext, explicit=None):
+    if explicit:
+        assert explicit[0] == nbits_ext
+        return list(explicit)
     steps = [nbits_ext]
     for d in (5, 5, 4, 4):
         if steps[-1] - d >= 3:
@@ -61,10 +83,12 @@ def fri_steps(nbits_ext):
 def shape(args):
     """-> (starkinfo dict, {step: (ops, args)}, sections per step) of the synthetic zkEVM-shaped STARK; deterministic in args."""
     import chelpers_programs as cpg
-    nbits, nbits_ext = args.log_n, args.log_n + 1
+    nbits, nbits_ext = args.log_n, args.log_n + args.ext_bits
     N, NE = 1 << nbits, 1 << nbits_ext
     w1, w2, w3 = args.widths
-    cols = {"cm1_n": w1, "cm2_n": w2, "cm3_n": w3, "cm4_n": 6, "tmpExp_n": args.tmpexp, "cm1_2ns": w1, "cm2_2ns": w2, "cm3_2ns": w3, "cm4_2ns": 6, "q_2ns": 3, "f_2ns": 3}
+    w4 = 3 * args.qdeg
+    shift_ext = 1 << args.ext_bits                         # "prime" (next-row) reads in the extended domain
+    cols = {"cm1_n": w1, "cm2_n": w2, "cm3_n": w3, "cm4_n": w4, "tmpExp_n": args.tmpexp, "cm1_2ns": w1, "cm2_2ns": w2, "cm3_2ns": w3, "cm4_2ns": w4, "q_2ns": 3, "f_2ns": 3}
     off, o = {}, 0
     for k in ORDER:
         off[k] = o
@@ -119,10 +143,10 @@ def shape(args):
         v = vpm[pid]
         ext_of[pid] = pol(v["section"].replace("_n", "_2ns"), v["dim"], v["sectionPos"])
     cm_2ns = [ext_of[p] for p in cm_n]
-    qs = [pol("cm4_2ns", 3, 0), pol("cm4_2ns", 3, 3)]
+    qs = [pol("cm4_2ns", 3, 3 * i) for i in range(args.qdeg)]
     pol("q_2ns", 3, 0); pol("f_2ns", 3, 0)
     rng = np.random.default_rng(7)
-    ev = [{"type": "q", "id": 0, "prime": False}, {"type": "q", "id": 1, "prime": False}]
+    ev = [{"type": "q", "id": i, "prime": False} for i in range(args.qdeg)]
     while len(ev) < args.n_evals:
         r = rng.random()
         if r < 0.25:
@@ -131,8 +155,8 @@ def shape(args):
             ev.append({"type": "cm", "id": int(rng.integers(0, len(cm_n))), "prime": bool(rng.random() < 0.25)})
     sec = lambda f: {k: f(k) for k in ORDER}
     si = {"starkStruct": {"nBits": nbits, "nBitsExt": nbits_ext, "nQueries": args.n_queries, "verificationHashType": "GL",
-                          "steps": [{"nBits": b} for b in fri_steps(nbits_ext)]},
-          "mapTotalN": total, "nConstants": args.n_const, "nPublics": 8, "nCm1": w1, "nCm2": len(h_ids), "nCm3": n_prod, "nCm4": 2, "qDeg": 2, "qDim": 3,
+                          "steps": [{"nBits": b} for b in fri_steps(nbits_ext, args.fri_steps)]},
+          "mapTotalN": total, "nConstants": args.n_const, "nPublics": 8, "nCm1": w1, "nCm2": len(h_ids), "nCm3": n_prod, "nCm4": args.qdeg, "qDeg": args.qdeg, "qDim": 3,
           "friExpId": 1, "nExps": next_exp,
           "mapDeg": sec(lambda k: NE if k.endswith("2ns") else N), "mapOffsets": sec(lambda k: off[k]),
           "mapSections": sec(lambda k: [i for i, v in enumerate(vpm) if v["section"] == k]), "mapSectionsN": sec(lambda k: cols[k]),
@@ -142,23 +166,27 @@ def shape(args):
     # ---- the five programs, in the reference's table formats, over the map's absolute offsets
     f2, f3p, f3, f42, f52 = args.field_ops
     base1 = [(off["cm1_n"], w1)]
+    base2 = base1 + ([(off["cm2_n"], w2, pos2)] if pos2 else [])
     progs, secs = {}, {}
     ll = lambda f: min(70, max(4, f // 40))
-    progs["step2prev"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(20), N, base1, args.n_const, 8, field_ops=f2, next_shift=1, vc=1,
-                                                           long_lived=ll(f2), base_out=(off["tmpExp_n"], args.tmpexp, lookups_T + 4))
-    progs["step3prev"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(30), N, base1 + [(off["cm2_n"], w2, pos2)], args.n_const, 8, field_ops=f3p, next_shift=1,
-                                                           vc=3, long_lived=ll(f3p), base_out=(off["tmpExp_n"] + lookups_T, args.tmpexp, 6 * n_prod + 4))
-    progs["step3"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(31), N, base1 + [(off["cm2_n"], w2, pos2), (off["cm3_n"], w3, 3 * n_prod)], args.n_const, 8, field_ops=f3,
-                                                       next_shift=1, vc=3, long_lived=ll(f3), base_out=(off["cm3_n"] + 3 * n_prod, w3, w3 - 3 * n_prod))
-    ext3 = [(off["cm1_2ns"], w1), (off["cm2_2ns"], w2), (off["cm3_2ns"], w3)]
-    progs["step42ns"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(42), NE, ext3, args.n_const, 8, field_ops=f42, long_lived=ll(f42))
-    ext4 = ext3 + [(off["cm4_2ns"], 6)]
+    if f2 and lookups_T:
+        progs["step2prev"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(20), N, base1, args.n_const, 8, field_ops=f2, next_shift=1, vc=1,
+                                                               long_lived=ll(f2), base_out=(off["tmpExp_n"], args.tmpexp, lookups_T + 4))
+    if f3p and n_prod:
+        progs["step3prev"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(30), N, base2, args.n_const, 8, field_ops=f3p, next_shift=1,
+                                                               vc=3, long_lived=ll(f3p), base_out=(off["tmpExp_n"] + lookups_T, args.tmpexp, 6 * n_prod + 4))
+    if f3 and w3 - 3 * n_prod >= 8:
+        progs["step3"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(31), N, base2 + ([(off["cm3_n"], w3, 3 * n_prod)] if n_prod else []), args.n_const, 8,
+                                                           field_ops=f3, next_shift=1, vc=3, long_lived=ll(f3), base_out=(off["cm3_n"] + 3 * n_prod, w3, w3 - 3 * n_prod))
+    ext3 = [(off[k], cols[k]) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns") if cols[k]]
+    progs["step42ns"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(42), NE, ext3, args.n_const, 8, field_ops=f42, next_shift=shift_ext, long_lived=ll(f42))
+    ext4 = ext3 + [(off["cm4_2ns"], w4)]
     import mi_stark
     probe = mi_stark.ChelpersProgram(None, *cpg.synthetic_program52(np.random.default_rng(52), ext4, args.n_const, args.n_evals, length=200), step=52)
     per_len = probe.stats["field_ops"] / 200.0
     probe.close()
     progs["step52ns"] = cpg.synthetic_program52(np.random.default_rng(52), ext4, args.n_const, args.n_evals, length=max(20, int(round(f52 / per_len))))
-    bsec = [(off[k], cols[k], N) for k in ("cm1_n", "cm2_n", "cm3_n", "tmpExp_n")]
+    bsec = [(off[k], cols[k], N) for k in ("cm1_n", "cm2_n", "cm3_n", "tmpExp_n") if cols[k]]
     for k in ("step2prev", "step3prev", "step3"):
         secs[k] = bsec
     secs["step42ns"] = [(o_, w_, NE) for (o_, w_) in ext3]
@@ -171,7 +199,7 @@ def compiled_programs(args, shard=None):
     Starks does on first use, done ahead so that the GPU box finds every kernel in the cache."""
     import mi_stark
     si, progs, secs, off, cols = shape(args)
-    n, ne = 1 << args.log_n, 1 << (args.log_n + 1)
+    n, ne = 1 << args.log_n, 1 << (args.log_n + args.ext_bits)
     stats = {}
     for name, (ops, ar) in progs.items():
         base = name in ("step2prev", "step3prev", "step3")
@@ -185,7 +213,7 @@ def compiled_programs(args, shard=None):
 
 
 def main():
-    args = arg_parser().parse_args()
+    args = parse()
     if args.precompile is not None:
         compiled_programs(args, tuple(args.precompile))
         return
@@ -194,7 +222,7 @@ def main():
     import glo                     # the oracle: only in the checks after the timed proofs
 
     si, progs, secs, off, cols = shape(args)
-    nbits, nbits_ext = args.log_n, args.log_n + 1
+    nbits, nbits_ext = args.log_n, args.log_n + args.ext_bits
     N, NE = 1 << nbits, 1 << nbits_ext
     w1 = cols["cm1_n"]
     ctx = mi_stark.Context(0)
@@ -210,7 +238,7 @@ def main():
     t0 = time.perf_counter()
     witness = torch.empty(N * w1, dtype=torch.int64, pin_memory=False)
     chunk = 1 << 28
-    d = ctx.empty(min(chunk, N * w1))
+    d = ctx.empty(min(chunk, max(N * w1, N * args.n_const)))
     for o_ in range(0, N * w1, chunk):
         k = min(chunk, N * w1 - o_)
         ctx.fill_synthetic(d, k, 0x5EED0104 + o_ // chunk)
@@ -260,7 +288,7 @@ def main():
     # ------------------------------------------------------------------ checks (oracle), after the clock
     checks = {}
     U = lambda x: np.array(x, dtype=object).astype(np.uint64)
-    steps = fri_steps(nbits_ext)
+    steps = fri_steps(nbits_ext, args.fri_steps)
     tr = glo.Transcript()
     tr.put(publics)
     chal = np.zeros(8 * 3, dtype=np.uint64)
@@ -280,6 +308,8 @@ def main():
     ok_paths, n_paths = 0, 0
     for q in range(min(args.n_queries, 16)):
         for t_, root in (("1", "root1"), ("2", "root2"), ("3", "root3"), ("4", "root4")):
+            if "s0_vals" + t_ not in z:                      # a stage without columns is not opened (proof2zkinStark.cpp:30-77)
+                continue
             ok_paths += bool(glo.merkle_verify(U(z[root]), U(z["s0_vals" + t_][q]).reshape(-1), U(z["s0_siblings" + t_][q]).reshape(-1), ys[q]))
             n_paths += 1
     checks["merkle_paths_ok"] = "%d/%d" % (ok_paths, n_paths)
@@ -315,8 +345,8 @@ def main():
     ok_q = ok_f = 0
     for r in rows:
         got = {}
-        for rr in sorted({r, (r + 2) % NE}):
-            got[rr] = {k: peek(off[k] + rr * cols[k], cols[k]) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")}
+        for rr in sorted({r, (r + (1 << args.ext_bits)) % NE}):
+            got[rr] = {k: peek(off[k] + rr * cols[k], cols[k]) if cols[k] else np.zeros(0, dtype=np.uint64) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")}
             got[rr]["const"] = peek(const_off + rr * args.n_const, args.n_const)
         ok_q += int(_check_row42(glo, progs["step42ns"], got, r, NE, off, cols, args.n_const, chal, publics, zh, nbits_ext, peek(off["q_2ns"] + 3 * r, 3)))
         ok_f += int(_check_row52(glo, progs["step52ns"], got, r, NE, off, cols, args.n_const, chal, evals, peek(xd_off + 3 * r, 3), peek(xdw_off + 3 * r, 3),

@@ -26,6 +26,7 @@ STARKS_CONFIGS = [
     [],
     ["--log-n", "12", "--widths", "37", "20", "40", "--tmpexp", "60", "--n-const", "11", "--n-evals", "24", "--n-queries", "16", "--n-lookups", "2", "2",
      "--n-products", "6", "--field-ops", "200", "300", "400", "1500", "700"],
+    ["--shape", "recursive1"],
 ]
 
 
@@ -38,7 +39,7 @@ def precompile_starks(jobs, only):
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench_starks.py")] + argv + ["--precompile", str(s), str(jobs)]) for s in range(jobs)]
         if any(p.wait() for p in procs):
             raise SystemExit("a precompile shard of bench_starks.py failed")
-        st = bench_starks.compiled_programs(bench_starks.arg_parser().parse_args(argv))
+        st = bench_starks.compiled_programs(bench_starks.parse(argv))
         print("precompiled bench_starks", argv or "(default)", {k: (v["kernels"], v["cache_hits"], v["code_bytes"]) for k, v in st.items()},
               "%.1f s" % (time.time() - t0), flush=True)
 
