@@ -217,6 +217,17 @@ def test_golden_merkle_paths_on_gpu(ctx, path):
             assert np.array_equal(cur, root)
 
 
+def test_golden_root2_is_the_tree_without_columns_on_gpu(ctx):
+    """Every golden proof's root2 is the root of MerkleTreeGL(2^20 rows, 0 columns) -- the recursive STARKs commit nothing in stage 2
+    (tests/test_oracle_golden.py): the tree builder on a width of 0 at the golden height must produce exactly it."""
+    d = np.load(FILES[0])
+    n = 1 << 20
+    nodes = ctx.empty((2 * n - 1) * 4)
+    ctx.merkle_build(nodes, ctx.empty(16), 0, n)
+    assert np.array_equal(ctx.to_host(nodes[-4:]), d["root2"])
+    assert all(np.array_equal(np.load(f)["root2"], d["root2"]) for f in FILES)
+
+
 # ------------------------------------------------------------------ NTT / LDE
 NTT_CASES = [(1, 1), (1, 5), (2, 1), (2, 3), (4, 6), (8, 1), (16, 3), (32, 7), (64, 33), (128, 2), (256, 37), (512, 3),
              (1024, 1), (1024, 65), (2048, 6), (4096, 32), (1 << 13, 5), (1 << 16, 3), (1 << 17, 1)]

@@ -92,3 +92,22 @@ def test_fri_group_layout_matches_transpose():
     folded = glo.fri_fold(pol, prev, cur, 10, x)
     for g in (0, 7, 31):
         assert np.array_equal(folded[g], glo.fri_fold_group(aux[g], prev - cur, prev, 10, g, x))
+
+
+@pytest.mark.parametrize("path", FILES)
+def test_root2_is_the_root_of_a_tree_without_columns(path):
+    """The recursive STARKs commit nothing in stage 2 (no s0_vals2 in the files), yet every golden proof carries a root2: the root of
+    MerkleTreeGL(2^20, 0 columns).  linear_hash of an empty row is four zeros (no permutation), so root2 is twenty levels of
+    hash(node | node | 0000) starting from zeros -- the same value in all seven files, and a reference-held pin of the node hash and
+    of the size <= 4 pass-through rule at size 0."""
+    g = np.load(path)
+    node = np.zeros(4, dtype=np.uint64)
+    for _ in range(20):
+        node = glo.perm(np.concatenate([node, node, np.zeros(4, dtype=np.uint64)]))[:4]
+    assert np.array_equal(node, g["root2"])
+    n = 1 << 7                                           # the tree builder takes the same path on a width of 0
+    nodes = glo.merkletree(np.zeros((n, 0), dtype=np.uint64), 0, n)
+    want = np.zeros(4, dtype=np.uint64)
+    for _ in range(7):
+        want = glo.perm(np.concatenate([want, want, np.zeros(4, dtype=np.uint64)]))[:4]
+    assert np.array_equal(nodes[-4:], want) and not nodes[:4 * n].any()

@@ -120,6 +120,24 @@ def test_reference_steps_headers_and_tables_compile_into_the_replacement_unit(tm
     assert str(inc_dir / "zkevmSteps.hpp") in pre and str(inc_dir / "steps.hpp") in pre and "standalone/steps.hpp" not in pre
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="/root/reference not present")
+@pytest.mark.parametrize("rel", ["starkRecursive1/chelpers/recursive1.chelpers.step2.cpp", "starkRecursive1/chelpers/recursive1.chelpers.step3prev.cpp",
+                                 "starkRecursive1/chelpers/recursive1.chelpers.step3.cpp", "starkRecursive1/chelpers/recursive1.chelpers.step52ns.cpp",
+                                 "zkevm/chelpers/zkevm.chelpers.step2.cpp"])
+def test_generated_per_row_steps_compile_against_level0(tmp_path, rel):
+    """The per-row forms a Steps class consists of (generated C++: Goldilocks::add / Goldilocks3::mul ... over params.pols) are the
+    caller's host code in the host-steps mode of Starks::genProof; the reference's own files compile unchanged against host/."""
+    inc_dir = tmp_path / "ref_inc"
+    inc_dir.mkdir()
+    for name, r in {"steps.hpp": "starkpil/steps.hpp", "zkevmSteps.hpp": "starkpil/zkevm/chelpers/zkevmSteps.hpp",
+                    "recursive1Steps.hpp": "starkpil/starkRecursive1/chelpers/recursive1Steps.hpp", "zhInv.hpp": "starkpil/zhInv.hpp",
+                    "constant_pols_starks.hpp": "starkpil/constant_pols_starks.hpp", "zkassert.hpp": "utils/zkassert.hpp"}.items():
+        os.symlink(os.path.join(REF, r), inc_dir / name)
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-fopenmp", "-I", str(inc_dir), "-I", HOST, "-I", os.path.join(HOST, "standalone"),
+                        os.path.join(REF, "starkpil", rel)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nbits,n_queries", [(10, 12), (13, 24)])
 def test_starks_genproof_is_accepted_by_the_independent_verifier(tmp_path, nbits, n_queries):
