@@ -42,7 +42,7 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 7
 def valu_roofline(perms, leaf_ms, pmc):
     """Issue-rate roofline of the Poseidon leaf kernel (the kernel is VALU-bound, not HBM-bound).
     Instructions per permutation: MEASURED (rocprofv3 --pmc SQ_INSTS_VALU over the launch / wave-permutations,
-    profiles/r02_pmc_leaf.json).  The kernel's loop-weighted static mix of the two issue classes comes from
+    profiles/r03_pmc_leaf.json).  The kernel's loop-weighted static mix of the two issue classes comes from
     tools/valu_mix.py (2-clk: v_mov_b32 and plain 32-bit add/sub/logic; 4-clk: everything else, v_cndmask and compares
     included -- profiles/r02_ubench_int3_issue_rates.txt).  peak = 1 / (f2 / R2 + f4 / R4) wave-instructions per second for
     the whole chip, quoted at the nominal 2.4 GHz clock (R = 1024 SIMDs x 2.4 GHz / 2 resp. 4) -- the PMC capture puts
@@ -54,7 +54,7 @@ def valu_roofline(perms, leaf_ms, pmc):
            "unit": "permutations/s", "valu_instructions_per_permutation": instrs, "issue_mix": {"frac_2clk": f2, "frac_4clk": f4},
            "achieved_wave_instr_per_s": ach / 64.0 * instrs, "effective_clock_ghz_pmc": pmc.get("effective_clock_ghz"),
            "wave_time_split_pmc": pmc.get("wave_time_split"),
-           "source": "profiles/r02_pmc_leaf.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAIT_*, GRBM_GUI_ACTIVE), tools/valu_mix.py, tools/ubench_int3.hip"}
+           "source": "profiles/r03_pmc_leaf.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAIT_*, GRBM_GUI_ACTIVE), tools/valu_mix.py, tools/ubench_int3.hip"}
     for key, rates in pmc["issue_rates_wave_instr_per_s"].items():
         blended = 1.0 / (f2 / rates["2clk"] + f4 / rates["4clk"])
         peak_perms = blended * 64.0 / instrs
@@ -455,12 +455,12 @@ def main():
         out["roofline_lde"]["frac"] = out["roofline_lde"]["achieved"] / HBM_PEAK_GBS
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (they cannot run inside the
         # timed process); the committed summary of the same command is read back here when the workload matches
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_leaf.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_leaf.json")
         if (world == 1 and args.log_n == 23 and ncols == 665 and args.leaf_mode == 1 and args.poseidon_variant == 2
                 and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))["kernels"]["k_linear_hash_rows_lines"]
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r02_pmc_leaf.json <- profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction)"
+            out["roofline"]["traffic_source"] = "profiles/r03_pmc_leaf.json (round-3 rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, gfx950 x2 read correction; raw: profiles/r03_pmc_leaf_raw.txt)"
             out["valu"] = valu_roofline(perms, leaf_ms, pmc)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols)
