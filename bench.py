@@ -87,6 +87,12 @@ def cpu_baseline(log_n, ncols):
                       anyone should quote.
     Phase names mirror the reference's timers (starks.cpp:50-57)."""
     share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                    # a container's CPU quota (the GPU box: 16 cores per GPU) is not in the affinity mask
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            share = min(share, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes
     import glo
