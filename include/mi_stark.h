@@ -83,7 +83,11 @@ int mi_lde(mi_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t n_ext, uint6
  * Replaces PoseidonGoldilocks::{hash_full_result, hash, linear_hash, merkletree_avx, merkletree_avx512,
  * merkletree} (transcript.cpp:23,46; merkleTreeGL.cpp:37-44; build_const_tree.cpp:382). */
 int mi_poseidon_hash_full_result(mi_ctx *ctx, uint64_t out[12], const uint64_t in[12]);          /* host ptrs */
-int mi_poseidon_hash(mi_ctx *ctx, uint64_t out[4], const uint64_t in[12]);                       /* host ptrs */
+int mi_poseidon_hash(mi_ctx *ctx, uint64_t out[4], const uint64_t in[12]);
+/* Transcript::put (transcript.cpp:4-29) as one call: the class's members (state, pending, out, the two cursors; HOST pointers, updated in
+ * place) absorb n input elements; every completed block of 8 is hashed on the device, all inside one launch. */
+int mi_transcript_put(mi_ctx *ctx, uint64_t state[4], uint64_t pending[8], uint64_t out[12], uint32_t *pending_cursor,
+                      uint32_t *out_cursor, const uint64_t *input, uint64_t n);                       /* host ptrs */
 int mi_poseidon_linear_hash(mi_ctx *ctx, uint64_t out[4], const uint64_t *in, uint64_t size);    /* host ptrs */
 /* count independent permutations, in/out: count x 12 (device) */
 int mi_poseidon_permute_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *in, uint64_t count);
@@ -302,6 +306,11 @@ int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
  * 0 = naive rounds throughout, MDS on 32-bit halves; 1 = naive rounds, MDS on 22-bit limbs (v_mad_u32_u24).
  * All are bit-identical; exposed for benchmarking. */
 int mi_set_poseidon_variant(mi_ctx *ctx, int variant);
+/* Launches of at most max_states independent permutations (a single hash, the states of a small batch, the nodes of a small tree level,
+ * the top of every tree) take the WAVE-COOPERATIVE form: one state across 12 lanes, ~10 us per dependent permutation instead of the
+ * 58 us a lane needs for a whole state on its own.  Default 16384; 0 = always one state per lane.  Results are identical; exposed for
+ * benchmarking and for testing both paths. */
+int mi_set_poseidon_coop_max(mi_ctx *ctx, uint64_t max_states);
 /* NTT tile width in elements per row segment: log_b = 4 (128-byte segments, 4 workgroups per CU) or 5
  * (256-byte segments, 2 per CU).  Results are identical; exposed for benchmarking. */
 int mi_set_ntt_tile(mi_ctx *ctx, int log_b);

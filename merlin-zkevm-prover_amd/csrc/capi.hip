@@ -221,6 +221,13 @@ int mi_ensure_workspace(mi_ctx *c, uint64_t bytes)
     return MI_OK;
 }
 
+extern "C" int mi_set_poseidon_coop_max(mi_ctx *c, uint64_t max_states)
+{
+    CTX_OK(c);
+    c->poseidon_coop_max = max_states;
+    return MI_OK;
+}
+
 extern "C" int mi_set_leaf_mode(mi_ctx *c, int line_aligned)
 {
     CTX_OK(c);
@@ -334,6 +341,37 @@ extern "C" int mi_poseidon_hash_full_result(mi_ctx *c, uint64_t out[12], const u
     MI_HIP_CHECK(hipMemcpyAsync(c->pinned + 16, c->small + 16, 96, hipMemcpyDeviceToHost, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
     memcpy(out, c->pinned + 16, 96);
+    return MI_OK;
+}
+
+// Transcript::put (transcript.cpp:4-29) over the class's members, all HOST pointers: n elements absorbed in one launch (the per-hash
+// form costs a launch, two copies and a synchronisation for every 8 elements: a put of the 118 evaluations of a recursive STARK is 44
+// of them).  Puts that complete no block of 8 stay on the host.
+extern "C" int mi_transcript_put(mi_ctx *c, uint64_t state[4], uint64_t pending[8], uint64_t out[12], uint32_t *pending_cursor,
+                                 uint32_t *out_cursor, const uint64_t *input, uint64_t n)
+{
+    CTX_OK(c);
+    MI_REQUIRE(state && pending && out && pending_cursor && out_cursor && (input || n == 0), "null buffer");
+    MI_REQUIRE(*pending_cursor < 8, "pending cursor out of range");
+    if (n == 0) return MI_OK;
+    if (*pending_cursor + n < 8) { // nothing to hash: the elements wait in `pending`
+        for (uint64_t i = 0; i < n; i++) pending[(*pending_cursor)++] = input[i];
+        *out_cursor = 0;
+        return MI_OK;
+    }
+    MI_REQUIRE(n <= (1ull << 20), "transcript input too long for one call");
+    DevBuf d;
+    MI_TRY(d.alloc((32 + n) * 8));
+    std::vector<uint64_t> h(32 + n);
+    memcpy(&h[0], state, 32); memcpy(&h[4], pending, 64); memcpy(&h[12], out, 96);
+    h[24] = *pending_cursor; h[25] = *out_cursor;
+    memcpy(&h[32], input, n * 8);
+    MI_HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_transcript_put(c, (u64 *)d.p, (const u64 *)d.p + 32, n));
+    MI_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, 26 * 8, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(state, &h[0], 32); memcpy(pending, &h[4], 64); memcpy(out, &h[12], 96);
+    *pending_cursor = (uint32_t)h[24]; *out_cursor = (uint32_t)h[25];
     return MI_OK;
 }
 

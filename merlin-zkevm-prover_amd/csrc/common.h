@@ -98,6 +98,7 @@ struct mi_ctx {
     static constexpr int N_TIMERS = 64;
     hipEvent_t ev_start[N_TIMERS] = {}, ev_stop[N_TIMERS] = {};
     int cu_count = 256;
+    uint64_t poseidon_coop_max = 16384; // at most this many independent permutations per launch take the wave-cooperative form (0 = never)
     bool leaf_line_aligned = true; // leaf sponge fetches whole aligned 128-byte lines (k_linear_hash_rows_lines)
     bool lde_fuse_mid = true; // extendPol: last INTT pass and first NTT pass in one kernel (k_lde_mid) when the splits line up
     uint32_t ntt_log_b = 5; // log2 of the NTT tile's batch width (elements per row segment): 4 or 5
@@ -143,6 +144,7 @@ static inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 
 // ---- internal launchers (defined in the .hip files)
 int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count);
+int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n);
 int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows);
 int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const u64 *const *bases, const uint64_t *pitches,
                               const uint64_t *widths, uint64_t nrows, bool first, bool final);

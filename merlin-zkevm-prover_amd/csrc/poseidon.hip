@@ -44,6 +44,129 @@ __global__ __launch_bounds__(256) void k_permute(u64 *__restrict__ out, const u6
     for (int j = 0; j < 12; j++) out[i * 12 + j] = s[j];
 }
 
+// ---- wave-cooperative permutation: ONE STATE ACROSS 12 LANES (north_star's "warp-cooperative Poseidon round").
+// A whole state per lane is the right mapping when there are millions of sponges (the leaves): every VALU slot does useful work.  It
+// is the wrong one for the few DEPENDENT hashes a proof also needs -- a transcript permutation, the top of a Merkle tree, the levels of
+// the small FRI trees: there a lane walks through all ~17 000 instructions alone (58-66 us measured) while the chip idles.  Here
+// element j of a state lives in lane 16 q + j (j < 12; four states per wave, lanes 12-15 of a row compute on zeros): the S-box is one
+// element per lane (in the 22 partial rounds only lane 0's result is kept -- the other lanes would idle either way), the MDS is
+// circulant, out_j = sum_k MC[k] s[(j + k) mod 12] (+ 8 s_0 for j = 0), so the coefficient of the k-th rotation is a compile-time
+// constant and the rotation is a ds_bpermute of the two 32-bit halves: 22 cross-lane reads, 24 multiply-adds and one closing per round.
+// ~3 600 instructions per wave and permutation instead of ~17 000 per lane: a dependent hash in ~10 us.  Naive round structure
+// (poseidon_g_executor.cpp:174-205), bit-identical with the per-lane variants (same tests).
+__device__ __forceinline__ u64 permute_coop(u64 x, uint32_t j /* lane & 15 */)
+{
+    const uint32_t lane = __lane_id(), row = lane & ~15u;
+    const bool live = j < 12;
+    const uint32_t jj = live ? j : 0;
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        x = gl::add_wc(x, live ? c_rc[r * 12 + jj] : 0);
+        const u64 sb = pos::sbox(x);
+        x = (r < 4 || r >= 26 || j == 0) ? sb : x;
+        // MDS on 32-bit halves, rotations through the LDS crossbar
+        const u32 lo = (u32)x, hi = (u32)(x >> 32);
+        u64 al = (u64)lo * (u32)(pos::MC[0] + (j == 0 ? pos::MD0 : 0)), ah = (u64)hi * (u32)(pos::MC[0] + (j == 0 ? pos::MD0 : 0));
+        pos::nttm_static_for<1, 12>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            uint32_t src = jj + k;
+            src = (src >= 12 ? src - 12 : src) + row;
+            const u32 l = (u32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)lo);
+            const u32 h = (u32)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)hi);
+            al += (u64)l * (u32)pos::MC[k];
+            ah += (u64)h * (u32)pos::MC[k];
+        });
+        // value = al + ah * 2^32, 2^64 = 2^32 - 1 (as mds_half32)
+        const u32 ahl = (u32)ah, ahh = (u32)(ah >> 32);
+        const u64 t = (u64)ahh * 0xFFFFFFFFu + al;
+        const u32 thi = (u32)(t >> 32) + ahl;
+        x = (((u64)thi << 32) | (u32)t) + (thi < ahl ? GL_EPS : 0);
+    }
+    return gl::canon_sel(x);
+}
+
+// count states (12 words each), one per 16 lanes
+__global__ __launch_bounds__(256) void k_permute_coop(u64 *__restrict__ out, const u64 *__restrict__ in, uint64_t count)
+{
+    const uint64_t q = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const uint32_t j = threadIdx.x & 15;
+    const bool mine = q < count && j < 12;
+    const u64 x = permute_coop(mine ? in[q * 12 + j] : 0, j);
+    if (mine) out[q * 12 + j] = x;
+}
+
+// Transcript::put (transcript.cpp:12-29) of n elements as ONE launch: the sponge is sequential (a permutation per 8 elements, each fed
+// the previous one's first four outputs), so the whole absorb runs in the first 16 lanes of one wave with the cooperative permutation.
+// io = state[4] | pending[8] | out[12] | pending_cursor | out_cursor (the class's members, in and out).
+__global__ __launch_bounds__(64) void k_transcript_put(u64 *io, const u64 *__restrict__ input, uint64_t n)
+{
+    __shared__ u64 st[4], pend[8], outp[12];
+    const uint32_t j = threadIdx.x & 15;
+    const bool row0 = threadIdx.x < 16;
+    if (threadIdx.x < 4) st[threadIdx.x] = io[threadIdx.x];
+    if (threadIdx.x < 8) pend[threadIdx.x] = io[4 + threadIdx.x];
+    if (threadIdx.x < 12) outp[threadIdx.x] = io[12 + threadIdx.x];
+    uint32_t pc = (uint32_t)io[24], oc = (uint32_t)io[25];
+    __syncthreads();
+    for (uint64_t i = 0; i < n; i++) { // uniform over the wave
+        if (threadIdx.x == 0) pend[pc] = input[i];
+        pc++;
+        oc = 0;
+        __syncthreads();
+        if (pc == 8) {
+            const u64 x = permute_coop(row0 ? (j < 8 ? pend[j] : j < 12 ? st[j - 8] : 0) : 0, j);
+            __syncthreads();
+            if (row0 && j < 12) outp[j] = x;
+            if (row0 && j < 4) st[j] = x;
+            if (row0 && j < 8) pend[j] = 0;
+            pc = 0;
+            oc = 12;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x < 4) io[threadIdx.x] = st[threadIdx.x];
+    if (threadIdx.x < 8) io[4 + threadIdx.x] = pend[threadIdx.x];
+    if (threadIdx.x < 12) io[12 + threadIdx.x] = outp[threadIdx.x];
+    if (threadIdx.x == 0) { io[24] = pc; io[25] = oc; }
+}
+
+int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n)
+{
+    MI_TRY(upload_rc_once(ctx));
+    hipLaunchKernelGGL(k_transcript_put, dim3(1), dim3(64), 0, ctx->stream, io, input, n);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+// parent = hash(left || right || 0^4)[0..4), one node per 16 lanes: the levels of small trees
+__global__ __launch_bounds__(256) void k_merkle_level_coop(u64 *__restrict__ out, const u64 *__restrict__ in, uint64_t n_out)
+{
+    const uint64_t q = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const uint32_t j = threadIdx.x & 15;
+    const u64 x = permute_coop((q < n_out && j < 8) ? in[q * 8 + j] : 0, j);
+    if (q < n_out && j < 4) out[q * 4 + j] = x;
+}
+
+// the last levels (n <= 64 nodes) in one 512-thread workgroup, one node per 16 lanes: six dependent levels at ~20 us each instead of 58 us
+// (wider levels are spread over the chip by k_merkle_level_coop: one CU would serialise their sweeps)
+__global__ __launch_bounds__(512) void k_merkle_top_coop(u64 *level, uint64_t n)
+{
+    const uint32_t j = threadIdx.x & 15, slot = threadIdx.x >> 4; // 32 nodes per sweep
+    while (n > 1) {
+        const uint64_t n_out = n >> 1;
+        u64 *nxt = level + n * 4;
+        for (uint64_t i0 = 0; i0 < n_out; i0 += 32) { // trip count is workgroup-uniform
+            const uint64_t i = i0 + slot;
+            const u64 x = permute_coop((i < n_out && j < 8) ? level[i * 8 + j] : 0, j);
+            if (i < n_out && j < 4) nxt[i * 4 + j] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        level = nxt;
+        n = n_out;
+    }
+}
+
 // linear_hash of every row: ncols <= 4 -> copy + zero pad, else rate-8 sponge with the
 // previous block's out[0..4) carried in the capacity.
 template <int MDS>
@@ -280,10 +403,20 @@ static int by_variant(mi_ctx *ctx, F f)
     return MI_OK;
 }
 
+// Below this many independent permutations (nodes of a level, states of a batch) the cooperative form wins: 16 lanes per state keep
+// the chip busy where one lane per state would leave most of it idle behind a 58 us dependent chain (crossover measured: DESIGN.md)
+static constexpr uint64_t COOP_MAX = 16384;
+
 int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count)
 {
     if (count == 0) return MI_OK;
     MI_REQUIRE_1D_GRID(count);
+    if (count <= ctx->poseidon_coop_max) {
+        MI_TRY(upload_rc_once(ctx));
+        hipLaunchKernelGGL(k_permute_coop, dim3((unsigned)((count * 16 + 255) / 256)), dim3(256), 0, ctx->stream, out, in, count);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
     const unsigned grid = (unsigned)((count + 255) / 256);
     return by_variant(ctx, [&](auto v) {
         hipLaunchKernelGGL((k_permute<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, out, in, count);
@@ -355,20 +488,32 @@ int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)
     MI_REQUIRE_1D_GRID(nleaves);
     u64 *level = nodes;
     uint64_t n = nleaves;
-    while (n > 512) {
+    const bool coop = ctx->poseidon_coop_max > 0;
+    MI_TRY(upload_rc_once(ctx));
+    while (n > (coop ? 64 : 512)) {
         const uint64_t n_out = n >> 1;
         u64 *nxt = level + n * 4;
-        const unsigned grid = (unsigned)((n_out + 255) / 256);
-        MI_TRY(by_variant(ctx, [&](auto v) {
-            hipLaunchKernelGGL((k_merkle_level<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, nxt, level, n_out);
-        }));
+        if (n_out <= ctx->poseidon_coop_max) { // a small level: one node per 16 lanes
+            hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, ctx->stream, nxt, level, n_out);
+            MI_HIP_CHECK(hipGetLastError());
+        } else {
+            const unsigned grid = (unsigned)((n_out + 255) / 256);
+            MI_TRY(by_variant(ctx, [&](auto v) {
+                hipLaunchKernelGGL((k_merkle_level<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, nxt, level, n_out);
+            }));
+        }
         level = nxt;
         n = n_out;
     }
     if (n > 1) {
-        MI_TRY(by_variant(ctx, [&](auto v) {
-            hipLaunchKernelGGL((k_merkle_top<decltype(v)::value>), dim3(1), dim3(256), 0, ctx->stream, level, n);
-        }));
+        if (coop) {
+            hipLaunchKernelGGL(k_merkle_top_coop, dim3(1), dim3(512), 0, ctx->stream, level, n);
+            MI_HIP_CHECK(hipGetLastError());
+        } else {
+            MI_TRY(by_variant(ctx, [&](auto v) {
+                hipLaunchKernelGGL((k_merkle_top<decltype(v)::value>), dim3(1), dim3(256), 0, ctx->stream, level, n);
+            }));
+        }
     }
     return MI_OK;
 }

@@ -1,5 +1,7 @@
-// transcript.hpp -- Fiat-Shamir transcript, same state machine as transcript.cpp:4-87.  Sequential by nature and
-// kept on the host; every permutation runs on the GPU through PoseidonGoldilocks::hash_full_result.
+// transcript.hpp (standalone stand-in) -- Fiat-Shamir transcript, same state machine as transcript.cpp:4-87.  Sequential by nature and
+// kept on the host; every permutation runs on the GPU (a whole put in one launch: mi_transcript_put; a squeeze through
+// PoseidonGoldilocks::hash_full_result).  Only for builds without the reference tree (the GPU-box tests, libmi_starks.so): the
+// reference's own transcript.{hpp,cpp} compile unchanged against Level 0 and are what a maintainer's build uses.
 #ifndef TRANSCRIPT_CLASS
 #define TRANSCRIPT_CLASS
 #include <cmath>
@@ -7,6 +9,7 @@
 #include "goldilocks_base_field.hpp"
 #include "goldilocks_cubic_extension.hpp"
 #include "poseidon_goldilocks.hpp"
+#include "mi_runtime.hpp"
 
 #define TRANSCRIPT_STATE_SIZE 4
 #define TRANSCRIPT_PENDING_SIZE 8
@@ -25,13 +28,6 @@ class Transcript
         pending_cursor = 0;
         std::memcpy(state, out, TRANSCRIPT_STATE_SIZE * sizeof(Goldilocks::Element));
     }
-    void _add1(Goldilocks::Element input)
-    {
-        pending[pending_cursor] = input;
-        pending_cursor++;
-        out_cursor = 0;
-        if (pending_cursor == TRANSCRIPT_PENDING_SIZE) _updateState();
-    }
 
 public:
     Goldilocks::Element state[TRANSCRIPT_STATE_SIZE];
@@ -49,7 +45,11 @@ public:
     }
     void put(Goldilocks::Element *input, uint64_t size)
     {
-        for (uint64_t i = 0; i < size; i++) _add1(input[i]);
+        // the same state machine as _add1 element by element, one launch for the whole put (mi_transcript_put)
+        uint32_t pc = pending_cursor, oc = out_cursor;
+        mi::check(mi_transcript_put(mi::ctx(), (uint64_t *)state, (uint64_t *)pending, (uint64_t *)out, &pc, &oc, (const uint64_t *)input, size), "Transcript::put");
+        pending_cursor = pc;
+        out_cursor = oc;
     }
     Goldilocks::Element getFields1()
     {

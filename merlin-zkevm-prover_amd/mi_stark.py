@@ -47,13 +47,13 @@ EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_set_stream", "mi_ctx_sync", "mi_ctx_set_workspace_limit",
     "mi_last_error", "mi_version", "mi_device_count",
     "mi_ntt_dev", "mi_lde_dev", "mi_ntt", "mi_lde",
-    "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
+    "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_transcript_put", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
     "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
     "mi_merkle_group_proofs_dev",
     "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
-    "mi_set_poseidon_variant", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
+    "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
     "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_get_host_pack_threads",
@@ -137,6 +137,18 @@ class Context:
 
     def set_chelpers_min_words(self, words):
         _check(lib().mi_set_chelpers_min_words(self.h, u64(words)))
+
+    def transcript_put(self, tr, vals):
+        """Transcript::put on a dict {state[4], pending[8], out[12], pending_cursor, out_cursor} (host numpy), one launch"""
+        v = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1)
+        pc, oc = ctypes.c_uint32(tr["pending_cursor"]), ctypes.c_uint32(tr["out_cursor"])
+        _check(lib().mi_transcript_put(self.h, _hp(tr["state"]), _hp(tr["pending"]), _hp(tr["out"]), ctypes.byref(pc), ctypes.byref(oc),
+                                       _hp(v) if v.size else None, u64(v.size)))
+        tr["pending_cursor"], tr["out_cursor"] = pc.value, oc.value
+
+    def set_poseidon_coop_max(self, max_states):
+        """launches of at most this many independent permutations use the wave-cooperative kernel (0: never)"""
+        _check(lib().mi_set_poseidon_coop_max(self.h, u64(max_states)))
 
     def set_ntt_tile(self, log_b):
         _check(lib().mi_set_ntt_tile(self.h, ctypes.c_int(log_b)))

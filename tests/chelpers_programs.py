@@ -157,7 +157,9 @@ def synthetic_program(rng, nrows, sections, n_const, n_chal, n_pub, passes=3, nt
     return np.array(ops, dtype=np.uint64), np.array([a % (1 << 64) for a in args], dtype=np.uint64)
 
 
-def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_ops=17986, next_shift=2, vc=4, long_lived=70, base_out=None):
+def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_ops=17986, next_shift=2, vc=4, long_lived=70, base_out=None,
+                                  sec_weights=None, kind_weights=None, mean_len=4.6, ext_frac=0.09, run_ops=750, pool_scale=1.0, zipf=0.7, ll_generations=1,
+                                  ll_use=0.5, burst=None, shared_scale=1.0, partition=False, neighbour=0.0, class_p=(0.46, 0.29, 0.25)):
     """A random valid step42ns program in the SHAPE of the zkEVM one (the real tables cannot travel to the GPU box): ~2 200
     constraint values, each a short base-field expression (on average 5.6 multiplications / additions / subtractions) over
     polynomial elements, shifted ("prime") elements, constants and numbers, every one folded into the running extension
@@ -168,7 +170,21 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     rescheduled program keeps about as many words live as the real one (86).  Uses challenges 0..vc; ends with the q store.
     sections: [(offset, stride[, readable columns])].  base_out = (offset, stride[, columns]): the same shape in the BASE-DOMAIN steps' numbering (opcodes 0-83 are shared): about every other
     constraint value is stored into a column of that section instead of being accumulated (opcode 100; the zkEVM step3 stores 430 elements) and the accumulator goes to
-    three of its columns (opcode 90) instead of q."""
+    three of its columns (opcode 90) instead of q.
+    The remaining parameters shape the statistics tools/chelpers_match.py fits to the real program (defaults = the r02 generator, bit for
+    bit): sec_weights = probability of each section as the home of a polynomial operand; kind_weights = {operand kind: weight} biasing the
+    choice among opcodes of a class by their operand kinds (constants, shifted reads ...); mean_len = mean operations per constraint;
+    ext_frac = share of extension-valued constraints; run_ops = field operations per run (a run draws its operands from its own pool);
+    pool_scale = size of a run's pool; zipf = skew of the picks inside a pool; ll_generations = the long-lived values are defined in that
+    many generations spread over the program instead of all up front (a value then crosses fewer kernel boundaries; 0 = every run
+    redefines them from its own operands: values shared inside a state machine's constraints and dead at its end); ll_use = how often a
+    two-temporary operation takes a long-lived value as its second operand; burst = (position in [0, 1), values): one run defines that many
+    extra shared values and combines them heavily (the real program's peak of live temporaries sits in one state machine's constraints,
+    while only a handful of values cross a kernel boundary); partition = the columns of every section (and the constants) are dealt to the
+    runs as contiguous slices -- a state machine owns a range of columns -- so that every column is read somewhere and an operand is read
+    by one or two kernels, as in the real program (2 167 distinct operands, each loaded by 2.0 kernels on average); neighbour = share of
+    a partitioned run's picks that go to the PREVIOUS run's slices instead (constraints that tie two state machines together); class_p =
+    shares of multiplications / additions / subtractions among the base-field operations."""
     ops, args = [], []
     ACC = 0
     cls_of = lambda o: "add" if o <= 20 else "sub" if o <= 44 else "mul" if o <= 77 else "copy"
@@ -178,24 +194,52 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     # operand locality like the real program's (2 167 distinct polynomial elements, 12 525 reads, 4 327 loads left after common-
     # subexpression elimination within each of 28 kernels): the constraints come in runs -- one per state machine -- and a run
     # draws its operands from its own pool of elements, plus a few that the whole program shares
-    n_runs = max(1, field_ops // 750)
-    per_run = max(6, min(130, field_ops // 30))
+    n_runs = max(1, field_ops // run_ops)
+    per_run = max(6, int(min(130, field_ops // 30) * pool_scale))
     cur_pool = {"pol": [], "pols": [], "const": []}
 
     def zipf_pick(pool):
-        w = 1.0 / (np.arange(len(pool)) + 4.0) ** 0.7
+        w = 1.0 / (np.arange(len(pool)) + 4.0) ** zipf
         return pool[int(rng.choice(len(pool), p=w / w.sum()))]
 
     def rand_col(three=False):
-        sec = sections[int(rng.integers(0, len(sections)))]          # (offset, stride[, readable columns])
+        sec = sections[int(rng.integers(0, len(sections))) if sec_weights is None else int(rng.choice(len(sections), p=np.asarray(sec_weights) / np.sum(sec_weights)))]  # (offset, stride[, readable columns])
         off, stride = sec[0], sec[1]
         return off + int(rng.integers(0, (sec[2] if len(sec) > 2 else stride) - (2 if three else 0))), stride
-    shared = {"pol": [rand_col() for _ in range(12)], "pols": [rand_col() for _ in range(4)], "const": [int(rng.integers(0, n_const)) for _ in range(4)]}
+    n_sh = lambda k: max(0, int(round(k * shared_scale)))    # operands the whole program shares (shared_scale: fit parameter)
+    shared = {"pol": [rand_col() for _ in range(n_sh(12))], "pols": [rand_col() for _ in range(n_sh(4))], "const": [int(rng.integers(0, n_const)) for _ in range(n_sh(4))]}
+
+    run_idx = [0]
+
+    def slice_of(total, r):
+        lo, hi = r * total // n_runs, (r + 1) * total // n_runs
+        return range(lo, max(hi, lo + 1)) if total else range(0)
 
     def new_run():
+        if partition:
+            r = run_idx[0] % n_runs
+            run_idx[0] += 1
+            per_sec = []
+            for sec in sections:
+                cols = sec[2] if len(sec) > 2 else sec[1]
+                per_sec.append([(sec[0] + c % cols, sec[1]) for c in slice_of(cols, r)])
+            cur_pool["sec_prev"] = cur_pool.get("sec", per_sec)
+            cur_pool["sec"] = per_sec
+            cur_pool["pol"] = [e for lst in per_sec for e in lst] + shared["pol"]
+            cur_pool["pols"] = cur_pool["pol"]
+            cur_pool["const"] = [c % n_const for c in slice_of(n_const, r)] + shared["const"]
+            return
         cur_pool["pol"] = [rand_col() for _ in range(max(3, per_run * 6 // 10))] + shared["pol"]
         cur_pool["pols"] = [rand_col() for _ in range(max(2, per_run * 2 // 10))] + shared["pols"]
         cur_pool["const"] = [int(rng.integers(0, n_const)) for _ in range(max(2, per_run * 2 // 10))] + shared["const"]
+
+    def pick_part():
+        """a polynomial operand of the current run: section by sec_weights, column by a skewed pick inside the run's slice of it"""
+        w = np.asarray(sec_weights if sec_weights is not None else [1.0] * len(sections), dtype=np.float64)
+        w = np.array([wi if cur_pool["sec"][i] else 0.0 for i, wi in enumerate(w)])
+        which = "sec_prev" if (neighbour and rng.random() < neighbour) else "sec"
+        lst = cur_pool[which][int(rng.choice(len(sections), p=w / w.sum()))]
+        return zipf_pick(lst)
     new_run()
     pol_pool, pols_pool, const_pool = cur_pool["pol"], cur_pool["pols"], cur_pool["const"]
 
@@ -205,9 +249,9 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
         if kind == CONST: return [zipf_pick(cur_pool["const"])]
         if kind == CONSTS: return [zipf_pick(cur_pool["const"]), next_shift, nrows]
         if kind == PUB: return [int(rng.integers(0, n_pub))]
-        if kind == POL: return list(zipf_pick(cur_pool["pol"]))
+        if kind == POL: return list(pick_part() if partition else zipf_pick(cur_pool["pol"]))
         if kind == POLS:
-            c, st = zipf_pick(cur_pool["pols"])
+            c, st = pick_part() if partition else zipf_pick(cur_pool["pols"])
             return [c, next_shift, nrows, st]
         raise ValueError(kind)
 
@@ -217,25 +261,64 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     out_cursor = [0]
     push(13, [ACC, 1, vc])                       # acc = 1 + challenge[vc]
     LL0 = 10
-    for k in range(long_lived):
-        push(50, [LL0 + k] + list(zipf_pick(pol_pool)) + list(zipf_pick(pol_pool)))
-    count, slot, eslot = 1 + long_lived, 0, 1
+    # long-lived values: generation g (slots LL0 + g * per_gen ...) is (re)defined when the program reaches g / ll_generations of its length
+    per_gen = (-(-long_lived // ll_generations) if ll_generations else long_lived) if long_lived else 0
+    ll_live = [0]                                # long-lived slots defined so far (the later generations overwrite nothing: own slots)
+
+    def define_generation(g):
+        lo, hi = g * per_gen, min(long_lived, (g + 1) * per_gen)
+        for k in range(lo, hi):
+            push(50, [LL0 + k] + list(zipf_pick(cur_pool["pol"])) + list(zipf_pick(cur_pool["pol"])))
+        ll_live[0] = hi
+        return hi - lo
+    count, slot, eslot = 1 + define_generation(0), 0, 1
+    next_gen = 1
+    in_burst, BURST0 = [False], LL0 + long_lived + 4
     next_run = count + field_ops // n_runs
+    op_w = {}
+    if kind_weights is not None:                 # opcode choice biased by the kinds of its operands
+        for lst in list(first.values()) + list(later.values()):
+            for o in lst:
+                op_w[o] = float(np.prod([kind_weights.get(k, 1.0) for k in OPS[o][1:] if k is not None]))
+
+    def pick_op(lst):
+        if kind_weights is None:
+            return int(rng.choice(lst))
+        w = np.array([op_w[o] for o in lst])
+        return int(lst[int(rng.choice(len(lst), p=w / w.sum()))])
     while count < field_ops - 1:
         if count >= next_run:
             new_run()
             next_run += field_ops // n_runs
-        g = min(14, 1 + int(rng.geometric(1 / 4.6)))
+            if ll_generations == 0 and long_lived:      # the shared values belong to the run: redefined (same slots) from its own operands
+                per_gen = long_lived
+                count += define_generation(0)
+            in_burst[0] = burst is not None and count <= burst[0] * field_ops < count + field_ops // n_runs
+            if in_burst[0]:
+                for k in range(burst[1]):
+                    push(50, [BURST0 + k] + list(zipf_pick(cur_pool["pol"])) + list(zipf_pick(cur_pool["pol"])))
+                count += burst[1]
+        if next_gen < ll_generations and count >= next_gen * field_ops // ll_generations:
+            count += define_generation(next_gen)
+            next_gen += 1
+        g = min(14, 1 + int(rng.geometric(1 / mean_len))) if mean_len <= 8 else min(24, 1 + int(rng.geometric(1 / mean_len)))
         cur = None
         for k in range(g):
-            c = ("mul", "add", "sub")[int(rng.choice(3, p=[0.46, 0.29, 0.25]))]
-            o = int(rng.choice(first[c] if cur is None else later[c]))
+            c = ("mul", "add", "sub")[int(rng.choice(3, p=list(class_p)))]
+            o = pick_op(first[c] if cur is None else later[c])
+            if in_burst[0] and cur is not None and rng.random() < 0.6:
+                o = {"mul": 45, "add": 0, "sub": 21}[c]              # temp (op) temp: combines the burst's shared values
             d, a, b = OPS[o]
             dst = slot % 10
             slot += 1
             temps = [cur, cur] if cur is not None else []
             if cur is not None and a == T1 and b == T1:
-                if long_lived and rng.random() < 0.5: temps = [cur, LL0 + int(rng.integers(0, long_lived))]
+                if in_burst[0] and rng.random() < 0.9:
+                    temps = [cur, BURST0 + int(rng.integers(0, burst[1]))]
+                elif long_lived and rng.random() < ll_use:
+                    # a long-lived value of the current or the previous generation
+                    lo = max(0, ll_live[0] - 2 * per_gen) if ll_generations > 1 else 0
+                    temps = [cur, LL0 + int(rng.integers(lo, ll_live[0]))]
                 elif k >= 2: temps = [cur, prev] # a product / sum of two values of this constraint
             ar = [dst] + gen_src(a, temps) + gen_src(b, temps)
             push(o, ar)
@@ -248,7 +331,7 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
             out_cursor[0] += 1
             count += 1
             continue
-        if rng.random() < 0.09:                  # extension-valued constraint
+        if rng.random() < ext_frac:              # extension-valued constraint
             e1, e2 = 1 + eslot % 4, 1 + (eslot + 1) % 4
             eslot += 2
             push(59, [e1, cur, int(rng.integers(0, vc))])                   # e1 = value * challenge

@@ -217,6 +217,45 @@ def test_golden_merkle_paths_on_gpu(ctx, path):
             assert np.array_equal(cur, root)
 
 
+def test_transcript_put_in_one_launch_matches_the_oracle_state_machine(ctx):
+    """mi_transcript_put (a whole Transcript::put per launch, wave-cooperative permutation) against the oracle's transcript: the same
+    members after every put, for puts that complete no block, exactly one, many, and that start mid-block."""
+    rng = np.random.default_rng(77)
+    tr = {"state": np.zeros(4, dtype=np.uint64), "pending": np.zeros(8, dtype=np.uint64), "out": np.zeros(12, dtype=np.uint64), "pending_cursor": 0, "out_cursor": 0}
+    ref = glo.Transcript()
+    for n in (3, 4, 1, 8, 16, 5, 354, 7, 1, 192, 0, 9):
+        v = glo.rand_fe(rng, n)
+        ctx.transcript_put(tr, v)
+        ref.put(v)
+        t = ref.t
+        assert [int(x) for x in t.state] == [int(x) for x in tr["state"]] and [int(x) for x in t.pending] == [int(x) for x in tr["pending"]], n
+        assert int(t.pending_cursor) == tr["pending_cursor"] and int(t.out_cursor) == tr["out_cursor"], n
+        if tr["out_cursor"]:
+            assert [int(x) for x in t.out] == [int(x) for x in tr["out"]], n
+    # and both permutation forms give the same single hash
+    st = glo.rand_fe(rng, 12)
+    a = ctx.hash_full_result(st)
+    ctx.set_poseidon_coop_max(0)
+    b = ctx.hash_full_result(st)
+    ctx.set_poseidon_coop_max(16384)
+    assert np.array_equal(a, b) and np.array_equal(a, glo.perm(st))
+
+
+@pytest.mark.parametrize("coop_max", [0, 16384])
+def test_merkle_levels_both_permutation_forms(ctx, coop_max):
+    """Tree levels through the one-state-per-lane kernels only (coop_max 0) and with the wave-cooperative kernels for the small levels
+    and the top: the same node array as the oracle's, heights around every switch-over (64, 512, 1024, 16384 nodes)."""
+    ctx.set_poseidon_coop_max(coop_max)
+    try:
+        for h in (1, 2, 32, 64, 128, 1024, 2048, 1 << 15, 1 << 16):
+            src = glo.splitmix64(h, h * 9).reshape(h, 9)
+            nodes = ctx.empty((2 * h - 1) * 4)
+            ctx.merkle_build(nodes, ctx.to_device(src), 9, h)
+            assert np.array_equal(ctx.to_host(nodes), glo.merkletree(src, 9, h)), h
+    finally:
+        ctx.set_poseidon_coop_max(16384)
+
+
 def test_golden_root2_is_the_tree_without_columns_on_gpu(ctx):
     """Every golden proof's root2 is the root of MerkleTreeGL(2^20 rows, 0 columns) -- the recursive STARKs commit nothing in stage 2
     (tests/test_oracle_golden.py): the tree builder on a width of 0 at the golden height must produce exactly it."""
