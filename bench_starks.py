@@ -49,6 +49,9 @@ def arg_parser():
     ap.add_argument("--shape", choices=("zkevm", "recursive1"), default="zkevm",
                     help="recursive1: the shape the golden proofs testvectors/aggregatedProof/recursive1.zkin.proof_*.json imply (2^17 rows, blow-up 8, "
                          "18 / 0 / 39 / 21 columns, 52 constants, 118 evaluations, 43 queries, FRI 20/16/12/9/6); sets every size argument")
+    ap.add_argument("--step42-generic", action="store_true",
+                    help="step42ns from the r02 generator defaults instead of the parameters fitted to the real program's statistics "
+                         "(tests/chelpers_programs.ZKEVM_STEP42NS_FIT; the fit applies when the three committed sections are all present)")
     ap.add_argument("--proofs", type=int, default=2, help="genProof runs; the last one is reported (the first pays first-touch / code loading)")
     ap.add_argument("--check-rows", type=int, default=6)
     ap.add_argument("--chelpers-batch-rows", type=int, default=0)
@@ -179,7 +182,12 @@ def shape(args):
         progs["step3"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(31), N, base2 + ([(off["cm3_n"], w3, 3 * n_prod)] if n_prod else []), args.n_const, 8,
                                                            field_ops=f3, next_shift=1, vc=3, long_lived=ll(f3), base_out=(off["cm3_n"] + 3 * n_prod, w3, w3 - 3 * n_prod))
     ext3 = [(off[k], cols[k]) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns") if cols[k]]
-    progs["step42ns"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(42), NE, ext3, args.n_const, 8, field_ops=f42, next_shift=shift_ext, long_lived=ll(f42))
+    if len(ext3) == 3 and not args.step42_generic:       # the stand-in with the real zkEVM program's statistics, scaled to the requested size
+        fit = dict(cpg.ZKEVM_STEP42NS_FIT, field_ops=f42, next_shift=shift_ext)
+        fit["burst"] = [fit["burst"][0], max(4, fit["burst"][1] * f42 // 17986)]
+        progs["step42ns"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(42), NE, ext3, args.n_const, 8, **fit)
+    else:
+        progs["step42ns"] = cpg.synthetic_program_zkevm_shape(np.random.default_rng(42), NE, ext3, args.n_const, 8, field_ops=f42, next_shift=shift_ext, long_lived=ll(f42))
     ext4 = ext3 + [(off["cm4_2ns"], w4)]
     import mi_stark
     probe = mi_stark.ChelpersProgram(None, *cpg.synthetic_program52(np.random.default_rng(52), ext4, args.n_const, args.n_evals, length=200), step=52)

@@ -525,3 +525,35 @@ def test_base_step_program_on_gpu_matches_oracle(seed, tmp_path):
         assert np.array_equal(ctx.to_host(d_pols), want), batch
     prog.close()
     ctx.close()
+
+
+def _fit_stats():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import chelpers_match as cm
+    return cm, cm.program_stats(*cm.synthetic(cp.ZKEVM_STEP42NS_FIT))
+
+
+def test_fitted_synthetic_step42ns_has_the_committed_statistics_of_the_real_program():
+    """The synthetic step42ns program that stands in for the reference's on the GPU box (bench_starks.py) against the real program's
+    statistics as committed in profiles/r03_chelpers_step42ns_target.json (numbers only): each within the tolerance stated next to the
+    fit (5 % for what decides kernel cost and the section mix; loads per row and distinct operands are the stated residual gap).  No GPU,
+    no reference needed."""
+    import json
+    cm, st = _fit_stats()
+    target = json.load(open(cm.TARGET))["stats"]
+    for k, tol in cp.ZKEVM_STEP42NS_FIT_TOLERANCE.items():
+        assert abs(st[k] - target[k]) <= tol * target[k], (k, st[k], target[k])
+
+
+@needs_ref
+def test_committed_target_statistics_are_the_real_programs():
+    """... and that file is what tools/chelpers_match.py measures on the reference's own tables today."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import chelpers_match as cm
+    real = cm.program_stats(*cp.parse_reference_tables(open(REF_HPP).read()))
+    target = json.load(open(cm.TARGET))["stats"]
+    for k in cm.KEYS:
+        assert abs(real[k] - target[k]) <= 1e-9 * max(1.0, abs(target[k])), (k, real[k], target[k])
