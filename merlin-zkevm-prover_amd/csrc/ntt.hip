@@ -27,6 +27,18 @@
 
 // MI_NTT_NO_ARITH: A/B diagnosis build -- the passes move the same bytes through the same LDS round trips and barriers, the
 // field arithmetic (butterflies in ntt_math.h, twiddle multiplies, canonical form) is replaced by an xor that keeps the data flow
+// MI_NTT_SETPRIO (A/B experiment, profiles/r03_pmc_ntt.txt): 1 = the waves of a workgroup that is issuing its tile loads run at a higher
+// issue priority than the ones computing (their few instructions put 64 KB in flight), 2 = the opposite
+#if defined(MI_NTT_SETPRIO) && MI_NTT_SETPRIO == 1
+#define NTT_PRIO_LOAD() __builtin_amdgcn_s_setprio(3)
+#define NTT_PRIO_COMPUTE() __builtin_amdgcn_s_setprio(0)
+#elif defined(MI_NTT_SETPRIO) && MI_NTT_SETPRIO == 2
+#define NTT_PRIO_LOAD() __builtin_amdgcn_s_setprio(0)
+#define NTT_PRIO_COMPUTE() __builtin_amdgcn_s_setprio(3)
+#else
+#define NTT_PRIO_LOAD() do { } while (0)
+#define NTT_PRIO_COMPUTE() do { } while (0)
+#endif
 #ifdef MI_NTT_NO_ARITH
 #define NTT_MULW(x, t) ((x) ^ (t))
 #define NTT_CANON(x) (x)
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     };
 
     // ---- load (any encoding; dft_reg accepts it)
+    NTT_PRIO_LOAD();
     if (WIDE) { // lanes run along column PAIRS: 16 lanes cover a 256-byte row segment, 32 rows per sweep
         constexpr int NW = (R * (B / 2) + NTT_THREADS - 1) / NTT_THREADS; // 16-byte loads per thread (8 at r = 256)
         const uint32_t bp = (tid & (B / 2 - 1)) * 2, tj = bp >> a.tcp_log, c = bp & (TCP - 1);
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
         }
     }
     __syncthreads();
+    NTT_PRIO_COMPUTE();
 
     // ---- step A (high bits, in place) and step B (low bits) + inter-pass twiddle / scale + store in natural order
     tile_step_a<LOG_R, INV, LOG_B>(tile, w256, tid);
@@ -337,6 +351,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
     const uint32_t c0 = (uint32_t)(lt % a.n_col_tiles) << a.tcp_log;
 
     if (tid < 256) w256[tid] = a.w256[tid];
+    NTT_PRIO_LOAD();
     // ---- R1 input rows i1 * K1 + kappa, two adjacent columns per lane
     constexpr int NW = (R1 * (B / 2) + NTT_THREADS - 1) / NTT_THREADS;
     const uint32_t bp = (tid & (B / 2 - 1)) * 2, ltj = bp >> a.tcp_log, lc = bp & (TCP - 1);
@@ -385,6 +400,7 @@ __global__ __launch_bounds__(16 << LOG_B) void k_lde_mid(const LdeMid a)
         if (i1 < (uint32_t)R1) *reinterpret_cast<ulonglong2 *>(&tile[i1 * B + bp]) = v[k];
     }
     __syncthreads();
+    NTT_PRIO_COMPUTE();
 
     // ---- INTT over the R1 rows; results (times scale) go back to rows k1 in natural order, rows R1.. are zeroed
     tile_step_a<LOG_R1, true, LOG_B>(tile, w256, tid);

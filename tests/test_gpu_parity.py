@@ -256,6 +256,19 @@ def test_merkle_levels_both_permutation_forms(ctx, coop_max):
         ctx.set_poseidon_coop_max(16384)
 
 
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_golden_final_polynomial_is_low_degree_under_the_gpu_intt(ctx, path):
+    """The reference's own data through the device INTT (tests/test_oracle_golden.py has the argument): finalPol's 64 evaluations must
+    transform to eight coefficients and 56 zeros."""
+    fp = np.ascontiguousarray(np.load(path)["finalPol"].reshape(64, 3))
+    d = ctx.to_device(fp)
+    out = ctx.empty(64 * 3)
+    ctx.ntt(out, d, 64, 3, inverse=True)
+    c = ctx.to_host(out).reshape(64, 3)
+    assert c[:8].any(axis=1).all() and not c[8:].any()
+    assert np.array_equal(c, glo.ntt(fp, 64, 3, inverse=True).reshape(64, 3))
+
+
 def test_golden_root2_is_the_tree_without_columns_on_gpu(ctx):
     """Every golden proof's root2 is the root of MerkleTreeGL(2^20 rows, 0 columns) -- the recursive STARKs commit nothing in stage 2
     (tests/test_oracle_golden.py): the tree builder on a width of 0 at the golden height must produce exactly it."""

@@ -111,3 +111,17 @@ def test_root2_is_the_root_of_a_tree_without_columns(path):
     for _ in range(7):
         want = glo.perm(np.concatenate([want, want, np.zeros(4, dtype=np.uint64)]))[:4]
     assert np.array_equal(nodes[-4:], want) and not nodes[:4 * n].any()
+
+
+@pytest.mark.parametrize("path", FILES)
+def test_final_polynomial_is_low_degree_under_the_inverse_transform(path):
+    """finalPol of a golden proof is the last FRI layer: 64 evaluations over <w_64> (natural order) of a polynomial of degree
+    < 2^(6 - 3) = 8 (blow-up 8).  INTT_64 in the oracle's convention -- natural order in and out, w(6) = 8 -- must therefore give exactly
+    eight leading coefficients and 56 zeros on the reference's own data: a transform with another root or ordering smears them (checked:
+    the bit-reversed reading of the same data has 64 non-zero coefficients)."""
+    g = np.load(path)
+    fp = g["finalPol"].reshape(64, 3)
+    c = glo.ntt(fp, 64, 3, inverse=True).reshape(64, 3)
+    assert c[:8].any(axis=1).all() and not c[8:].any()
+    br = [int(format(i, "06b")[::-1], 2) for i in range(64)]
+    assert glo.ntt(np.ascontiguousarray(fp[br]), 64, 3, inverse=True).reshape(64, 3)[8:].any()
