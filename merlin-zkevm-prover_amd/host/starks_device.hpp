@@ -59,6 +59,19 @@ class StarksDevice
         if (!p) mi::fail(what);
         return p;
     }
+    // per-call scratch of the stages (coefficient buffers of q, LEv / LpEv, evaluations, opening buffers): grown once and kept -- memory
+    // handed back to the driver is wiped in the background on the GPU's own bandwidth
+    uint64_t *d_scratch = nullptr;
+    uint64_t scratchElems = 0;
+    uint64_t *scratch(uint64_t elems, const char *what)
+    {
+        if (elems > scratchElems) {
+            if (d_scratch) mi_dev_free(mi::ctx(), d_scratch);
+            d_scratch = alloc(elems, what);
+            scratchElems = elems;
+        }
+        return d_scratch;
+    }
 
 public:
     // sectionCols: columns of cm1, cm2, cm3; qDeg, qDim as in StarkInfo (zkEVM: 665, 128, 371; 2, 3)
@@ -82,6 +95,7 @@ public:
         if (prog42) mi_chelpers_free(c, prog42);
         if (prog52) mi_chelpers_free(c, prog52);
         for (auto &pb : progBase) mi_chelpers_free(c, pb.second);
+        mi_dev_free(c, d_scratch);
         mi_dev_free(c, d_baseArea); mi_dev_free(c, d_constN); mi_dev_free(c, d_xn);
         mi_dev_free(c, d_xdiv); mi_dev_free(c, d_xdivw); mi_dev_free(c, d_f2ns);
         for (uint64_t *p : d_nodes) mi_dev_free(c, p);
@@ -171,12 +185,11 @@ public:
     void commitQ(Goldilocks::Element *root, uint64_t qDeg = 2, uint64_t qDim = FIELD_EXTENSION)
     {
         mi_ctx *c = mi::ctx();
-        uint64_t *qq1 = alloc(NExtended * qDim, "StarksDevice::commitQ"), *qq2 = alloc(NExtended * qDim * qDeg, "StarksDevice::commitQ");
+        uint64_t *qq1 = scratch(NExtended * qDim * (1 + qDeg), "StarksDevice::commitQ"), *qq2 = qq1 + NExtended * qDim;
         mi::check(mi_ntt_dev(c, qq1, qDim, section(4), qDim, NExtended, qDim, 1), "StarksDevice::commitQ (INTT)");
         mi::check(mi_q_split_dev(c, qq2, qq1, N, NExtended, (unsigned)qDeg), "StarksDevice::commitQ (split)");
         mi::check(mi_ntt_dev(c, section(3), qDim * qDeg, qq2, qDim * qDeg, NExtended, qDim * qDeg, 0), "StarksDevice::commitQ (NTT)");
         mi::check(mi_merkle_build_dev(c, d_nodes[3], section(3), qDim * qDeg, qDim * qDeg, NExtended), "StarksDevice::commitQ (merkelize)");
-        mi_dev_free(c, qq1); mi_dev_free(c, qq2);
         getRoot(3, root);
     }
     // ---- stages 2 and 3 with the base domain in HBM.  Sections 0..2 = cm1_n .. cm3_n (the columns given to the constructor), 3 =
@@ -260,12 +273,12 @@ public:
         mi_ctx *c = mi::ctx();
         Goldilocks::Element sinv = Goldilocks::inv(Goldilocks::shift()), wN = Goldilocks::w(nBits), xis[3], wxis[3];
         for (int d = 0; d < 3; d++) { xis[d] = xi[d] * sinv; wxis[d] = xi[d] * wN * sinv; } // :314-316
-        uint64_t *lev = alloc(2 * N * 3, "StarksDevice::calculateEvals (LEv)"), *lpev = lev + N * 3;
+        const uint64_t n = evMap.size();
+        uint64_t *lev = scratch(2 * N * 3 + n * 3 + 16, "StarksDevice::calculateEvals (LEv)"), *lpev = lev + N * 3;
         mi::check(mi_geom_seq3_dev(c, lev, N, (const uint64_t *)xis), "StarksDevice::calculateEvals (LEv)");     // :318-322
         mi::check(mi_geom_seq3_dev(c, lpev, N, (const uint64_t *)wxis), "StarksDevice::calculateEvals (LpEv)");
         mi::check(mi_ntt_dev(c, lev, 3, lev, 3, N, 3, 1), "StarksDevice::calculateEvals (INTT LEv)");             // :323-324
         mi::check(mi_ntt_dev(c, lpev, 3, lpev, 3, N, 3, 1), "StarksDevice::calculateEvals (INTT LpEv)");
-        const uint64_t n = evMap.size();
         std::vector<const uint64_t *> ptr(n);
         std::vector<uint32_t> dim(n);
         std::vector<uint64_t> stride(n);
@@ -277,11 +290,10 @@ public:
             dim[i] = (uint32_t)e.dim;
             prime[i] = e.prime ? 1 : 0;
         }
-        uint64_t *d_evals = alloc(n * 3 + 1, "StarksDevice::calculateEvals (evals)");
+        uint64_t *d_evals = lev + 2 * N * 3;
         mi::check(mi_evmap_dev(c, d_evals, n, N, (unsigned)(nBitsExt - nBits), ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev),
                   "StarksDevice::calculateEvals (evmap)");
         mi::check(mi_copy_d2h(c, evals, d_evals, n * 3 * 8), "StarksDevice::calculateEvals (d2h)");
-        mi_dev_free(c, d_evals); mi_dev_free(c, lev);
     }
     // ---- FRI over the resident f_2ns (starks.cpp:393-394): the four resident trees are lent to FRIProve as MerkleTreeGL views, the
     // fifth is the caller's constant tree (as treesGL[4] in the reference); transcript by value like there
@@ -305,10 +317,9 @@ public:
     {
         mi_ctx *c = mi::ctx();
         const uint64_t stride = cols[t] + nBitsExt * HASH_SIZE;
-        uint64_t *d = alloc(nq * stride, "StarksDevice::getGroupProofs");
+        uint64_t *d = scratch(nq * stride, "StarksDevice::getGroupProofs");
         mi::check(mi_merkle_group_proofs_dev(c, d, d_nodes[t], section(t), cols[t], NExtended, cols[t], idx, nq), "StarksDevice::getGroupProofs");
         mi::check(mi_copy_d2h(c, proofs, d, nq * stride * 8), "StarksDevice::getGroupProofs (d2h)");
-        mi_dev_free(c, d);
     }
 };
 #endif

@@ -4,7 +4,8 @@ under which the SYNTHETIC zkEVM-shaped program (tests/chelpers_programs.syntheti
 are reference source and do not travel to the GPU box) has the statistics of the REAL one.
 
     tools/chelpers_match.py stats            the real program's statistics (needs /root/reference) -> profiles/r03_chelpers_step42ns_target.json
-    tools/chelpers_match.py fit [--iters N]  coordinate search over the generator's parameters against that file
+    tools/chelpers_match.py fit [--iters N] [--from-fit]   coordinate search over the generator's parameters against that file
+    tools/chelpers_match.py show             the committed fit (tests/chelpers_programs.ZKEVM_STEP42NS_FIT) next to the target
 
 Only NUMBERS about the reference's program are written (counts, fractions): no table text.  No GPU needed."""
 import json
@@ -88,8 +89,9 @@ def main():
         iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 6
         P = dict(field_ops=17986, long_lived=78, sec_weights=[0.93, 0.012, 0.055], kind_weights={cp.CONST: 0.35, cp.CONSTS: 0.12, cp.POLS: 0.12, cp.POL: 1.0},
                  mean_len=5.4, ext_frac=0.09, run_ops=750, pool_scale=1.3, zipf=0.7, ll_generations=3, ll_use=0.5)
-        if os.environ.get("FIT_START"):
-            P = eval(os.environ["FIT_START"], {"cp": cp})
+        if "--from-fit" in sys.argv:                       # continue from the committed parameters
+            P = json.loads(json.dumps({k: v for k, v in cp.ZKEVM_STEP42NS_FIT.items() if k != "kind_weights"}))
+            P["kind_weights"] = dict(cp.ZKEVM_STEP42NS_FIT["kind_weights"])
 
         def score(par):
             st = program_stats(*synthetic(par))
