@@ -189,9 +189,16 @@ int mi_calculate_h1h2_dev(mi_ctx *ctx, uint64_t *h1, uint64_t h1_stride, uint64_
                           uint64_t f_stride, const uint64_t *t, uint64_t t_stride, unsigned dim, uint64_t n);
 /* grand product (Polinomial::calculateZ, polinomial.hpp:586-607; starks.cpp:174-187 between step3prev and step3): z[0] = 1,
  * z[i] = z[i-1] * num[i-1] / den[i-1] in the cubic extension; strided device views of dim 3.  *closes (HOST, optional) receives 1
- * when z[n-1] * num[n-1] / den[n-1] == 1 -- the reference's zkassert -- else 0. */
+ * when z[n-1] * num[n-1] / den[n-1] == 1 -- the reference's zkassert -- else 0.  z may not overlap num or den (it holds the
+ * quotients between the two passes). */
 int mi_calculate_z_dev(mi_ctx *ctx, uint64_t *z, uint64_t z_stride, const uint64_t *num, uint64_t num_stride, const uint64_t *den,
                        uint64_t den_stride, uint64_t n, int *closes);
+/* nprod grand products over the same n rows in one pass (the loop of starks.cpp:174-187 over puCtx / peCtx / ciCtx: every product of
+ * the stage reads 2 x 3 words of the same rows of tmpExp_n, so one pass over those rows serves them all).  z / num / den and the
+ * strides are HOST arrays of nprod device pointers / word strides; results identical to nprod calls of mi_calculate_z_dev.
+ * closes: HOST array of nprod flags, optional. */
+int mi_calculate_z_batch_dev(mi_ctx *ctx, unsigned nprod, uint64_t *const *z, const uint64_t *z_stride, const uint64_t *const *num,
+                             const uint64_t *num_stride, const uint64_t *const *den, const uint64_t *den_stride, uint64_t n, int *closes);
 /* out[i] = start * ratio^i  (x_n, x_2ns: starks.hpp:149-160,176-183) */
 int mi_geom_seq_dev(mi_ctx *ctx, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio);
 /* out[k] = ratio^k in the cubic extension (LEv / LpEv: starks.cpp:311-323) */

@@ -782,6 +782,14 @@ extern "C" int mi_calculate_z_dev(mi_ctx *c, uint64_t *z, uint64_t z_stride, con
     return launch_calculate_z(c, (u64 *)z, z_stride, (const u64 *)num, num_stride, (const u64 *)den, den_stride, n, closes);
 }
 
+extern "C" int mi_calculate_z_batch_dev(mi_ctx *c, unsigned nprod, uint64_t *const *z, const uint64_t *z_stride, const uint64_t *const *num,
+                                        const uint64_t *num_stride, const uint64_t *const *den, const uint64_t *den_stride, uint64_t n, int *closes)
+{
+    CTX_OK(c);
+    MI_REQUIRE(nprod == 0 || (z && z_stride && num && num_stride && den && den_stride), "null argument array");
+    return launch_calculate_z_batch(c, nprod, (u64 *const *)z, z_stride, (const u64 *const *)num, num_stride, (const u64 *const *)den, den_stride, n, closes);
+}
+
 extern "C" int mi_geom_seq_dev(mi_ctx *c, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio)
 {
     CTX_OK(c);

@@ -167,6 +167,8 @@ int launch_calculate_h1h2(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uin
                           uint64_t t_stride, unsigned dim, uint64_t n);
 int launch_calculate_z(mi_ctx *ctx, u64 *z, uint64_t z_stride, const u64 *num, uint64_t num_stride, const u64 *den, uint64_t den_stride,
                        uint64_t n, int *closes);
+int launch_calculate_z_batch(mi_ctx *ctx, uint32_t nprod, u64 *const *z, const uint64_t *z_stride, const u64 *const *num, const uint64_t *num_stride,
+                             const u64 *const *den, const uint64_t *den_stride, uint64_t n, int *closes);
 int launch_geom_seq(mi_ctx *ctx, u64 *out, uint64_t n, u64 start, u64 ratio);
 int launch_geom_seq3(mi_ctx *ctx, u64 *out, uint64_t n, const u64 ratio[3]);
 int launch_x_div_x_sub(mi_ctx *ctx, u64 *out, const u64 *x, uint64_t n, const u64 xi[3]);

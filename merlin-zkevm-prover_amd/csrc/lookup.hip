@@ -242,28 +242,63 @@ __device__ __forceinline__ E3 block_exclusive_scan_e3(const E3 &v, u64 *lds, E3 
     return excl;
 }
 
-// FINAL = false: prods[block] = product of the block's quotients.  FINAL = true: z over the block's rows, from prods[block] = the
-// product of everything before the block.
+// FINAL = false: z = the rows' quotients num / den, prods[block] = their product over the block.  FINAL = true: z (holding the quotients)
+// becomes the running product over the block's rows, from prods[block] = the product of everything before the block.  z may not
+// overlap num or den.
 template <bool FINAL>
-__global__ __launch_bounds__(256) void k_z_blocks(u64 *__restrict__ z, uint64_t z_stride, const u64 *__restrict__ num, uint64_t num_stride,
-                                                  const u64 *__restrict__ den, uint64_t den_stride, uint64_t n, u64 *__restrict__ prods)
+__device__ __forceinline__ void z_block(u64 *__restrict__ z, uint64_t z_stride, const u64 *__restrict__ num, uint64_t num_stride,
+                                        const u64 *__restrict__ den, uint64_t den_stride, uint64_t n, u64 *__restrict__ prods, uint32_t blk)
 {
     __shared__ u64 lds[768];
-    const uint64_t base = (uint64_t)blockIdx.x * Z_PER_BLOCK + (uint64_t)threadIdx.x * Z_ROWS;
+    const uint64_t base = (uint64_t)blk * Z_PER_BLOCK + (uint64_t)threadIdx.x * Z_ROWS;
     E3 q[Z_ROWS], local = one3();
+    if (!FINAL) {
+        // The thread's Z_ROWS denominators share ONE inversion (Montgomery's trick: invert the running product, peel the factors off
+        // backwards): 1 inversion (an adjugate + a 96-multiplication Fermat power) + 3 (Z_ROWS - 1) products instead of Z_ROWS
+        // inversions.  Exact arithmetic, so the quotients are the same field elements; a zero denominator (inverse defined as 0, like
+        // the reference's Goldilocks3::inv) is taken out of the chain and its quotient set to 0.
+        // The quotients are parked in z (which the second pass overwrites with the running product), so the second pass reads 3 words
+        // a row instead of 6 and inverts nothing.
+        E3 pre[Z_ROWS], acc = one3();
+        bool dead[Z_ROWS];
 #pragma unroll
-    for (uint32_t j = 0; j < Z_ROWS; j++) {
-        q[j] = one3();
-        if (base + j < n) q[j] = gl::e3_mul(load3(num + (base + j) * num_stride), gl::e3_inv(load3(den + (base + j) * den_stride)));
-        local = gl::e3_mul(local, q[j]);
+        for (uint32_t j = 0; j < Z_ROWS; j++) {
+            E3 d = one3();
+            if (base + j < n) d = load3(den + (base + j) * den_stride);
+            dead[j] = (d.v[0] | d.v[1] | d.v[2]) == 0;
+            if (dead[j]) d = one3();
+            pre[j] = acc;
+            acc = gl::e3_mul(acc, d);
+            q[j] = d; // the denominator for now
+        }
+        E3 inv = gl::e3_inv(acc);
+#pragma unroll
+        for (int j = Z_ROWS - 1; j >= 0; j--) {
+            const E3 dinv = gl::e3_mul(inv, pre[j]);
+            inv = gl::e3_mul(inv, q[j]);
+            q[j] = one3();
+            if (base + j < n) {
+                q[j] = dead[j] ? E3{{0, 0, 0}} : gl::e3_mul(load3(num + (base + j) * num_stride), dinv);
+                u64 *o = z + (base + j) * z_stride;
+                o[0] = q[j].v[0]; o[1] = q[j].v[1]; o[2] = q[j].v[2];
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < Z_ROWS; j++) {
+            q[j] = one3();
+            if (base + j < n) q[j] = load3(z + (base + j) * z_stride);
+        }
     }
+#pragma unroll
+    for (uint32_t j = 0; j < Z_ROWS; j++) local = gl::e3_mul(local, q[j]);
     E3 total;
     E3 run = block_exclusive_scan_e3(local, lds, total);
     if (!FINAL) {
-        if (threadIdx.x == 0) { prods[(uint64_t)blockIdx.x * 3] = total.v[0]; prods[(uint64_t)blockIdx.x * 3 + 1] = total.v[1]; prods[(uint64_t)blockIdx.x * 3 + 2] = total.v[2]; }
+        if (threadIdx.x == 0) { prods[(uint64_t)blk * 3] = total.v[0]; prods[(uint64_t)blk * 3 + 1] = total.v[1]; prods[(uint64_t)blk * 3 + 2] = total.v[2]; }
         return;
     }
-    run = gl::e3_mul(load3(prods + (uint64_t)blockIdx.x * 3), run);
+    run = gl::e3_mul(load3(prods + (uint64_t)blk * 3), run);
 #pragma unroll
     for (uint32_t j = 0; j < Z_ROWS; j++) {
         if (base + j < n) {
@@ -273,10 +308,36 @@ __global__ __launch_bounds__(256) void k_z_blocks(u64 *__restrict__ z, uint64_t 
         run = gl::e3_mul(run, q[j]);
     }
 }
-// one block: prods[0..nb) -> exclusive products in place; total[0..3) = the product of all
-__global__ __launch_bounds__(256) void k_z_scan_top(u64 *prods, uint32_t nb, u64 *total_out)
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_z_blocks(u64 *__restrict__ z, uint64_t z_stride, const u64 *__restrict__ num, uint64_t num_stride,
+                                                  const u64 *__restrict__ den, uint64_t den_stride, uint64_t n, u64 *__restrict__ prods)
+{
+    z_block<FINAL>(z, z_stride, num, num_stride, den, den_stride, n, prods, blockIdx.x);
+}
+
+// Several grand products over the same rows in one launch (a stage's products read their numerators and denominators from columns of
+// the SAME rows -- 24 bytes of each polynomial out of a row of hundreds of words -- so a cache line a product fetches holds its
+// neighbours' operands too).  Workgroups are numbered product-fastest within a block of rows, and so that every product of one block
+// of rows lands on the same XCD (workgroup id mod 8): the lines the first product pulls into that XCD's L2 serve the others.
+constexpr uint32_t Z_BATCH = 32;
+struct ZBatch {
+    u64 *z[Z_BATCH];
+    const u64 *num[Z_BATCH], *den[Z_BATCH];
+    uint32_t z_stride[Z_BATCH], num_stride[Z_BATCH], den_stride[Z_BATCH];
+};
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_z_blocks_batch(const ZBatch b, uint32_t nprod, uint32_t nb, uint64_t n, u64 *__restrict__ prods)
+{
+    const uint32_t per = 8 * nprod, g = blockIdx.x / per, r = blockIdx.x % per, prod = r >> 3, blk = g * 8 + (r & 7);
+    if (blk >= nb) return; // (uniform over the workgroup)
+    z_block<FINAL>(b.z[prod], b.z_stride[prod], b.num[prod], b.num_stride[prod], b.den[prod], b.den_stride[prod], n,
+                   prods + (uint64_t)prod * ((uint64_t)nb + 1) * 3, blk);
+}
+// one block per product: prods[0..nb) -> exclusive products in place; prods[nb] = the product of all
+__global__ __launch_bounds__(256) void k_z_scan_top(u64 *prods_all, uint32_t nb)
 {
     __shared__ u64 lds[768];
+    u64 *prods = prods_all + (uint64_t)blockIdx.x * ((uint64_t)nb + 1) * 3, *total_out = prods + (uint64_t)nb * 3;
     const uint32_t per = (nb + 255) / 256, lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
     E3 s = one3();
     for (uint32_t j = lo; j < hi; j++) s = gl::e3_mul(s, load3(prods + (uint64_t)j * 3));
@@ -347,7 +408,7 @@ int launch_calculate_z(mi_ctx *ctx, u64 *z, uint64_t z_stride, const u64 *num, u
     MI_TRY(mi_scratch(ctx, ((uint64_t)nb + 1) * 24, (void **)&prods));
     u64 *total = prods + (uint64_t)nb * 3;
     hipLaunchKernelGGL(k_z_blocks<false>, dim3(nb), dim3(256), 0, ctx->stream, z, z_stride, num, num_stride, den, den_stride, n, prods);
-    hipLaunchKernelGGL(k_z_scan_top, dim3(1), dim3(256), 0, ctx->stream, prods, nb, total);
+    hipLaunchKernelGGL(k_z_scan_top, dim3(1), dim3(256), 0, ctx->stream, prods, nb);
     hipLaunchKernelGGL(k_z_blocks<true>, dim3(nb), dim3(256), 0, ctx->stream, z, z_stride, num, num_stride, den, den_stride, n, prods);
     MI_HIP_CHECK(hipGetLastError());
     if (closes) { // polinomial.hpp:603-606 (a zkassert there): does the product return to one?
@@ -355,6 +416,48 @@ int launch_calculate_z(mi_ctx *ctx, u64 *z, uint64_t z_stride, const u64 *num, u
         MI_HIP_CHECK(hipMemcpyAsync(ctx->pinned, total, 24, hipMemcpyDeviceToHost, ctx->stream));
         MI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *closes = tot[0] == 1 && tot[1] == 0 && tot[2] == 0;
+    }
+    return MI_OK;
+}
+
+int launch_calculate_z_batch(mi_ctx *ctx, uint32_t nprod, u64 *const *z, const uint64_t *z_stride, const u64 *const *num, const uint64_t *num_stride,
+                             const u64 *const *den, const uint64_t *den_stride, uint64_t n, int *closes)
+{
+    if (!n || !nprod) {
+        for (uint32_t i = 0; closes && i < nprod; i++) closes[i] = 1;
+        return MI_OK;
+    }
+    MI_REQUIRE(n < (1ull << 32), "too many rows");
+    const uint32_t nb = (uint32_t)((n + Z_PER_BLOCK - 1) / Z_PER_BLOCK), nb8 = (nb + 7) / 8 * 8;
+    for (uint32_t i = 0; i < nprod; i++) {
+        MI_REQUIRE(z[i] && num[i] && den[i], "null buffer");
+        MI_REQUIRE(z_stride[i] >= 3 && num_stride[i] >= 3 && den_stride[i] >= 3, "stride smaller than dim");
+        MI_REQUIRE(z_stride[i] < (1ull << 32) && num_stride[i] < (1ull << 32) && den_stride[i] < (1ull << 32), "stride too large");
+    }
+    const uint32_t chunk_max = nprod < Z_BATCH ? nprod : Z_BATCH;
+    MI_REQUIRE((uint64_t)nb8 * chunk_max < (1ull << 31), "too many workgroups");
+    u64 *prods = nullptr;
+    MI_TRY(mi_scratch(ctx, (uint64_t)chunk_max * ((uint64_t)nb + 1) * 24, (void **)&prods));
+    for (uint32_t first = 0; first < nprod; first += Z_BATCH) {
+        const uint32_t cnt = nprod - first < Z_BATCH ? nprod - first : Z_BATCH;
+        ZBatch b;
+        for (uint32_t i = 0; i < Z_BATCH; i++) {
+            const uint32_t k = first + (i < cnt ? i : 0);
+            b.z[i] = z[k]; b.num[i] = num[k]; b.den[i] = den[k];
+            b.z_stride[i] = (uint32_t)z_stride[k]; b.num_stride[i] = (uint32_t)num_stride[k]; b.den_stride[i] = (uint32_t)den_stride[k];
+        }
+        hipLaunchKernelGGL(k_z_blocks_batch<false>, dim3(nb8 * cnt), dim3(256), 0, ctx->stream, b, cnt, nb, n, prods);
+        hipLaunchKernelGGL(k_z_scan_top, dim3(cnt), dim3(256), 0, ctx->stream, prods, nb);
+        hipLaunchKernelGGL(k_z_blocks_batch<true>, dim3(nb8 * cnt), dim3(256), 0, ctx->stream, b, cnt, nb, n, prods);
+        MI_HIP_CHECK(hipGetLastError());
+        if (closes) { // the totals of this chunk in one copy (3 words each, (nb + 1) * 3 words apart)
+            MI_HIP_CHECK(hipMemcpy2DAsync(ctx->pinned, 24, prods + (uint64_t)nb * 3, ((uint64_t)nb + 1) * 24, 24, cnt, hipMemcpyDeviceToHost, ctx->stream));
+            MI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (uint32_t i = 0; i < cnt; i++) {
+                const u64 *tot = ctx->pinned + 3 * i;
+                closes[first + i] = tot[0] == 1 && tot[1] == 0 && tot[2] == 0;
+            }
+        } // (the next chunk reuses prods: same stream, so it runs after this one)
     }
     return MI_OK;
 }

@@ -404,8 +404,8 @@ static int by_variant(mi_ctx *ctx, F f)
 }
 
 // Below this many independent permutations (nodes of a level, states of a batch) the cooperative form wins: 16 lanes per state keep
-// the chip busy where one lane per state would leave most of it idle behind a 58 us dependent chain (crossover measured: DESIGN.md)
-static constexpr uint64_t COOP_MAX = 16384;
+// the chip busy where one lane per state would leave most of it idle behind a 58 us dependent chain (crossover measured: DESIGN.md).
+// The threshold is ctx->poseidon_coop_max (common.h; mi_set_poseidon_coop_max).
 
 int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count)
 {

@@ -369,14 +369,20 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         for (auto &x : starkInfo.puCtx) gp.push_back({x.numId, x.denId});
         for (auto &x : starkInfo.peCtx) gp.push_back({x.numId, x.denId});
         for (auto &x : starkInfo.ciCtx) gp.push_back({x.numId, x.denId});
-        for (uint64_t i = 0; i < gp.size(); i++) {
+        // all of them in one pass over the rows (mi_calculate_z_batch_dev): each reads 2 x 3 words of the same rows of tmpExp_n
+        const uint64_t k = gp.size();
+        std::vector<uint64_t *> zp(k);
+        std::vector<const uint64_t *> np_(k), dp(k);
+        std::vector<uint64_t> zs(k), ns(k), ds(k);
+        std::vector<int> closes(k, 0);
+        for (uint64_t i = 0; i < k; i++) {
             const PolRef num = polRef(exp2pol(gp[i].numId)), den = polRef(exp2pol(gp[i].denId)), z = polRef(starkInfo.cm_n[numCommited + i]);
-            int closes = 0;
-            mi::check(mi_calculate_z_dev(c, d_mem + z.offset, z.stride, d_mem + num.offset, num.stride, d_mem + den.offset, den.stride, N, &closes),
-                      "Starks::genProof (calculateZ)");
-            zkassert(closes); // polinomial.hpp:606
-            (void)closes;
+            zp[i] = d_mem + z.offset; np_[i] = d_mem + num.offset; dp[i] = d_mem + den.offset;
+            zs[i] = z.stride; ns[i] = num.stride; ds[i] = den.stride;
         }
+        mi::check(mi_calculate_z_batch_dev(c, (unsigned)k, zp.data(), zs.data(), np_.data(), ns.data(), dp.data(), ds.data(), N, closes.data()),
+                  "Starks::genProof (calculateZ)");
+        for (uint64_t i = 0; i < k; i++) { zkassert(closes[i]); (void)closes[i]; } // polinomial.hpp:606
     }
     TimerStopAndLog(STARK_STEP_3_CALCULATE_Z);
     TimerStart(STARK_STEP_3_CALCULATE_EXPS_2);

@@ -50,7 +50,7 @@ EXPORTS = [
     "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_transcript_put", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
     "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
     "mi_merkle_group_proofs_dev",
-    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev",
+    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev", "mi_calculate_z_batch_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
     "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
@@ -305,6 +305,18 @@ class Context:
         _check(lib().mi_calculate_z_dev(self.h, _dp(z), u64(z_stride), _dp(num), u64(num_stride), _dp(den), u64(den_stride), u64(n),
                                         ctypes.byref(closes)))
         return bool(closes.value)
+
+    def calculate_z_batch(self, products, n):
+        """The grand products of one stage in one pass (mi_calculate_z_batch_dev); products = [(z, z_stride, num, num_stride, den,
+        den_stride), ...] of strided device views over the same n rows.  Returns the list of closes flags."""
+        k = len(products)
+        P, U = ctypes.c_void_p * k, ctypes.c_uint64 * k
+        z, zs = P(*[p[0].data_ptr() for p in products]), U(*[p[1] for p in products])
+        nu, ns = P(*[p[2].data_ptr() for p in products]), U(*[p[3] for p in products])
+        de, ds = P(*[p[4].data_ptr() for p in products]), U(*[p[5] for p in products])
+        closes = (ctypes.c_int * k)()
+        _check(lib().mi_calculate_z_batch_dev(self.h, ctypes.c_uint(k), z, zs, nu, ns, de, ds, u64(n), closes))
+        return [bool(c) for c in closes]
 
     def geom_seq(self, out, n, start, ratio):
         _check(lib().mi_geom_seq_dev(self.h, _dp(out), u64(n), u64(start), u64(ratio)))

@@ -180,6 +180,10 @@ def test_z_matches_oracle(ctx):
         num, den = glo.rand_fe(rng, (n, 3)), glo.rand_fe(rng, (n, 3))
         if n > 8:
             den[5] = 0  # inverse of zero is zero on both sides
+            den[6] = 0  # (two in one thread's run of rows: they share one batched inversion)
+        if n > 2000:
+            den[n - 1] = 0
+            den[1024] = 0
         cols = 11
         area = lay_out(rng, n, cols, {"num": (0, num), "den": (4, den)})
         d = ctx.to_device(area)
@@ -187,6 +191,32 @@ def test_z_matches_oracle(ctx):
         want_closes = glo.calculate_z(area, 8, cols, 0, cols, 4, cols, n)
         assert np.array_equal(ctx.to_host(d), area), n
         assert closes == bool(want_closes)
+
+
+@pytest.mark.gpu
+def test_z_batch_matches_oracle(ctx):
+    """mi_calculate_z_batch_dev: the products of a stage in one pass over a shared area (numerators / denominators in one wide section,
+    z columns in another, like tmpExp_n and cm3_n) = the oracle's product by product; more products than one launch takes (32)."""
+    rng = np.random.default_rng(15)
+    for n, k in ((1, 3), (9, 2), (2049, 5), (40000, 35), (1 << 16, 13)):
+        wt, wz = 6 * k + 1, 3 * k + 2
+        area = glo.rand_fe(rng, (n * (wt + wz),))
+        t_off, z_off = 0, n * wt
+        src = area[:n * wt].reshape(n, wt)
+        closing = k - 1                       # the last product's numerators are a permutation of its denominators: it closes
+        if n > 8:
+            src[5, 3:6] = 0                   # zero denominators in product 0 (inverse of zero is zero on both sides)
+            src[n - 1, 3:6] = 0
+            src[:, 6 * closing:6 * closing + 3] = src[rng.permutation(n), 6 * closing + 3:6 * closing + 6]
+        d = ctx.to_device(area)
+        prods = [(d[z_off + 3 * i:], wz, d[t_off + 6 * i:], wt, d[t_off + 6 * i + 3:], wt) for i in range(k)]
+        closes = ctx.calculate_z_batch(prods, n)
+        want = [bool(glo.calculate_z(area, z_off + 3 * i, wz, t_off + 6 * i, wt, t_off + 6 * i + 3, wt, n)) for i in range(k)]
+        assert np.array_equal(ctx.to_host(d), area), (n, k)
+        assert closes == want, (n, k)
+        if n > 8:
+            assert closes[closing] is True and not any(closes[:closing])
+    assert ctx.calculate_z_batch([], 10) == []
 
 
 @pytest.mark.gpu
