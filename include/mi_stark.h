@@ -256,6 +256,46 @@ typedef struct {
 int mi_chelpers_compile(mi_ctx *ctx, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops,
                         const uint64_t *args, uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections,
                         uint64_t n_const, uint64_t nrows_ext);
+/* The same, from the program as FIELD OPERATIONS rather than as one of the reference's opcode tables: what host/steps_tracer.hpp
+ * records when it runs a Steps class's generated per-row code (recursive1.chelpers.step3.cpp etc.: straight-line
+ * Goldilocks::add / sub / mul / copy, Goldilocks3::... on params.pols, constants, challenges; starks.cpp:84-88 calls them row by row)
+ * once.  An operation is dst = a (cls) b; temporaries are numbered freely (dst_slot; an operand T1 / T3 names the latest
+ * operation that wrote that slot); operand words v[] by kind:
+ *   T1 T3: slot | NUM: value | CONST: column | CHAL PUB EVAL: index | POL POL3 DPOL: offset, row stride |
+ *   CONSTS: column, row shift, modulus | POLS POL3S DPOLS: offset, row shift, modulus, row stride | X ZHINV XD XDW: none.
+ * STOREQ: q[row] = a (T3) * ZhInv (b = ZHINV), dst_kind Q; STOREF: f[row] = a (T3), dst_kind Q; STOREP: params.pols[b] = a
+ * (T1 / T3), b = DPOL / DPOLS, dst_kind = b's kind.  `step` says which domain and outputs (as for mi_chelpers_compile). */
+#define MI_CHP_NONE 0
+#define MI_CHP_T1 1
+#define MI_CHP_T3 2
+#define MI_CHP_POL 3
+#define MI_CHP_POLS 4
+#define MI_CHP_NUM 5
+#define MI_CHP_CONST 6
+#define MI_CHP_CONSTS 7
+#define MI_CHP_CHAL 8
+#define MI_CHP_PUB 9
+#define MI_CHP_POL3 10
+#define MI_CHP_POL3S 11
+#define MI_CHP_X 12
+#define MI_CHP_ZHINV 13
+#define MI_CHP_Q 14
+#define MI_CHP_EVAL 15
+#define MI_CHP_XD 16
+#define MI_CHP_XDW 17
+#define MI_CHP_DPOL 18
+#define MI_CHP_DPOLS 19
+#define MI_CHP_ADD 0
+#define MI_CHP_SUB 1
+#define MI_CHP_MUL 2
+#define MI_CHP_COPY 3
+#define MI_CHP_STOREQ 4
+#define MI_CHP_STOREF 5
+#define MI_CHP_STOREP 6
+typedef struct { uint32_t kind, reserved; uint64_t v[4]; } mi_chelpers_operand;
+typedef struct { uint32_t cls, dst_kind; uint64_t dst_slot; mi_chelpers_operand a, b; } mi_chelpers_microop;
+int mi_chelpers_compile_micro(mi_ctx *ctx, mi_chelpers_prog **out, int step, const mi_chelpers_microop *ops, uint64_t n_ops,
+                              const mi_chelpers_section *sections, uint64_t n_sections, uint64_t n_const, uint64_t nrows_ext);
 void mi_chelpers_free(mi_ctx *ctx, mi_chelpers_prog *prog);
 /* out[0..8) = opcodes in, field operations decoded, after copy forwarding, after dead-code removal, live 64-bit words per
  * row as generated, after the reschedule, base temps, extension temps (host form); out[8..16) = device instructions per row,

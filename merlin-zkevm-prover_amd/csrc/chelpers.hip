@@ -927,16 +927,10 @@ static int build_staged(mi_chelpers_prog *P, uint64_t n_zhinv_max)
 
 } // namespace chp
 
-extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops, const uint64_t *args,
-                                   uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections, uint64_t n_const, uint64_t nrows_ext)
+// what mi_chelpers_compile and mi_chelpers_compile_micro share: sections, translation, the kernel's form, the device copy
+static int compile_decoded(mi_ctx *c, mi_chelpers_prog **out, mi_chelpers_prog *P, std::vector<chp::MicroOp> &prog, int st, const mi_chelpers_section *sections,
+                           uint64_t n_sections, uint64_t n_const, uint64_t nrows_ext)
 {
-    if (!out) return MI_ERR_INVALID;
-    *out = nullptr;
-    MI_REQUIRE(ops && (args || nargs == 0) && nops > 0, "null program tables");
-    MI_REQUIRE(n_sections + 4 <= (uint64_t)chp::MAX_SECTIONS && (sections || n_sections == 0), "at most 4 sections");
-    std::vector<chp::MicroOp> prog;
-    mi_chelpers_prog *P = new mi_chelpers_prog();
-    P->stats[0] = nops;
     P->n_const = n_const;
     P->nrows_ext = nrows_ext;
     uint64_t col0 = 0;
@@ -944,8 +938,6 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
         P->sections.push_back({sections[i].offset, sections[i].ncols, sections[i].nrows, (uint32_t)col0, 0});
         col0 += sections[i].ncols;
     }
-    P->step = step;
-    int st = chp::decode(step, ops, nops, args, nargs, prog, P->max_chal, P->max_pub, P->max_eval);
     bool uses_const = false, uses_x = false, uses_xd = false, uses_xdw = false;
     for (const chp::MicroOp &m : prog)
         for (const chp::HOpd *o : {&m.a, &m.b}) {
@@ -987,6 +979,87 @@ extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, 
     }
     *out = P;
     return MI_OK;
+}
+
+extern "C" int mi_chelpers_compile(mi_ctx *c, mi_chelpers_prog **out, int step, const uint64_t *ops, uint64_t nops, const uint64_t *args,
+                                   uint64_t nargs, const mi_chelpers_section *sections, uint64_t n_sections, uint64_t n_const, uint64_t nrows_ext)
+{
+    if (!out) return MI_ERR_INVALID;
+    *out = nullptr;
+    MI_REQUIRE(ops && (args || nargs == 0) && nops > 0, "null program tables");
+    MI_REQUIRE(n_sections + 4 <= (uint64_t)chp::MAX_SECTIONS && (sections || n_sections == 0), "at most 4 sections");
+    std::vector<chp::MicroOp> prog;
+    mi_chelpers_prog *P = new mi_chelpers_prog();
+    P->stats[0] = nops;
+    P->step = step;
+    const int st = chp::decode(step, ops, nops, args, nargs, prog, P->max_chal, P->max_pub, P->max_eval);
+    return compile_decoded(c, out, P, prog, st, sections, n_sections, n_const, nrows_ext);
+}
+
+// the public numbering of mi_stark.h is the internal one
+static_assert(MI_CHP_T1 == chp::K_T1 && MI_CHP_T3 == chp::K_T3 && MI_CHP_POL == chp::K_POL && MI_CHP_POLS == chp::K_POLS && MI_CHP_NUM == chp::K_NUM &&
+              MI_CHP_CONST == chp::K_CONST && MI_CHP_CONSTS == chp::K_CONSTS && MI_CHP_CHAL == chp::K_CHAL && MI_CHP_PUB == chp::K_PUB &&
+              MI_CHP_POL3 == chp::K_POL3 && MI_CHP_POL3S == chp::K_POL3S && MI_CHP_X == chp::K_X && MI_CHP_ZHINV == chp::K_ZHINV && MI_CHP_Q == chp::K_Q &&
+              MI_CHP_EVAL == chp::K_EVAL && MI_CHP_XD == chp::K_XD && MI_CHP_XDW == chp::K_XDW && MI_CHP_DPOL == chp::K_DPOL && MI_CHP_DPOLS == chp::K_DPOLS,
+              "operand kinds of mi_stark.h");
+static_assert(MI_CHP_ADD == chp::C_ADD && MI_CHP_SUB == chp::C_SUB && MI_CHP_MUL == chp::C_MUL && MI_CHP_COPY == chp::C_COPY && MI_CHP_STOREQ == chp::C_STOREQ &&
+              MI_CHP_STOREF == chp::C_STOREF && MI_CHP_STOREP == chp::C_STOREP, "operation classes of mi_stark.h");
+
+extern "C" int mi_chelpers_compile_micro(mi_ctx *c, mi_chelpers_prog **out, int step, const mi_chelpers_microop *mops, uint64_t n_mops,
+                                         const mi_chelpers_section *sections, uint64_t n_sections, uint64_t n_const, uint64_t nrows_ext)
+{
+    using namespace chp;
+    if (!out) return MI_ERR_INVALID;
+    *out = nullptr;
+    MI_REQUIRE(mops && n_mops > 0, "null program");
+    MI_REQUIRE(step == MI_CHELPERS_STEP42NS || step == MI_CHELPERS_STEP52NS || is_base_step(step), "unknown step");
+    MI_REQUIRE(n_sections + 4 <= (uint64_t)MAX_SECTIONS && (sections || n_sections == 0), "at most 4 sections");
+    std::vector<MicroOp> prog;
+    prog.reserve(n_mops);
+    uint64_t max_chal = 0, max_pub = 0, max_eval = 0;
+    auto is_src = [](uint32_t k) { return k <= K_XDW && k != K_Q; };
+    for (uint64_t i = 0; i < n_mops; i++) {
+        const mi_chelpers_microop &u = mops[i];
+        MicroOp m;
+        MI_REQUIRE(u.cls <= C_STOREP, "operation class out of range");
+        m.cls = (Cls)u.cls;
+        m.dst = (Kind)u.dst_kind;
+        m.dst_slot = u.dst_slot;
+        const mi_chelpers_operand *us[2] = {&u.a, &u.b};
+        HOpd *os[2] = {&m.a, &m.b};
+        for (int s = 0; s < 2; s++) {
+            const bool is_dest = m.cls == C_STOREP && s == 1;
+            MI_REQUIRE(is_dest ? (us[s]->kind == K_DPOL || us[s]->kind == K_DPOLS) : is_src(us[s]->kind), "operand kind out of range");
+            os[s]->k = (Kind)us[s]->kind;
+            for (int j = 0; j < 4; j++) os[s]->v[j] = us[s]->v[j];
+            if (os[s]->k == K_NUM) os[s]->v[0] = gl::canon(os[s]->v[0]);
+            if (os[s]->k == K_CHAL) max_chal = std::max(max_chal, os[s]->v[0] + 1);
+            if (os[s]->k == K_PUB) max_pub = std::max(max_pub, os[s]->v[0] + 1);
+            if (os[s]->k == K_EVAL) max_eval = std::max(max_eval, os[s]->v[0] + 1);
+        }
+        switch (m.cls) {
+        case C_STOREQ: // q = zhInv * a
+            MI_REQUIRE(step == MI_CHELPERS_STEP42NS && m.dst == K_Q && m.a.k == K_T3 && m.b.k == K_ZHINV, "STOREQ: q = an extension temporary times ZhInv, in step42ns");
+            break;
+        case C_STOREF:
+            MI_REQUIRE(step == MI_CHELPERS_STEP52NS && m.dst == K_Q && m.a.k == K_T3, "STOREF: f = an extension temporary, in step52ns");
+            break;
+        case C_STOREP:
+            MI_REQUIRE(is_base_step(step) && (m.a.k == K_T1 || m.a.k == K_T3) && m.dst == m.b.k, "STOREP: a temporary into params.pols, in the base-domain steps");
+            break;
+        default:
+            MI_REQUIRE(m.dst == K_T1 || m.dst == K_T3, "the destination of an arithmetic operation is a temporary");
+            MI_REQUIRE(m.a.k != K_NONE && (m.cls == C_COPY ? m.b.k == K_NONE : m.b.k != K_NONE), "operand count");
+            MI_REQUIRE(m.dst == K_T3 || (!kind_is3(m.a.k) && !kind_is3(m.b.k)), "an extension operand needs an extension destination");
+            break;
+        }
+        prog.push_back(m);
+    }
+    mi_chelpers_prog *P = new mi_chelpers_prog();
+    P->stats[0] = n_mops;
+    P->step = step;
+    P->max_chal = max_chal; P->max_pub = max_pub; P->max_eval = max_eval;
+    return compile_decoded(c, out, P, prog, MI_OK, sections, n_sections, n_const, nrows_ext);
 }
 
 extern "C" void mi_chelpers_free(mi_ctx *c, mi_chelpers_prog *p)

@@ -46,33 +46,40 @@ inline StarkMirror *&currentMirror()
 
 inline bool isBaseStep(int step) { return step == MI_CHELPERS_STEP2PREV || step == MI_CHELPERS_STEP3PREV || step == MI_CHELPERS_STEP3; }
 
-// One constraint program over rows [0, nrows) of its domain, on the device image of params.pols.
-inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, StepsParams &params, uint64_t nrows)
+inline StarkMirror *mirrorOf(StepsParams &params)
 {
     StarkMirror *m = currentMirror();
     if (!m || m->hostPols != (const void *)params.pols) {
         // no silent host fallback: the interpreter this replaces does not exist here
-        std::fprintf(stderr, "mi_stark: step*_parser_first_avx called on a polynomial area that has no device image "
+        std::fprintf(stderr, "mi_stark: a device step was called on a polynomial area that has no device image "
                              "(these entry points run inside Starks::genProof of host/starks.hpp)\n");
         std::exit(-1);
     }
-    mi_ctx *c = ctx();
+    return m;
+}
+// the sections a program of this step may read, as mi_chelpers_compile wants them
+inline std::vector<mi_chelpers_section> stepSections(const StarkMirror *m, int step)
+{
     const bool base = isBaseStep(step);
-    mi_chelpers_prog *&prog = (*m->progs)[{step, (const void *)ops}];
-    if (!prog) {
-        std::vector<mi_chelpers_section> secs;
-        const unsigned nsec = base ? 4 : step == MI_CHELPERS_STEP52NS ? 4 : 3;
-        for (unsigned s = 0; s < nsec; s++) {
-            const StarkMirror::Sec &S = base ? m->cmN[s] : m->cm2ns[s];
-            if (S.cols) secs.push_back({S.offset, S.cols, base ? m->N : m->NExtended});
-        }
-        check(mi_chelpers_compile(c, &prog, step, ops, nops, args, nargs, secs.data(), secs.size(), m->nConst, base ? m->N : m->NExtended),
-              "Steps::step*_parser_first_avx (translate the program)");
-        const char *backend = std::getenv("MI_CHELPERS_BACKEND"); // "interpreter": the extended-domain steps through the SIMT interpreter (A/B)
-        if (base || !backend || std::string(backend) != "interpreter")
-            check(mi_chelpers_build_native(prog, m->cacheDir.empty() ? nullptr : m->cacheDir.c_str(), 0), "Steps::step*_parser_first_avx (compile the program)");
+    std::vector<mi_chelpers_section> secs;
+    const unsigned nsec = base ? 4 : step == MI_CHELPERS_STEP52NS ? 4 : 3;
+    for (unsigned s = 0; s < nsec; s++) {
+        const StarkMirror::Sec &S = base ? m->cmN[s] : m->cm2ns[s];
+        if (S.cols) secs.push_back({S.offset, S.cols, base ? m->N : m->NExtended});
     }
-    mi_chelpers_params p = {};
+    return secs;
+}
+inline void buildStepProgram(const StarkMirror *m, int step, mi_chelpers_prog *prog)
+{
+    const char *backend = std::getenv("MI_CHELPERS_BACKEND"); // "interpreter": the extended-domain steps through the SIMT interpreter (A/B)
+    if (isBaseStep(step) || !backend || std::string(backend) != "interpreter")
+        check(mi_chelpers_build_native(prog, m->cacheDir.empty() ? nullptr : m->cacheDir.c_str(), 0), "Steps (compile the program)");
+}
+// a translated program over rows [0, nrows) of its domain, on the device image
+inline void runStepProgram(StarkMirror *m, int step, const mi_chelpers_prog *prog, StepsParams &params, uint64_t nrows)
+{
+    const bool base = isBaseStep(step);
+    mi_chelpers_params p = {}; // every table the StepsParams of this domain has: a program reads what it reads
     p.pols = m->d_mem;
     p.const_pols = base ? m->d_constN : m->d_const2ns;
     p.n_const = m->nConst;
@@ -82,19 +89,33 @@ inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const 
     p.n_publics = m->nPublics;
     p.x = base ? m->d_xn : m->d_x2ns;
     p.x_stride = 1;
-    p.zhinv = m->zhinv.data();
-    p.n_zhinv = m->zhinv.size();
-    p.q = m->d_mem + m->qOffset;
-    if (step == MI_CHELPERS_STEP52NS) {
-        p.x = nullptr; p.x_stride = 0; p.zhinv = nullptr; p.n_zhinv = 0; p.publics = nullptr; p.n_publics = 0; p.q = nullptr;
+    if (step == MI_CHELPERS_STEP42NS) {
+        p.zhinv = m->zhinv.data();
+        p.n_zhinv = m->zhinv.size();
+        p.q = m->d_mem + m->qOffset;
+    } else if (step == MI_CHELPERS_STEP52NS) {
         p.evals = (const uint64_t *)params.evals.address();
         p.n_evals = m->nEvals;
         p.xdiv = m->d_xdiv;
         p.xdivw = m->d_xdivw;
         p.f = m->d_mem + m->fOffset;
     }
-    if (base) { p.zhinv = nullptr; p.n_zhinv = 0; p.q = nullptr; }
-    check(mi_chelpers_run_dev(c, prog, &p, 0, nrows), "Steps::step*_parser_first_avx");
+    check(mi_chelpers_run_dev(ctx(), prog, &p, 0, nrows), "Steps (run the program)");
+}
+
+// One constraint program, given as the reference's tables, over rows [0, nrows) of its domain, on the device image of params.pols.
+inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, StepsParams &params, uint64_t nrows)
+{
+    StarkMirror *m = mirrorOf(params);
+    mi_chelpers_prog *&prog = (*m->progs)[{step, (const void *)ops}];
+    if (!prog) {
+        const std::vector<mi_chelpers_section> secs = stepSections(m, step);
+        const bool base = isBaseStep(step);
+        check(mi_chelpers_compile(ctx(), &prog, step, ops, nops, args, nargs, secs.data(), secs.size(), m->nConst, base ? m->N : m->NExtended),
+              "Steps::step*_parser_first_avx (translate the program)");
+        buildStepProgram(m, step, prog);
+    }
+    runStepProgram(m, step, prog, params, nrows);
 }
 } // namespace mi
 

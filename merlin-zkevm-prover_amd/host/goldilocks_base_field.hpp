@@ -18,6 +18,33 @@
 
 #define GOLDILOCKS_PRIME 0xFFFFFFFF00000001ULL
 
+// Recording hook (host/steps_tracer.hpp): while a recorder is installed on the calling thread, every destination-form field operation
+// below (and of Goldilocks3) reports its operands' ADDRESSES and dimensions before it computes.  That is how a Steps class's generated
+// per-row code (straight-line calls of exactly these functions) is turned into a program for the device by running it once.
+// cls: 0 add, 1 sub, 2 mul, 3 copy.  The value-returning forms and operators cannot be followed (their results have no address yet):
+// used outside a destination form while a recorder is installed they set `untracked`, and the recorder refuses the function.
+// One predictable branch per operation when no recorder is installed.
+struct MiFieldRecorder
+{
+    int depth = 0;          // inside a destination form (whose own arithmetic is not the caller's)
+    bool untracked = false; // the caller computed with operators / value-returning forms
+    virtual void op(int cls, void *r, int rdim, const void *a, int adim, const void *b, int bdim) = 0; // r: written, not read
+    virtual ~MiFieldRecorder() {}
+};
+inline thread_local MiFieldRecorder *mi_field_recorder = nullptr;
+struct MiFieldScope
+{
+    MiFieldRecorder *const r;
+    MiFieldScope(MiFieldRecorder *rec, int cls, void *d, int ddim, const void *a, int adim, const void *b, int bdim) : r(rec)
+    {
+        if (__builtin_expect(r != nullptr, 0)) { if (r->depth == 0) r->op(cls, d, ddim, a, adim, b, bdim); r->depth++; }
+    }
+    ~MiFieldScope() { if (__builtin_expect(r != nullptr, 0)) r->depth--; }
+};
+#define MI_FIELD_RECORD(cls, r, rdim, a, adim, b, bdim) MiFieldScope mi_field_scope_(mi_field_recorder, cls, r, rdim, a, adim, b, bdim)
+#define MI_FIELD_VALUE_FORM() \
+    do { if (__builtin_expect(mi_field_recorder != nullptr, 0) && mi_field_recorder->depth == 0) mi_field_recorder->untracked = true; } while (0)
+
 class Goldilocks
 {
 public:
@@ -39,17 +66,20 @@ public:
 
     static inline Element add(const Element &a, const Element &b)
     {
+        MI_FIELD_VALUE_FORM();
         uint64_t x = toU64(a), y = toU64(b), s = x + y;
         if (s < x || s >= GOLDILOCKS_PRIME) s -= GOLDILOCKS_PRIME;
         return {s};
     }
     static inline Element sub(const Element &a, const Element &b)
     {
+        MI_FIELD_VALUE_FORM();
         uint64_t x = toU64(a), y = toU64(b);
         return {x >= y ? x - y : x + (GOLDILOCKS_PRIME - y)};
     }
     static inline Element mul(const Element &a, const Element &b)
     {
+        MI_FIELD_VALUE_FORM();
         unsigned __int128 p = (unsigned __int128)a.fe * b.fe;
         uint64_t lo = (uint64_t)p, hi = (uint64_t)(p >> 64), hh = hi >> 32, hl = hi & 0xFFFFFFFFULL;
         uint64_t t0 = lo - hh;
@@ -68,12 +98,12 @@ public:
     static inline Element inv(const Element &a) { return exp(a, GOLDILOCKS_PRIME - 2); }
     static inline Element neg(const Element &a) { return sub(zero(), a); }
     // out-parameter forms used by the reference (e.g. zhInv.cpp:21-27, starks.hpp:153)
-    static inline void add(Element &r, const Element &a, const Element &b) { r = add(a, b); }
-    static inline void sub(Element &r, const Element &a, const Element &b) { r = sub(a, b); }
-    static inline void mul(Element &r, const Element &a, const Element &b) { r = mul(a, b); }
-    static inline void square(Element &r, const Element &a) { r = mul(a, a); }
+    static inline void add(Element &r, const Element &a, const Element &b) { MI_FIELD_RECORD(0, &r, 1, &a, 1, &b, 1); r = add(a, b); }
+    static inline void sub(Element &r, const Element &a, const Element &b) { MI_FIELD_RECORD(1, &r, 1, &a, 1, &b, 1); r = sub(a, b); }
+    static inline void mul(Element &r, const Element &a, const Element &b) { MI_FIELD_RECORD(2, &r, 1, &a, 1, &b, 1); r = mul(a, b); }
+    static inline void square(Element &r, const Element &a) { MI_FIELD_RECORD(2, &r, 1, &a, 1, &a, 1); r = mul(a, a); }
     static inline void inv(Element &r, const Element &a) { r = inv(a); }
-    static inline void copy(Element &r, const Element &a) { r = a; }
+    static inline void copy(Element &r, const Element &a) { MI_FIELD_RECORD(3, &r, 1, &a, 1, nullptr, 0); r = a; }
     static inline bool isZero(const Element &a) { return toU64(a) == 0; }
     static inline bool isOne(const Element &a) { return toU64(a) == 1; }
     static inline bool equal(const Element &a, const Element &b) { return toU64(a) == toU64(b); }

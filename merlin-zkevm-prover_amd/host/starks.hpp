@@ -28,8 +28,11 @@
 //
 // Steps: with nrowsStepBatch 4 or 8 (the zkEVM: prover.cpp:129) the batched entry points step*_parser_first_avx[512] run on the image
 // (host/chelpers_steps.hpp).  With nrowsStepBatch 1 (c12a, recursive1/2: generated per-row C++, starks.cpp:84-88 ...) the Steps
-// callbacks are the CALLER'S host code and need host memory: the sections they read are copied down into pAddress, the loop runs
-// on the host cores as in the reference, and what it wrote is copied back up ("host steps"; everything else stays on the device).
+// callbacks are the CALLER'S compiled host code: each is run once under a recorder (host/steps_tracer.hpp), which writes the row's
+// field operations down as a program; that program is compiled for the device like the zkEVM's tables and runs over the image
+// ("traced steps"; once per proving key).  A Steps class the recorder cannot follow (it branches on the row, or touches memory the
+// recorder does not know) stops the proof with the reason; MI_STEPS_ON_HOST=1 asks for the reference's own loop instead: the sections
+// the callbacks read are copied down into pAddress, the loop runs on the host cores, what it wrote is copied back up ("host steps").
 #ifndef STARKS_HPP
 #define STARKS_HPP
 #include <algorithm>
@@ -52,6 +55,9 @@
 #include "merkleTreeGL.hpp"
 #include "ntt_goldilocks.hpp"
 #include "chelpers_steps.hpp"
+#include "steps_tracer.hpp"
+#include <set>
+#include <typeinfo>
 
 #define STARK_C12_A_NUM_TREES 5
 #define NUM_CHALLENGES 8
@@ -222,6 +228,9 @@ private:
         }
     }
     void hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
+    void tracedStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
+    mi_chelpers_prog *tracedProgram(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
+    std::set<std::pair<int, const void *>> emptySteps; // per-row steps that compute nothing (recursive1's step2prev)
 };
 
 // Host steps (nrowsStepBatch == 1): the caller's per-row code over pAddress, as starks.cpp:84-88,166-170,204-208,252-256,382-386 run
@@ -257,19 +266,84 @@ inline void Starks::hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &para
     }
 }
 
+// Traced steps (nrowsStepBatch == 1): the caller's per-row function recorded once (host/steps_tracer.hpp), compiled, run over the image.
+inline void Starks::tracedStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which)
+{
+    static const int ids[5] = {MI_CHELPERS_STEP2PREV, MI_CHELPERS_STEP3PREV, MI_CHELPERS_STEP3, MI_CHELPERS_STEP42NS, MI_CHELPERS_STEP52NS};
+    if (mi_chelpers_prog *prog = tracedProgram(m, steps, params, which)) mi::runStepProgram(&m, ids[which], prog, params, which <= 2 ? N : NExtended);
+}
+// the recorded and compiled program of a per-row step (once per Steps class); null for a step that computes nothing
+inline mi_chelpers_prog *Starks::tracedProgram(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which)
+{
+    static const int ids[5] = {MI_CHELPERS_STEP2PREV, MI_CHELPERS_STEP3PREV, MI_CHELPERS_STEP3, MI_CHELPERS_STEP42NS, MI_CHELPERS_STEP52NS};
+    const int step = ids[which];
+    const bool base = which <= 2;
+    const std::pair<int, const void *> key = {step | 0x10000, (const void *)&typeid(*steps)}; // per Steps class: one per proving key
+    if (emptySteps.count(key)) return nullptr;
+    mi_chelpers_prog *&prog = progs[key];
+    if (!prog) {
+        mi::TraceLayout L;
+        L.step = step;
+        L.rows = base ? N : NExtended;
+        L.pols = (const uint64_t *)mem;
+        for (int sct = 0; sct < (int)eSectionMax; sct++) {
+            const eSection e = (eSection)sct;
+            const bool baseDomain = e == cm1_n || e == cm2_n || e == cm3_n || e == cm4_n || e == tmpExp_n; // (the enum interleaves the domains)
+            L.secs.push_back({off(e), cols(e), baseDomain ? N : NExtended});
+        }
+        L.qOffset = off(q_2ns); L.fOffset = off(f_2ns);
+        ConstantPolsStarks *cp = base ? params.pConstPols : params.pConstPols2ns;
+        L.constPols = cp ? (const uint64_t *)cp->address() : nullptr;
+        L.nConst = starkInfo.nConstants;
+        L.chal = (const uint64_t *)params.challenges.address(); L.nChal = params.challenges.degree();
+        L.evals = (const uint64_t *)params.evals.address(); L.nEvals = params.evals.degree();
+        L.pub = (const uint64_t *)params.publicInputs; L.nPub = starkInfo.nPublics;
+        Polinomial &x = base ? params.x_n : params.x_2ns;
+        L.x = (const uint64_t *)x.address(); L.xStride = x.offset();
+        if (!base) { L.xd = (const uint64_t *)params.xDivXSubXi.address(); L.xdw = (const uint64_t *)params.xDivXSubWXi.address(); }
+        std::vector<mi_chelpers_microop> mops;
+        std::string err;
+        auto call = [&](uint64_t i) {
+            switch (which) { // the forms the reference's loops call: starks.cpp:86,168,206,254,384
+            case 0: steps->step2prev_first(params, i); break;
+            case 1: steps->step3prev_first(params, i); break;
+            case 2: steps->step3_first(params, i); break;
+            case 3: steps->step42ns_first(params, i); break;
+            default: steps->step52ns_first(params, i); break;
+            }
+        };
+        if (!mi::traceStep(L, call, [&](uint64_t i) { return Goldilocks::toU64(zi.zhInv(i)); }, mops, err)) mi::fail(err.c_str());
+        if (mops.empty()) {
+            progs.erase(key);
+            emptySteps.insert(key);
+            return nullptr;
+        }
+        const std::vector<mi_chelpers_section> secs = mi::stepSections(&m, step);
+        mi::check(mi_chelpers_compile_micro(mi::ctx(), &prog, step, mops.data(), mops.size(), secs.data(), secs.size(), m.nConst, base ? N : NExtended),
+                  "Starks::genProof (traced steps: translate the recorded program)");
+        mi::buildStepProgram(&m, step, prog);
+    }
+    return prog;
+}
+
 inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs, Steps *steps)
 {
     TimerStart(STARK_INITIALIZATION);
     mi_ctx *c = mi::ctx();
-    const bool deviceSteps = nrowsStepBatch == 4 || nrowsStepBatch == 8; // starks.cpp:69-90: the batched ("parser") forms
+    const bool parserSteps = nrowsStepBatch == 4 || nrowsStepBatch == 8; // starks.cpp:69-90: the batched ("parser") forms
+    const char *onHost = std::getenv("MI_STEPS_ON_HOST");
+    const bool hostSteps = !parserSteps && onHost && onHost[0] == '1';
+    const bool deviceSteps = !hostSteps; // parser tables or traced per-row code: nothing of the image comes down for a step
+    auto perRowStep = [&](mi::StarkMirror &mm, StepsParams &pp, int which) { if (hostSteps) hostStep(mm, steps, pp, which); else tracedStep(mm, steps, pp, which); };
     const uint64_t nBits = starkInfo.starkStruct.nBits, nBitsExt = starkInfo.starkStruct.nBitsExt, extendBits = nBitsExt - nBits;
     const uint64_t nEvals = starkInfo.evMap.size();
     Transcript transcript;
     Polinomial evals(std::max<uint64_t>(nEvals, 1), FIELD_EXTENSION);
     Polinomial challenges(NUM_CHALLENGES, FIELD_EXTENSION);
     // host tables only the host steps read (starks.hpp:149-160; starks.cpp:17-18): empty with device steps
-    Polinomial x_n(deviceSteps ? 0 : N, 1), x_2ns(deviceSteps ? 0 : NExtended, 1);
-    Polinomial xDivXSubXi(deviceSteps ? 0 : NExtended, FIELD_EXTENSION), xDivXSubWXi(deviceSteps ? 0 : NExtended, FIELD_EXTENSION);
+    // (traced steps only need them addressable: the recorder looks at addresses, at rows 0 and n - 1)
+    Polinomial x_n(parserSteps ? 0 : N, 1), x_2ns(parserSteps ? 0 : NExtended, 1);
+    Polinomial xDivXSubXi(parserSteps ? 0 : NExtended, FIELD_EXTENSION), xDivXSubWXi(parserSteps ? 0 : NExtended, FIELD_EXTENSION);
     Polinomial root0(HASH_SIZE, 1), root1(HASH_SIZE, 1), root2(HASH_SIZE, 1), root3(HASH_SIZE, 1);
 
     // ---- the HBM plan: image | trees | late scratch
@@ -299,6 +373,10 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     transcript.put(&publicInputs[0], starkInfo.nPublics);
     ConstantPolsStarks *cp = pConstPols, *cp2 = pConstPols2ns;
     StepsParams params = {mem, cp, cp2, challenges, x_n, x_2ns, zi, evals, xDivXSubXi, xDivXSubWXi, publicInputs, mem + off(q_2ns), mem + off(f_2ns)};
+    // traced steps: record and compile the five per-row functions now (first proof of this Steps class only), the two that every STARK
+    // has first -- a Steps class the recorder cannot follow is refused before any work is done
+    if (!parserSteps && !hostSteps)
+        for (int which : {3, 4, 0, 1, 2}) (void)tracedProgram(m, steps, params, which);
     // x_n (starks.hpp:149-154), N elements read by the base-domain steps only: it borrows the head of the q_2ns section, whose first
     // writer (step42ns) runs after the last of them
     m.d_xn = sec(q_2ns);
@@ -329,7 +407,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStart(STARK_STEP_2_CALCULATE_EXPS);
     if (nrowsStepBatch == 4) steps->step2prev_parser_first_avx(params, N, nrowsStepBatch);
     else if (nrowsStepBatch == 8) steps->step2prev_parser_first_avx512(params, N, nrowsStepBatch);
-    else hostStep(m, steps, params, 0);
+    else perRowStep(m, params, 0);
     TimerStopAndLog(STARK_STEP_2_CALCULATE_EXPS);
     TimerStart(STARK_STEP_2_CALCULATEH1H2);
     uint64_t numCommited = starkInfo.nCm1;
@@ -360,7 +438,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStart(STARK_STEP_3_CALCULATE_EXPS);
     if (nrowsStepBatch == 4) steps->step3prev_parser_first_avx(params, N, nrowsStepBatch);
     else if (nrowsStepBatch == 8) steps->step3prev_parser_first_avx512(params, N, nrowsStepBatch);
-    else hostStep(m, steps, params, 1);
+    else perRowStep(m, params, 1);
     TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS);
     TimerStart(STARK_STEP_3_CALCULATE_Z);
     {
@@ -388,7 +466,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStart(STARK_STEP_3_CALCULATE_EXPS_2);
     if (nrowsStepBatch == 4) steps->step3_parser_first_avx(params, N, nrowsStepBatch);
     else if (nrowsStepBatch == 8) steps->step3_parser_first_avx512(params, N, nrowsStepBatch);
-    else hostStep(m, steps, params, 2);
+    else perRowStep(m, params, 2);
     TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS_2);
     TimerStart(STARK_STEP_3_LDE_AND_MERKLETREE);
     lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run
@@ -437,7 +515,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     if (!deviceSteps) mi::check(mi_copy_d2h(c, x_2ns.address(), m.d_x2ns, NExtended * 8), "Starks::genProof (x_2ns d2h)");
     if (nrowsStepBatch == 4) steps->step42ns_parser_first_avx(params, NExtended, nrowsStepBatch);
     else if (nrowsStepBatch == 8) steps->step42ns_parser_first_avx512(params, NExtended, nrowsStepBatch);
-    else hostStep(m, steps, params, 3);
+    else perRowStep(m, params, 3);
     TimerStopAndLog(STARK_STEP_4_CALCULATE_EXPS_2NS);
     TimerStart(STARK_STEP_4_CALCULATE_EXPS_2NS_INTT);
     mi::check(mi_ntt_dev(c, qq1, qDim, sec(q_2ns), qDim, NExtended, qDim, 1), "Starks::genProof (INTT of q)");
@@ -506,7 +584,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStart(STARK_STEP_5_CALCULATE_EXPS);
     if (nrowsStepBatch == 4) steps->step52ns_parser_first_avx(params, NExtended, nrowsStepBatch);
     else if (nrowsStepBatch == 8) steps->step52ns_parser_first_avx512(params, NExtended, nrowsStepBatch);
-    else hostStep(m, steps, params, 4);
+    else perRowStep(m, params, 4);
     TimerStopAndLog(STARK_STEP_5_CALCULATE_EXPS);
     TimerStopAndLog(STARK_STEP_5);
 

@@ -10,8 +10,8 @@
 // for the mini STARK of tests/ministark.py: its starkinfo.json, constant polynomials, witness and generated tables are files written
 // by tests/test_starks_class.py, which afterwards gives the zkin.json this writes to the independent verifier.  ZkevmSteps' batched
 // entry points are DEFINED here over those tables (MI_DEFINE_PARSER_STEP: what replaces the reference's *.parser.cpp); its per-row
-// forms -- generated C++ in the reference -- are the CPU oracle's interpreters over host memory, so that a second run with
-// nrowsStepBatch = 1 exercises the host-steps path (the caller's code on pAddress) and must produce the same proof.
+// forms -- generated C++ in the reference -- come in two variants (below), so that a second run with nrowsStepBatch = 1 exercises the
+// traced-steps path (the per-row code recorded and run on the device) or the host-steps path, and must produce the same proof.
 //
 //     usage: test_starks_genproof <dir> <nrowsStepBatch> [second nrowsStepBatch]
 #include <cstdio>
@@ -51,8 +51,15 @@ MI_FORWARD_PARSER_STEP(ZkevmSteps, step42ns, , _avx)
 MI_FORWARD_PARSER_STEP(ZkevmSteps, step42ns, _avx_jump, _avx)
 MI_FORWARD_PARSER_STEP(ZkevmSteps, step52ns, , _avx)
 
-// per-row forms: the caller's host code.  Here: the oracle's interpreters, one row at a time over params' HOST pointers
+// per-row forms (in the reference: generated C++, e.g. recursive1.chelpers.step3.cpp).  Two variants:
+//   -DMI_TEST_GENERATED_ROWS="file": the AIR's programs written out as generated per-row C++ by tests/gen_steps_cpp.py -- what
+//      Starks::genProof RECORDS and runs on the device with nrowsStepBatch = 1 (host/steps_tracer.hpp);
+//   otherwise: the CPU oracle's interpreters, one row at a time over params' HOST pointers -- plain C arithmetic the recorder cannot
+//      follow, for the host-steps path (MI_STEPS_ON_HOST=1).
 static uint64_t g_nConst, g_N, g_NExt;
+#ifdef MI_TEST_GENERATED_ROWS
+#include MI_TEST_GENERATED_ROWS
+#else
 static void rowBase(const Tables &t, StepsParams &p, uint64_t i)
 {
     if (glo_chelpers_stepbase(t.ops.data(), t.ops.size(), t.args.data(), t.args.size(), (uint64_t *)p.pols, (const uint64_t *)p.pConstPols->address(), g_nConst,
@@ -77,6 +84,7 @@ void ZkevmSteps::step52ns_first(StepsParams &p, uint64_t i)
 }
 #define UNUSED_ROW(s) void ZkevmSteps::s##_i(StepsParams &, uint64_t) {} void ZkevmSteps::s##_last(StepsParams &, uint64_t) {}
 UNUSED_ROW(step2prev) UNUSED_ROW(step3prev) UNUSED_ROW(step3) UNUSED_ROW(step42ns) UNUSED_ROW(step52ns)
+#endif
 
 int main(int argc, char **argv)
 {

@@ -43,3 +43,24 @@ def test_starks_flow_proof_is_consistent_and_rows_match_the_oracle(argv, tmp_pat
         a, b = v.split("/")
         assert a == b and int(b) > 0, (k, v)
     assert out["hbm"]["peak_hbm_gb"] < out["hbm"]["total_gb"] and "STARK_STEP_3_CALCULATE_EXPS_2" in out["phase_ms"]
+
+
+@pytest.mark.gpu
+def test_starks_flow_at_zkevm_size_fits_one_gpu_and_rows_match_the_oracle(tmp_path):
+    """The whole flow at the zkEVM's shape (2^23 rows, 665 / 128 / 371 committed columns, blow-up 2, the statistics-matched step42ns
+    program of tests/chelpers_programs.ZKEVM_STEP42NS_FIT at 2^24 rows): one genProof, the proof's openings and folds are consistent,
+    sampled rows of q_2ns / f_2ns equal the oracle interpreters', and the low-water mark of free HBM stays above zero on ONE GPU."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 300e9:
+        pytest.skip("needs the MI355X's 288 GiB")
+    env = dict(os.environ, MI_BENCH_TMP=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_starks.py"), "--proofs", "1", "--check-rows", "4"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for k, v in out["checks"].items():
+        a, b = v.split("/")
+        assert a == b and int(b) > 0, (k, v)
+    assert out["hbm"]["fits_one_gpu"] and out["hbm"]["peak_hbm_gb"] < out["hbm"]["total_gb"]
+    assert out["config"]["field_ops_per_row"]["step42ns"] == 17986
+    for ph in ("STARK_STEP_2_CALCULATE_EXPS", "STARK_STEP_3_CALCULATE_EXPS", "STARK_STEP_3_CALCULATE_EXPS_2", "STARK_STEP_4_CALCULATE_EXPS_2NS"):
+        assert out["phase_ms"][ph] > 0

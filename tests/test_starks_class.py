@@ -3,7 +3,8 @@
 * GPU: tests/cpp/test_starks_genproof.cpp constructs a Starks from files exactly as prover.cpp:128-132 does (starkinfo.json, constant
   polynomials, constant tree, pAddress with the witness), calls genProof(fproof, publics, &zkevmSteps) as prover.cpp:541-544 does, and
   writes zkin.json through proof2zkinStark; the independent verifier of tests/ministark.py must accept it -- with the device steps
-  (nrowsStepBatch 4) and with the caller's per-row host code (nrowsStepBatch 1), which must give the same proof.
+  (nrowsStepBatch 4) and with the caller's generated per-row code (nrowsStepBatch 1: recorded and run on the device, or -- on request --
+  run on the host), which must give the same proof.
 * CPU: the call shapes of prover.cpp compile against host/; the reference's own steps.hpp / zkevmSteps.hpp and its five generated
   tables compile into the translation unit that replaces the *.parser.cpp files (where the reference is present).
 """
@@ -138,19 +139,26 @@ def test_generated_per_row_steps_compile_against_level0(tmp_path, rel):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("nbits,n_queries", [(10, 12), (13, 24)])
-def test_starks_genproof_is_accepted_by_the_independent_verifier(tmp_path, nbits, n_queries):
-    build_exe()
-    d = str(tmp_path)
-    write_inputs(d, nbits, n_queries)
-    env = dict(os.environ, MI_CHELPERS_CACHE=os.path.join(d, "cache"))
-    os.makedirs(env["MI_CHELPERS_CACHE"], exist_ok=True)
-    r = subprocess.run([EXE, d, "4", "1"], capture_output=True, text=True, timeout=900, env=env)
-    print(r.stdout[-3000:], r.stderr[-3000:])
-    assert r.returncode == 0 and "ALL OK" in r.stdout
+def build_exe_generated_rows(tmp_path, nbits):
+    """The same caller with ZkevmSteps' per-row forms as GENERATED C++ (tests/gen_steps_cpp.py writes the AIR's five programs out in the
+    style of the reference's recursive1.chelpers.*.cpp): what Starks::genProof records and runs on the device when nrowsStepBatch is 1."""
+    import gen_steps_cpp as gs
+    n = 1 << nbits
+    lay = ms.Layout(n, 2 * n)
+    progs = {"step2prev": ms.stage2_program(lay), "step3prev": ms.stage3_program(lay), "step3": ms.step3_program(lay),
+             "step42ns": ms.step42ns_program(lay, 2), "step52ns": ms.step52ns_program(lay)}
+    rows = tmp_path / "generated_rows.inc"
+    rows.write_text(gs.steps_source("ZkevmSteps", progs))
+    exe = str(tmp_path / "test_starks_genproof_rows")
+    glo.build()
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-fopenmp", "-DMI_TEST_GENERATED_ROWS=\"%s\"" % rows] + STANDALONE +
+                          [os.path.join(ROOT, "tests", "cpp", "test_starks_genproof.cpp"), "-o", exe] + LINK)
+    return exe
+
+
+def check_proofs(d, nbits, n_queries, names):
     const_root = np.array(json.load(open(os.path.join(d, "mini.verkey.json")))["constRoot"], dtype=np.uint64)
-    for name in ("zkin.json", "zkin.1.json"):
+    for name in names:
         z = json.load(open(os.path.join(d, name)))
         proof = ms.proof_from_zkin(z, nbits)
         proof["const_root"] = const_root
@@ -160,3 +168,40 @@ def test_starks_genproof_is_accepted_by_the_independent_verifier(tmp_path, nbits
         proof["evals"][3 * ms.EV_B] ^= np.uint64(1)
         ok, why = ms.verify(proof, const_root, n_queries=n_queries)
         assert not ok and "constraint identity" in why
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbits,n_queries", [(10, 12), (13, 24)])
+def test_starks_genproof_is_accepted_by_the_independent_verifier(tmp_path, nbits, n_queries):
+    """nrowsStepBatch 4 (the tables on the device), then 1 with generated per-row code: recorded (host/steps_tracer.hpp), compiled and
+    run on the device; the two proofs are the same bytes and the independent verifier accepts them."""
+    exe = build_exe_generated_rows(tmp_path, nbits)
+    d = str(tmp_path)
+    write_inputs(d, nbits, n_queries)
+    env = dict(os.environ, MI_CHELPERS_CACHE=os.path.join(d, "cache"))
+    env.pop("MI_STEPS_ON_HOST", None)
+    os.makedirs(env["MI_CHELPERS_CACHE"], exist_ok=True)
+    r = subprocess.run([exe, d, "4", "1"], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "ALL OK" in r.stdout
+    check_proofs(d, nbits, n_queries, ("zkin.json", "zkin.1.json"))
+
+
+@pytest.mark.gpu
+def test_starks_genproof_with_the_callers_rows_on_the_host(tmp_path):
+    """MI_STEPS_ON_HOST=1: per-row code the recorder cannot follow (here the oracle's interpreters: plain C arithmetic) runs as in the
+    reference, on the host over pAddress, between copies of the sections it reads and writes; same proof.  Without the variable such a
+    Steps class is refused, not silently skipped."""
+    nbits, n_queries = 10, 12
+    build_exe()
+    d = str(tmp_path)
+    write_inputs(d, nbits, n_queries)
+    env = dict(os.environ, MI_CHELPERS_CACHE=os.path.join(d, "cache"), MI_STEPS_ON_HOST="1")
+    os.makedirs(env["MI_CHELPERS_CACHE"], exist_ok=True)
+    r = subprocess.run([EXE, d, "4", "1"], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:], r.stderr[-3000:])
+    assert r.returncode == 0 and "ALL OK" in r.stdout
+    check_proofs(d, nbits, n_queries, ("zkin.json", "zkin.1.json"))
+    env.pop("MI_STEPS_ON_HOST")
+    r = subprocess.run([EXE, d, "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode != 0 and "recorded nothing" in (r.stdout + r.stderr)

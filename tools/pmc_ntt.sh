@@ -8,6 +8,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_ntt
 mkdir -p $OUT
+# the A/B library is scratch (ab_libs/ is not tracked): build it when it is not there
+[ -f ab_libs/libmi_stark_noarith.so ] || make -C merlin-zkevm-prover_amd/csrc ab-noarith > $OUT/ab_build.log 2>&1 || { echo "ab-noarith build failed" >> $OUT/status.txt; exit 1; }
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-verify --no-cpu-baseline --pcie-steps 0"
 python3 -c "import torch; f,t=torch.cuda.mem_get_info(); print('hbm free/total bytes', f, t)" > $OUT/meminfo.txt 2>&1
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
