@@ -360,15 +360,19 @@ extern "C" int mi_transcript_put(mi_ctx *c, uint64_t state[4], uint64_t pending[
         return MI_OK;
     }
     MI_REQUIRE(n <= (1ull << 20), "transcript input too long for one call");
-    DevBuf d;
-    MI_TRY(d.alloc((32 + n) * 8));
-    std::vector<uint64_t> h(32 + n);
+    // no allocation on this path (a proof makes dozens of these calls): the context's 4 KiB words when they suffice, its scratch otherwise
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    const bool fits = (32 + n) * 8 <= 4096;
+    u64 *dev = c->small;
+    if (!fits) MI_TRY(mi_scratch(c, (32 + n) * 8, (void **)&dev));
+    std::vector<uint64_t> big(fits ? 0 : 32 + n);
+    uint64_t *h = fits ? (uint64_t *)c->pinned : big.data();
     memcpy(&h[0], state, 32); memcpy(&h[4], pending, 64); memcpy(&h[12], out, 96);
     h[24] = *pending_cursor; h[25] = *out_cursor;
     memcpy(&h[32], input, n * 8);
-    MI_HIP_CHECK(hipMemcpyAsync(d.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
-    MI_TRY(launch_transcript_put(c, (u64 *)d.p, (const u64 *)d.p + 32, n));
-    MI_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, 26 * 8, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP_CHECK(hipMemcpyAsync(dev, h, (32 + n) * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_transcript_put(c, dev, (const u64 *)dev + 32, n));
+    MI_HIP_CHECK(hipMemcpyAsync(h, dev, 26 * 8, hipMemcpyDeviceToHost, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
     memcpy(state, &h[0], 32); memcpy(pending, &h[4], 64); memcpy(out, &h[12], 96);
     *pending_cursor = (uint32_t)h[24]; *out_cursor = (uint32_t)h[25];
@@ -432,6 +436,7 @@ extern "C" int mi_merkle_build_dev(mi_ctx *c, uint64_t *nodes, const uint64_t *s
     MI_REQUIRE(nodes && (src || ncols == 0), "null buffer");
     MI_REQUIRE(is_pow2(nrows), "number of rows must be a power of two");
     MI_REQUIRE(pitch >= ncols, "pitch smaller than ncols");
+    if (ncols == 0) return launch_merkle_zero_width(c, (u64 *)nodes, nrows);
     MI_TRY(launch_linear_hash_rows(c, (u64 *)nodes, (const u64 *)src, pitch, ncols, nrows));
     return launch_merkle_levels(c, (u64 *)nodes, nrows);
 }
@@ -458,11 +463,12 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
     if (nq == 0) return MI_OK;
     MI_REQUIRE(proofs && nodes && (src || width == 0) && idx, "null buffer"); // width 0: sibling paths only
     for (uint64_t q = 0; q < nq; q++) MI_REQUIRE(idx[q] < height, "query index out of range");
-    DevBuf di;
-    MI_TRY(di.alloc(nq * 8));
-    MI_HIP_CHECK(hipMemcpyAsync(di.p, idx, nq * 8, hipMemcpyHostToDevice, c->stream));
-    MI_TRY(launch_group_proofs(c, (u64 *)proofs, (const u64 *)nodes, (const u64 *)src, pitch, height, width, (const u64 *)di.p, nq));
-    MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // di is released on return
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    u64 *di = c->small; // the indices: the context's 4 KiB words (512 queries) or its scratch, no allocation per call
+    if (nq * 8 > 4096) MI_TRY(mi_scratch(c, nq * 8, (void **)&di));
+    MI_HIP_CHECK(hipMemcpyAsync(di, idx, nq * 8, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_group_proofs(c, (u64 *)proofs, (const u64 *)nodes, (const u64 *)src, pitch, height, width, (const u64 *)di, nq));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // idx is the caller's pageable memory: it may go once this returns
     return MI_OK;
 }
 

@@ -149,6 +149,7 @@ int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t 
 int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const u64 *const *bases, const uint64_t *pitches,
                               const uint64_t *widths, uint64_t nrows, bool first, bool final);
 int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves);
+int launch_merkle_zero_width(mi_ctx *ctx, u64 *nodes, uint64_t nleaves); // the tree over rows of width 0: one value per level
 int launch_group_proofs(mi_ctx *ctx, u64 *proofs, const u64 *nodes, const u64 *src, uint64_t pitch, uint64_t height,
                         uint64_t width, const u64 *idx_dev, uint64_t nq);
 int launch_ntt(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t n, uint64_t ncols,

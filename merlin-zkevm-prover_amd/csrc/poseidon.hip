@@ -138,6 +138,46 @@ int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n)
     return MI_OK;
 }
 
+// The tree over rows of width 0 (a STARK without stage-2 polynomials commits to it all the same: root2 of the recursive STARKs'
+// golden proofs, starks.cpp:133-137): every leaf is the zero digest, so every level is one value repeated -- log2(n) dependent
+// hashes in one wave, then a fill, instead of n - 1 hashes.
+__global__ __launch_bounds__(64) void k_uniform_tree_values(u64 *vals, uint32_t nlevels) // vals[l * 4 ..]: the node value of level l; level 0 = 0
+{
+    __shared__ u64 cur[4];
+    const uint32_t j = threadIdx.x & 15;
+    const bool row0 = threadIdx.x < 16;
+    if (threadIdx.x < 4) { cur[threadIdx.x] = 0; vals[threadIdx.x] = 0; }
+    __syncthreads();
+    for (uint32_t l = 1; l < nlevels; l++) { // uniform over the wave
+        const u64 x = permute_coop(row0 && j < 8 ? cur[j & 3] : 0, j);
+        __syncthreads();
+        if (row0 && j < 4) { cur[j] = x; vals[l * 4 + j] = x; }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_uniform_tree_fill(u64 *__restrict__ nodes, const u64 *__restrict__ vals, uint64_t nleaves)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; // node index, level-major: level l at [2n - 2(n >> l) ... )
+    if (g >= 2 * nleaves - 1) return;
+    uint32_t l = 0;
+    while (g >= 2 * nleaves - 2 * (nleaves >> (l + 1))) l++;
+    u64 *o = nodes + g * 4;
+    const u64 *v = vals + l * 4;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+int launch_merkle_zero_width(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)
+{
+    MI_TRY(upload_rc_once(ctx));
+    uint32_t nlevels = 1;
+    while ((nleaves >> (nlevels - 1)) > 1) nlevels++;
+    u64 *vals = nullptr;
+    MI_TRY(mi_scratch(ctx, (uint64_t)nlevels * 32, (void **)&vals));
+    hipLaunchKernelGGL(k_uniform_tree_values, dim3(1), dim3(64), 0, ctx->stream, vals, nlevels);
+    hipLaunchKernelGGL(k_uniform_tree_fill, dim3(mi_grid_256(2 * nleaves - 1)), dim3(256), 0, ctx->stream, nodes, (const u64 *)vals, nleaves);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
 // parent = hash(left || right || 0^4)[0..4), one node per 16 lanes: the levels of small trees
 __global__ __launch_bounds__(256) void k_merkle_level_coop(u64 *__restrict__ out, const u64 *__restrict__ in, uint64_t n_out)
 {

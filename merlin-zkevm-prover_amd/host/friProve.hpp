@@ -68,7 +68,7 @@ private:
             } else { // friProve.cpp:128-134: the last polynomial goes into the transcript and the proof
                 std::vector<Goldilocks::Element> last(pol2N * 3);
                 mi::check(mi_copy_d2h(c, last.data(), d_next, pol2N * 3 * 8), "FRIProve::prove (final pol)");
-                for (uint64_t i = 0; i < pol2N; i++) transcript.put(&last[i * 3], FIELD_EXTENSION);
+                transcript.put(&last[0], pol2N * FIELD_EXTENSION); // friProve.cpp:131-134 element by element: the same elements in the same order
                 fproof.proofs.fri.setPol(last.data());
                 // the reference copies every step's folded polynomial over the head of friPol (friProve.cpp:136-140); a
                 // caller can only observe the final state, of which the head -- the last polynomial -- is reproduced

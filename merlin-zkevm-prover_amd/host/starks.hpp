@@ -575,7 +575,9 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     }
     TimerStopAndLog(STARK_STEP_5_EVMAP);
     TimerStart(STARK_STEP_5_XDIVXSUB);
-    for (uint64_t i = 0; i < nEvals; i++) transcript.put(evals[i], 3);
+    // starks.cpp:342-345 puts evals[i] one by one; they are contiguous, so one put absorbs the same elements in the same order
+    if (evals.offset() == FIELD_EXTENSION) { if (nEvals) transcript.put(evals[0], nEvals * FIELD_EXTENSION); }
+    else for (uint64_t i = 0; i < nEvals; i++) transcript.put(evals[i], 3);
     transcript.getField(challenges[5]); // v1
     transcript.getField(challenges[6]); // v2
     mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, NExtended, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");    // :350-365

@@ -3,6 +3,7 @@
 // proof as zkin / proof JSON text, the phase times, the free-HBM low-water mark, and -- for checks after the fact -- any range of
 // the device image of the polynomial area.  Errors follow the host classes: message on stderr, exit(-1) (the reference's convention).
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -48,6 +49,7 @@ struct Handle {
     Starks *starks = nullptr;
     TableSteps steps;
     std::string zkin, proof;
+    double genproofMs = 0, jsonMs = 0;
 };
 } // namespace
 
@@ -92,15 +94,20 @@ int mis_gen_proof(void *hv, const uint64_t *publics, uint64_t nrowsStepBatch, co
     for (size_t i = 0; i < pub.size(); i++) pub[i] = Goldilocks::fromU64(publics[i]);
     const uint64_t polBits = st->starkInfo.starkStruct.steps[st->starkInfo.starkStruct.steps.size() - 1].nBits;
     FRIProof fproof((1 << polBits), FIELD_EXTENSION, st->starkInfo.starkStruct.steps.size(), st->starkInfo.evMap.size(), st->starkInfo.nPublics);
+    const auto t0 = std::chrono::steady_clock::now();
     st->genProof(fproof, pub.data(), &h->steps);
     mi::check(mi_ctx_sync(mi::ctx()), "mis_gen_proof (sync)");
+    const auto t1 = std::chrono::steady_clock::now();
     fproof.publics = pub;
     h->zkin = proof2zkinStark(fproof, true);
     h->proof = fproof.proofs.proof2json();
+    h->genproofMs = std::chrono::duration<double, std::milli>(t1 - t0).count();                           // Starks::genProof alone (prover.cpp:544)
+    h->jsonMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(); // proof2json + proof2zkinStark (prover.cpp:549-552)
     if (zkin_path && zkin_path[0]) std::ofstream(zkin_path) << h->zkin;
     if (proof_path && proof_path[0]) std::ofstream(proof_path) << h->proof;
     return 0;
 }
+void mis_last_wall_ms(void *hv, double out[2]) { out[0] = ((Handle *)hv)->genproofMs; out[1] = ((Handle *)hv)->jsonMs; }
 const char *mis_zkin(void *hv) { return ((Handle *)hv)->zkin.c_str(); }
 const char *mis_proof(void *hv) { return ((Handle *)hv)->proof.c_str(); }
 // elements [offset, offset + n) of the device image of the polynomial area (StarkInfo::mapOffsets; trees follow at mapTotalN)

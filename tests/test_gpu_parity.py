@@ -278,6 +278,14 @@ def test_golden_root2_is_the_tree_without_columns_on_gpu(ctx):
     ctx.merkle_build(nodes, ctx.empty(16), 0, n)
     assert np.array_equal(ctx.to_host(nodes[-4:]), d["root2"])
     assert all(np.array_equal(np.load(f)["root2"], d["root2"]) for f in FILES)
+    # (such a tree is one value per level: the builder computes log2(n) hashes and fills) -- every node, against the oracle's tree
+    for m in (1, 2, 4, 8, 1024, 1 << 16):
+        got = ctx.empty((2 * m - 1) * 4 + 4)
+        got.fill_(-1)
+        ctx.merkle_build(got, ctx.empty(16), 0, m)
+        h = ctx.to_host(got)
+        assert np.array_equal(h[:-4], glo.merkletree(np.zeros(1, dtype=np.uint64), 0, m)), m
+        assert (h[-4:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all(), m       # nothing past the last node
 
 
 # ------------------------------------------------------------------ NTT / LDE
