@@ -4,8 +4,8 @@ behind libmi_starks.so) over a synthetic zkEVM-SHAPED STARK at full size, the wa
 
 What is synthetic and why: the zkEVM's starkinfo.json, constant polynomials, witness and generated chelpers tables are not in the
 reference tree and its tables may not travel to the GPU box.  This driver generates a STARK of the same SHAPE -- the memory
-map of SURVEY App. A (665 / 128 / 371 / 6 / 265 columns over 2^23 rows, 360 constant polynomials, 2^24 extended rows), 21 lookups and
-30 grand products described by puCtx / peCtx / ciCtx, 512 evaluations, 128 queries, FRI 24/19/14/10/6, and five constraint programs of
+map of SURVEY App. A (665 / 128 / 371 / 6 / 265 columns over 2^23 rows, 218 constant polynomials, 2^24 extended rows), 21 lookups and
+30 grand products described by puCtx / peCtx / ciCtx, 1 768 evaluations, 128 queries, FRI 24/19/14/10/6, and five constraint programs of
 the real ones' sizes in the reference's table formats -- writes it as a starkinfo.json + tables, and hands it to Starks exactly like
 the mini STARK of the tests.  The programs describe no satisfiable system (the proof is not meant to verify); what is measured is every
 phase of genProof at zkEVM size inside the product class, with its HBM plan, and what is CHECKED afterwards is that the proof is
@@ -36,8 +36,8 @@ def arg_parser():
     ap.add_argument("--log-n", type=int, default=23)
     ap.add_argument("--widths", type=int, nargs=3, default=[665, 128, 371], help="columns of cm1, cm2, cm3")
     ap.add_argument("--tmpexp", type=int, default=265, help="columns of tmpExp_n")
-    ap.add_argument("--n-const", type=int, default=360)
-    ap.add_argument("--n-evals", type=int, default=512)
+    ap.add_argument("--n-const", type=int, default=218, help="constant polynomials (zkEVM: ConstantPols::numPols() = 218, pols_generated/constant_pols.hpp:689)")
+    ap.add_argument("--n-evals", type=int, default=1768, help="evaluations (zkEVM: the per-row step52ns reads params.evals[0..1767])")
     ap.add_argument("--n-queries", type=int, default=128)
     ap.add_argument("--n-lookups", type=int, nargs=2, default=[11, 10], help="plookups of dimension 1 and of dimension 3")
     ap.add_argument("--n-products", type=int, default=30, help="grand products (lookups + permutations + connections)")

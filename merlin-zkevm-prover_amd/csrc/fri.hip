@@ -7,6 +7,7 @@
 // All of it is exact field arithmetic, so any evaluation order is bit-identical to the reference's.
 #include "common.h"
 #include "ntt_math.h"
+#include "chelpers_acc.h"
 #include <algorithm>
 
 using gl::E3;
@@ -183,17 +184,41 @@ __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial
     if (i >= n_evals) return;
     const EvDesc d = desc[i];
     const u64 *L = d.prime ? lpev : lev;
-    E3 acc = {{0, 0, 0}};
-    for (uint64_t k = k0; k < k1; k++) {
-        const E3 l = {{L[k * 3], L[k * 3 + 1], L[k * 3 + 2]}};
-        const u64 *b = d.ptr + (k << ext_bits) * d.stride;
-        E3 t;
-        if (d.dim == 1) t = gl::e3_mul1(l, gl::canon(b[0]));
-        else t = gl::e3_mul(l, E3{{gl::canon(b[0]), gl::canon(b[1]), gl::canon(b[2])}});
-        acc = gl::e3_add(acc, t);
+    // the slice's sum of products unreduced in limb accumulators (chelpers_acc.h: a multiply-accumulate is 8 instructions, no reduction),
+    // reduced once at the end: exact integer sums, so the evaluations are the same field elements
+    chpa::Acc r0, r1, r2;
+    chpa::acc_set(r0, 0); chpa::acc_set(r1, 0); chpa::acc_set(r2, 0);
+    if (d.dim == 1) {
+        // four rows' loads issued together: a wave has one 512-byte row segment per load in flight, and latency, not bandwidth, is what
+        // a one-load-at-a-time loop runs into
+        uint64_t k = k0;
+        const uint64_t step = d.stride << ext_bits;
+        const u64 *p = d.ptr + k0 * step;
+        for (; k + 4 <= k1; k += 4, p += 4 * step) {
+            const u64 v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
+            const u64 *l = L + k * 3;
+            u64 w[12];
+#pragma unroll
+            for (int j = 0; j < 12; j++) w[j] = l[j];
+            chpa::acc_mac(r0, v0, w[0]); chpa::acc_mac(r1, v0, w[1]); chpa::acc_mac(r2, v0, w[2]);
+            chpa::acc_mac(r0, v1, w[3]); chpa::acc_mac(r1, v1, w[4]); chpa::acc_mac(r2, v1, w[5]);
+            chpa::acc_mac(r0, v2, w[6]); chpa::acc_mac(r1, v2, w[7]); chpa::acc_mac(r2, v2, w[8]);
+            chpa::acc_mac(r0, v3, w[9]); chpa::acc_mac(r1, v3, w[10]); chpa::acc_mac(r2, v3, w[11]);
+        }
+        for (; k < k1; k++, p += step) {
+            const u64 v = p[0];
+            chpa::acc_mac(r0, v, L[k * 3]);
+            chpa::acc_mac(r1, v, L[k * 3 + 1]);
+            chpa::acc_mac(r2, v, L[k * 3 + 2]);
+        }
+    } else {
+        for (uint64_t k = k0; k < k1; k++) {
+            const u64 *b = d.ptr + (k << ext_bits) * d.stride;
+            chpa::acc_mul33(r0, r1, r2, b[0], b[1], b[2], L[k * 3], L[k * 3 + 1], L[k * 3 + 2]);
+        }
     }
     u64 *o = partial + ((uint64_t)blockIdx.y * n_evals + i) * 3;
-    o[0] = acc.v[0]; o[1] = acc.v[1]; o[2] = acc.v[2];
+    o[0] = gl::canon(chpa::acc_reduce(r0)); o[1] = gl::canon(chpa::acc_reduce(r1)); o[2] = gl::canon(chpa::acc_reduce(r2));
 }
 
 __global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ partial,

@@ -8,7 +8,9 @@
 //
 //     usage: test_steps_tracer <layout file>     layout: nBits nBitsExt nConst nPublics nEvals cols[11 sections in eSection order]
 #include <cstdio>
+#include <sys/mman.h>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <random>
 #include <set>
@@ -22,6 +24,9 @@
 #include "steps_tracer.hpp"
 #include STEPS_HEADER
 
+#ifdef MI_TEST_WITH_TABLES
+extern "C" int mi_test_tables(int which, const uint64_t **ops, uint64_t *nops, const uint64_t **args, uint64_t *nargs); // tests/cpp/test_steps_tables.cpp
+#endif
 static std::mt19937_64 rng(20260);
 static uint64_t fe() { return rng() % GOLDILOCKS_PRIME; }
 
@@ -38,9 +43,13 @@ int main(int argc, char **argv)
     off[0] = 0;
     for (int i = 0; i < 11; i++) off[i + 1] = off[i] + cols[i] * (i < 5 ? N : NExt);
     // the area and the tables: calloc'ed (pages appear when touched), random in three windows of rows, which is where the test looks
-    Goldilocks::Element *mem = (Goldilocks::Element *)std::calloc(off[11], 8);
-    Goldilocks::Element *cN = (Goldilocks::Element *)std::calloc(std::max<uint64_t>(nConst * N, 1), 8), *c2 = (Goldilocks::Element *)std::calloc(std::max<uint64_t>(nConst * NExt, 1), 8);
-    if (!mem || !cN || !c2) { std::fprintf(stderr, "out of memory\n"); return 2; }
+    // (address space without commitment: the zkEVM's area is 254 GB, of which a few hundred pages are touched)
+    auto reserve = [](uint64_t words) {
+        void *p = mmap(nullptr, std::max<uint64_t>(words, 1) * 8, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        return p == MAP_FAILED ? nullptr : (Goldilocks::Element *)p;
+    };
+    Goldilocks::Element *mem = reserve(off[11]), *cN = reserve(nConst * N), *c2 = reserve(nConst * NExt);
+    if (!mem || !cN || !c2) { std::fprintf(stderr, "cannot reserve the address space\n"); return 2; }
     Polinomial challenges(8, 3), evals(std::max<uint64_t>(nEvals, 1), 3), x_n(N, 1), x_2ns(NExt, 1), xd(NExt, 3), xdw(NExt, 3);
     std::vector<Goldilocks::Element> publics(std::max<uint64_t>(nPublics, 1));
     auto windows = [&](uint64_t n, auto f) {
@@ -70,7 +79,9 @@ int main(int argc, char **argv)
     static const int ids[5] = {MI_CHELPERS_STEP2PREV, MI_CHELPERS_STEP3PREV, MI_CHELPERS_STEP3, MI_CHELPERS_STEP42NS, MI_CHELPERS_STEP52NS};
     static const char *names[5] = {"step2prev", "step3prev", "step3", "step42ns", "step52ns"};
     int bad = 0;
+    const char *skip = std::getenv("MI_TEST_SKIP_STEPS"); // e.g. "3": a step whose per-row file the tree does not have
     for (int which = 0; which < 5; which++) {
+        if (skip && std::strchr(skip, '0' + which)) { std::printf("%s: skipped\n", names[which]); continue; }
         const bool base = which <= 2;
         const uint64_t n = base ? N : NExt;
         mi::TraceLayout L;
@@ -126,15 +137,18 @@ int main(int argc, char **argv)
         }
         std::vector<uint64_t> rows = {0, 1, 2, 3, n / 2, n / 2 + 1, n - 2, n - 1};
         if (n < 8) rows = {0, n - 1};
-        auto snapshot = [&](bool poison) {
+        auto snapshot = [&](bool poison) { // read everything first, poison afterwards: a step may store one element from two rows (t at row i + 1 = t' at row i)
             std::vector<uint64_t> v;
-            for (uint64_t r : rows)
-                for (const Out &o : outs)
-                    for (int d = 0; d < o.dim; d++) {
-                        Goldilocks::Element &e = mem[o.off + ((r + o.shift) % n) * o.stride + d];
-                        v.push_back(e.fe);
-                        if (poison) e.fe = 0xDEAD0000ULL + v.size();
-                    }
+            for (int pass = 0; pass < (poison ? 2 : 1); pass++) {
+                size_t k = 0;
+                for (uint64_t r : rows)
+                    for (const Out &o : outs)
+                        for (int d = 0; d < o.dim; d++, k++) {
+                            Goldilocks::Element &e = mem[o.off + ((r + o.shift) % n) * o.stride + d];
+                            if (pass == 0) v.push_back(e.fe);
+                            else e.fe = 0xDEAD0000ULL + k;
+                        }
+            }
             return v;
         };
         mi_chelpers_params hp = {};
@@ -155,6 +169,23 @@ int main(int argc, char **argv)
         rc = mi_dbg_host_chelpers_run_lowered(prog, &hp, rows.data(), rows.size(), 0);
         if (rc != 0) { std::printf("%s: LOWERED EXECUTOR FAILED: %s\n", names[which], mi_last_error()); bad++; mi_chelpers_free(nullptr, prog); continue; }
         const std::vector<uint64_t> l = snapshot(true);
+        std::vector<uint64_t> t;
+#ifdef MI_TEST_WITH_TABLES
+        { // the same step as the reference's generated TABLE, through the library's table decoder
+            const uint64_t *tops, *targs;
+            uint64_t tnops, tnargs;
+            mi_test_tables(which, &tops, &tnops, &targs, &tnargs);
+            mi_chelpers_prog *tprog = nullptr;
+            if (mi_chelpers_compile(nullptr, &tprog, ids[which], tops, tnops, targs, tnargs, secs.data(), secs.size(), nConst, n) != 0 ||
+                mi_dbg_host_chelpers_run(tprog, &hp, rows.data(), rows.size()) != 0) {
+                std::printf("%s: TABLE PROGRAM FAILED: %s\n", names[which], mi_last_error());
+                bad++;
+            } else {
+                t = snapshot(true);
+            }
+            if (tprog) mi_chelpers_free(nullptr, tprog);
+        }
+#endif
         for (uint64_t r : rows) call(r);
         std::vector<uint64_t> b = snapshot(false);
         for (uint64_t &w : b) w = w >= GOLDILOCKS_PRIME ? w - GOLDILOCKS_PRIME : w; // the host classes may leave a non-canonical word; the device writes canonical ones
@@ -165,6 +196,19 @@ int main(int argc, char **argv)
         std::printf("%s: %zu recorded operations (%llu after dead-code removal), %zu stores, %zu words compared, %zu differ (translated) %zu differ (lowered)\n", names[which],
                     mops.size(), (unsigned long long)st[3], outs.size(), a.size(), diff, diffl);
         if (diff || diffl || a.empty()) bad++;
+        if (diff) { // say where: (row, offset, shift, stride, dim) of the first few stores that differ
+            size_t k = 0, shown = 0;
+            for (uint64_t r : rows)
+                for (const Out &o : outs)
+                    for (int d = 0; d < o.dim; d++, k++)
+                        if (a[k] != b[k] && shown < 6) { std::printf("    differs: row %llu store (offset %llu, shift %llu, stride %llu, dim %d) word %d\n", (unsigned long long)r, (unsigned long long)o.off, (unsigned long long)o.shift, (unsigned long long)o.stride, o.dim, d); shown++; }
+        }
+#ifdef MI_TEST_WITH_TABLES
+        size_t difft = t.size() == b.size() ? 0 : b.size();
+        for (size_t k = 0; k < t.size() && k < b.size(); k++) difft += t[k] != b[k];
+        std::printf("%s: the reference's TABLE for this step, decoded and run on the same rows: %zu words compared, %zu differ\n", names[which], t.size(), difft);
+        if (difft || t.empty()) bad++;
+#endif
         mi_chelpers_free(nullptr, prog);
     }
     std::printf(bad ? "FAIL\n" : "OK\n");

@@ -111,7 +111,7 @@ def test_reference_program_translates_and_matches_oracle():
     st = prog.stats
     assert st["field_ops"] == 19198 and st["live_words_as_generated"] > 1000 and st["live_words_rescheduled"] <= 128, st
     assert st["base_temps"] + 3 * st["ext_temps"] <= 160, st
-    n_ext, numpols, rows = 1 << 24, 360, [0, 1, 5, (1 << 24) - 3, (1 << 24) - 1, 123456]
+    n_ext, numpols, rows = 1 << 24, 218, [0, 1, 5, (1 << 24) - 3, (1 << 24) - 1, 123456]
     rng = np.random.default_rng(42)
     pa, ca = cp.touched_addresses(micro, rows, numpols)
     size = (max(pa) + 8) * 8
@@ -223,7 +223,7 @@ def test_step52ns_tables_agree_with_the_reference_and_its_program_matches_the_or
         assert cp.nargs52_of(int(num)) == sum(int(k) for k in re.findall(r"i_args \+= (\d+);", text.split("default:")[0])), num
     ops, args = cp.parse_reference_tables(open(REF52_HPP).read(), "op52", "args52")
     assert ops.size == 2675 and args.size == 6761
-    n_ext, numpols, rows = 1 << 24, 360, [0, 7, (1 << 24) - 1, 999999]
+    n_ext, numpols, rows = 1 << 24, 218, [0, 7, (1 << 24) - 1, 999999]
     pa, ca, used = cp.touched_addresses52(ops, args, rows, numpols)
     assert used == args.size
     rng = np.random.default_rng(9)
@@ -469,7 +469,7 @@ def test_base_step_tables_agree_with_the_reference_and_its_programs_match_the_or
     assert ops.size == nops and args.size == nargs
     dec, used = cp.decode_base(ops, args)
     assert used == args.size
-    N, numpols = 1 << 23, 360
+    N, numpols = 1 << 23, 218
     secs = sorted({((a[0] // N) * N, a[1] if k in (cp.POL, cp.POL3) else a[3]) for (_, _, _, _, _, srcs) in dec for k, a in srcs if k in (cp.POL, cp.POL3, cp.POLS, cp.POL3S)})
     rows = [0, 1, N - 2, N - 1, 4242]
     rd, wr, ca = cp.touched_addresses_base(dec, rows, numpols)

@@ -54,14 +54,25 @@ public:
 """
 
 
-def run_driver(tmp_path, sources, header, cls, layout, extra_inc=(), opt="-O1"):
+def run_driver(tmp_path, sources, header, cls, layout, extra_inc=(), opt="-O1", defines=(), env=None):
+    from concurrent.futures import ThreadPoolExecutor
     exe = str(tmp_path / "tracer_test")
     lay = tmp_path / "layout.txt"
     lay.write_text(" ".join(str(int(v)) for v in layout))
-    cmd = ["g++", "-std=c++17", opt, "-fopenmp", "-DSTEPS_HEADER=\"%s\"" % header, "-DSTEPS_CLASS=%s" % cls] + list(extra_inc) + INC + [DRIVER] + list(sources) + ["-o", exe] + LINK
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    flags = ["-std=c++17", opt, "-fopenmp", "-DSTEPS_HEADER=\"%s\"" % header, "-DSTEPS_CLASS=%s" % cls] + list(defines) + list(extra_inc) + INC
+
+    def compile_one(k_src):
+        k, src = k_src
+        obj = str(tmp_path / ("obj%d.o" % k))
+        r = subprocess.run(["g++"] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        assert r.returncode == 0, (src, r.stderr[-4000:])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=6) as pool:          # (the generated files are tens of thousands of lines each)
+        objs = list(pool.map(compile_one, enumerate([DRIVER] + list(sources))))
+    r = subprocess.run(["g++", "-fopenmp"] + objs + ["-o", exe] + LINK, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
-    r = subprocess.run([exe, str(lay)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, str(lay)], capture_output=True, text=True, timeout=900, env=dict(os.environ, **(env or {})))
     print(r.stdout[-3000:], r.stderr[-2000:])
     return r
 
@@ -184,3 +195,35 @@ def test_the_references_generated_steps_are_recorded_and_reproduced(tmp_path, na
         assert m and int(m.group(2)) > 0, step
         if step == "step42ns":
             assert int(m.group(1)) > 3000
+
+
+# the zkEVM's polynomial map (read off the tables' offsets): N = 2^23, blow-up 2, cm1 665 | cm2 128 | cm3 371 | cm4 6 | tmpExp 265;
+# constants up to column 217, evaluations up to index 1767 in the per-row files (counted here as 218 and 1768), 48 publics
+ZKEVM = [23, 24, 218, 48, 1768, 665, 128, 371, 6, 265, 665, 128, 371, 6, 3, 3]
+
+
+@needs_ref
+def test_the_zkevm_tables_compute_what_the_zkevm_per_row_code_computes(tmp_path):
+    """The zkEVM's constraint system exists twice in the reference: as the generated TABLES the batched interpreters run
+    (zkevm.chelpers.step*.parser.hpp) and as generated per-row C++ (zkevm.chelpers.step{2,3prev,3,52ns}.cpp; the step42ns file is an absent
+    blob).  Both come from one generator, so they compute the same polynomials.  Here the library's TABLE DECODER (its transcription of
+    the interpreters' opcodes: mi_chelpers_compile) is run on the reference's tables beside the reference's compiled per-row code, on
+    random rows of the 254 GB map (address space only): every word either stores must agree -- 30 / 79 / ... polynomials of tmpExp_n and
+    cm3_n, and f_2ns.  That pins the opcode semantics of four of the five numberings with reference code run here; the recorder's programs
+    of the same functions are checked alongside."""
+    d = "zkevm/chelpers"
+    inc = tmp_path / "ref_inc"
+    inc.mkdir()
+    for name in ["zkevmSteps.hpp"] + ["zkevm.chelpers.%s.parser.hpp" % s for s in ("step2prev", "step3prev", "step3", "step42ns", "step52ns")]:
+        os.symlink(os.path.join(REF, d, name), inc / name)
+    srcs = [os.path.join(REF, d, "zkevm.chelpers.%s.cpp" % s) for s in ("step2", "step3prev", "step3", "step52ns")]
+    srcs.append(os.path.join(ROOT, "tests", "cpp", "test_steps_tables.cpp"))
+    r = run_driver(tmp_path, srcs, "zkevmSteps.hpp", "ZkevmSteps", ZKEVM, extra_inc=["-I", str(inc)], opt="-O0", defines=["-DMI_TEST_WITH_TABLES"],
+                   env={"MI_TEST_SKIP_STEPS": "3"})
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK")
+    assert "step42ns: skipped" in r.stdout
+    for step in ("step2prev", "step3prev", "step3", "step52ns"):
+        m = re.search(r"%s: (\d+) recorded operations .* (\d+) words compared, 0 differ \(translated\) 0 differ \(lowered\)" % step, r.stdout)
+        assert m and int(m.group(2)) > 0, step
+        m = re.search(r"%s: the reference's TABLE for this step, decoded and run on the same rows: (\d+) words compared, 0 differ" % step, r.stdout)
+        assert m and int(m.group(1)) > 0, step

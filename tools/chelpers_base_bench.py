@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--field-ops", type=int, default=12729)
     ap.add_argument("--widths", type=int, nargs=3, default=[665, 371, 265])
     ap.add_argument("--out-cols", type=int, default=430, help="columns of the section the results go to (the zkEVM step3 stores 430)")
-    ap.add_argument("--n-const", type=int, default=360)
+    ap.add_argument("--n-const", type=int, default=218)
     ap.add_argument("--precompile", type=int, default=0)
     ap.add_argument("--shard", type=int, default=-1, help="internal")
     a = ap.parse_args()

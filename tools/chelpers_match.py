@@ -23,7 +23,7 @@ TARGET = os.path.join(ROOT, "profiles", "r03_chelpers_step42ns_target.json")
 N = 1 << 23
 NE = 2 * N
 SECS = [(1435 * N, 665), (2765 * N, 128), (3021 * N, 371)]
-N_CONST = 360
+N_CONST = 218                                   # ConstantPols::numPols() (pols_generated/constant_pols.hpp:689)
 # the statistics the fit is judged on (5 % each): what decides the generated kernels' cost and memory behaviour
 KEYS = ["field_ops", "live_words_rescheduled", "kernels", "estimated_valu_per_row", "operand_loads_per_row", "distinct_operands",
         "spill_words_moved_per_row", "horner_chain_steps", "frac_reads_cm1", "frac_reads_cm2", "frac_reads_cm3", "frac_reads_const", "frac_reads_prime"]

@@ -18,7 +18,7 @@ import glo
 log_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 words = [int(w) for w in sys.argv[2:]] or [96]
 NE = 1 << log_rows
-w1, w2, w3, n_const = 665, 128, 371, 360
+w1, w2, w3, n_const = 665, 128, 371, 218
 ctx = mi_stark.Context(0)
 off = [0, NE * w1, NE * (w1 + w2)]
 pols = ctx.empty(NE * (w1 + w2 + w3))
