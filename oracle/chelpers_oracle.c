@@ -11,9 +11,14 @@
  * row i + j).  Temporaries are the reference's tmp1[] / tmp3[] arrays, indexed by the table's own slot numbers -- no
  * rescheduling, no renaming: this is deliberately the naive reading the product's translator has to agree with.
  *
- * PARITY UNPINNED: the reference tree holds no input / output pair for any chelpers step (zkevm.starkinfo.json, the
- * constant polynomials and every proof-time trace are absent), so nothing pins this restatement to reference results;
- * tests/test_chelpers.py cross-checks the argument bookkeeping against the reference's source text where it is present.
+ * PARITY: pinned in part, by reference CODE run in the tests.  The reference tree holds no input / output pair for any chelpers step
+ * (zkevm.starkinfo.json, the constant polynomials and every proof-time trace are absent).  But it holds the zkEVM's constraint system
+ * a second time, as generated per-row C++ (zkevm.chelpers.step{2,3prev,3,52ns}.cpp), which compiles against the Level-0 field classes:
+ * tests/test_steps_tracer.py runs those functions beside the product's table decoder on the reference's tables (identical stores), and
+ * tests/test_chelpers.py runs the product's decoder beside these interpreters on the same tables (identical) -- so for step2prev,
+ * step3prev, step3 and step52ns this restatement computes what the reference's compiled code computes.  STILL UNPINNED: the 19 opcodes
+ * only step42ns's table uses (9, 14, 25, 28, 29, 33, 34, 36, 39-42, 55, 60, 69, 72, 74, 75, 77; its per-row file is an absent blob),
+ * for which tests/test_chelpers.py cross-checks the argument bookkeeping against the reference's source text.
  */
 #include "gl_oracle.h"
 #include <stdlib.h>
