@@ -2,7 +2,7 @@
 // path ahead of host/polinomial.hpp) compiled against the Level-0 field classes, and its lookup / grand-product bodies
 //     Polinomial::calculateH1H2_opt1 / _opt3 / calculateH1H2_   (polinomial.hpp:303-584; starks.cpp:106-124 calls them)
 //     Polinomial::calculateZ                                     (polinomial.hpp:586-607; starks.cpp:179-185)
-// run beside the CPU oracle's restatements (glo_calculate_h1h2, glo_calculate_z) on the same data.  The GPU kernels are tested against
+// and ZhInv::ZhInv (zhInv.cpp:7-31), run beside the CPU oracle's restatements (glo_calculate_h1h2, glo_calculate_z, glo_zhinv) on the same data.  The GPU kernels are tested against
 // the oracle bit for bit (tests/test_lookup.py); this is what says the oracle -- and through it the kernels -- follow the reference's
 // conventions: which of equal table rows takes the repeats, the order of h1 / h2, z[0] = 1 and the running quotient.
 #include <cstdio>
@@ -10,6 +10,8 @@
 #include <random>
 #include <vector>
 #include "polinomial.hpp"
+#include "zhInv.hpp"
+#include "merkleTreeGL.hpp"
 #include "../../oracle/gl_oracle.h"
 
 // (zkassert.hpp brings the reference's exit_process.hpp, a declaration; its definition lives in a file that needs gmp and json)
@@ -91,9 +93,53 @@ static int products()
     return bad;
 }
 
+// ZhInv::ZhInv (zhInv.cpp:7-31, the reference's translation unit, linked in) beside glo_zhinv
+static int zhinvs()
+{
+    int bad = 0;
+    const unsigned cases[][2] = {{3, 4}, {10, 11}, {17, 20}, {20, 22}, {23, 24}, {5, 13}};
+    for (auto &c : cases) {
+        ZhInv zi(c[0], c[1]);
+        std::vector<uint64_t> o(1ULL << (c[1] - c[0]));
+        glo_zhinv(o.data(), c[0], c[1]);
+        uint64_t diff = 0;
+        for (uint64_t i = 0; i < 3 * o.size(); i++) diff += o[i % o.size()] != Goldilocks::toU64(zi.zhInv(i)); // (periodic: zhInv.hpp:22-25)
+        std::printf("zhinv nBits=%u nBitsExt=%u: %llu differences\n", c[0], c[1], (unsigned long long)diff);
+        bad += diff != 0;
+    }
+    return bad;
+}
+
+// MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35, the reference's translation unit) over a node array the oracle built, beside
+// glo_merkle_group_proof: the proof layout (row, then the sibling of every level, level-major node array)
+static int openings()
+{
+    int bad = 0;
+    const uint64_t shapes[][2] = {{2, 5}, {8, 1}, {64, 18}, {1024, 39}, {4096, 3}};
+    for (auto &sh : shapes) {
+        const uint64_t h = sh[0], w = sh[1];
+        MerkleTreeGL tree(h, w, NULL);
+        for (uint64_t i = 0; i < h * w; i++) tree.source[i].fe = fe();
+        glo_merkletree((uint64_t *)tree.nodes, (const uint64_t *)tree.source, w, h);
+        const uint64_t plen = w + tree.MerkleProofSize() * HASH_SIZE;
+        uint64_t diff = 0;
+        for (uint64_t q = 0; q < 16; q++) {
+            const uint64_t idx = q == 0 ? 0 : q == 1 ? h - 1 : rng() % h;
+            std::vector<Goldilocks::Element> p(plen);
+            std::vector<uint64_t> o(plen);
+            tree.getGroupProof(p.data(), idx);
+            glo_merkle_group_proof(o.data(), (const uint64_t *)tree.nodes, (const uint64_t *)tree.source, h, w, idx);
+            for (uint64_t i = 0; i < plen; i++) diff += o[i] != p[i].fe;
+        }
+        std::printf("openings height=%llu width=%llu: %llu differences\n", (unsigned long long)h, (unsigned long long)w, (unsigned long long)diff);
+        bad += diff != 0;
+    }
+    return bad;
+}
+
 int main()
 {
-    const int bad = lookups() + products();
+    const int bad = lookups() + products() + zhinvs() + openings();
     std::printf(bad ? "FAIL\n" : "OK\n");
     return bad ? 1 : 0;
 }

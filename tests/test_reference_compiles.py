@@ -57,10 +57,10 @@ def test_blocked_files_fail_only_for_the_missing_third_party_header(rel, missing
     assert "nlohmann" in first, first
 
 
-def test_the_references_lookup_and_product_bodies_agree_with_the_oracle(tmp_path):
+def test_reference_bodies_run_beside_the_oracle(tmp_path):
     """The reference's own polinomial.hpp -- calculateH1H2_opt1 / _opt3 / calculateH1H2_ and calculateZ (polinomial.hpp:303-607), header-only
     -- compiled against the Level-0 field classes and RUN beside the oracle's restatements on the same tables (distinct rows, runs of
-    equal rows, one heavy value; closing and non-closing products): identical h1 / h2 / z.  The GPU kernels equal the oracle bit for bit
+    equal rows, one heavy value; closing and non-closing products): identical h1 / h2 / z; and ZhInv::ZhInv (zhInv.cpp, the reference's translation unit) beside glo_zhinv; MerkleTreeGL::getGroupProof (merkleTreeGL.cpp) over an oracle-built node array beside glo_merkle_group_proof.  The GPU kernels equal the oracle bit for bit
     (tests/test_lookup.py), so this is reference code deciding their conventions (no longer "parity unpinned" for the
     lookup columns and grand products).  compare_fe.cpp is the reference's too; zklog / exit_process are the stand-ins (the reference's
     drag in utils.hpp and with it gmp / json)."""
@@ -71,10 +71,13 @@ def test_the_references_lookup_and_product_bodies_agree_with_the_oracle(tmp_path
     inc.mkdir()
     os.symlink(os.path.join(REF, "starkpil", "polinomial.hpp"), inc / "polinomial.hpp")
     os.symlink(os.path.join(REF, "utils", "compare_fe.hpp"), inc / "compare_fe.hpp")
+    os.symlink(os.path.join(REF, "starkpil", "zhInv.hpp"), inc / "zhInv.hpp")
+    os.symlink(os.path.join(REF, "utils", "zkassert.hpp"), inc / "zkassert.hpp")
+    os.symlink(os.path.join(REF, "starkpil", "merkleTree", "merkleTreeGL.hpp"), inc / "merkleTreeGL.hpp")
     exe = str(tmp_path / "ref_polinomial")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = ["g++", "-std=c++17", "-O1", "-fopenmp", "-include", os.path.join(REF, "utils", "zkassert.hpp"), "-I", str(inc), "-I", HOST, "-I", os.path.join(HOST, "standalone"),
-           os.path.join(root, "tests", "cpp", "test_ref_polinomial.cpp"), os.path.join(REF, "utils", "compare_fe.cpp"), "-o", exe,
+           os.path.join(root, "tests", "cpp", "test_ref_polinomial.cpp"), os.path.join(REF, "utils", "compare_fe.cpp"), os.path.join(REF, "starkpil", "zhInv.cpp"), os.path.join(REF, "starkpil", "merkleTree", "merkleTreeGL.cpp"), "-o", exe,
            "-L", os.path.join(root, "oracle"), "-lgl_oracle", "-Wl,-rpath," + os.path.join(root, "oracle"),
            "-L", os.path.join(root, "merlin-zkevm-prover_amd"), "-lmi_stark", "-Wl,-rpath," + os.path.join(root, "merlin-zkevm-prover_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -82,4 +85,4 @@ def test_the_references_lookup_and_product_bodies_agree_with_the_oracle(tmp_path
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
-    assert r.stdout.count(": 0 differences") == 24 + 9
+    assert r.stdout.count(": 0 differences") == 24 + 9 + 6 + 5
