@@ -86,3 +86,24 @@ def test_reference_bodies_run_beside_the_oracle(tmp_path):
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
     assert r.stdout.count(": 0 differences") == 24 + 9 + 6 + 5
+
+
+def test_reference_transcript_state_machine_runs_beside_the_oracle(tmp_path):
+    """transcript.{hpp,cpp} of the reference, compiled unchanged over a CPU permutation (the oracle's: tests/cpp/cpu_poseidon), through random
+    interleavings of put / getField / getFields1 / getPermutations beside glo_transcript_*: identical values.  The golden proofs cannot
+    replay a transcript (the verification key that enters it is absent); this pins the state machine -- buffering of 8, the
+    out cursor, 63 bits per field for the query indices -- with the reference's code.  The product's Transcript (hashes on the GPU) is
+    compared with the oracle's in the GPU tests."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import glo
+    glo.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "ref_transcript")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "tests", "cpp", "cpu_poseidon"), "-I", os.path.join(REF, "starkpil", "transcript"), "-I", HOST,
+           os.path.join(root, "tests", "cpp", "test_ref_transcript.cpp"), os.path.join(REF, "starkpil", "transcript", "transcript.cpp"), "-o", exe,
+           "-L", os.path.join(root, "oracle"), "-lgl_oracle", "-Wl,-rpath," + os.path.join(root, "oracle")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and " 0 differences" in r.stdout
