@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of mi_calculate_h1h2_dev / mi_calculate_z_dev against the oracle (run on a GPU box): random row counts, dimensions,
+"""Differential fuzz of mi_calculate_h1h2_dev / mi_calculate_z_dev / mi_calculate_z_batch_dev against the oracle (run on a GPU box): random row counts, dimensions,
 strides, alphabets (from all-equal to all-distinct), duplicate table rows, heavy hitters, occasional missing values (the failing row
 must be the oracle's), zero denominators.  The oracle is the checker here, as in tests/.  Usage: lookup_fuzz.py [count] [first seed]."""
 import os
@@ -67,6 +67,21 @@ def main():
         closes = ctx.calculate_z(dz[6:], zc, dz, zc, dz[3:], zc, n)
         wcloses = glo.calculate_z(za, 6, zc, 0, zc, 3, zc, n)
         okz = np.array_equal(ctx.to_host(dz), za) and closes == bool(wcloses) and (mode != 1 or closes)
+        # the batch entry point: k products over one wide area (numerators / denominators side by side, z columns behind them), several zero
+        # denominators, one product that closes; more products than one launch takes now and then
+        k = int(rng.choice([1, 2, 5, 13, 33, 40]))
+        nb = min(n, 20000)
+        wt, wz = 6 * k + int(rng.integers(0, 3)), 3 * k + int(rng.integers(0, 3))
+        ba = glo.rand_fe(rng, (nb * (wt + wz),))
+        src = ba[:nb * wt].reshape(nb, wt)
+        for _ in range(int(rng.integers(0, 4))):
+            src[rng.integers(0, nb), 6 * int(rng.integers(0, k)) + 3:][:3] = 0
+        cl = int(rng.integers(0, k))
+        src[:, 6 * cl:6 * cl + 3] = src[rng.permutation(nb), 6 * cl + 3:6 * cl + 6]
+        db = ctx.to_device(ba)
+        got = ctx.calculate_z_batch([(db[nb * wt + 3 * i:], wz, db[6 * i:], wt, db[6 * i + 3:], wt) for i in range(k)], nb)
+        want = [bool(glo.calculate_z(ba, nb * wt + 3 * i, wz, 6 * i, wt, 6 * i + 3, wt, nb)) for i in range(k)]
+        okz = okz and np.array_equal(ctx.to_host(db), ba) and got == want
         if not (ok and okz):
             bad += 1
         if not (ok and okz) or seed % 25 == 0:
