@@ -52,6 +52,10 @@ def arg_parser():
     ap.add_argument("--step42-generic", action="store_true",
                     help="step42ns from the r02 generator defaults instead of the parameters fitted to the real program's statistics "
                          "(tests/chelpers_programs.ZKEVM_STEP42NS_FIT; the fit applies when the three committed sections are all present)")
+    ap.add_argument("--per-row-steps", action="store_true",
+                    help="nrowsStepBatch = 1, as the reference proves c12a / recursive1 / recursive2 (prover.cpp:577,611): the five programs are written out "
+                         "as generated per-row C++ (tests/gen_steps_cpp.py), compiled into a Steps library, and Starks::genProof RECORDS them and runs the "
+                         "recordings on the device (host/steps_tracer.hpp).  pAddress is then the whole polynomial map in host memory, as the reference has it")
     ap.add_argument("--proofs", type=int, default=2, help="genProof runs; the last one is reported (the first pays first-touch / code loading)")
     ap.add_argument("--check-rows", type=int, default=6)
     ap.add_argument("--chelpers-batch-rows", type=int, default=0)
@@ -248,7 +252,8 @@ def main():
     # ---- host inputs: the witness (cm1_n, the only part of pAddress genProof reads), the constant polynomials, and the image of the
     # constant-tree file -- never written here: zero pages, of which the query phase reads 128 rows and paths
     t0 = time.perf_counter()
-    witness = torch.empty(N * w1, dtype=torch.int64, pin_memory=False)
+    # (per-row steps: the whole map, as the reference allocates it -- the recorder runs each function once at rows 0 and n - 1 over it)
+    witness = torch.zeros(si["mapTotalN"], dtype=torch.int64) if args.per_row_steps else torch.empty(N * w1, dtype=torch.int64, pin_memory=False)
     chunk = 1 << 28
     d = ctx.empty(min(chunk, max(N * w1, N * args.n_const)))
     for o_ in range(0, N * w1, chunk):
@@ -269,7 +274,7 @@ def main():
     publics = np.arange(1, 9, dtype=np.uint64)
     t_inputs = time.perf_counter() - t0
 
-    L = ctypes.CDLL(os.path.join(ROOT, "merlin-zkevm-prover_amd", "libmi_starks.so"))
+    L = ctypes.CDLL(os.path.join(ROOT, "merlin-zkevm-prover_amd", "libmi_starks.so"), mode=ctypes.RTLD_GLOBAL)
     L.mis_create.restype = ctypes.c_void_p
     L.mis_hbm_plan_bytes.restype = ctypes.c_uint64
     L.mis_min_free_bytes.restype = ctypes.c_uint64
@@ -282,13 +287,28 @@ def main():
     for name, (ops, ar) in progs.items():
         ops, ar = np.ascontiguousarray(ops, dtype=np.uint64), np.ascontiguousarray(ar, dtype=np.uint64)
         L.mis_set_tables(h, ctypes.c_int(STEP_ID[name]), vp(ops.ctypes.data), ctypes.c_uint64(ops.size), vp(ar.ctypes.data), ctypes.c_uint64(ar.size))
+    t_steps_lib = 0.0
+    if args.per_row_steps:
+        import subprocess
+        import gen_steps_cpp as gs
+        t0 = time.perf_counter()
+        host = os.path.join(ROOT, "merlin-zkevm-prover_amd", "host")
+        src = os.path.join(workdir, "bench_starks_steps.cpp")
+        open(os.path.join(workdir, "genSteps.hpp"), "w").write(gs.GEN_HEADER)
+        open(src, "w").write(gs.steps_source("GenSteps", progs, header='#include "genSteps.hpp"\n') + gs.GEN_FACTORY)
+        so = os.path.join(workdir, "libbench_starks_steps.so")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-fPIC", "-shared", "-I", workdir, "-I", host, "-I", os.path.join(host, "standalone"), src, "-o", so])
+        if L.mis_load_steps(h, so.encode()) != 0:
+            raise SystemExit("bench_starks: cannot load the generated Steps library")
+        t_steps_lib = time.perf_counter() - t0
+    batch = 1 if args.per_row_steps else 4
     plan = L.mis_hbm_plan_bytes(h)
     L.mis_phase_timer(1)
     walls, inner = [], []
     for it in range(args.proofs):
         L.mis_phase_timer(1)                                 # (resets the low-water mark)
         t0 = time.perf_counter()
-        L.mis_gen_proof(h, vp(publics.ctypes.data), ctypes.c_uint64(4), b"", b"")
+        L.mis_gen_proof(h, vp(publics.ctypes.data), ctypes.c_uint64(batch), b"", b"")
         walls.append(1e3 * (time.perf_counter() - t0))
         two = (ctypes.c_double * 2)()
         L.mis_last_wall_ms(h, two)
@@ -372,14 +392,14 @@ def main():
     total = phases.get("STARK_STEP_1", 0) + phases.get("STARK_STEP_2", 0) + phases.get("STARK_STEP_3", 0) + phases.get("STARK_STEP_4", 0) + \
         phases.get("STARK_STEP_5", 0) + phases.get("STARK_STEP_FRI", 0) + phases.get("STARK_INITIALIZATION", 0)
     out = {"metric": "Starks::genProof wall time, synthetic zkEVM-shaped STARK (BASELINE config 4 substitute)", "unit": "ms", "value": inner[-1][0],
-           "higher_is_better": False, "n_gpus": 1, "flow": "host/starks.hpp class Starks through libmi_starks.so, device steps (nrowsStepBatch 4)",
+           "higher_is_better": False, "n_gpus": 1, "flow": "host/starks.hpp class Starks through libmi_starks.so, " + ("generated per-row Steps code recorded and run on the device (nrowsStepBatch 1)" if args.per_row_steps else "device steps (nrowsStepBatch 4)"),
            "config": {"workload": "2^%d rows, sections %s / tmpExp %d / %d constants, %d + %d lookups, %d grand products, %d evaluations, %d queries, FRI %s"
                       % (nbits, args.widths, args.tmpexp, args.n_const, args.n_lookups[0], args.n_lookups[1], args.n_products, args.n_evals, args.n_queries, steps),
                       "field_ops_per_row": dict(zip(("step2prev", "step3prev", "step3", "step42ns", "step52ns"), args.field_ops))},
            "genproof_wall_ms": [a for a, _ in inner], "proof_to_json_ms": [b for _, b in inner], "call_wall_ms_incl_json": walls, "phase_ms_sum": total, "phase_ms": phases,
            "hbm": {"total_gb": total_hbm / 1e9, "free_before_gb": free0 / 1e9, "plan_gb": plan / 1e9, "peak_hbm_gb": (total_hbm - min_free) / 1e9,
                    "fits_one_gpu": bool(total_hbm - min_free < total_hbm)},
-           "setup_s": {"inputs": t_inputs, "starks_ctor_incl_const_upload": t_create},
+           "setup_s": {"inputs": t_inputs, "starks_ctor_incl_const_upload": t_create, "per_row_steps_library_build": t_steps_lib},
            "checks": checks, "dtype": "u64", "data": "synthetic"}
     print(json.dumps(out))
     L.mis_destroy(h)

@@ -4,6 +4,7 @@
 // the device image of the polynomial area.  Errors follow the host classes: message on stderr, exit(-1) (the reference's convention).
 #include <cstring>
 #include <chrono>
+#include <dlfcn.h>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -50,6 +51,7 @@ struct Handle {
     TableSteps steps;
     std::string zkin, proof;
     double genproofMs = 0, jsonMs = 0;
+    Steps *external = nullptr; // a Steps class with per-row code out of a shared library (mis_load_steps): used when nrowsStepBatch is 1
 };
 } // namespace
 
@@ -83,6 +85,19 @@ int mis_set_tables(void *hv, int step, const uint64_t *ops, uint64_t nops, const
     h->steps.t[s].args.assign(args, args + nargs);
     return 0;
 }
+// a Steps class compiled elsewhere (generated per-row C++ against these headers): the library exports `Steps *mi_make_steps()`.  It must see
+// THIS library's field-class recorder hook (an inline thread_local of goldilocks_base_field.hpp): load libmi_starks.so with RTLD_GLOBAL.
+int mis_load_steps(void *hv, const char *so_path)
+{
+    Handle *h = (Handle *)hv;
+    void *lib = dlopen(so_path, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { std::fprintf(stderr, "mis_load_steps: %s\n", dlerror()); return -1; }
+    typedef Steps *(*Make)();
+    Make make = (Make)dlsym(lib, "mi_make_steps");
+    if (!make) { std::fprintf(stderr, "mis_load_steps: no mi_make_steps in %s\n", so_path); return -1; }
+    h->external = make();
+    return h->external ? 0 : -1;
+}
 uint64_t mis_hbm_plan_bytes(void *hv) { return ((Handle *)hv)->starks->hbmPlanBytes(); }
 // genProof as prover.cpp:541-552; the JSON texts are kept in the handle (mis_zkin / mis_proof) and optionally written to files
 int mis_gen_proof(void *hv, const uint64_t *publics, uint64_t nrowsStepBatch, const char *zkin_path, const char *proof_path)
@@ -95,7 +110,7 @@ int mis_gen_proof(void *hv, const uint64_t *publics, uint64_t nrowsStepBatch, co
     const uint64_t polBits = st->starkInfo.starkStruct.steps[st->starkInfo.starkStruct.steps.size() - 1].nBits;
     FRIProof fproof((1 << polBits), FIELD_EXTENSION, st->starkInfo.starkStruct.steps.size(), st->starkInfo.evMap.size(), st->starkInfo.nPublics);
     const auto t0 = std::chrono::steady_clock::now();
-    st->genProof(fproof, pub.data(), &h->steps);
+    st->genProof(fproof, pub.data(), nrowsStepBatch == 1 && h->external ? h->external : &h->steps);
     mi::check(mi_ctx_sync(mi::ctx()), "mis_gen_proof (sync)");
     const auto t1 = std::chrono::steady_clock::now();
     fproof.publics = pub;

@@ -145,3 +145,23 @@ def steps_source(cls_name, programs, header=None):
         out.append(_function(step + "_first", cls_name, micro, base=step in ("step2prev", "step3prev", "step3")))
         out.append("void %s::%s_i(StepsParams &, uint64_t) {}\nvoid %s::%s_last(StepsParams &, uint64_t) {}\n" % (cls_name, step, cls_name, step))
     return "\n".join(out)
+
+
+GEN_HEADER = """#ifndef GEN_STEPS_HPP
+#define GEN_STEPS_HPP
+#include "goldilocks_cubic_extension.hpp"
+#include "zhInv.hpp"
+#include "polinomial.hpp"
+#include "constant_pols_starks.hpp"
+#include "steps.hpp"
+class GenSteps : public Steps
+{
+public:
+#define ROWS(s) void s##_first(StepsParams &params, uint64_t i) override; void s##_i(StepsParams &params, uint64_t i) override; void s##_last(StepsParams &params, uint64_t i) override;
+    ROWS(step2prev) ROWS(step3prev) ROWS(step3) ROWS(step42ns) ROWS(step52ns)
+#undef ROWS
+};
+#endif
+"""
+# for a shared library a host program loads (libmi_starks.so: mis_load_steps)
+GEN_FACTORY = 'extern "C" Steps *mi_make_steps() { return new GenSteps(); }\n'

@@ -64,3 +64,19 @@ def test_starks_flow_at_zkevm_size_fits_one_gpu_and_rows_match_the_oracle(tmp_pa
     assert out["config"]["field_ops_per_row"]["step42ns"] == 17986
     for ph in ("STARK_STEP_2_CALCULATE_EXPS", "STARK_STEP_3_CALCULATE_EXPS", "STARK_STEP_3_CALCULATE_EXPS_2", "STARK_STEP_4_CALCULATE_EXPS_2NS"):
         assert out["phase_ms"][ph] > 0
+
+
+@pytest.mark.gpu
+def test_starks_flow_with_generated_per_row_steps_recorded_on_the_device(tmp_path):
+    """nrowsStepBatch = 1 as the reference proves the recursive STARKs: bench_starks.py writes the five programs out as generated per-row C++,
+    builds a Steps library from it, and Starks::genProof records the functions and runs the recordings on the device; the sampled q_2ns /
+    f_2ns rows must equal the oracle interpreters' results on the TABLES the C++ was generated from, and the proof must be consistent."""
+    env = dict(os.environ, MI_BENCH_TMP=str(tmp_path))
+    env.pop("MI_STEPS_ON_HOST", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_starks.py")] + SMALL + ["--per-row-steps", "--check-rows", "8"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "nrowsStepBatch 1" in out["flow"]
+    for k, v in out["checks"].items():
+        a, b = v.split("/")
+        assert a == b and int(b) > 0, (k, v)

@@ -36,22 +36,7 @@ LINK = ["-L", os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-lmi_stark", "-Wl,
 INC = ["-I", os.path.join(ROOT, "tests", "cpp", "host_zhinv"), "-I", os.path.join(ROOT, "include"), "-I", HOST, "-I", os.path.join(HOST, "standalone")]
 DRIVER = os.path.join(ROOT, "tests", "cpp", "test_steps_tracer.cpp")
 
-GEN_HEADER = """#ifndef GEN_STEPS_HPP
-#define GEN_STEPS_HPP
-#include "goldilocks_cubic_extension.hpp"
-#include "zhInv.hpp"
-#include "polinomial.hpp"
-#include "constant_pols_starks.hpp"
-#include "steps.hpp"
-class GenSteps : public Steps
-{
-public:
-#define ROWS(s) void s##_first(StepsParams &params, uint64_t i) override; void s##_i(StepsParams &params, uint64_t i) override; void s##_last(StepsParams &params, uint64_t i) override;
-    ROWS(step2prev) ROWS(step3prev) ROWS(step3) ROWS(step42ns) ROWS(step52ns)
-#undef ROWS
-};
-#endif
-"""
+GEN_HEADER = gs.GEN_HEADER
 
 
 def run_driver(tmp_path, sources, header, cls, layout, extra_inc=(), opt="-O1", defines=(), env=None):
@@ -94,34 +79,41 @@ def test_generated_per_row_code_of_the_mini_stark_is_recorded_and_reproduced(tmp
         assert re.search(r"%s: \d+ recorded operations .* 0 differ \(translated\) 0 differ \(lowered\)" % step, r.stdout), step
 
 
-def test_generated_per_row_code_of_synthetic_zkevm_shaped_programs(tmp_path):
-    """Every opcode of the three table formats, shifted reads in both domains (blow-up 4: shifts of 4 rows), stores at shifted rows."""
-    rng = np.random.default_rng(5)
-    nbits, ext = 6, 2
+def synthetic_case(tmp_path, seed, nbits=6, ext=2, widths=(9, 7, 12), tmpexp=10, n_const=6, n_pub=3, n_evals=12, sizes=(120, 200, 40), with3prev=False):
+    """One random Steps class in generated per-row C++ (every opcode of the three table formats, shifted reads of 2^ext rows in the
+    extended domain, stores at shifted rows) through the driver; returns the driver's output.  Also used by tools/steps_tracer_fuzz.py."""
+    rng = np.random.default_rng(seed)
     n, ne = 1 << nbits, 1 << (nbits + ext)
-    cols = {"cm1_n": 9, "cm2_n": 7, "cm3_n": 12, "cm4_n": 6, "tmpExp_n": 10}
-    off, o = {}, 0
+    w1, w2, w3 = widths
     order = ["cm1_n", "cm2_n", "cm3_n", "cm4_n", "tmpExp_n", "cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns", "q_2ns", "f_2ns"]
-    allc = dict(cols, cm1_2ns=9, cm2_2ns=7, cm3_2ns=12, cm4_2ns=6, q_2ns=3, f_2ns=3)
+    allc = dict(cm1_n=w1, cm2_n=w2, cm3_n=w3, cm4_n=6, tmpExp_n=tmpexp, cm1_2ns=w1, cm2_2ns=w2, cm3_2ns=w3, cm4_2ns=6, q_2ns=3, f_2ns=3)
+    off, o = {}, 0
     for k in order:
         off[k] = o
         o += allc[k] * (ne if k.endswith("2ns") else n)
-    n_const, n_pub, n_evals = 6, 3, 12
     base_secs = [(off[k], allc[k]) for k in ("cm1_n", "cm2_n")]
     progs = {
-        "step2prev": cp.synthetic_program_base(rng, n, base_secs, (off["tmpExp_n"], allc["tmpExp_n"]), n_const, 8, n_pub, n_ops=120),
-        "step3": cp.synthetic_program_base(rng, n, base_secs, (off["cm3_n"], allc["cm3_n"]), n_const, 8, n_pub, n_ops=200),
+        "step2prev": cp.synthetic_program_base(rng, n, base_secs, (off["tmpExp_n"], allc["tmpExp_n"]), n_const, 8, n_pub, n_ops=sizes[0]),
+        "step3": cp.synthetic_program_base(rng, n, base_secs, (off["cm3_n"], allc["cm3_n"]), n_const, 8, n_pub, n_ops=sizes[1]),
         "step42ns": cp.synthetic_program(rng, ne, [(off[k], allc[k]) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns")], n_const, 8, n_pub),
-        "step52ns": cp.synthetic_program52(rng, [(off[k], allc[k]) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")], n_const, n_evals, length=40),
+        "step52ns": cp.synthetic_program52(rng, [(off[k], allc[k]) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")], n_const, n_evals, length=sizes[2]),
     }
+    if with3prev:
+        progs["step3prev"] = cp.synthetic_program_base(rng, n, base_secs, (off["tmpExp_n"], allc["tmpExp_n"]), n_const, 8, n_pub, n_ops=sizes[0])
+        del progs["step2prev"]               # (both write tmpExp_n: one of them per case)
     (tmp_path / "genSteps.hpp").write_text(GEN_HEADER)
     src = tmp_path / "gen_steps.cpp"
     src.write_text(gs.steps_source("GenSteps", progs, header='#include "genSteps.hpp"\n'))
     layout = [nbits, nbits + ext, n_const, n_pub, n_evals] + [allc[k] for k in order]
-    r = run_driver(tmp_path, [str(src)], "genSteps.hpp", "GenSteps", layout, extra_inc=["-I", str(tmp_path)])
+    return run_driver(tmp_path, [str(src)], "genSteps.hpp", "GenSteps", layout, extra_inc=["-I", str(tmp_path)]), sorted(progs)
+
+
+def test_generated_per_row_code_of_synthetic_zkevm_shaped_programs(tmp_path):
+    """Every opcode of the three table formats, shifted reads in both domains (blow-up 4: shifts of 4 rows), stores at shifted rows."""
+    r, steps = synthetic_case(tmp_path, 5)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
     assert "step3prev: empty" in r.stdout
-    for step in ("step2prev", "step3", "step42ns", "step52ns"):
+    for step in steps:
         assert re.search(r"%s: \d+ recorded operations .* 0 differ \(translated\) 0 differ \(lowered\)" % step, r.stdout), step
 
 
