@@ -16,13 +16,13 @@
 //     image of pAddress[0, mapTotalN)     254.1   cm1_n 44.6 | cm2_n 8.6 | cm3_n 24.9 | cm4_n 0.4 | tmpExp_n 17.8 | cm1_2ns 89.3 | cm2_2ns 17.2 |
 //                                                 cm3_2ns 49.8 | cm4_2ns 0.8 | q_2ns 0.4 | f_2ns 0.4
 //     four Merkle trees                     4.3
-//     constant polynomials, base domain    24.2   (persistent per Starks: uploaded once, not per proof)
+//     constant polynomials, base domain    14.6   (218 of them; persistent per Starks: uploaded once, not per proof)
 //   and nothing else of size: like the reference (starks.cpp:52 lends p_cm2_2ns, :102-104 reuses cm3_2ns) sections that are not live
 //   yet, or no longer, serve as scratch --
 //     stage 1 LDE scratch  = the cm2_2ns | cm3_2ns regions         stage 3 LDE scratch = cm1_n | cm2_n (their last reader, step3, has run)
 //     stage 2 LDE scratch  = the cm3_2ns region                    stages 4, 5, FRI    = the whole base-domain part [0, cm1_2ns): the extended
-//   constant polynomials are RE-EXTENDED there from the resident base-domain ones (an LDE of nConstants columns, ~0.1 s at zkEVM size,
-//   instead of 48 GB over PCIe per proof; the constant TREE is only opened at the query points, from the mapped file), next to
+//   constant polynomials are RE-EXTENDED there from the resident base-domain ones (an LDE of nConstants columns, 68 ms at zkEVM size,
+//   instead of 29 GB over PCIe per proof; the constant TREE is only opened at the query points, from the mapped file), next to
 //   x_2ns, the quotient's coefficient buffers, LEv / LpEv, xDivXSubXi / xDivXSubWXi and the FRI polynomials.
 //   A STARK whose base-domain part is smaller than that (the recursive ones) gets the difference as extra arena.
 //
