@@ -46,8 +46,9 @@ def arg_parser():
     ap.add_argument("--ext-bits", type=int, default=1, help="log2 of the blow-up factor (zkEVM 1; c12a / recursive1 / recursive2: 3)")
     ap.add_argument("--qdeg", type=int, default=2, help="chunks of the quotient polynomial: cm4 has 3 * qdeg columns (recursive STARKs: 7)")
     ap.add_argument("--fri-steps", type=int, nargs="*", default=None, help="FRI layer sizes in bits (default: nBitsExt, then -5, -5, -4, -4)")
-    ap.add_argument("--shape", choices=("zkevm", "recursive1"), default="zkevm",
-                    help="recursive1: the shape the golden proofs testvectors/aggregatedProof/recursive1.zkin.proof_*.json imply (2^17 rows, blow-up 8, "
+    ap.add_argument("--shape", choices=("zkevm", "recursive1", "c12a", "batch"), default="zkevm",
+                    help="c12a: bench_starks.C12A; batch: zkevm, c12a and recursive1 one after the other (genBatchProof's three proofs); "
+                         "recursive1: the shape the golden proofs testvectors/aggregatedProof/recursive1.zkin.proof_*.json imply (2^17 rows, blow-up 8, "
                          "18 / 0 / 39 / 21 columns, 52 constants, 118 evaluations, 43 queries, FRI 20/16/12/9/6); sets every size argument")
     ap.add_argument("--step42-generic", action="store_true",
                     help="step42ns from the r02 generator defaults instead of the parameters fitted to the real program's statistics "
@@ -72,11 +73,21 @@ RECURSIVE1 = ["--log-n", "17", "--ext-bits", "3", "--qdeg", "7", "--widths", "18
               "--field-ops", "0", "201", "1761", "3483", "463"]
 
 
+# c12a (the STARK that wraps the zkEVM proof's verifier circuit, prover.cpp:560-600): the map read off c12a.chelpers.*.cpp as for recursive1
+# (2^20 rows, blow-up 4, 18 / 0 / 78 / 12 columns, 52 constants, 146 evaluations; programs of 205 / 1 916 / 3 556 / 603 operations); its
+# starkStruct is not in the tree: 64 queries and FRI 22/18/14/10/6 are ASSUMED (blow-up 4 needs about twice recursive1's 43 queries)
+C12A = ["--log-n", "20", "--ext-bits", "2", "--qdeg", "4", "--widths", "18", "0", "78", "--tmpexp", "14", "--n-const", "52", "--n-evals", "146",
+        "--n-queries", "64", "--n-lookups", "0", "0", "--n-products", "1", "--fri-steps", "22", "18", "14", "10", "6",
+        "--field-ops", "0", "205", "1916", "3556", "603"]
+
+
 def parse(argv=None):
     ap = arg_parser()
     args = ap.parse_args(argv)
     if args.shape == "recursive1":
         args = ap.parse_args(RECURSIVE1 + (list(argv) if argv is not None else sys.argv[1:]))
+    if args.shape == "c12a":
+        args = ap.parse_args(C12A + (list(argv) if argv is not None else sys.argv[1:]))
     return args
 
 
@@ -229,10 +240,26 @@ def compiled_programs(args, shard=None):
 
 
 def main():
+    argv = sys.argv[1:]
+    if "--shape" in argv and argv[argv.index("--shape") + 1] == "batch":
+        # genBatchProof's three Starks::genProof calls (prover.cpp:541 zkEVM, :577 c12a, :611 recursive1) one after the other in ONE process,
+        # as the prover runs them: they share the process's HBM arena like they share pAddress in the reference
+        k = argv.index("--shape")
+        rest = argv[:k] + argv[k + 2:]
+        outs = [run(parse(["--shape", sh] + rest)) for sh in ("zkevm", "c12a", "recursive1")]
+        print(json.dumps({"metric": "the three Starks::genProof calls of genBatchProof (zkEVM, c12a, recursive1 shapes), one process, one MI355X", "unit": "ms",
+                          "value": sum(o["value"] for o in outs), "higher_is_better": False, "n_gpus": 1,
+                          "starks": {sh: {"genproof_ms": o["value"], "workload": o["config"]["workload"], "peak_hbm_gb": o["hbm"]["peak_hbm_gb"], "checks": o["checks"]}
+                                     for sh, o in zip(("zkevm", "c12a", "recursive1"), outs)}, "dtype": "u64", "data": "synthetic"}))
+        return
     args = parse()
     if args.precompile is not None:
         compiled_programs(args, tuple(args.precompile))
         return
+    print(json.dumps(run(args)))
+
+
+def run(args):
     import torch
     import mi_stark
     import glo                     # the oracle: only in the checks after the timed proofs
@@ -401,8 +428,8 @@ def main():
                    "fits_one_gpu": bool(total_hbm - min_free < total_hbm)},
            "setup_s": {"inputs": t_inputs, "starks_ctor_incl_const_upload": t_create, "per_row_steps_library_build": t_steps_lib},
            "checks": checks, "dtype": "u64", "data": "synthetic"}
-    print(json.dumps(out))
     L.mis_destroy(h)
+    return out
 
 
 def _check_row42(glo, prog, got, r, NE, off, cols, n_const, chal, publics, zh, nbits_ext, want):

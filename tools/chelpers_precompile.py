@@ -27,6 +27,7 @@ STARKS_CONFIGS = [
     ["--log-n", "12", "--widths", "37", "20", "40", "--tmpexp", "60", "--n-const", "11", "--n-evals", "24", "--n-queries", "16", "--n-lookups", "2", "2",
      "--n-products", "6", "--field-ops", "200", "300", "400", "1500", "700"],
     ["--shape", "recursive1"],
+    ["--shape", "c12a"],
 ]
 
 
