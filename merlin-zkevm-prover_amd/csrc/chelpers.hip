@@ -457,11 +457,16 @@ static int decode(int step, const uint64_t *ops, uint64_t nops, const uint64_t *
             st.b = dst;
             out.push_back(st);
             const bool sh = r.dst == K_DPOLS;
-            for (int j = 0; j < r.ddim; j++)
-                if (read_elems.count({dst.v[0] + (uint64_t)j, sh ? dst.v[3] : dst.v[1], sh ? dst.v[1] : 0})) {
+            // (at ANY row shift: on the device another row's store would race with that read; in the reference's row-by-row loop it sees
+            // what an earlier or a later iteration left there -- no generated program does it, host/steps_tracer.hpp refuses it as well)
+            for (int j = 0; j < r.ddim; j++) {
+                const uint64_t elem = dst.v[0] + (uint64_t)j, stride = sh ? dst.v[3] : dst.v[1];
+                auto it = read_elems.lower_bound({elem, stride, 0});
+                if (it != read_elems.end() && (*it)[0] == elem && (*it)[1] == stride) {
                     mi_set_error("mi_chelpers_compile: the program overwrites a polynomial element it has read before");
                     return MI_ERR_INVALID;
                 }
+            }
             stored[{dst.v[0], sh ? dst.v[3] : dst.v[1], sh ? dst.v[1] : 0, (uint64_t)r.ddim}] = st.a;
         }
         return MI_OK;

@@ -121,7 +121,16 @@ public:
         for (int j = 0; j < rdim; j++) written.push_back({S->offset + col + (uint64_t)j, S->cols});
     }
     // after the traced call has returned
-    void finish() { if (error.empty()) settle(); }
+    void finish()
+    {
+        if (!error.empty()) return;
+        settle();
+        // a column the step writes may not be read from memory at all -- not even BEFORE the write in program order: in the reference's
+        // row-by-row loop such a read sees what an earlier or a later iteration left there, on the device it would race with another row's store
+        for (const Col &r : memoryReads)
+            for (const Col &w : written)
+                if (w.stride == r.stride && w.elem == r.elem) { fail("a polynomial the step writes is also read from memory (another row's value)"); return; }
+    }
 
 private:
     struct Val { uint64_t slot; int dim; uint64_t v[3]; bool settled; };
@@ -131,7 +140,7 @@ private:
     std::unordered_map<const uint64_t *, Val> vals; // address of a value the function has written -> which temporary it is
     const uint64_t *pending = nullptr;
     struct Col { uint64_t elem, stride; };
-    std::vector<Col> written;
+    std::vector<Col> written, memoryReads; // columns (first-row element index, row stride) stored / read from polynomial memory
 
     void fail(const char *what)
     {
@@ -214,6 +223,7 @@ private:
                     return false;
                 }
             const uint64_t shift = (prow + L.rows - row) % L.rows;
+            for (int j = 0; j < dim; j++) memoryReads.push_back({S->offset + col + (uint64_t)j, S->cols});
             if (shift == 0) { o.kind = dim == 3 ? MI_CHP_POL3 : MI_CHP_POL; o.v[0] = S->offset + col; o.v[1] = S->cols; }
             else { o.kind = dim == 3 ? MI_CHP_POL3S : MI_CHP_POLS; o.v[0] = S->offset + col; o.v[1] = shift; o.v[2] = L.rows; o.v[3] = S->cols; }
             return true;

@@ -141,20 +141,26 @@ void GenSteps::step3_first(StepsParams &params, uint64_t i) {
      Goldilocks::mul(v, params.pols[2 + ((i + 1)%%%d)*5], t); // ... and reads it at the next row
      Goldilocks::copy(params.pols[3 + i*5], v);
 }
+void GenSteps::step3prev_first(StepsParams &params, uint64_t i) {
+     Goldilocks::Element t;
+     Goldilocks::add(t, params.pols[4 + ((i + 1)%%%d)*5], params.pols[1 + i*5]); // reads cm1_n column 4 at the next row ...
+     Goldilocks::copy(params.pols[4 + i*5], t);                                  // ... and writes it afterwards
+}
 #define E(s) void GenSteps::s(StepsParams &, uint64_t) {}
-E(step2prev_first) E(step2prev_i) E(step2prev_last) E(step3prev_first) E(step3prev_i) E(step3prev_last) E(step3_i) E(step3_last)
+E(step2prev_first) E(step2prev_i) E(step2prev_last) E(step3prev_i) E(step3prev_last) E(step3_i) E(step3_last)
 E(step42ns_i) E(step42ns_last) E(step52ns_i) E(step52ns_last)
 """
     nbits = 5
     lay = ms.Layout(1 << nbits, 2 << nbits)
     src = tmp_path / "bad_steps.cpp"
-    src.write_text(body % (lay.off["cm1_2ns"], lay.off["cm1_2ns"] + 1, 1 << nbits))
+    src.write_text(body % (lay.off["cm1_2ns"], lay.off["cm1_2ns"] + 1, 1 << nbits, 1 << nbits))
     layout = [nbits, nbits + 1, 4, 2, 4] + [ms.Layout.COLS[k] for k in ms.Layout.ORDER]
     r = run_driver(tmp_path, [str(src)], "genSteps.hpp", "GenSteps", layout, extra_inc=["-I", str(tmp_path)])
     assert r.returncode == 1
     assert re.search(r"step42ns: TRACE FAILED: .*operators or value-returning forms", r.stdout)
     assert re.search(r"step52ns: TRACE FAILED: .*does not compute the same program at row 0 and at the last row", r.stdout)
     assert re.search(r"step3: TRACE FAILED: .*a polynomial the step writes is read back at another row", r.stdout)
+    assert re.search(r"step3prev: TRACE FAILED: .*a polynomial the step writes is also read from memory", r.stdout)
 
 
 # the reference's generated per-row files; polynomial maps read off their offsets / strides (see the module docstring)
