@@ -177,46 +177,57 @@ __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial
                                                        uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
                                                        const u64 *__restrict__ lev, const u64 *__restrict__ lpev)
 {
+    // LEv / LpEv of 64 rows at a time through LDS: the same three words for every lane, which as vector loads cost an address-path slot
+    // each (12 a four-row step against 4 for the polynomial values: the kernel was bound there, not by HBM or issue)
+    constexpr uint32_t CH = 64, LW = CH * 3 + 2; // (+2: the two tables' rows fall into different banks)
+    __shared__ u64 sL[2][LW];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint64_t k0 = (uint64_t)blockIdx.y * rows_per_slice;
     uint64_t k1 = k0 + rows_per_slice;
     if (k1 > n) k1 = n;
-    if (i >= n_evals) return;
-    const EvDesc d = desc[i];
-    const u64 *L = d.prime ? lpev : lev;
+    const bool active = i < n_evals;
+    EvDesc d = {nullptr, 0, 1, 0, 0, 0};
+    if (active) d = desc[i];
+    const u64 *sl = sL[d.prime ? 1 : 0];
     // the slice's sum of products unreduced in limb accumulators (chelpers_acc.h: a multiply-accumulate is 8 instructions, no reduction),
     // reduced once at the end: exact integer sums, so the evaluations are the same field elements
     chpa::Acc r0, r1, r2;
     chpa::acc_set(r0, 0); chpa::acc_set(r1, 0); chpa::acc_set(r2, 0);
-    if (d.dim == 1) {
-        // four rows' loads issued together: a wave has one 512-byte row segment per load in flight, and latency, not bandwidth, is what
-        // a one-load-at-a-time loop runs into
-        uint64_t k = k0;
-        const uint64_t step = d.stride << ext_bits;
-        const u64 *p = d.ptr + k0 * step;
-        for (; k + 4 <= k1; k += 4, p += 4 * step) {
-            const u64 v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
-            const u64 *l = L + k * 3;
-            u64 w[12];
-#pragma unroll
-            for (int j = 0; j < 12; j++) w[j] = l[j];
-            chpa::acc_mac(r0, v0, w[0]); chpa::acc_mac(r1, v0, w[1]); chpa::acc_mac(r2, v0, w[2]);
-            chpa::acc_mac(r0, v1, w[3]); chpa::acc_mac(r1, v1, w[4]); chpa::acc_mac(r2, v1, w[5]);
-            chpa::acc_mac(r0, v2, w[6]); chpa::acc_mac(r1, v2, w[7]); chpa::acc_mac(r2, v2, w[8]);
-            chpa::acc_mac(r0, v3, w[9]); chpa::acc_mac(r1, v3, w[10]); chpa::acc_mac(r2, v3, w[11]);
+    const uint64_t step = d.stride << ext_bits;
+    for (uint64_t kc = k0; kc < k1; kc += CH) { // trip count is uniform over the workgroup
+        const uint32_t cnt = (uint32_t)(k1 - kc < CH ? k1 - kc : CH);
+        __syncthreads(); // the previous rows' readers are done
+        for (uint32_t e = threadIdx.x; e < 2 * CH * 3; e += 256) {
+            const uint32_t t = e >= CH * 3, j = e - t * CH * 3;
+            sL[t][j] = j < cnt * 3 ? (t ? lpev : lev)[kc * 3 + j] : 0;
         }
-        for (; k < k1; k++, p += step) {
-            const u64 v = p[0];
-            chpa::acc_mac(r0, v, L[k * 3]);
-            chpa::acc_mac(r1, v, L[k * 3 + 1]);
-            chpa::acc_mac(r2, v, L[k * 3 + 2]);
-        }
-    } else {
-        for (uint64_t k = k0; k < k1; k++) {
-            const u64 *b = d.ptr + (k << ext_bits) * d.stride;
-            chpa::acc_mul33(r0, r1, r2, b[0], b[1], b[2], L[k * 3], L[k * 3 + 1], L[k * 3 + 2]);
+        __syncthreads();
+        if (!active) continue;
+        const u64 *p = d.ptr + kc * step;
+        if (d.dim == 1) {
+            // four rows' loads issued together: a wave has one 512-byte row segment per load in flight, and latency, not bandwidth, is
+            // what a one-load-at-a-time loop runs into
+            uint32_t r = 0;
+            for (; r + 4 <= cnt; r += 4, p += 4 * step) {
+                const u64 v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
+                const u64 *w = sl + r * 3;
+                chpa::acc_mac(r0, v0, w[0]); chpa::acc_mac(r1, v0, w[1]); chpa::acc_mac(r2, v0, w[2]);
+                chpa::acc_mac(r0, v1, w[3]); chpa::acc_mac(r1, v1, w[4]); chpa::acc_mac(r2, v1, w[5]);
+                chpa::acc_mac(r0, v2, w[6]); chpa::acc_mac(r1, v2, w[7]); chpa::acc_mac(r2, v2, w[8]);
+                chpa::acc_mac(r0, v3, w[9]); chpa::acc_mac(r1, v3, w[10]); chpa::acc_mac(r2, v3, w[11]);
+            }
+            for (; r < cnt; r++, p += step) {
+                const u64 v = p[0];
+                chpa::acc_mac(r0, v, sl[r * 3]);
+                chpa::acc_mac(r1, v, sl[r * 3 + 1]);
+                chpa::acc_mac(r2, v, sl[r * 3 + 2]);
+            }
+        } else {
+            for (uint32_t r = 0; r < cnt; r++, p += step)
+                chpa::acc_mul33(r0, r1, r2, p[0], p[1], p[2], sl[r * 3], sl[r * 3 + 1], sl[r * 3 + 2]);
         }
     }
+    if (!active) return;
     u64 *o = partial + ((uint64_t)blockIdx.y * n_evals + i) * 3;
     o[0] = gl::canon(chpa::acc_reduce(r0)); o[1] = gl::canon(chpa::acc_reduce(r1)); o[2] = gl::canon(chpa::acc_reduce(r2));
 }
