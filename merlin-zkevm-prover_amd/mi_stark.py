@@ -405,6 +405,43 @@ class ChelpersProgram:
         _check(lib().mi_chelpers_stats(self.h, _hp(st)))
         self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}
 
+    # operand kinds / operation classes of mi_chelpers_compile_micro (mi_stark.h: MI_CHP_*)
+    K = dict(NONE=0, T1=1, T3=2, POL=3, POLS=4, NUM=5, CONST=6, CONSTS=7, CHAL=8, PUB=9, POL3=10, POL3S=11, X=12, ZHINV=13, Q=14, EVAL=15, XD=16, XDW=17,
+             DPOL=18, DPOLS=19)
+    C = dict(ADD=0, SUB=1, MUL=2, COPY=3, STOREQ=4, STOREF=5, STOREP=6)
+
+    @classmethod
+    def from_microops(cls, ctx, microops, sections=(), n_const=0, nrows_ext=0, step=MI_CHELPERS_STEP42NS):
+        """The program as field operations (mi_chelpers_compile_micro: what host/steps_tracer.hpp records from per-row Steps code):
+        microops = [(class, dst kind, dst slot, (kind, [words]), (kind, [words]) or None)], kinds / classes by name (K / C) or number."""
+        class Operand(ctypes.Structure):
+            _fields_ = [("kind", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("v", ctypes.c_uint64 * 4)]
+
+        class MicroOp(ctypes.Structure):
+            _fields_ = [("cls", ctypes.c_uint32), ("dst_kind", ctypes.c_uint32), ("dst_slot", ctypes.c_uint64), ("a", Operand), ("b", Operand)]
+
+        def num(table, v):
+            return table[v] if isinstance(v, str) else int(v)
+        arr = (MicroOp * max(len(microops), 1))()
+        for m, (c_, dk, slot, a, b) in zip(arr, microops):
+            m.cls, m.dst_kind, m.dst_slot = num(cls.C, c_), num(cls.K, dk), int(slot)
+            for o, src in ((m.a, a), (m.b, b)):
+                if src is None:
+                    continue
+                o.kind = num(cls.K, src[0])
+                for j, w in enumerate(src[1]):
+                    o.v[j] = int(w)
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        sec = np.ascontiguousarray(np.array(list(sections), dtype=np.uint64).reshape(-1, 3))
+        self.h = ctypes.c_void_p()
+        _check(lib().mi_chelpers_compile_micro(ctx.h if ctx is not None else None, ctypes.byref(self.h), ctypes.c_int(step), arr, u64(len(microops)),
+                                               _hp(sec.reshape(-1)) if sec.size else None, u64(sec.shape[0]), u64(n_const), u64(nrows_ext)))
+        st = np.zeros(16, dtype=np.uint64)
+        _check(lib().mi_chelpers_stats(self.h, _hp(st)))
+        self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}
+        return self
+
     NATIVE_STAT_NAMES = ("kernels", "code_bytes", "build_ms", "cache_hits", "estimated_valu_per_row", "spill_words_moved_per_row",
                          "horner_chain_steps", "constant_words")
 

@@ -65,6 +65,47 @@ def test_translated_program_matches_oracle_on_the_host(seed):
     prog.close()
 
 
+def _microops42(ops, args):
+    """A step42ns table as the field operations mi_chelpers_compile_micro takes (what host/steps_tracer.hpp records from per-row code)."""
+    K = {cp.T1: "T1", cp.T3: "T3", cp.POL: "POL", cp.POLS: "POLS", cp.NUM: "NUM", cp.CONST: "CONST", cp.CONSTS: "CONSTS", cp.CHAL: "CHAL", cp.PUB: "PUB",
+         cp.POL3: "POL3", cp.POL3S: "POL3S", cp.X: "X"}
+    out = []
+    for (o, d, slot, srcs) in cp.decode(ops, args)[0]:
+        a = (K[srcs[0][0]], srcs[0][1])
+        if o == 69:
+            out.append(("STOREQ", "Q", 0, a, ("ZHINV", [])))
+            continue
+        b = (K[srcs[1][0]], srcs[1][1]) if len(srcs) > 1 else None
+        out.append((cp._cls42(o).upper(), K[d], slot, a, b))
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_a_program_given_as_field_operations_matches_its_table(seed):
+    """mi_chelpers_compile_micro: the same program handed over as field operations instead of a table computes the same rows (translated
+    and lowered host executors), and malformed operations are refused."""
+    import mi_stark
+    nrows = 64
+    ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(seed, nrows)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step42ns(ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv, want, 0, nrows)
+    mops = _microops42(ops, args)
+    prog = mi_stark.ChelpersProgram.from_microops(None, mops, sections=_synthetic_sections(nrows), n_const=n_const, nrows_ext=nrows)
+    got = np.zeros(nrows * 3, dtype=np.uint64)
+    prog.run_host(pols, cpols, n_const, chal, pub, x, xs, zhinv, got, np.arange(nrows))
+    assert np.array_equal(got, want) and want.any()
+    assert prog.stats["field_ops"] == len(mops)
+    prog.close()
+    bad = list(mops)
+    bad[3] = ("MUL", "T1", 5, ("CHAL", [0]), ("T1", [0]))            # an extension operand into a base-field destination
+    with pytest.raises(mi_stark.MiStarkError, match="extension operand needs an extension destination"):
+        mi_stark.ChelpersProgram.from_microops(None, bad)
+    with pytest.raises(mi_stark.MiStarkError, match="operand kind out of range"):
+        mi_stark.ChelpersProgram.from_microops(None, [("ADD", "T1", 0, (77, [0]), ("NUM", [1]))])
+    with pytest.raises(mi_stark.MiStarkError, match="STOREP"):
+        mi_stark.ChelpersProgram.from_microops(None, [("COPY", "T1", 0, ("NUM", [1]), None), ("STOREP", "DPOL", 0, ("T1", [0]), ("DPOL", [0, 5]))])   # step42ns stores q only
+
+
 def test_compile_rejects_malformed_tables():
     import mi_stark
     ops, args, *_ = _synthetic_case(5, 16, passes=1)
