@@ -332,23 +332,46 @@ int launch_geom_seq3(mi_ctx *ctx, u64 *out, uint64_t n, const u64 ratio[3])
     return MI_OK;
 }
 
-// out[k] = x[k] * (x[k] - xi)^-1, x in the base field, xi in the extension
+// out[k] = x[k] * (x[k] - xi)^-1, x in the base field, xi in the extension.  A thread's four elements (a grid stride apart, so the
+// accesses stay coalesced) share ONE inversion, Montgomery's trick as in the reference's batchInverse (polinomial.hpp:698-720): exact
+// arithmetic, the same field elements; a zero denominator (inverse defined as 0) is taken out of the chain.
 __global__ __launch_bounds__(256) void k_x_div_x_sub(u64 *out, const u64 *x, uint64_t n, E3 xi)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const u64 xv = gl::canon(x[i]);
-    const E3 d = {{gl::sub(xv, xi.v[0]), gl::neg(xi.v[1]), gl::neg(xi.v[2])}};
-    const E3 r = gl::e3_mul1(gl::e3_inv(d), xv);
-    out[i * 3] = r.v[0]; out[i * 3 + 1] = r.v[1]; out[i * 3 + 2] = r.v[2];
+    constexpr int XB = 4;
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    u64 xv[XB];
+    E3 d[XB], pre[XB], acc = {{1, 0, 0}};
+    bool dead[XB];
+#pragma unroll
+    for (int j = 0; j < XB; j++) {
+        const uint64_t i = t + (uint64_t)j * stride;
+        xv[j] = i < n ? gl::canon(x[i]) : 0;
+        d[j] = E3{{gl::sub(xv[j], xi.v[0]), gl::neg(xi.v[1]), gl::neg(xi.v[2])}};
+        dead[j] = i >= n || (d[j].v[0] | d[j].v[1] | d[j].v[2]) == 0;
+        if (dead[j]) d[j] = E3{{1, 0, 0}};
+        pre[j] = acc;
+        acc = gl::e3_mul(acc, d[j]);
+    }
+    E3 inv = gl::e3_inv(acc);
+#pragma unroll
+    for (int j = XB - 1; j >= 0; j--) {
+        const uint64_t i = t + (uint64_t)j * stride;
+        const E3 dinv = gl::e3_mul(inv, pre[j]);
+        inv = gl::e3_mul(inv, d[j]);
+        if (i < n) {
+            const E3 r = dead[j] ? E3{{0, 0, 0}} : gl::e3_mul1(dinv, xv[j]);
+            out[i * 3] = r.v[0]; out[i * 3 + 1] = r.v[1]; out[i * 3 + 2] = r.v[2];
+        }
+    }
 }
 
 int launch_x_div_x_sub(mi_ctx *ctx, u64 *out, const u64 *x, uint64_t n, const u64 xi[3])
 {
     if (!n) return MI_OK;
     const E3 e = {{gl::canon(xi[0]), gl::canon(xi[1]), gl::canon(xi[2])}};
-    MI_REQUIRE_1D_GRID(n);
-    hipLaunchKernelGGL(k_x_div_x_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, x, n, e);
+    const uint64_t threads = (n + 3) / 4;
+    MI_REQUIRE_1D_GRID(threads);
+    hipLaunchKernelGGL(k_x_div_x_sub, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, out, x, n, e);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

@@ -687,6 +687,21 @@ def test_q_split_batch_inverse_tables(ctx):
         den = np.array([(int(xs[k]) - int(xi[0])) % P, (-int(xi[1])) % P, (-int(xi[2])) % P], dtype=np.uint64)
         want = glo.e3_mul(glo.e3_inv(den), np.array([xs[k], 0, 0], dtype=np.uint64))
         assert np.array_equal(got[k], want)
+    # (four elements of a thread share one inversion) every row, sizes that leave a thread's batch ragged, and a denominator that is zero:
+    # xi in the base field and equal to one of the x (its inverse is defined as 0, like Goldilocks3::inv's)
+    for n_ in (1, 2, 3, 5, 257, 1023, 4096):
+        for xi_ in (xi, np.array([xs[min(2, n_ - 1)], 0, 0], dtype=np.uint64)):
+            o = ctx.empty(n_ * 3 + 3)
+            o.fill_(-1)
+            ctx.x_div_x_sub(o, ctx.to_device(xs[:n_]), n_, xi_)
+            got = ctx.to_host(o)
+            assert (got[-3:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+            den = np.zeros((n_, 3), dtype=np.uint64)
+            den[:, 0] = [(int(v) - int(xi_[0])) % P for v in xs[:n_]]
+            den[:, 1], den[:, 2] = (-int(xi_[1])) % P, (-int(xi_[2])) % P
+            inv = glo.batch_inverse3(den.reshape(-1)).reshape(-1, 3)
+            want = np.array([glo.e3_mul(inv[k], np.array([xs[k], 0, 0], dtype=np.uint64)) for k in range(n_)], dtype=np.uint64)
+            assert np.array_equal(got[:-3].reshape(-1, 3), want), (n_, xi_)
 
 
 def test_evmap_matches_oracle(ctx):
