@@ -275,21 +275,40 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned
     return MI_OK;
 }
 
-// ---- element-wise inverse in F_p^3 (res == src allowed)
+// ---- element-wise inverse in F_p^3 (res == src allowed): Polinomial::batchInverse / batchInverseParallel (polinomial.hpp:612-720).  As
+// there, a run of elements shares one inversion (Montgomery's trick; here four elements of a thread, a grid stride apart); inv(0) = 0.
 __global__ __launch_bounds__(256) void k_batch_inverse3(u64 *res, const u64 *src, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const E3 a = {{gl::canon(src[i * 3]), gl::canon(src[i * 3 + 1]), gl::canon(src[i * 3 + 2])}};
-    const E3 r = gl::e3_inv(a);
-    res[i * 3] = r.v[0]; res[i * 3 + 1] = r.v[1]; res[i * 3 + 2] = r.v[2];
+    constexpr int XB = 4;
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    E3 d[XB], pre[XB], acc = {{1, 0, 0}};
+    bool dead[XB];
+#pragma unroll
+    for (int j = 0; j < XB; j++) {
+        const uint64_t i = t + (uint64_t)j * stride;
+        d[j] = E3{{1, 0, 0}};
+        if (i < n) d[j] = E3{{gl::canon(src[i * 3]), gl::canon(src[i * 3 + 1]), gl::canon(src[i * 3 + 2])}};
+        dead[j] = (d[j].v[0] | d[j].v[1] | d[j].v[2]) == 0;
+        if (dead[j]) d[j] = E3{{1, 0, 0}};
+        pre[j] = acc;
+        acc = gl::e3_mul(acc, d[j]);
+    }
+    E3 inv = gl::e3_inv(acc);
+#pragma unroll
+    for (int j = XB - 1; j >= 0; j--) {
+        const uint64_t i = t + (uint64_t)j * stride;
+        const E3 r = dead[j] ? E3{{0, 0, 0}} : gl::e3_mul(inv, pre[j]);
+        inv = gl::e3_mul(inv, d[j]);
+        if (i < n) { res[i * 3] = r.v[0]; res[i * 3 + 1] = r.v[1]; res[i * 3 + 2] = r.v[2]; }
+    }
 }
 
 int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n)
 {
     if (!n) return MI_OK;
-    MI_REQUIRE_1D_GRID(n);
-    hipLaunchKernelGGL(k_batch_inverse3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, res, src, n);
+    const uint64_t threads = (n + 3) / 4;
+    MI_REQUIRE_1D_GRID(threads);
+    hipLaunchKernelGGL(k_batch_inverse3, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, res, src, n);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

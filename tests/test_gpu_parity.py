@@ -667,6 +667,13 @@ def test_q_split_batch_inverse_tables(ctx):
     d = ctx.to_device(src)
     ctx.batch_inverse3(d, d, 999)
     assert np.array_equal(ctx.to_host(d), glo.batch_inverse3(src))
+    for n_ in (1, 2, 3, 4, 5, 1025, 70000):                          # (four elements of a thread share one inversion) ragged sizes, zeros anywhere
+        src = glo.rand_fe(rng, n_ * 3, canonical=False)
+        src.reshape(-1, 3)[rng.integers(0, n_, 3)] = 0
+        d = ctx.to_device(np.concatenate([src, np.full(3, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)]))
+        ctx.batch_inverse3(d, d, n_)
+        got = ctx.to_host(d)
+        assert np.array_equal(got[:-3], glo.batch_inverse3(src)) and (got[-3:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all(), n_
     w = glo.lib().glo_w(13)
     out = ctx.empty(1 << 13)
     ctx.geom_seq(out, 1 << 13, 49, w)                                 # x_2ns (starks.hpp:154-159)
