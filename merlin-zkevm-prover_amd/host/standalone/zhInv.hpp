@@ -7,16 +7,16 @@
 #include "mi_runtime.hpp"
 class ZhInv
 {
-    std::vector<Goldilocks::Element> ZHInv;
+    std::vector<Goldilocks::Element> table_;
 
 public:
     ZhInv() {}
     ZhInv(uint64_t nBits, uint64_t nBitsExt)
     {
         if (nBits == 0 || nBitsExt == 0) return;
-        ZHInv.resize(1ULL << (nBitsExt - nBits));
-        mi::check(mi_zhinv(mi::ctx(), (uint64_t *)ZHInv.data(), (unsigned)nBits, (unsigned)nBitsExt), "ZhInv::ZhInv");
+        table_.resize(1ULL << (nBitsExt - nBits));
+        mi::check(mi_zhinv(mi::ctx(), (uint64_t *)table_.data(), (unsigned)nBits, (unsigned)nBitsExt), "ZhInv::ZhInv");
     }
-    Goldilocks::Element zhInv(int64_t i) { return ZHInv[i % ZHInv.size()]; }
+    Goldilocks::Element zhInv(int64_t i) { return table_[i % table_.size()]; }
 };
 #endif

@@ -6,7 +6,7 @@
 #include "goldilocks_base_field.hpp"
 class ZhInv
 {
-    std::vector<Goldilocks::Element> ZHInv;
+    std::vector<Goldilocks::Element> table_;
 
 public:
     ZhInv() {}
@@ -16,10 +16,10 @@ public:
         Goldilocks::Element sn = Goldilocks::shift(), w = Goldilocks::one();
         for (uint64_t i = 0; i < nBits; i++) sn = Goldilocks::square(sn);
         for (uint64_t i = 0; i < (1ULL << ext); i++) {
-            ZHInv.push_back(Goldilocks::inv(Goldilocks::sub(Goldilocks::mul(sn, w), Goldilocks::one())));
+            table_.push_back(Goldilocks::inv(Goldilocks::sub(Goldilocks::mul(sn, w), Goldilocks::one())));
             w = Goldilocks::mul(w, Goldilocks::w(ext));
         }
     }
-    Goldilocks::Element zhInv(int64_t i) { return ZHInv[i % ZHInv.size()]; }
+    Goldilocks::Element zhInv(int64_t i) { return table_[i % table_.size()]; }
 };
 #endif
