@@ -1,20 +1,22 @@
 // constant_pols_starks.hpp (standalone stand-in) -- the view of the constant polynomials the reference hands to the Steps
-// (constant_pols_starks.hpp:8-29): numPols columns, element (pol, row) at address[pol + row * numPols].
+// (interface of constant_pols_starks.hpp:8-29): a row-major matrix of `cols` columns, polynomial p at row r is base[r * cols + p].
 #ifndef CONSTANT_POLS_STARKS_HPP
 #define CONSTANT_POLS_STARKS_HPP
 #include <cstdint>
 #include "goldilocks_base_field.hpp"
 class ConstantPolsStarks
 {
-    void *_pAddress;
-    uint64_t _degree, _numPols;
-
 public:
-    ConstantPolsStarks(void *pAddress, uint64_t degree, uint64_t numPols) : _pAddress(pAddress), _degree(degree), _numPols(numPols) {}
-    uint64_t numPols(void) { return _numPols; }
-    void *address(void) { return _pAddress; }
-    uint64_t degree(void) { return _degree; }
-    uint64_t size(void) { return _degree * _numPols * sizeof(Goldilocks::Element); }
-    Goldilocks::Element &getElement(uint64_t pol, uint64_t evaluation) { return ((Goldilocks::Element *)_pAddress)[pol + evaluation * _numPols]; }
+    ConstantPolsStarks(void *matrix, uint64_t rows, uint64_t cols) : base((Goldilocks::Element *)matrix), rows_(rows), cols_(cols) {}
+    // the reference's accessors, by its names
+    Goldilocks::Element &getElement(uint64_t pol, uint64_t evaluation) { return base[evaluation * cols_ + pol]; }
+    void *address() { return base; }
+    uint64_t numPols() { return cols_; }
+    uint64_t degree() { return rows_; }
+    uint64_t size() { return rows_ * cols_ * sizeof(Goldilocks::Element); }
+
+private:
+    Goldilocks::Element *base;
+    uint64_t rows_, cols_;
 };
 #endif

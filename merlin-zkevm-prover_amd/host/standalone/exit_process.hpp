@@ -1,6 +1,8 @@
-// exit_process.hpp (standalone stand-in) -- src/utils/exit_process.cpp:7-22 without the call-stack print and the 5 s grace sleep
+// exit_process.hpp (standalone stand-in) -- how the reference's call sites give up (src/utils/exit_process.cpp:7-22), without its
+// call-stack print and its five-second grace period: the status the reference exits with, at once.
+// (the reference's own guard: where its header was seen first, this one stands back)
 #ifndef EXIT_PROCESS_HPP
 #define EXIT_PROCESS_HPP
 #include <cstdlib>
-inline void exitProcess(void) { std::exit(-1); }
+[[noreturn]] inline void exitProcess() { std::exit(-1); }
 #endif

@@ -68,7 +68,7 @@ int main(int argc, char **argv)
     for (uint64_t k = 0; k < 8; k++) for (int d = 0; d < 3; d++) challenges[k][d].fe = fe();
     for (uint64_t k = 0; k < nEvals; k++) for (int d = 0; d < 3; d++) evals[k][d].fe = fe();
     for (auto &p : publics) p.fe = fe();
-    ConstantPolsStarks cpN(cN, nConst * N * 8, nConst), cp2(c2, nConst * NExt * 8, nConst);
+    ConstantPolsStarks cpN(cN, N, nConst), cp2(c2, NExt, nConst);
     ZhInv zi(nBits, nBitsExt);
     StepsParams params = {mem, &cpN, &cp2, challenges, x_n, x_2ns, zi, evals, xd, xdw, publics.data(), mem + off[9], mem + off[10]};
     STEPS_CLASS stepsObj;
