@@ -14,8 +14,7 @@
 #include "merkleTreeGL.hpp"
 #include "../../oracle/gl_oracle.h"
 
-// (zkassert.hpp brings the reference's exit_process.hpp, a declaration; its definition lives in a file that needs gmp and json)
-void exitProcess(void) { std::exit(-1); }
+// (zkassert.hpp brings the reference's exit_process.hpp, declarations only: the function comes from the stand-in header, the flag from here)
 bool bExitingProcess = false;
 
 static std::mt19937_64 rng(77);
