@@ -226,6 +226,9 @@ private:
             if (!d_constN) mi::fail("Starks::Starks (constant polynomials)");
             mi::check(mi_copy_h2d(mi::ctx(), d_constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (constant polynomials h2d)");
         }
+        // the proof's HBM now, not inside the first genProof: like the reference, which allocates pAddress when the prover starts
+        // (prover.cpp:99-120).  273 GB of fresh device memory take the driver 5.7 s; a later, larger Starks grows the arena once more.
+        mi::arena().reserve(starkInfo.mapTotalN + 4 * treeElems + scratchElems);
     }
     void hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
     void tracedStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
