@@ -23,7 +23,7 @@
 // per-row code (straight-line calls of exactly these functions) is turned into a program for the device by running it once.
 // cls: 0 add, 1 sub, 2 mul, 3 copy.  The value-returning forms and operators cannot be followed (their results have no address yet):
 // used outside a destination form while a recorder is installed they set `untracked`, and the recorder refuses the function.
-// One predictable branch per operation when no recorder is installed.
+// One predictable branch on a plain global per operation when no recorder is installed.
 struct MiFieldRecorder
 {
     int depth = 0;          // inside a destination form (whose own arithmetic is not the caller's)
@@ -32,6 +32,12 @@ struct MiFieldRecorder
     virtual ~MiFieldRecorder() {}
 };
 inline thread_local MiFieldRecorder *mi_field_recorder = nullptr;
+// set while ANY thread has a recorder installed and tested first: in -fPIC objects (libmi_starks.so, a generated Steps library) a
+// thread_local costs a __tls_get_addr call, which an ordinary run -- MI_STEPS_ON_HOST's row loops, any host code on these headers -- must
+// not pay per field operation; a plain global is one load through the GOT.  (Both variables must unify across shared objects: a Steps
+// library is loaded RTLD_GLOBAL after the library that records it, INTEGRATION.md.)
+inline bool mi_field_recording = false;
+#define MI_FIELD_RECORDER() (__builtin_expect(mi_field_recording, 0) ? mi_field_recorder : (MiFieldRecorder *)nullptr)
 struct MiFieldScope
 {
     MiFieldRecorder *const r;
@@ -41,9 +47,9 @@ struct MiFieldScope
     }
     ~MiFieldScope() { if (__builtin_expect(r != nullptr, 0)) r->depth--; }
 };
-#define MI_FIELD_RECORD(cls, r, rdim, a, adim, b, bdim) MiFieldScope mi_field_scope_(mi_field_recorder, cls, r, rdim, a, adim, b, bdim)
+#define MI_FIELD_RECORD(cls, r, rdim, a, adim, b, bdim) MiFieldScope mi_field_scope_(MI_FIELD_RECORDER(), cls, r, rdim, a, adim, b, bdim)
 #define MI_FIELD_VALUE_FORM() \
-    do { if (__builtin_expect(mi_field_recorder != nullptr, 0) && mi_field_recorder->depth == 0) mi_field_recorder->untracked = true; } while (0)
+    do { if (MiFieldRecorder *mi_r_ = MI_FIELD_RECORDER()) { if (mi_r_->depth == 0) mi_r_->untracked = true; } } while (0)
 
 class Goldilocks
 {

@@ -9,8 +9,10 @@
 // What changes is where the work happens.  The reference keeps every section of StarkInfo's memory map in the host area behind
 // pAddress (zkEVM: 254 GB + a 50 GB buffer) and walks it with OpenMP loops; here genProof keeps a DEVICE IMAGE of that area --
 // same offsets, so the generated constraint programs address it as they address pAddress -- and strings the library's entry points
-// together in the reference's order.  pAddress is read (the witness) and never written; roots, evaluations and the query
-// openings are what returns.
+// together in the reference's order.  With the batched steps (nrowsStepBatch 4 / 8) pAddress is read (the witness) and never
+// written; with per-row steps the caller's functions run on the HOST -- once at row 0 and once at the last row under the recorder,
+// or over every row with MI_STEPS_ON_HOST=1 -- and write those rows of pAddress as they do in the reference.  Roots, evaluations
+// and the query openings are what returns.
 //
 // HBM plan (one arena per process, carved per proof; zkEVM sizes in GB, N = 2^23):
 //     image of pAddress[0, mapTotalN)     254.1   cm1_n 44.6 | cm2_n 8.6 | cm3_n 24.9 | cm4_n 0.4 | tmpExp_n 17.8 | cm1_2ns 89.3 | cm2_2ns 17.2 |
@@ -205,6 +207,16 @@ public:
 
     void genProof(FRIProof &proof, Goldilocks::Element *publicInputs, Steps *steps);
 
+    // Not in the reference: drop the compiled program cached for (step, the address of its opcode table) -- for a caller that REPLACES a
+    // step's tables in place (the reference's tables are constants of the binary and never change)
+    void forgetProgram(int step, const void *opsTable)
+    {
+        auto it = progs.find({step, opsTable});
+        if (it == progs.end()) return;
+        if (it->second) mi_chelpers_free(mi::ctx(), it->second);
+        progs.erase(it);
+    }
+
     // device image of the last proof's polynomial area (valid until the next genProof of any Starks): for checks after the fact.
     // lateOffsets: where the stage-4 re-plan put the extended constant polynomials, xDivXSubXi and xDivXSubWXi (elements from the image's start)
     const uint64_t *deviceImage() const { return mi::arena().base; }
@@ -217,6 +229,7 @@ private:
         pConstPols = new ConstantPolsStarks(pConstPolsAddress, constPolsSize, starkInfo.nConstants);
         pConstPols2ns = new ConstantPolsStarks((uint8_t *)pConstTreeAddress + MERKLEHASHGOLDILOCKS_HEADER_SIZE * sizeof(Goldilocks::Element), NExtended, starkInfo.nConstants);
         mem = (Goldilocks::Element *)pAddress;
+        checkMemoryMap();
         treesGL[4] = new MerkleTreeGL((Goldilocks::Element *)pConstTreeAddress); // opened at the query points from the file (merkleTreeGL.hpp:24-32)
         treeElems = MerklehashGoldilocks::getTreeNumElements(NExtended);
         // everything of stages 4, 5 and FRI fits the dead base-domain part of the image (the zkEVM: 51 of 96 GB), or gets an area of its own
@@ -229,6 +242,34 @@ private:
         // the proof's HBM now, not inside the first genProof: like the reference, which allocates pAddress when the prover starts
         // (prover.cpp:99-120).  273 GB of fresh device memory take the driver 5.7 s; a later, larger Starks grows the arena once more.
         mi::arena().reserve(starkInfo.mapTotalN + 4 * treeElems + scratchElems);
+    }
+    // genProof lends sections that are not live as LDE / NTT / FRI scratch and re-plans the base-domain part from stage 4 on (see the
+    // header): that is only sound for pil-stark's section order with every section starting where the previous one ends.  The reference
+    // takes each offset from starkinfo.json and assumes nothing; a map laid out differently is refused here, with the reason, instead of
+    // being proved with scratch that overlaps live polynomials.
+    void checkMemoryMap()
+    {
+        static const eSection order[11] = {cm1_n, cm2_n, cm3_n, cm4_n, tmpExp_n, cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns, q_2ns, f_2ns};
+        static const char *names[11] = {"cm1_n", "cm2_n", "cm3_n", "cm4_n", "tmpExp_n", "cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns", "q_2ns", "f_2ns"};
+        uint64_t next = 0;
+        for (int i = 0; i < 11; i++) {
+            const eSection e = order[i];
+            if (off(e) != next) {
+                zklog.error("Starks: starkinfo's memory map is not the contiguous pil-stark layout this prover's HBM plan relies on: section " + std::string(names[i]) +
+                            " starts at " + std::to_string(off(e)) + ", expected " + std::to_string(next) + " (the end of the section before it)");
+                exitProcess();
+            }
+            next += cols(e) * (i < 5 ? N : NExtended);
+        }
+        if (cols(q_2ns) != starkInfo.qDim || cols(f_2ns) != FIELD_EXTENSION || cols(cm1_2ns) != cols(cm1_n) || cols(cm2_2ns) != cols(cm2_n) || cols(cm3_2ns) != cols(cm3_n) ||
+            cols(cm4_2ns) != starkInfo.qDim * starkInfo.qDeg) {
+            zklog.error("Starks: starkinfo's section widths are inconsistent (cmK_2ns must be as wide as cmK_n, cm4_2ns = qDim * qDeg, q_2ns = qDim, f_2ns = 3)");
+            exitProcess();
+        }
+        if (starkInfo.mapTotalN != next) {
+            zklog.error("Starks: starkinfo's mapTotalN is " + std::to_string(starkInfo.mapTotalN) + ", the sections end at " + std::to_string(next));
+            exitProcess();
+        }
     }
     void hostStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);
     void tracedStep(mi::StarkMirror &m, Steps *steps, StepsParams &params, int which);

@@ -81,6 +81,9 @@ int mis_set_tables(void *hv, int step, const uint64_t *ops, uint64_t nops, const
     Handle *h = (Handle *)hv;
     const int s = TableSteps::slot(step);
     if (!h || s < 0) return -1;
+    // the compiled program of this step is cached under the tables' ADDRESS (host/chelpers_steps.hpp), and assign() below keeps the vector's
+    // buffer when the new tables fit: forget it, or a later proof would run the old program without any error
+    h->starks->forgetProgram(step, h->steps.t[s].ops.data());
     h->steps.t[s].ops.assign(ops, ops + nops);
     h->steps.t[s].args.assign(args, args + nargs);
     return 0;

@@ -279,11 +279,36 @@ inline bool traceStep(const TraceLayout &L, Call call, ZhInvAt zhinvAt, std::vec
     const uint64_t rows[2] = {0, L.rows - 1};
     for (int t = 0; t < 2; t++) {
         StepRecorder rec(L, rows[t], zhinvAt(rows[t]));
+        // the rows of every section a per-row function at this row can reach (itself and the shifted rows around it), as they are before the call:
+        // a function that records nothing must not have changed them either (it would be arithmetic that bypasses the hooked forms -- a plain
+        // Element assignment, a memcpy, a translation unit built against another field header -- and the step would be dropped silently)
+        std::vector<uint64_t> snapshot;
+        auto window = [&](bool compare) -> bool {
+            size_t k = 0;
+            for (const TraceLayout::Sec &S : L.secs) {
+                if (!S.cols || !S.rows || !L.pols) continue;
+                for (int64_t d = -8; d <= 8; d++) {
+                    const uint64_t r = (rows[t] + S.rows + (uint64_t)(d + 64) - 64) % S.rows;
+                    const uint64_t *p = L.pols + S.offset + r * S.cols;
+                    if (!compare) snapshot.insert(snapshot.end(), p, p + S.cols);
+                    else if (std::memcmp(snapshot.data() + k, p, S.cols * 8)) return false;
+                    k += S.cols;
+                }
+            }
+            return true;
+        };
+        window(false);
         MiFieldRecorder *before = mi_field_recorder;
+        const bool recordingBefore = mi_field_recording;
         mi_field_recorder = &rec;
+        mi_field_recording = true;
         call(rows[t]);
         mi_field_recorder = before;
+        mi_field_recording = recordingBefore;
         rec.finish();
+        if (rec.error.empty() && rec.ops.empty() && !window(true))
+            rec.error = "steps tracer: the function recorded nothing but changed params.pols: its arithmetic does not go through Goldilocks:: / Goldilocks3:: "
+                        "(set MI_STEPS_ON_HOST=1 to run such a Steps class on the host)";
         if (rec.error.empty() && rec.untracked)
             rec.error = "steps tracer: the function computes with Goldilocks operators or value-returning forms, which leave no addresses to follow";
         if (rec.error.empty() && rec.ops.empty() && (L.step == MI_CHELPERS_STEP42NS || L.step == MI_CHELPERS_STEP52NS))

@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE: one `Starks::genProof` of the PRODUCT class (host/starks.hpp behind libmi_starks.so) over inputs held in numpy
+arrays, returning the zkin.json text -- the device side of tests/test_genproof_parity.py, whose other side is tests/oracle_genproof.py.
+Also builds the inputs both sides share: the constant-tree file image [nPols, nExt, extended polynomials, nodes] (build_const_tree.cpp:
+366-403 / merkleTreeGL.hpp:24-32) made by the ORACLE, so that the product's re-extension of the constant polynomials on the device is
+checked against the file the reference would read them from."""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+
+import glo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEP_ID = {"step2prev": 20, "step3prev": 30, "step3": 31, "step42ns": 42, "step52ns": 52}
+vp = ctypes.c_void_p
+
+
+def const_tree_image(const_n, n_const, nbits, nbits_ext):
+    n, ne = 1 << nbits, 1 << nbits_ext
+    c2 = glo.extend_pol(glo.A(const_n).reshape(n, n_const), ne, n, n_const)
+    nodes = glo.merkletree(c2, n_const, ne)
+    return np.concatenate([np.array([n_const, ne], dtype=np.uint64), c2.reshape(-1), nodes])
+
+
+_LIB = None
+_N_LIBS = 0
+
+
+def starks_lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(os.path.join(ROOT, "merlin-zkevm-prover_amd", "libmi_starks.so"), mode=ctypes.RTLD_GLOBAL)
+        L.mis_create.restype = ctypes.c_void_p
+        L.mis_zkin.restype = ctypes.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def steps_library(progs, workdir, tag="steps"):
+    """The programs written out as generated per-row C++ (tests/gen_steps_cpp.py) and compiled into a Steps library: what a caller with
+    nrowsStepBatch = 1 (c12a, recursive1/2: prover.cpp:577,611) links."""
+    import gen_steps_cpp as gs
+    global _N_LIBS
+    _N_LIBS += 1
+    # a class name of its own per library: they are loaded RTLD_GLOBAL into one test process, where a second `GenSteps` would resolve to the first's code
+    cls = "GenSteps_%d_%d" % (os.getpid(), _N_LIBS)
+    host = os.path.join(ROOT, "merlin-zkevm-prover_amd", "host")
+    src = os.path.join(workdir, tag + ".cpp")
+    open(os.path.join(workdir, "genSteps.hpp"), "w").write(gs.GEN_HEADER.replace("GenSteps", cls))
+    open(src, "w").write(gs.steps_source(cls, progs, header='#include "genSteps.hpp"\n') + gs.GEN_FACTORY.replace("GenSteps", cls))
+    so = os.path.join(workdir, "lib%s.so" % tag)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-fPIC", "-shared", "-I", workdir, "-I", host, "-I", os.path.join(host, "standalone"), src, "-o", so])
+    return so
+
+
+def gen_proof_on_device(si, progs, const_n, const_tree, witness, publics, workdir, batches=(4,), steps_so=None, env=None):
+    """-> [zkin text per entry of batches].  batches: nrowsStepBatch values (4: the tables on the device; 1: the per-row Steps library
+    `steps_so`, recorded and run on the device).  Runs in a CHILD process: the host classes follow the reference's error convention
+    (message + exit), which must fail one test, not end the test run."""
+    import sys
+    json.dump(si, open(os.path.join(workdir, "parity.starkinfo.json"), "w"))
+    arrays = {"const_n": glo.A(const_n).reshape(-1), "const_tree": glo.A(const_tree).reshape(-1), "witness": glo.A(witness).reshape(-1), "publics": glo.A(publics).reshape(-1)}
+    for name, (ops, ar) in progs.items():
+        arrays["ops_" + name], arrays["args_" + name] = glo.A(ops), glo.A(ar)
+    np.savez(os.path.join(workdir, "parity.inputs.npz"), **arrays)
+    cmd = [sys.executable, os.path.abspath(__file__), workdir, ",".join(str(b) for b in batches)] + ([steps_so] if steps_so else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("Starks::genProof child failed (rc %d):\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-4000:]))
+    return [open(os.path.join(workdir, "zkin.%d.json" % b)).read() for b in batches]
+
+
+def _child(workdir, batches, steps_so):
+    """pAddress is the whole polynomial map, as the reference allocates it (prover.cpp:95-120)."""
+    L = starks_lib()
+    os.environ.setdefault("MI_CHELPERS_CACHE", os.path.join(ROOT, "merlin-zkevm-prover_amd", "_chelpers_cache"))
+    si_path = os.path.join(workdir, "parity.starkinfo.json")
+    si = json.load(open(si_path))
+    a = np.load(os.path.join(workdir, "parity.inputs.npz"))
+    n = 1 << si["starkStruct"]["nBits"]
+    w1 = si["mapSectionsN"]["cm1_n"]
+    p_address = np.zeros(int(si["mapTotalN"]), dtype=np.uint64)
+    p_address[:n * w1] = a["witness"]
+    const_n, const_tree, publics = glo.A(a["const_n"]), glo.A(a["const_tree"]), glo.A(a["publics"])
+    h = vp(L.mis_create(si_path.encode(), vp(const_n.ctypes.data), vp(const_tree.ctypes.data), vp(p_address.ctypes.data)))
+    keep = []
+    for name in STEP_ID:
+        if "ops_" + name not in a:
+            continue
+        ops, ar = glo.A(a["ops_" + name]), glo.A(a["args_" + name])
+        keep += [ops, ar]
+        L.mis_set_tables(h, ctypes.c_int(STEP_ID[name]), vp(ops.ctypes.data), ctypes.c_uint64(ops.size), vp(ar.ctypes.data), ctypes.c_uint64(ar.size))
+    if steps_so is not None and L.mis_load_steps(h, steps_so.encode()) != 0:
+        raise SystemExit("cannot load the generated Steps library")
+    for b in batches:
+        L.mis_gen_proof(h, vp(publics.ctypes.data), ctypes.c_uint64(b), b"", b"")
+        open(os.path.join(workdir, "zkin.%d.json" % b), "w").write(L.mis_zkin(h).decode())
+    L.mis_destroy(h)
+
+
+if __name__ == "__main__":
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    _child(sys.argv[1], [int(b) for b in sys.argv[2].split(",")], sys.argv[3] if len(sys.argv) > 3 else None)

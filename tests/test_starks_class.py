@@ -26,16 +26,18 @@ REF = "/root/reference/src"
 import glo
 import ministark as ms
 
-EXE = os.path.join(ROOT, "tests", "cpp", "test_starks_genproof")
 LINK = ["-L", os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-lmi_stark", "-L", os.path.join(ROOT, "oracle"), "-lgl_oracle",
         "-Wl,-rpath," + os.path.join(ROOT, "merlin-zkevm-prover_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath,/opt/rocm/lib",
         "-L/opt/rocm/lib", "-lamdhip64"]
 STANDALONE = ["-I", HOST, "-I", os.path.join(HOST, "standalone")]
 
 
-def build_exe():
+def build_exe(tmp_path):
+    """-> the test executable, built into the test's own directory (nothing is written into the source tree)."""
     glo.build()
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-fopenmp"] + STANDALONE + [os.path.join(ROOT, "tests", "cpp", "test_starks_genproof.cpp"), "-o", EXE] + LINK)
+    exe = str(tmp_path / "test_starks_genproof")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-fopenmp"] + STANDALONE + [os.path.join(ROOT, "tests", "cpp", "test_starks_genproof.cpp"), "-o", exe] + LINK)
+    return exe
 
 
 def write_inputs(d, nbits, n_queries):
@@ -55,9 +57,8 @@ def write_inputs(d, nbits, n_queries):
         args.tofile(os.path.join(d, name + ".args"))
 
 
-def test_starks_program_compiles_and_links():
-    build_exe()
-    assert os.path.exists(EXE)
+def test_starks_program_compiles_and_links(tmp_path):
+    assert os.path.exists(build_exe(tmp_path))
 
 
 def test_prover_call_shapes_compile_against_host(tmp_path):
@@ -193,7 +194,7 @@ def test_starks_genproof_with_the_callers_rows_on_the_host(tmp_path):
     reference, on the host over pAddress, between copies of the sections it reads and writes; same proof.  Without the variable such a
     Steps class is refused, not silently skipped."""
     nbits, n_queries = 10, 12
-    build_exe()
+    EXE = build_exe(tmp_path)
     d = str(tmp_path)
     write_inputs(d, nbits, n_queries)
     env = dict(os.environ, MI_CHELPERS_CACHE=os.path.join(d, "cache"), MI_STEPS_ON_HOST="1")
@@ -205,3 +206,38 @@ def test_starks_genproof_with_the_callers_rows_on_the_host(tmp_path):
     env.pop("MI_STEPS_ON_HOST")
     r = subprocess.run([EXE, d, "1"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode != 0 and "recorded nothing" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_a_starks_whose_hbm_plan_does_not_fit_stops_with_the_reason(tmp_path):
+    """One proof's device image lives in ONE arena (host/starks.hpp mi::Arena); a STARK whose plan exceeds the device -- here 2^24 rows x
+    3 000 witness columns: 403 GB for cm1_n alone -- must stop in the constructor with the plan's size and the free memory, the
+    reference's convention (message + exit), not with a HIP error somewhere inside a proof."""
+    import bench_starks as b
+    a = b.parse(["--log-n", "10", "--widths", "3000", "20", "40", "--tmpexp", "60", "--n-const", "1", "--n-evals", "8", "--n-queries", "8", "--n-lookups", "1", "1",
+                 "--n-products", "4", "--field-ops", "0", "0", "0", "100", "100"])
+    si, *_ = b.shape(a)
+    # the same map at 2^24 rows: only the sizes matter, nothing is proved
+    nbits, n, ne = 24, 1 << 24, 1 << 25
+    si["starkStruct"]["nBits"], si["starkStruct"]["nBitsExt"] = nbits, nbits + 1
+    si["starkStruct"]["steps"] = [{"nBits": 25}, {"nBits": 20}, {"nBits": 15}, {"nBits": 10}, {"nBits": 6}]
+    o = 0
+    for k in b.ORDER:
+        si["mapOffsets"][k] = o
+        si["mapDeg"][k] = ne if k.endswith("2ns") else n
+        o += si["mapSectionsN"][k] * si["mapDeg"][k]
+    si["mapTotalN"] = o
+    json.dump(si, open(tmp_path / "big.starkinfo.json", "w"))
+    code = """
+import ctypes, numpy as np, sys
+L = ctypes.CDLL(%r, mode=ctypes.RTLD_GLOBAL)
+L.mis_create.restype = ctypes.c_void_p
+const_n = np.zeros(1 << 24, dtype=np.uint64)
+tree = np.zeros(16, dtype=np.uint64); tree[0], tree[1] = 1, 1 << 25
+pa = np.zeros(16, dtype=np.uint64)
+L.mis_create(%r, ctypes.c_void_p(const_n.ctypes.data), ctypes.c_void_p(tree.ctypes.data), ctypes.c_void_p(pa.ctypes.data))
+print("constructed")
+""" % (os.path.join(ROOT, "merlin-zkevm-prover_amd", "libmi_starks.so"), str(tmp_path / "big.starkinfo.json").encode())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "constructed" not in r.stdout
+    assert "HBM plan needs" in r.stderr and "GB free" in r.stderr, r.stderr[-2000:]

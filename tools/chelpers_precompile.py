@@ -28,6 +28,14 @@ STARKS_CONFIGS = [
      "--n-products", "6", "--field-ops", "200", "300", "400", "1500", "700"],
     ["--shape", "recursive1"],
     ["--shape", "c12a"],
+    # tests/test_genproof_parity.py: the shapes proved by the device AND by the oracle prover (byte-for-byte comparison)
+    ["--log-n", "14", "--widths", "96", "40", "71", "--tmpexp", "110", "--n-const", "30", "--n-evals", "200", "--n-queries", "32", "--n-lookups", "3", "3",
+     "--n-products", "12", "--field-ops", "300", "700", "900", "3000", "1200"],
+    ["--log-n", "10", "--ext-bits", "3", "--qdeg", "7", "--widths", "18", "0", "39", "--tmpexp", "90", "--n-const", "9", "--n-evals", "30",
+     "--n-queries", "8", "--n-lookups", "0", "0", "--n-products", "13", "--fri-steps", "13", "9", "5", "--field-ops", "0", "300", "0", "900", "400"],
+    ["--log-n", "12", "--ext-bits", "3", "--qdeg", "7", "--widths", "18", "0", "39", "--tmpexp", "14", "--n-const", "52", "--n-evals", "118",
+     "--n-queries", "43", "--n-lookups", "0", "0", "--n-products", "1", "--fri-steps", "15", "11", "7", "4", "--field-ops", "0", "201", "1761", "3483", "463"],
+    ["--log-n", "12"],                                      # the zkEVM's full widths, counts and program sizes at 2^12 rows
 ]
 
 
