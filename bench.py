@@ -55,6 +55,17 @@ def valu_roofline(perms, leaf_ms, pmc):
            "achieved_wave_instr_per_s": ach / 64.0 * instrs, "effective_clock_ghz_pmc": pmc.get("effective_clock_ghz"),
            "wave_time_split_pmc": pmc.get("wave_time_split"),
            "source": "profiles/r03_pmc_leaf.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAIT_*, GRBM_GUI_ACTIVE), tools/valu_mix.py, tools/ubench_int3.hip"}
+    # what the ALGORITHM needs (tools/valu_floor.py: 472 modular multiplies at 4 partial products + a 5-instruction reduction, 8 full-round MDS
+    # layers on 32-bit halves, the grouped partial rounds' 737 dot terms + 44 closings; no data movement) against what the compiler emitted
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import valu_floor
+    fl = valu_floor.poseidon_floor()
+    out["algorithmic_floor_instr"] = fl["floor_instr_per_permutation"]
+    out["frac_of_floor"] = fl["floor_instr_per_permutation"] / instrs
+    out["floor_breakdown"] = {k: fl[k] for k in ("modular_multiplies", "sbox_instr", "full_round_mds_instr", "partial_round_linear_instr", "constant_adds_instr")}
+    out["floor_note"] = ("floor = instructions one permutation NEEDS if every 32x32 partial product is one v_mad_u64_u32, a 128-bit reduction is 5 instructions and no "
+                         "register-pair data movement exists (tools/valu_floor.py); frac_of_floor = floor / measured count; the kernel's time at the floor count and the "
+                         "same issue rate would be avg_launch_ms * frac_of_floor")
     for key, rates in pmc["issue_rates_wave_instr_per_s"].items():
         blended = 1.0 / (f2 / rates["2clk"] + f4 / rates["4clk"])
         peak_perms = blended * 64.0 / instrs
@@ -99,9 +110,23 @@ def cpu_baseline(log_n, ncols):
     u64 = ctypes.c_uint64
     threads = max(1, min(share, 64))
 
+    def synthetic(n):                                       # glo.splitmix64 in pieces (its temporaries are several times the result)
+        out = np.empty(n * ncols, dtype=np.uint64)
+        piece = 1 << 26
+        for o in range(0, n * ncols, piece):
+            k = min(piece, n * ncols - o)
+            idx = np.arange(o + 1, o + k + 1, dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                z = np.uint64(0x5EED0003) + idx * np.uint64(0x9E3779B97F4A7C15)
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                z = z ^ (z >> np.uint64(31))
+            out[o:o + k] = np.where(z >= np.uint64(glo.P), z - np.uint64(glo.P), z)
+        return out.reshape(n, ncols)
+
     def run(L, extend, tree, n, label):
         n_ext = 2 * n
-        trace = glo.splitmix64(0x5EED0003, n * ncols).reshape(n, ncols)
+        trace = synthetic(n)
         L.glo_set_num_threads(threads)
         cores = int(L.glo_num_threads())
         t0 = time.perf_counter()
@@ -109,16 +134,16 @@ def cpu_baseline(log_n, ncols):
         t1 = time.perf_counter()
         nodes = tree(ext, n_ext)
         t2 = time.perf_counter()
-        L.glo_set_num_threads(1)                           # 1 thread: 32 of the columns at the same row count, tree over 2^13 extended rows
-        c1, h1 = min(32, ncols), min(n_ext, 1 << 13)
-        sub = np.ascontiguousarray(trace[:, :c1])
+        L.glo_set_num_threads(1)                           # 1 thread: 32 of the columns over at most 2^20 rows, tree over 2^13 extended rows
+        c1, h1, n1 = min(32, ncols), min(n_ext, 1 << 13), min(n, 1 << 20)
+        sub = np.ascontiguousarray(trace[:n1, :c1])
         u0 = time.perf_counter()
-        extend(sub, n_ext, n)
+        extend(sub, 2 * n1, n1)
         u1 = time.perf_counter()
         tree(np.ascontiguousarray(ext[:h1]), h1)
         u2 = time.perf_counter()
         L.glo_set_num_threads(cores)
-        lde_1t, mrk_1t = n * c1 / (u1 - u0), (h1 / 2) * ncols / (u2 - u1)
+        lde_1t, mrk_1t = n1 * c1 / (u1 - u0), (h1 / 2) * ncols / (u2 - u1)
         perms = n_ext * ((ncols + 7) // 8) + n_ext - 1
         return {"value": n * ncols / (t2 - t0), "unit": "field-elements/s", "cores": cores, "kind": "port", "label": label,
                 "sample": f"2^{n.bit_length() - 1} rows x {ncols} cols -> LDE 2^{n.bit_length()} + Poseidon Merkle tree, {cores} threads; "
@@ -144,11 +169,94 @@ def cpu_baseline(log_n, ncols):
 
     out = run(Lb, extend_fast, tree_fast, 1 << log_n,
               "restatement, not upstream (oracle/cpu_baseline_avx2.c: hand-vectorised AVX2 + OpenMP; the reference's src/goldilocks library is absent)")
-    out["cpu_model"], out["nproc"], out["omp_threads"] = cpu_model(), os.cpu_count(), out["cores"]
+    out["cpu_model"], out["nproc"], out["omp_threads"], out["cgroup_cpu_share"] = cpu_model(), os.cpu_count(), out["cores"], share
     Ln = glo.lib("avx2")
     out["naive"] = run(Ln, lambda t, ne, n: glo.extend_pol(t, ne, n, t.shape[1], flavour="avx2"),
-                       lambda e, rows: glo.merkletree(e, e.shape[1], rows, flavour="avx2"), 1 << max(log_n - 2, 8),
+                       lambda e, rows: glo.merkletree(e, e.shape[1], rows, flavour="avx2"), 1 << max(min(log_n - 2, 18), 8),
                        "the CHECKER's scalar restatement (oracle/gl_oracle.c, gcc -O3 -mavx2 -fopenmp): not an optimised CPU path")
+    return out
+
+
+def proof_kernel_rooflines(stats_csv, proofs_in_profile, zk):
+    """Roofline entries for the dominant kernels of ONE Starks::genProof at the zkEVM shape: average time per proof from the committed
+    rocprofv3 --kernel-trace --stats summary of the same command (bench_starks.py; a profiler cannot run inside this process), algorithmic
+    bytes per proof from the shape (Merkle 8 h w + 32 (2h - 1), LDE 8 N c + 8 Next c, NTT 16 n c; a constraint program
+    reads each declared section once per row).  zk: the shape's sizes."""
+    import csv
+    N, NE = zk["n"], zk["n_ext"]
+    w = zk["widths"]                                        # cm1, cm2, cm3, cm4_2ns, tmpExp, constants
+    fam = {"leaf_hashing": ("k_linear_hash_rows_lines",), "ntt_passes": ("k_ntt_pass", "k_lde_mid"), "constraint_kernels": ("chelpers_chunk",),
+           "operand_transpose": ("k_chp_transpose",), "linear_kernel": ("k_chp_linear",), "evmap": ("k_evmap_partial", "k_evmap_reduce")}
+    ns = {k: 0.0 for k in fam}
+    calls = {k: 0 for k in fam}
+    for row in csv.DictReader(open(stats_csv)):
+        for k, pats in fam.items():
+            if any(row["Name"].lstrip("void ").startswith(p_) or (p_ + "(") in row["Name"] or (p_ + "<") in row["Name"] for p_ in pats):
+                ns[k] += float(row["TotalDurationNs"])
+                calls[k] += int(row["Calls"])
+    committed = [w["cm1"], w["cm2"], w["cm3"], w["cm4"]]
+    ext_all = w["cm1"] + w["cm2"] + w["cm3"]
+    alg = {
+        "leaf_hashing": sum((8.0 * c + 32.0) * NE for c in committed),
+        "ntt_passes": (8.0 * N + 8.0 * NE) * (ext_all + w["const"]) + 16.0 * NE * 3 + 16.0 * NE * w["cm4"] + 2 * 16.0 * N * 3,
+        # step2prev / step3prev / step3 over N rows (cm1_n .. tmpExp_n + constants), step42ns over NE rows (cm1..3_2ns + constants); stores counted once
+        "constraint_kernels": 3 * 8.0 * N * (ext_all + w["tmpexp"] + w["const"]) + 8.0 * NE * (ext_all + w["const"]) + 24.0 * NE,
+        "operand_transpose": 0.0,
+        "linear_kernel": 8.0 * NE * (ext_all + w["cm4"] + w["const"]) + 72.0 * NE,
+        "evmap": 8.0 * N * zk["n_evals"],
+    }
+    bound = {"leaf_hashing": "hbm (VALU-issue-bound in fact: see valu)", "ntt_passes": "hbm", "constraint_kernels": "hbm (co-limited by integer issue)",
+             "operand_transpose": "hbm: pure data movement the algorithm does not ask for (tile-major copies of the operands)", "linear_kernel": "hbm",
+             "evmap": "hbm"}
+    out = {}
+    for k in fam:
+        ms = ns[k] / 1e6 / max(proofs_in_profile, 1)
+        if ms <= 0:
+            continue
+        ach = alg[k] / (ms * 1e-3) / 1e9
+        peak = HBM_PEAK_GBS
+        out[k] = {"kernels": list(fam[k]), "bound": bound[k], "ms_per_proof": ms, "launches_per_proof": calls[k] / max(proofs_in_profile, 1),
+                  "algorithmic_bytes_per_proof": alg[k], "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak}
+    return out
+
+
+def genproof_leg(shape):
+    """BASELINE's 'batch-proof wall time' and north_star's NTT + Merkle + FRI under the SAME command the driver times: after this process has
+    released its HBM, a child runs bench_starks.py -- Starks::genProof of the product class (host/starks.hpp) over the synthetic zkEVM-shaped
+    STARK at full size, then (shape 'batch') c12a's and recursive1's shapes, as genBatchProof's three calls (prover.cpp:541,577,611) -- and its
+    JSON is merged into this line.  A child: one proof's plan is 273 of the device's 309 GB, and the arena is a process-wide singleton."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench_starks.py"), "--shape", shape, "--proofs", "2", "--check-rows", "4"]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": "bench_starks.py exited %d" % r.returncode, "stderr_tail": r.stderr[-1500:]}
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    zk = j["starks"]["zkevm"] if "starks" in j else {"genproof_ms": j["value"], "phase_ms": j["phase_ms"], "hbm": j["hbm"], "checks": j["checks"],
+                                                     "genproof_wall_ms": j["genproof_wall_ms"], "setup_s": j["setup_s"], "workload": j["config"]["workload"],
+                                                     "field_ops_per_row": j["config"]["field_ops_per_row"], "flow": j["flow"], "peak_hbm_gb": j["hbm"]["peak_hbm_gb"]}
+    ph = zk["phase_ms"]
+    out = {"metric": "Starks::genProof wall time, one MI355X, synthetic zkEVM-shaped STARK at full size (BASELINE config 4 substitute; its inputs are absent from the reference tree)",
+           "ms": zk["genproof_ms"], "unit": "ms", "flow": zk["flow"], "workload": zk["workload"], "field_ops_per_row": zk["field_ops_per_row"],
+           "genproof_wall_ms_all_runs": zk["genproof_wall_ms"], "phase_ms": ph, "fri_ms": ph.get("STARK_STEP_FRI"),
+           "ntt_merkle_fri_ms": {"lde_and_merkle": sum(ph.get(k, 0.0) for k in ("STARK_STEP_1_LDE_AND_MERKLETREE", "STARK_STEP_2_LDE_AND_MERKLETREE",
+                                                                                  "STARK_STEP_3_LDE_AND_MERKLETREE", "STARK_STEP_4_MERKLETREE")),
+                                 "fri": ph.get("STARK_STEP_FRI")},
+           "peak_hbm_gb": zk["peak_hbm_gb"], "hbm": zk["hbm"], "checks": zk["checks"], "setup_s": zk["setup_s"], "child_wall_s": wall,
+           "checks_note": "after the clock: openings climb to their roots at the replayed transcript's indices, folds land on the next layer, sampled q_2ns / f_2ns rows "
+                          "equal the oracle interpreters'; whole-proof BYTE parity with an oracle prover is tests/test_genproof_parity.py (2^10 .. 2^14 rows)"}
+    if "starks" in j:
+        out["batch_ms"] = j["value"]
+        out["batch"] = {sh: {"genproof_ms": o["genproof_ms"], "workload": o["workload"], "peak_hbm_gb": o["peak_hbm_gb"], "checks": o["checks"],
+                             "fri_ms": o["phase_ms"].get("STARK_STEP_FRI")} for sh, o in j["starks"].items()}
+        out["batch_note"] = "the three Starks::genProof calls of genBatchProof (zkEVM, c12a, recursive1 shapes) in one process sharing the HBM arena; c12a's starkStruct is assumed (DESIGN.md)"
+    stats = os.path.join(ROOT, "profiles", "r04_starks_genproof_kernel_stats.csv")
+    if os.path.exists(stats):
+        out["kernel_rooflines"] = proof_kernel_rooflines(stats, 2, {"n": 1 << 23, "n_ext": 1 << 24, "n_evals": 1768,
+                                                                    "widths": {"cm1": 665, "cm2": 128, "cm3": 371, "cm4": 6, "tmpexp": 265, "const": 218}})
+        out["kernel_rooflines_source"] = ("profiles/r04_starks_genproof_kernel_stats.csv: rocprofv3 --kernel-trace --stats -- python3 bench_starks.py --proofs 2 --check-rows 0 "
+                                          "(same command as this leg's zkEVM proof, two proofs; per-proof averages)")
     return out
 
 
@@ -182,7 +290,12 @@ def main():
     ap.add_argument("--cols", type=int, default=665, help="committed columns (BASELINE: 665)")
     ap.add_argument("--workspace-gib", type=float, default=32.0)
     ap.add_argument("--poseidon-variant", type=int, default=2)
-    ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 rows of the CPU-baseline sample (the checker's scalar code runs on a quarter of it)")
+    ap.add_argument("--cpu-log-n", type=int, default=23,
+                    help="log2 rows of the CPU-baseline sample: 23 = the benchmark's own size (134 GB of host memory, about two minutes on 16 threads); "
+                         "the checker's scalar code runs on 2^18 rows at most")
+    ap.add_argument("--no-genproof", action="store_true",
+                    help="N = 1: skip the batch-proof leg (bench_starks.py --shape batch in a child process after this process has released its HBM)")
+    ap.add_argument("--genproof-shape", default="batch", help="batch (zkEVM + c12a + recursive1 shapes, as genBatchProof) or zkevm")
     ap.add_argument("--pcie-steps", type=int, default=2, help="N = 1: steps of the PCIe-inclusive leg (host trace streamed in by mi_lde_merkle_host); 0 = skip")
     ap.add_argument("--pack-threads", type=int, default=-1,
                     help="PCIe-inclusive leg: host threads packing column chunks into page-locked staging (0 = strided 2-D copies; "
@@ -472,11 +585,32 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not exchange and not args.no_genproof:
+            # everything this process holds in HBM goes first: the child's proof plans 273 of the device's 309 GB
+            del trace, root
+            ext_windows = verify = None
+            bufs.clear()
+            gc.collect()
+            torch.cuda.empty_cache()
+            ctx.close()
+            ctx = None
+            torch.cuda.synchronize()
+            free_b, total_b = torch.cuda.mem_get_info()
+            t_wait0 = time.perf_counter()
+            while free_b < 0.97 * total_b and time.perf_counter() - t_wait0 < 30:   # released memory is handed back (and wiped) asynchronously
+                time.sleep(0.5)
+                gc.collect()
+                torch.cuda.empty_cache()
+                free_b, total_b = torch.cuda.mem_get_info()
+            print("bench.py: %.1f of %.1f GB of HBM free before the batch-proof leg" % (free_b / 1e9, total_b / 1e9), file=sys.stderr, flush=True)
+            out["genproof"] = genproof_leg(args.genproof_shape)
+            out["genproof"]["hbm_free_before_child_gb"] = free_b / 1e9
         print(json.dumps(out), file=real_stdout, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

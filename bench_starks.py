@@ -249,7 +249,9 @@ def main():
         outs = [run(parse(["--shape", sh] + rest)) for sh in ("zkevm", "c12a", "recursive1")]
         print(json.dumps({"metric": "the three Starks::genProof calls of genBatchProof (zkEVM, c12a, recursive1 shapes), one process, one MI355X", "unit": "ms",
                           "value": sum(o["value"] for o in outs), "higher_is_better": False, "n_gpus": 1,
-                          "starks": {sh: {"genproof_ms": o["value"], "workload": o["config"]["workload"], "peak_hbm_gb": o["hbm"]["peak_hbm_gb"], "checks": o["checks"]}
+                          "starks": {sh: {"genproof_ms": o["value"], "workload": o["config"]["workload"], "peak_hbm_gb": o["hbm"]["peak_hbm_gb"], "checks": o["checks"],
+                                          "phase_ms": o["phase_ms"], "genproof_wall_ms": o["genproof_wall_ms"], "proof_to_json_ms": o["proof_to_json_ms"],
+                                          "hbm": o["hbm"], "setup_s": o["setup_s"], "field_ops_per_row": o["config"]["field_ops_per_row"], "flow": o["flow"]}
                                      for sh, o in zip(("zkevm", "c12a", "recursive1"), outs)}, "dtype": "u64", "data": "synthetic"}))
         return
     args = parse()

@@ -16,9 +16,12 @@
  * a second time, as generated per-row C++ (zkevm.chelpers.step{2,3prev,3,52ns}.cpp), which compiles against the Level-0 field classes:
  * tests/test_steps_tracer.py runs those functions beside the product's table decoder on the reference's tables (identical stores), and
  * tests/test_chelpers.py runs the product's decoder beside these interpreters on the same tables (identical) -- so for step2prev,
- * step3prev, step3 and step52ns this restatement computes what the reference's compiled code computes.  STILL UNPINNED: the 19 opcodes
- * only step42ns's table uses (9, 14, 25, 28, 29, 33, 34, 36, 39-42, 55, 60, 69, 72, 74, 75, 77; its per-row file is an absent blob),
- * for which tests/test_chelpers.py cross-checks the argument bookkeeping against the reference's source text.
+ * step3prev, step3 and step52ns this restatement computes what the reference's compiled code computes.  The 19 opcodes only
+ * step42ns's table uses (9, 14, 25, 28, 29, 33, 34, 36, 39-42, 55, 60, 69, 72, 74, 75, 77; its per-row file is an absent blob) are
+ * decided since round 4 by the reference's SCALAR interpreter itself: tests/test_reference_scalar_interpreter.py compiles
+ * step42ns_parser_first unchanged over test-only `_batch` helpers (tests/cpp/batch_helpers_test_only.hpp) and runs the real 11 959-opcode
+ * table beside this file and the product's decoder -- identical q_2ns.  The helpers' arithmetic is this repo's Level-0 stand-in, so that
+ * pins every case's operand ADDRESSING and helper choice; the field arithmetic itself is pinned by the golden proofs (gl_oracle.h).
  */
 #include "gl_oracle.h"
 #include <stdlib.h>
