@@ -260,6 +260,63 @@ def genproof_leg(shape):
     return out
 
 
+def single_process_main(args):
+    """`--single-process`: the N-shard step from ONE process through the C ABI (csrc/multi.hip: mi_multi_commit) -- the form a one-process
+    Prover links -- instead of N torch.distributed ranks.  Shard g runs on device g (or, with --logical-shards, all on device 0: how a
+    one-GPU box rehearses the path).  Timed with the trace resident in HBM on device 0 (tiles cross xGMI to their shards); the
+    PCIe-inclusive variant (trace in pageable host memory, every shard's tiles over its own PCIe link) is reported beside it."""
+    import torch
+    import mi_stark
+    G = args.gpus
+    have = torch.cuda.device_count()
+    devices = [0] * G if args.logical_shards else list(range(G))
+    if not args.logical_shards and have < G:
+        sys.stderr.write(f"bench.py: --gpus {G} --single-process needs {G} GPUs, this node shows {have} (add --logical-shards to rehearse on one)\n")
+        return 2
+    n, n_ext, ncols = 1 << args.log_n, 2 << args.log_n, args.cols
+    ctx = mi_stark.Context(0)
+    trace = ctx.empty(n * ncols)
+    ctx.fill_synthetic_2d(trace, n, ncols, ncols, 0, 0x5EED0003)
+    ctx.sync()
+    m = mi_stark.Multi(devices)
+
+    def run(src_ptr, src_device, steps, warmup):
+        root, st = None, None
+        for it in range(warmup + steps):
+            if it == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            t = m.commit(src_ptr, n, n_ext, ncols, src_device=src_device)
+            root = [int(v) for v in t.root]
+            st = m.last_stats()
+            t.free()
+        return (time.perf_counter() - t0) / max(steps, 1), root, st
+    dt, root, st = run(trace.data_ptr(), 0, args.steps, args.warmup)
+    pcie = None
+    if args.pcie_steps > 0:
+        host = torch.empty(n * ncols, dtype=torch.int64)
+        host.copy_(trace)
+        torch.cuda.synchronize()
+        dt_h, root_h, st_h = run(host.data_ptr(), -1, args.pcie_steps, 1)
+        pcie = {"ms_per_step": 1e3 * dt_h, "value": n * ncols / dt_h, "unit": "field-elements/s", "root_matches": root_h == root, "per_shard": st_h["per_shard"],
+                "path": "trace in pageable host memory; every shard's tiles packed by host threads and sent over that shard's own PCIe link"}
+        del host
+    out = {"metric": "goldilocks_field_elements_per_s_lde_merkleize_2^%d_rows" % args.log_n, "value": n * ncols / dt, "unit": "field-elements/s", "n_gpus": G,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "strong" if G > 1 else "none", "vs_baseline": None,
+           "dtype": "u64 (Goldilocks mod 2^64-2^32+1, 32-bit integer VALU)", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: 2^%d-row x %d-col trace -> LDE blow-up 2 -> Poseidon Merkle tree" % (args.log_n, ncols), "rows": n, "cols": ncols,
+                      "rows_ext": n_ext, "parallelism": "single process, %d shards on devices %s: column-tile LDE -> hipMemcpyPeerAsync exchange -> row-shard streaming Merkle" % (G, devices)},
+           "root": root, "root_matches_regression_constant": (root == ROOT_2P23_X665) if (args.log_n == 23 and ncols == 665) else None,
+           "comm": {"backend": "hipMemcpyPeerAsync / hipMemcpyAsync inside one process (csrc/multi.hip)", "shards": G, "devices": devices, "logical_shards_on_one_device": bool(args.logical_shards)},
+           "per_rank": [{"rank": s["shard"], "device": s["device"], "lde_ms": s["lde_ms"], "absorb_ms": s["absorb_ms"], "exchange_wait_ms": s["exchange_wait_ms"],
+                         "bytes_sent_to_peer": s["bytes_sent_to_shard"]} for s in st["per_shard"]],
+           "pcie_inclusive": pcie, "value_pcie_inclusive": (pcie or {}).get("value"), "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+    m.close()
+    ctx.close()
+    return 0
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks.  This parent never initialises a GPU
     (device_count() does not on this stack); the ranks are children of torch.distributed.run."""
@@ -312,7 +369,12 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the N > 1 code path (tile-by-tile LDE, streaming leaf absorption, subtree) on a one-rank "
                          "communicator, to rehearse it at full size on a single GPU")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 from ONE process through the C ABI (mi_multi_commit: what a one-process Prover links) instead of torch.distributed ranks")
+    ap.add_argument("--logical-shards", action="store_true", help="--single-process: all shards on device 0 (rehearsal on a one-GPU box)")
     args = ap.parse_args()
+    if args.single_process:
+        sys.exit(single_process_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

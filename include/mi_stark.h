@@ -51,6 +51,7 @@ int mi_ctx_create(mi_ctx **out, int device);
 void mi_ctx_destroy(mi_ctx *ctx);
 /* Use a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL (the initial
  * value) is the device's default stream. */
+int mi_ctx_device(const mi_ctx *ctx); /* the HIP device this context runs on */
 int mi_ctx_set_stream(mi_ctx *ctx, void *hip_stream);
 int mi_ctx_sync(mi_ctx *ctx);
 /* Scratch HBM the library may allocate lazily for NTT/LDE ping-pong buffers (default 32 GiB,
@@ -123,7 +124,8 @@ static inline uint64_t mi_merkle_proof_levels(uint64_t nrows)
 /* Replaces MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for a batch of queries:
  * proofs[q] = row idx[q] (width values) followed by levels x 4 siblings; proof stride = width + 4*levels.
  * idx is a HOST array; src/nodes/proofs are device pointers.  width = 0 (src may then be NULL) returns the sibling paths
- * alone: the row-sharded multi-GPU tree opens a row's values from its column windows and its path from a rank's subtree. */
+ * alone: the row-sharded multi-GPU tree opens a row's values from its column windows and its path from a rank's subtree.  nodes = NULL
+ * returns the row values alone (the sibling words of the proofs are left untouched). */
 int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src,
                                uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx,
                                uint64_t nqueries);
@@ -151,6 +153,43 @@ int mi_lde_merkle_host_keep(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_
                             const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
 int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister: page-lock a host range for DMA */
 int mi_host_unregister(mi_ctx *ctx, void *p);
+
+/* ------------------------------------------------------------------ one process, several devices (csrc/multi.hip)
+ * The stage commit -- NTT_Goldilocks::extendPol + MerkleTreeGL::merkelize of one section (starks.cpp:52-57,133-138,214-219) -- sharded over
+ * the GPUs of a node from ONE process, the form the reference's Prover has (one process, one proof in flight: prover.cpp:187-260;
+ * merlin-zkevm-prover_amd/shard.py is the same plan as torch.distributed ranks).  A shard is a device; several shards may name the same
+ * device (a single-GPU box rehearses the path that way).  Columns are dealt to the shards in rounds of tiles of at most 32, each shard
+ * extends its tile, the tile's rows go to the shards that own them (hipMemcpyPeerAsync per peer: all xGMI links at once), every shard
+ * absorbs the rounds' columns of its rows into the leaf sponges as they arrive and builds the subtree over its n_ext / G rows; the G
+ * subtree roots are hashed on shard 0.  Result: the single-device tree, node for node. */
+typedef struct mi_multi mi_multi;
+typedef struct mi_multi_tree mi_multi_tree;
+int mi_multi_create(mi_multi **out, const int *devices, int n_shards /* a power of two */);
+void mi_multi_destroy(mi_multi *m);
+int mi_multi_shards(const mi_multi *m);
+mi_ctx *mi_multi_ctx(mi_multi *m, int shard);
+int mi_multi_set_pack_threads(mi_multi *m, int threads); /* host threads that pack a tile for its upload (default min(64, hardware threads)) */
+/* src: the n x ncols row-major base-domain section at row pitch src_pitch (elements): HOST memory when src_device < 0 (pageable is fine:
+ * host threads pack each tile into page-locked staging and it crosses the PCIe link of the shard that extends it), else memory of that
+ * device.  image / base (either may be NULL; on device image_device): receive the whole extension (n_ext x ncols at row pitch
+ * image_pitch) and the section itself (n x ncols at base_pitch), row-major -- what a caller that evaluates constraints on one device
+ * keeps.  root: 4 words (host).  The call returns when everything has arrived.  *out: the sharded tree, for the openings. */
+int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t *src, uint64_t src_pitch, int src_device, uint64_t n, uint64_t n_ext,
+                    uint64_t ncols, uint64_t *image, uint64_t image_pitch, uint64_t *base, uint64_t base_pitch, int image_device, uint64_t root[4]);
+/* MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for nq rows: proofs (HOST) = nq x (ncols + 4 * log2(n_ext)) words, the row's
+ * values (zeros with with_values == 0: a caller that kept the image opens them there) then the siblings, leaves upward */
+int mi_multi_group_proofs(mi_multi_tree *t, uint64_t *proofs, const uint64_t *idx, uint64_t nq, int with_values);
+/* the NEXT commit carves shard `shard`'s row buffers, staging and NTT workspace from [ptr, ptr + bytes) (memory of that shard's device, not
+ * live for the duration of the commit) instead of allocating them: for a caller whose own plan fills the device (host/starks.hpp) */
+int mi_multi_lend(mi_multi *m, int shard, void *ptr, uint64_t bytes);
+int mi_multi_tree_release_rows(mi_multi_tree *t); /* give the shards' row buffers back, keep the subtrees (siblings can still be opened) */
+void mi_multi_tree_free(mi_multi_tree *t);
+int mi_multi_tree_info(const mi_multi_tree *t, uint64_t out[6]); /* shards, rows per shard, columns per shard, rounds, columns, rows */
+const uint64_t *mi_multi_tree_nodes(const mi_multi_tree *t, int shard); /* device pointer: the shard's subtree, level-0 digests first */
+int mi_multi_gather_rows(mi_multi_tree *t, uint64_t *out_host, uint64_t row0, uint64_t nrows); /* rows of the sharded extension, row-major */
+/* per shard of the last commit: lde_ms, absorb_ms, exchange_wait_ms (the compute stream stood still for the links), host_pack_ms, bytes
+ * sent to shard 0 .. G-1: (4 + G) doubles per shard */
+int mi_multi_last_stats(const mi_multi *m, double *out, double *wall_ms);
 
 /* ------------------------------------------------------------------ FRI
  * Replaces the fold loop of FRIProve::prove (friProve.cpp:44-108): pol holds 2^prev_bits cubic-extension

@@ -100,6 +100,8 @@ extern "C" int mi_ctx_create(mi_ctx **out, int device)
     return MI_OK;
 }
 
+extern "C" int mi_ctx_device(const mi_ctx *c) { return c ? c->device : -1; }
+
 extern "C" void mi_ctx_destroy(mi_ctx *c)
 {
     if (!c) return;
@@ -461,7 +463,7 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
 {
     CTX_OK(c);
     if (nq == 0) return MI_OK;
-    MI_REQUIRE(proofs && nodes && (src || width == 0) && idx, "null buffer"); // width 0: sibling paths only
+    MI_REQUIRE(proofs && (nodes || src) && (src || width == 0) && idx, "null buffer"); // width 0: sibling paths only; nodes NULL: row values only
     for (uint64_t q = 0; q < nq; q++) MI_REQUIRE(idx[q] < height, "query index out of range");
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     u64 *di = c->small; // the indices: the context's 4 KiB words (512 queries) or its scratch, no allocation per call

@@ -1,0 +1,581 @@
+// multi.hip -- ONE process, several devices: the stage commit (extendPol + merkelize, starks.cpp:48-59,133-141,214-221,284-292) sharded
+// over the GPUs of a node behind the C ABI, for a caller like the reference's Prover -- one process, one proof in flight
+// (prover.cpp:187-260) -- that cannot be split into torch.distributed ranks (shard.py is that other form; same plan, same result).
+//
+// the LDE is independent per COLUMN, a Merkle leaf needs a whole ROW, so there is exactly one exchange.  Shard g (a device;
+// several shards may share one, which is how a single-GPU box rehearses the path) is dealt column tiles in rounds -- round k: shard g
+// extends the g-th tile of the round, at most 32 columns, so that the G tiles of a round are a contiguous piece of every row -- and owns
+// the rows [g * n_ext / G, (g + 1) * n_ext / G) of the tree.  Per round and shard, each on its own stream:
+//     upload stream    the tile's columns of the base-domain trace come up over THAT device's PCIe link (host threads pack them into
+//                      page-locked staging, one contiguous copy each), or across from the device that holds the section (stages 2-4)
+//     compute stream   LDE of the tile  ->  [later]  absorb the previous round's columns of my rows into the leaf sponges
+//     exchange stream  my tile's rows go to the shard that owns them: one hipMemcpyPeerAsync per peer and round, every xGMI link of the
+//                      device busy at once (point-to-point, no ring); optionally the whole tile also goes into the ROW-MAJOR image of the
+//                      extension on one device (what Starks::genProof's constraint evaluation reads)
+// then each shard builds the subtree over its rows, the G subtree roots meet on shard 0 and the top log2 G levels are hashed there:
+// the same root, node for node, as the single-device tree.  Openings: the row's values from the owning shard's column windows, its
+// lower siblings from that shard's subtree, the top log2 G from the roots' tree.
+#include "common.h"
+#include <algorithm>
+#include <chrono>
+#include <emmintrin.h>
+#include <string.h>
+#include <thread>
+
+namespace {
+
+struct Plan { // merlin-zkevm-prover_amd/shard.py ShardPlan, word for word in meaning
+    uint64_t n = 0, n_ext = 0, ncols = 0;
+    uint32_t G = 1, tile = 32;
+    uint64_t per_rank = 0, rows_per_rank = 0;
+    std::vector<uint64_t> round_w, round_c0, local_c0;
+    void init(uint64_t n_, uint64_t n_ext_, uint64_t ncols_, uint32_t G_)
+    {
+        n = n_; n_ext = n_ext_; ncols = ncols_; G = G_;
+        per_rank = (ncols + 8 * G - 1) / (8 * G) * 8;
+        round_w.clear(); round_c0.clear(); local_c0.clear();
+        for (uint64_t c = 0; c < per_rank; c += tile) round_w.push_back(std::min<uint64_t>(tile, per_rank - c));
+        uint64_t acc = 0;
+        for (uint64_t w : round_w) { round_c0.push_back(G * acc); local_c0.push_back(acc); acc += w; }
+        rows_per_rank = n_ext / G;
+    }
+    size_t rounds() const { return round_w.size(); }
+    uint64_t c0(size_t k, uint32_t g) const { return round_c0[k] + g * round_w[k]; }
+    uint64_t width(size_t k, uint32_t g) const { const uint64_t c = c0(k, g); return c >= ncols ? 0 : std::min(round_w[k], ncols - c); }
+    uint64_t ext_base(size_t k) const { return n_ext * local_c0[k]; }                       // in a shard's `ext`: my round-k tile, [n_ext x w] at pitch w
+    uint64_t recv_off(size_t k, uint32_t peer) const { return rows_per_rank * c0(k, peer); } // in a shard's `recv`: peer's round-k tile restricted to my rows
+};
+
+struct Stats { double lde_ms = 0, absorb_ms = 0, wait_ms = 0, upload_ms = 0; std::vector<uint64_t> bytes_to; };
+
+} // namespace
+
+struct mi_multi {
+    uint32_t G = 0;
+    std::vector<int> dev;
+    std::vector<mi_ctx *> ctx;
+    std::vector<hipStream_t> cs, xs, us; // compute, exchange, upload
+    int pack_threads = 16;
+    static constexpr int HS = 3;         // page-locked staging ring of the host uploads (shared by the shards: the host packs one tile at a time)
+    u64 *hstage[HS] = {};
+    uint64_t hstage_bytes = 0;
+    std::vector<hipEvent_t> hstage_sent[HS]; // [ring slot][shard]: an event is recorded on streams of the device it was created on
+    int hstage_user[HS] = {-1, -1, -1};      // the shard whose upload last read the slot
+    std::vector<Stats> stats;
+    double last_wall_ms = 0;
+    // mi_multi_lend: a caller that plans a device's HBM (host/starks.hpp: the proof's image fills the device that also is shard 0) hands the
+    // next commit a region that is not live; the shard's row buffers, staging and NTT workspace are carved from it instead of allocated
+    std::vector<u64 *> lent;
+    std::vector<uint64_t> lent_elems;
+};
+
+struct mi_multi_tree {
+    mi_multi *m = nullptr;
+    Plan p;
+    std::vector<u64 *> ext, recv, nodes, stage; // per shard, on its device
+    u64 *roots = nullptr;                       // shard 0's device: (2G - 1) * 4
+    std::vector<u64> roots_host;
+    bool keep_rows = true;                      // ext / recv still hold the rows (openings read them)
+    std::vector<char> rows_lent;                // per shard: ext / recv / stage live in a lent region (not freed here)
+};
+
+#define MM_DEV(m, g) MI_HIP_CHECK(hipSetDevice((m)->dev[g]))
+
+extern "C" void mi_multi_destroy(mi_multi *m);
+
+extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
+{
+    MI_REQUIRE(out && devices && n_shards >= 1 && is_pow2((uint64_t)n_shards), "the number of shards must be a power of two");
+    *out = nullptr;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have == 0) {
+        mi_set_error("no HIP device available: libmi_stark has no CPU fallback");
+        return MI_ERR_NO_DEVICE;
+    }
+    for (int g = 0; g < n_shards; g++)
+        if (devices[g] < 0 || devices[g] >= have) {
+            mi_set_error("mi_multi_create: device %d out of range (%d devices)", devices[g], have);
+            return MI_ERR_INVALID;
+        }
+    mi_multi *m = new mi_multi();
+    m->G = (uint32_t)n_shards;
+    m->dev.assign(devices, devices + n_shards);
+    m->stats.resize(n_shards);
+    m->lent.assign(n_shards, nullptr);
+    m->lent_elems.assign(n_shards, 0);
+    for (int g = 0; g < n_shards; g++) {
+        mi_ctx *c = nullptr;
+        int st = mi_ctx_create(&c, devices[g]);
+        if (st != MI_OK) { mi_multi_destroy(m); return st; }
+        m->ctx.push_back(c);
+        hipStream_t s[3];
+        for (int i = 0; i < 3; i++)
+            if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) { mi_set_error("mi_multi_create: cannot create a stream"); mi_multi_destroy(m); return MI_ERR_HIP; }
+        m->cs.push_back(s[0]); m->xs.push_back(s[1]); m->us.push_back(s[2]);
+        mi_ctx_set_stream(c, s[0]);
+        for (int i = 0; i < mi_multi::HS; i++) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { mi_set_error("mi_multi_create: cannot create an event"); mi_multi_destroy(m); return MI_ERR_HIP; }
+            m->hstage_sent[i].push_back(e);
+        }
+    }
+    // every pair of distinct devices talks directly (xGMI): without peer access the runtime would stage the copies through the host
+    for (int a = 0; a < n_shards; a++)
+        for (int b = 0; b < n_shards; b++) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+            if (!can) continue;
+            (void)hipSetDevice(devices[a]);
+            hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); }
+        }
+    (void)hipGetLastError();
+    unsigned hw = std::thread::hardware_concurrency();
+    m->pack_threads = (int)std::max(1u, std::min(64u, hw ? hw : 16u));
+    *out = m;
+    return MI_OK;
+}
+
+extern "C" void mi_multi_destroy(mi_multi *m)
+{
+    if (!m) return;
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        (void)hipSetDevice(m->dev[g]);
+        if (g < m->cs.size()) { (void)hipStreamSynchronize(m->cs[g]); (void)hipStreamSynchronize(m->xs[g]); (void)hipStreamSynchronize(m->us[g]); }
+        if (m->ctx[g]) { mi_ctx_set_stream(m->ctx[g], nullptr); mi_ctx_destroy(m->ctx[g]); }
+        if (g < m->cs.size()) { (void)hipStreamDestroy(m->cs[g]); (void)hipStreamDestroy(m->xs[g]); (void)hipStreamDestroy(m->us[g]); }
+    }
+    for (int i = 0; i < mi_multi::HS; i++) {
+        if (m->hstage[i]) (void)hipHostFree(m->hstage[i]);
+        for (hipEvent_t e : m->hstage_sent[i]) if (e) (void)hipEventDestroy(e);
+    }
+    delete m;
+}
+
+extern "C" int mi_multi_shards(const mi_multi *m) { return m ? (int)m->G : 0; }
+extern "C" mi_ctx *mi_multi_ctx(mi_multi *m, int shard) { return (m && shard >= 0 && (uint32_t)shard < m->G) ? m->ctx[shard] : nullptr; }
+extern "C" int mi_multi_set_pack_threads(mi_multi *m, int threads)
+{
+    MI_REQUIRE(m && threads >= 1, "bad argument");
+    m->pack_threads = threads;
+    return MI_OK;
+}
+
+// The NEXT commit carves shard `shard`'s row buffers, staging and NTT workspace from [ptr, ptr + bytes) (memory of that shard's device)
+// instead of allocating them; the region is the caller's again when the commit returns and mi_multi_tree_release_rows has been called
+// (openings with values need the rows: a caller that lends opens the values from its own image).
+extern "C" int mi_multi_lend(mi_multi *m, int shard, void *ptr, uint64_t bytes)
+{
+    MI_REQUIRE(m && shard >= 0 && (uint32_t)shard < m->G, "bad shard");
+    m->lent[shard] = (u64 *)ptr;
+    m->lent_elems[shard] = ptr ? bytes / 8 : 0;
+    return MI_OK;
+}
+
+extern "C" void mi_multi_tree_free(mi_multi_tree *t)
+{
+    if (!t) return;
+    mi_multi *m = t->m;
+    for (uint32_t g = 0; g < m->G; g++) {
+        (void)hipSetDevice(m->dev[g]);
+        (void)hipStreamSynchronize(m->cs[g]); (void)hipStreamSynchronize(m->xs[g]); (void)hipStreamSynchronize(m->us[g]);
+        const bool lent = g < t->rows_lent.size() && t->rows_lent[g];
+        if (!lent && g < t->ext.size() && t->ext[g]) (void)hipFree(t->ext[g]);
+        if (!lent && g < t->recv.size() && t->recv[g]) (void)hipFree(t->recv[g]);
+        if (g < t->nodes.size() && t->nodes[g]) (void)hipFree(t->nodes[g]);
+        if (!lent && g < t->stage.size() && t->stage[g]) (void)hipFree(t->stage[g]);
+    }
+    if (t->roots) { (void)hipSetDevice(m->dev[0]); (void)hipFree(t->roots); }
+    delete t;
+}
+
+// the rows' values are no longer needed from the shards (a caller that keeps the row-major image of the extension opens them there):
+// ext / recv / staging go back, the subtrees stay
+extern "C" int mi_multi_tree_release_rows(mi_multi_tree *t)
+{
+    MI_REQUIRE(t, "null tree");
+    mi_multi *m = t->m;
+    for (uint32_t g = 0; g < m->G; g++) {
+        MM_DEV(m, g);
+        MI_HIP_CHECK(hipStreamSynchronize(m->cs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->xs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->us[g]));
+        if (!t->rows_lent[g]) {
+            if (t->ext[g]) MI_HIP_CHECK(hipFree(t->ext[g]));
+            if (t->recv[g]) MI_HIP_CHECK(hipFree(t->recv[g]));
+            if (t->stage[g]) MI_HIP_CHECK(hipFree(t->stage[g]));
+        }
+        t->ext[g] = t->recv[g] = t->stage[g] = nullptr;
+    }
+    t->keep_rows = false;
+    return MI_OK;
+}
+
+static int copy_dd(const mi_multi *m, void *dst, int gd, const void *src, int gs, uint64_t bytes, hipStream_t s)
+{
+    if (!bytes) return MI_OK;
+    if (m->dev[gd] == m->dev[gs]) MI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    else MI_HIP_CHECK(hipMemcpyPeerAsync(dst, m->dev[gd], src, m->dev[gs], bytes, s));
+    return MI_OK;
+}
+
+// Stage commit.  src: the n x ncols row-major base-domain section at row pitch src_pitch (elements) -- in HOST memory (src_device < 0;
+// pageable is fine, host threads read it) or on device `src_device` (the image of a proof: stages 2-4).  image / base (optional, on
+// device image_device): receive the whole extension (n_ext x ncols at image_pitch) / the section itself (n x ncols at base_pitch) in
+// row-major form.  root: 4 words, host.
+extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t *src, uint64_t src_pitch, int src_device, uint64_t n, uint64_t n_ext,
+                               uint64_t ncols, uint64_t *image, uint64_t image_pitch, uint64_t *base, uint64_t base_pitch, int image_device, uint64_t root[4])
+{
+    MI_REQUIRE(m && out && src && root, "null argument");
+    MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n && ncols > 4, "sizes: powers of two, more than 4 columns (linear_hash copies shorter rows)");
+    MI_REQUIRE(n_ext % m->G == 0 && n_ext / m->G >= 2, "too few rows for this many shards");
+    const auto t_begin = std::chrono::steady_clock::now();
+    const uint32_t G = m->G;
+    mi_multi_tree *t = new mi_multi_tree();
+    struct Guard { mi_multi_tree *t; ~Guard() { if (t) mi_multi_tree_free(t); } } guard{t};
+    t->m = m;
+    Plan &p = t->p;
+    p.init(n, n_ext, ncols, G);
+    const size_t R = p.rounds();
+    const uint64_t maxw = *std::max_element(p.round_w.begin(), p.round_w.end());
+    constexpr int NS = 2; // device staging buffers per shard
+    t->ext.assign(G, nullptr); t->recv.assign(G, nullptr); t->nodes.assign(G, nullptr); t->stage.assign(G, nullptr);
+    t->rows_lent.assign(G, 0);
+    struct LendGuard { mi_multi *m; ~LendGuard() { for (uint32_t g = 0; g < m->G; g++) if (m->lent[g]) { (void)hipSetDevice(m->dev[g]); (void)mi_ctx_lend_workspace(m->ctx[g], nullptr, 0); m->lent[g] = nullptr; m->lent_elems[g] = 0; } } } lendguard{m};
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        auto alloc = [&](u64 **q, uint64_t elems) -> int {
+            hipError_t e = hipMalloc((void **)q, std::max<uint64_t>(elems, 1) * 8);
+            if (e != hipSuccess) { mi_set_error("mi_multi_commit: shard %u cannot allocate %.2f GB: %s", g, elems * 8 / 1e9, hipGetErrorString(e)); return MI_ERR_NOMEM; }
+            return MI_OK;
+        };
+        const uint64_t e_ext = (n_ext * p.per_rank + 31) & ~31ull, e_recv = G > 1 ? (p.rows_per_rank * G * p.per_rank + 31) & ~31ull : 0, e_stage = (NS * n * maxw + 31) & ~31ull;
+        const uint64_t e_ws = 4 * (n + 2 * n_ext) * maxw; // room for the tile's transforms (its compact ping-pong buffers)
+        if (m->lent[g] && m->lent_elems[g] >= e_ext + e_recv + e_stage + e_ws) { // the row buffers, the staging and the transforms' workspace out of the lent region
+            u64 *q = m->lent[g];
+            t->ext[g] = q; q += e_ext;
+            if (G > 1) { t->recv[g] = q; q += e_recv; }
+            t->stage[g] = q; q += e_stage;
+            MI_TRY(mi_ctx_lend_workspace(m->ctx[g], q, (m->lent_elems[g] - (uint64_t)(q - m->lent[g])) * 8));
+            t->rows_lent[g] = 1;
+        } else {
+            MI_TRY(alloc(&t->ext[g], n_ext * p.per_rank));
+            if (G > 1) MI_TRY(alloc(&t->recv[g], p.rows_per_rank * G * p.per_rank));
+            MI_TRY(alloc(&t->stage[g], NS * n * maxw));
+        }
+        MI_TRY(alloc(&t->nodes[g], (2 * p.rows_per_rank - 1) * 4));
+        m->stats[g] = Stats();
+        m->stats[g].bytes_to.assign(G, 0);
+    }
+    MM_DEV(m, 0);
+    MI_HIP_CHECK(hipMalloc((void **)&t->roots, (2 * G - 1) * 4 * 8));
+    const bool from_host = src_device < 0;
+    if (from_host) {
+        const uint64_t need = n * maxw * 8;
+        if (m->hstage_bytes < need) {
+            for (int i = 0; i < mi_multi::HS; i++) {
+                if (m->hstage_user[i] >= 0) MI_HIP_CHECK(hipEventSynchronize(m->hstage_sent[i][m->hstage_user[i]]));
+                m->hstage_user[i] = -1;
+                if (m->hstage[i]) MI_HIP_CHECK(hipHostFree(m->hstage[i]));
+                m->hstage[i] = nullptr;
+                MI_HIP_CHECK(hipHostMalloc((void **)&m->hstage[i], need, hipHostMallocPortable));
+            }
+            m->hstage_bytes = need;
+        }
+    }
+    // events: per shard and round
+    std::vector<std::vector<hipEvent_t>> ev_lde(G), ev_sent(G);
+    std::vector<hipEvent_t> ev_up(G * NS), ev_consumed(G * NS), ev_based(G * NS), tm; // tm: timing events, destroyed at the end
+    struct EvGuard { std::vector<std::vector<hipEvent_t>> *a, *b; std::vector<hipEvent_t> *c, *d, *e, *f;
+                     ~EvGuard() { for (auto *vv : {a, b}) for (auto &v : *vv) for (hipEvent_t x : v) if (x) (void)hipEventDestroy(x);
+                                  for (auto *v : {c, d, e, f}) for (hipEvent_t x : *v) if (x) (void)hipEventDestroy(x); } } evguard{&ev_lde, &ev_sent, &ev_up, &ev_consumed, &ev_based, &tm};
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        ev_lde[g].assign(R, nullptr); ev_sent[g].assign(R, nullptr);
+        for (size_t k = 0; k < R; k++) {
+            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_lde[g][k], hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_sent[g][k], hipEventDisableTiming));
+        }
+        for (int s = 0; s < NS; s++) {
+            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_up[g * NS + s], hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_consumed[g * NS + s], hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_based[g * NS + s], hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventRecord(ev_consumed[g * NS + s], m->cs[g]));
+            MI_HIP_CHECK(hipEventRecord(ev_based[g * NS + s], m->xs[g]));
+        }
+    }
+    struct Timed { uint32_t g; int kind; hipEvent_t a, b; }; // kind 0 lde, 1 absorb, 2 wait
+    std::vector<Timed> timed;
+    auto stamp = [&](uint32_t g, hipStream_t s, hipEvent_t *e) -> int {
+        MI_HIP_CHECK(hipEventCreate(e));
+        tm.push_back(*e);
+        MI_HIP_CHECK(hipEventRecord(*e, s));
+        (void)g;
+        return MI_OK;
+    };
+    int hs_next = 0;
+    std::vector<int> slot_of(G, 0);
+    auto absorb_round = [&](size_t k) -> int {
+        for (uint32_t q = 0; q < G; q++) {
+            MM_DEV(m, q);
+            hipEvent_t w0, w1, a0, a1;
+            MI_TRY(stamp(q, m->cs[q], &w0));
+            for (uint32_t g = 0; g < G; g++)
+                if (g != q && p.width(k, g)) MI_HIP_CHECK(hipStreamWaitEvent(m->cs[q], ev_sent[g][k], 0));
+            MI_TRY(stamp(q, m->cs[q], &w1));
+            timed.push_back({q, 2, w0, w1});
+            const u64 *bases[MI_MAX_SLABS];
+            uint64_t pitches[MI_MAX_SLABS], widths[MI_MAX_SLABS];
+            uint32_t nw = 0;
+            for (uint32_t g = 0; g < G; g++) {
+                const uint64_t w = p.width(k, g);
+                if (!w) continue;
+                MI_REQUIRE(nw < MI_MAX_SLABS, "more shards than one absorb launch takes windows");
+                bases[nw] = g == q ? t->ext[q] + p.ext_base(k) + (uint64_t)q * p.rows_per_rank * w : t->recv[q] + p.recv_off(k, g);
+                pitches[nw] = w; widths[nw] = w;
+                nw++;
+            }
+            if (!nw) continue;
+            MI_TRY(stamp(q, m->cs[q], &a0));
+            MI_TRY(launch_linear_hash_absorb(m->ctx[q], t->nodes[q], nw, bases, pitches, widths, p.rows_per_rank, k == 0, k + 1 == R));
+            MI_TRY(stamp(q, m->cs[q], &a1));
+            timed.push_back({q, 1, a0, a1});
+        }
+        return MI_OK;
+    };
+    for (size_t k = 0; k < R; k++) {
+        for (uint32_t g = 0; g < G; g++) {
+            const uint64_t w = p.width(k, g), c0 = p.c0(k, g);
+            if (!w) continue;
+            MM_DEV(m, g);
+            const int slot = slot_of[g]++ % NS;
+            u64 *st = t->stage[g] + (uint64_t)slot * n * maxw;
+            // ---- the tile's base-domain columns onto shard g's device
+            MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], ev_consumed[g * NS + slot], 0));
+            MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], ev_based[g * NS + slot], 0));
+            if (from_host) {
+                const int hs = hs_next++ % mi_multi::HS;
+                const auto t0 = std::chrono::steady_clock::now();
+                if (m->hstage_user[hs] >= 0) MI_HIP_CHECK(hipEventSynchronize(m->hstage_sent[hs][m->hstage_user[hs]])); // the copy that last read this slot is done
+                u64 *hbuf = m->hstage[hs];
+                const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)m->pack_threads, (n * w * 8) >> 22));
+                const uint64_t rows_per = (n + T - 1) / T;
+                std::vector<std::thread> th;
+                for (int ti = 0; ti < T; ti++) {
+                    const uint64_t r0 = (uint64_t)ti * rows_per, r1 = std::min(n, r0 + rows_per);
+                    if (r0 >= r1) break;
+                    auto work = [=]() {
+                        const uint64_t *s_ = src + r0 * src_pitch + c0;
+                        u64 *d_ = hbuf + r0 * w;
+                        if (w % 8 == 0) {
+                            for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w)
+                                for (uint64_t j = 0; j < w; j += 2) _mm_stream_si128((__m128i *)(d_ + j), _mm_loadu_si128((const __m128i *)(s_ + j)));
+                            _mm_sfence();
+                        } else {
+                            for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w) memcpy(d_, s_, w * 8);
+                        }
+                    };
+                    if (T == 1) work(); else th.emplace_back(work);
+                }
+                for (auto &x : th) x.join();
+                m->stats[g].upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                MI_HIP_CHECK(hipMemcpyAsync(st, hbuf, n * w * 8, hipMemcpyHostToDevice, m->us[g]));
+                MI_HIP_CHECK(hipEventRecord(m->hstage_sent[hs][g], m->us[g]));
+                m->hstage_user[hs] = (int)g;
+            } else {
+                MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, src + c0, src_pitch * 8, w * 8, n, hipMemcpyDeviceToDevice, m->us[g]));
+            }
+            MI_HIP_CHECK(hipEventRecord(ev_up[g * NS + slot], m->us[g]));
+            // ---- LDE of the tile
+            MI_HIP_CHECK(hipStreamWaitEvent(m->cs[g], ev_up[g * NS + slot], 0));
+            hipEvent_t l0, l1;
+            MI_TRY(stamp(g, m->cs[g], &l0));
+            MI_TRY(launch_lde(m->ctx[g], t->ext[g] + p.ext_base(k), w, st, w, n_ext, n, w));
+            MI_TRY(stamp(g, m->cs[g], &l1));
+            timed.push_back({g, 0, l0, l1});
+            MI_HIP_CHECK(hipEventRecord(ev_consumed[g * NS + slot], m->cs[g]));
+            MI_HIP_CHECK(hipEventRecord(ev_lde[g][k], m->cs[g]));
+            // ---- exchange stream: the section itself and the whole extended tile into the row-major image (if asked), my tile's rows to their owners
+            if (base) {
+                MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_up[g * NS + slot], 0));
+                MI_HIP_CHECK(hipMemcpy2DAsync(base + c0, base_pitch * 8, st, w * 8, w * 8, n, hipMemcpyDeviceToDevice, m->xs[g]));
+            }
+            MI_HIP_CHECK(hipEventRecord(ev_based[g * NS + slot], m->xs[g]));
+            MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_lde[g][k], 0));
+            for (uint32_t q = 0; q < G; q++) {
+                if (q == g) continue;
+                const uint64_t cnt = p.rows_per_rank * w;
+                MI_TRY(copy_dd(m, t->recv[q] + p.recv_off(k, g), (int)q, t->ext[g] + p.ext_base(k) + (uint64_t)q * cnt, (int)g, cnt * 8, m->xs[g]));
+                m->stats[g].bytes_to[q] += cnt * 8;
+            }
+            if (image) MI_HIP_CHECK(hipMemcpy2DAsync(image + c0, image_pitch * 8, t->ext[g] + p.ext_base(k), w * 8, w * 8, n_ext, hipMemcpyDeviceToDevice, m->xs[g]));
+            MI_HIP_CHECK(hipEventRecord(ev_sent[g][k], m->xs[g]));
+        }
+        if (k > 0) MI_TRY(absorb_round(k - 1));
+    }
+    MI_TRY(absorb_round(R - 1));
+    // ---- subtrees, then the G roots meet on shard 0
+    std::vector<hipEvent_t> ev_root(G, nullptr);
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        MI_TRY(launch_merkle_levels(m->ctx[g], t->nodes[g], p.rows_per_rank));
+        MI_HIP_CHECK(hipEventCreateWithFlags(&ev_root[g], hipEventDisableTiming));
+        tm.push_back(ev_root[g]);
+        MI_HIP_CHECK(hipEventRecord(ev_root[g], m->cs[g]));
+        MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_root[g], 0));
+        MI_TRY(copy_dd(m, t->roots + 4 * g, 0, t->nodes[g] + (2 * p.rows_per_rank - 2) * 4, (int)g, 32, m->xs[g]));
+        MI_HIP_CHECK(hipEventRecord(ev_root[g], m->xs[g]));
+    }
+    MM_DEV(m, 0);
+    for (uint32_t g = 0; g < G; g++) MI_HIP_CHECK(hipStreamWaitEvent(m->cs[0], ev_root[g], 0));
+    if (G > 1) MI_TRY(launch_merkle_levels(m->ctx[0], t->roots, G));
+    t->roots_host.assign((2 * G - 1) * 4, 0);
+    MI_HIP_CHECK(hipMemcpyAsync(t->roots_host.data(), t->roots, (2 * G - 1) * 32, hipMemcpyDeviceToHost, m->cs[0]));
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        MI_HIP_CHECK(hipStreamSynchronize(m->us[g])); MI_HIP_CHECK(hipStreamSynchronize(m->xs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->cs[g]));
+    }
+    for (int i = 0; i < 4; i++) root[i] = t->roots_host[(2 * G - 2) * 4 + i];
+    for (const Timed &x : timed) {
+        float ms = 0;
+        (void)hipSetDevice(m->dev[x.g]);
+        if (hipEventElapsedTime(&ms, x.a, x.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+        (x.kind == 0 ? m->stats[x.g].lde_ms : x.kind == 1 ? m->stats[x.g].absorb_ms : m->stats[x.g].wait_ms) += ms;
+    }
+    m->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    guard.t = nullptr;
+    *out = t;
+    return MI_OK;
+}
+
+// per shard of the last commit: [lde_ms, absorb_ms, exchange_wait_ms, host_pack_ms, bytes sent to shard 0 .. G-1]  (4 + G doubles each)
+extern "C" int mi_multi_last_stats(const mi_multi *m, double *out, double *wall_ms)
+{
+    MI_REQUIRE(m && out, "null argument");
+    for (uint32_t g = 0; g < m->G; g++) {
+        double *o = out + (size_t)g * (4 + m->G);
+        o[0] = m->stats[g].lde_ms; o[1] = m->stats[g].absorb_ms; o[2] = m->stats[g].wait_ms; o[3] = m->stats[g].upload_ms;
+        for (uint32_t q = 0; q < m->G; q++) o[4 + q] = q < m->stats[g].bytes_to.size() ? (double)m->stats[g].bytes_to[q] : 0.0;
+    }
+    if (wall_ms) *wall_ms = m->last_wall_ms;
+    return MI_OK;
+}
+
+extern "C" int mi_multi_tree_info(const mi_multi_tree *t, uint64_t out[6])
+{
+    MI_REQUIRE(t && out, "null argument");
+    out[0] = t->p.G; out[1] = t->p.rows_per_rank; out[2] = t->p.per_rank; out[3] = t->p.rounds(); out[4] = t->p.ncols; out[5] = t->p.n_ext;
+    return MI_OK;
+}
+
+// level-0 digests of shard g's rows, device pointer on that shard's device (rows_per_rank * 4 words; the subtree's other levels follow)
+extern "C" const uint64_t *mi_multi_tree_nodes(const mi_multi_tree *t, int shard) { return (t && shard >= 0 && (uint32_t)shard < t->p.G) ? (const uint64_t *)t->nodes[shard] : nullptr; }
+
+// ---- openings (MerkleTreeGL::getGroupProof, merkleTreeGL.cpp:12-35) over the row-sharded tree
+namespace {
+struct OpenWin { const u64 *base; uint64_t pitch; uint32_t width, col0; };
+#define MM_MAX_WIN 512
+__global__ void k_multi_open(u64 *out, uint64_t stride, const uint64_t *rows, const OpenWin *wins, uint32_t nwin, const u64 *nodes, uint64_t height, uint32_t levels,
+                             uint32_t ncols, int with_values)
+{
+    const uint64_t q = blockIdx.x;
+    uint64_t idx = rows[q];
+    u64 *o = out + q * stride;
+    if (with_values)
+        for (uint32_t w = 0; w < nwin; w++) {
+            const OpenWin W = wins[w];
+            for (uint32_t c = threadIdx.x; c < W.width; c += blockDim.x) o[W.col0 + c] = W.base[idx * W.pitch + c];
+        }
+    // siblings: level l has height >> l nodes, the levels are appended (merkleTreeGL.hpp:61-68)
+    uint64_t off = 0, hcur = height;
+    for (uint32_t l = 0; l < levels; l++) {
+        if (threadIdx.x < 4) o[ncols + 4 * l + threadIdx.x] = nodes[(off + (idx ^ 1)) * 4 + threadIdx.x];
+        off += hcur;
+        hcur >>= 1;
+        idx >>= 1;
+    }
+}
+} // namespace
+
+// proofs (HOST): nq x (ncols + 4 * log2(n_ext)) words: row idx[q]'s ncols values (zeros when with_values == 0 or the rows were released:
+// the caller opens them from its own image), then the siblings, leaves upward.
+extern "C" int mi_multi_group_proofs(mi_multi_tree *t, uint64_t *proofs, const uint64_t *idx, uint64_t nq, int with_values)
+{
+    MI_REQUIRE(t && proofs && (idx || !nq), "null argument");
+    mi_multi *m = t->m;
+    const Plan &p = t->p;
+    const uint32_t G = p.G, lv_sub = ilog2_u64(p.rows_per_rank), lv_top = ilog2_u64(G);
+    const uint64_t stride = p.ncols + 4ull * (lv_sub + lv_top);
+    if (with_values) MI_REQUIRE(t->keep_rows, "the rows of this tree were released (mi_multi_tree_release_rows)");
+    memset(proofs, 0, nq * stride * 8);
+    for (uint32_t g = 0; g < G; g++) {
+        std::vector<uint64_t> local, which;
+        for (uint64_t q = 0; q < nq; q++) {
+            MI_REQUIRE(idx[q] < p.n_ext, "query index out of range");
+            if (idx[q] / p.rows_per_rank == g) { local.push_back(idx[q] % p.rows_per_rank); which.push_back(q); }
+        }
+        if (local.empty()) continue;
+        MM_DEV(m, g);
+        std::vector<OpenWin> wins;
+        if (with_values)
+            for (size_t k = 0; k < p.rounds(); k++)
+                for (uint32_t o = 0; o < G; o++) {
+                    const uint64_t w = p.width(k, o);
+                    if (!w) continue;
+                    const u64 *b = o == g ? t->ext[g] + p.ext_base(k) + (uint64_t)g * p.rows_per_rank * w : t->recv[g] + p.recv_off(k, o);
+                    wins.push_back({b, w, (uint32_t)w, (uint32_t)p.c0(k, o)});
+                }
+        MI_REQUIRE(wins.size() <= MM_MAX_WIN, "too many column windows");
+        const uint64_t lstride = p.ncols + 4ull * lv_sub;
+        void *scr = nullptr;
+        const uint64_t need = local.size() * lstride * 8 + local.size() * 8 + wins.size() * sizeof(OpenWin) + 64;
+        MI_TRY(mi_scratch(m->ctx[g], need, &scr));
+        u64 *d_out = (u64 *)scr;
+        uint64_t *d_rows = (uint64_t *)(d_out + local.size() * lstride);
+        OpenWin *d_wins = (OpenWin *)(d_rows + local.size());
+        MI_HIP_CHECK(hipMemcpyAsync(d_rows, local.data(), local.size() * 8, hipMemcpyHostToDevice, m->cs[g]));
+        if (!wins.empty()) MI_HIP_CHECK(hipMemcpyAsync(d_wins, wins.data(), wins.size() * sizeof(OpenWin), hipMemcpyHostToDevice, m->cs[g]));
+        MI_HIP_CHECK(hipStreamSynchronize(m->cs[g])); // (the host vectors go out of scope)
+        hipLaunchKernelGGL(k_multi_open, dim3((unsigned)local.size()), dim3(64), 0, m->cs[g], d_out, lstride, d_rows, d_wins, (uint32_t)wins.size(), t->nodes[g],
+                           p.rows_per_rank, lv_sub, (uint32_t)p.ncols, with_values ? 1 : 0);
+        MI_HIP_CHECK(hipGetLastError());
+        std::vector<u64> h(local.size() * lstride);
+        MI_HIP_CHECK(hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, m->cs[g]));
+        MI_HIP_CHECK(hipStreamSynchronize(m->cs[g]));
+        for (size_t j = 0; j < local.size(); j++) {
+            uint64_t *o = proofs + which[j] * stride;
+            if (with_values) memcpy(o, &h[j * lstride], p.ncols * 8);
+            memcpy(o + p.ncols, &h[j * lstride + p.ncols], 4ull * lv_sub * 8);
+            // the top log2 G levels: the roots' tree (on the host since the commit), leaf = shard g
+            uint64_t i2 = g, off = 0, hcur = G;
+            for (uint32_t l = 0; l < lv_top; l++) {
+                memcpy(o + p.ncols + 4ull * (lv_sub + l), &t->roots_host[(off + (i2 ^ 1)) * 4], 32);
+                off += hcur; hcur >>= 1; i2 >>= 1;
+            }
+        }
+    }
+    return MI_OK;
+}
+
+// rows [row0, row0 + nrows) x all columns of the sharded extension, gathered into HOST memory row-major (verification at sizes a host holds)
+extern "C" int mi_multi_gather_rows(mi_multi_tree *t, uint64_t *out, uint64_t row0, uint64_t nrows)
+{
+    MI_REQUIRE(t && out && t->keep_rows, "null argument or released rows");
+    mi_multi *m = t->m;
+    const Plan &p = t->p;
+    MI_REQUIRE(row0 + nrows <= p.n_ext, "rows out of range");
+    for (uint64_t r = row0; r < row0 + nrows;) {
+        const uint32_t g = (uint32_t)(r / p.rows_per_rank);
+        const uint64_t lr = r % p.rows_per_rank, cnt = std::min(row0 + nrows - r, p.rows_per_rank - lr);
+        MM_DEV(m, g);
+        for (size_t k = 0; k < p.rounds(); k++)
+            for (uint32_t o = 0; o < p.G; o++) {
+                const uint64_t w = p.width(k, o);
+                if (!w) continue;
+                const u64 *b = o == g ? t->ext[g] + p.ext_base(k) + (uint64_t)g * p.rows_per_rank * w : t->recv[g] + p.recv_off(k, o);
+                MI_HIP_CHECK(hipMemcpy2DAsync(out + (r - row0) * p.ncols + p.c0(k, o), p.ncols * 8, b + lr * w, w * 8, w * 8, cnt, hipMemcpyDeviceToHost, m->cs[g]));
+            }
+        MI_HIP_CHECK(hipStreamSynchronize(m->cs[g]));
+        r += cnt;
+    }
+    return MI_OK;
+}

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(64) void k_group_proofs(u64 *__restrict__ proofs, c
     const uint64_t id = idx[q];
     u64 *out = proofs + q * ((uint64_t)width + 4ull * levels);
     for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[id * pitch + i]);
+    if (!nodes) return; // values only: the siblings come from elsewhere (a tree sharded over several devices, csrc/multi.hip)
     for (uint32_t e = threadIdx.x; e < levels * 4; e += 64) {
         const uint32_t l = e >> 2, k = e & 3;
         // offset of level l = 4 * (h + h/2 + ... ) = 4 * (2h - (h >> (l-1)))   for l >= 1

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include "goldilocks_base_field.hpp"
 #include "poseidon_goldilocks.hpp"
 #include "merklehash_goldilocks.hpp"
@@ -19,8 +20,11 @@ class MerkleTreeGL
 {
     uint64_t *d_source = nullptr, *d_nodes = nullptr; // HBM copies
     bool d_source_borrowed = false, d_nodes_borrowed = false;
+    mi_multi_tree *multiTree = nullptr;               // set: the nodes are subtrees on several devices
     void releaseDevice()
     {
+        if (multiTree) mi_multi_tree_free(multiTree);
+        multiTree = nullptr;
         if (d_source && !d_source_borrowed) mi::devFree(d_source);
         if (d_nodes && !d_nodes_borrowed) mi::devFree(d_nodes);
         d_source = d_nodes = nullptr;
@@ -74,6 +78,15 @@ public:
         d_source = dev_source; d_nodes = dev_nodes;
         d_source_borrowed = d_nodes_borrowed = true;
     }
+    // a tree whose subtrees live on several devices (csrc/multi.hip) while the rows are read from a row-major image on this one: the view
+    // owns the sharded tree from here on
+    void setMultiTree(uint64_t *dev_source, mi_multi_tree *tree)
+    {
+        releaseDevice();
+        d_source = dev_source;
+        d_source_borrowed = true;
+        multiTree = tree;
+    }
     uint64_t *deviceNodes() { return d_nodes; }
     uint64_t *deviceSource() { return d_source; }
 
@@ -109,6 +122,17 @@ public:
     void getGroupProofs(Goldilocks::Element *proofs, const uint64_t *idx, uint64_t nq)
     {
         const uint64_t stride = width + MerkleProofSize() * HASH_SIZE;
+        if (multiTree) { // siblings from the shards' subtrees, the rows' values from the image on this device
+            mi_ctx *c = mi::ctx();
+            mi::check(mi_multi_group_proofs(multiTree, (uint64_t *)proofs, idx, nq, 0), "MerkleTreeGL::getGroupProofs (sharded tree)");
+            std::vector<uint64_t> sib((uint64_t *)proofs, (uint64_t *)proofs + nq * stride);
+            uint64_t *d_out = mi::devAlloc(nq * stride, "MerkleTreeGL::getGroupProofs (alloc)");
+            mi::check(mi_merkle_group_proofs_dev(c, d_out, nullptr, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs (rows of a sharded tree)");
+            mi::check(mi_copy_d2h(c, proofs, d_out, nq * stride * 8), "MerkleTreeGL::getGroupProofs (d2h)");
+            mi::devFree(d_out);
+            for (uint64_t q = 0; q < nq; q++) std::memcpy((uint64_t *)proofs + q * stride + width, &sib[q * stride + width], (stride - width) * 8);
+            return;
+        }
         if (d_nodes && d_source) {
             mi_ctx *c = mi::ctx();
             uint64_t *d_out = mi::devAlloc(nq * stride, "MerkleTreeGL::getGroupProofs (alloc)");

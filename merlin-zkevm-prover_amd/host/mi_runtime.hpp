@@ -31,6 +31,26 @@ inline void check(int status, const char *where)
 {
     if (status != MI_OK) fail(where);
 }
+// More than one device for the stage commits (csrc/multi.hip): MI_STARK_DEVICES = "0,1,2,3" -- shard g on that device, a power of two of
+// them, the first one the device of ctx() (where the proof's image lives); a device may be named twice (logical shards: how a one-GPU box
+// rehearses the path).  Unset or one entry: nullptr, everything runs on ctx()'s device.
+inline mi_multi *multi()
+{
+    static mi_multi *m = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *e = std::getenv("MI_STARK_DEVICES");
+        int devs[64], n = 0;
+        for (const char *p = e; p && *p && n < 64;) {
+            devs[n++] = std::atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        if (n > 1 && mi_multi_create(&m, devs, n) != MI_OK) fail("mi_multi_create (MI_STARK_DEVICES)");
+    }
+    return m;
+}
 // Device scratch of the host classes (FRI polynomials, step-tree leaves and nodes, opening buffers).  A caller that owns a plan of
 // the HBM (host/starks.hpp) lends a region and the classes carve it in order; without one every request is a device allocation.
 // Memory handed back to the driver is wiped in the background on the GPU's own bandwidth, so a proof that

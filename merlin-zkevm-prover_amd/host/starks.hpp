@@ -434,10 +434,29 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     //--------------------------------
     TimerStart(STARK_STEP_1);
     TimerStart(STARK_STEP_1_LDE_AND_MERKLETREE);
-    lend(sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns));
-    mi::check(mi_lde_merkle_host_keep(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
-                                      cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
-    mi::check(mi_copy_d2h(c, root0.address(), d_nodes[0] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 1)");
+    // more than one device (MI_STARK_DEVICES, csrc/multi.hip): the commit of a stage is sharded over them -- each device extends column
+    // tiles (stage 1: uploaded over ITS OWN PCIe link) and hashes the leaves and the subtree of its rows -- while the row-major extension
+    // still lands in this device's image, where the constraint evaluation reads it.  The shard on this device works in the same dead
+    // regions the single-device path lends as scratch.
+    mi_multi *mm = mi::multi();
+    mi_multi_tree *mtree[4] = {};
+    const int dev0 = mi_ctx_device(c);
+    auto sharded = [&](uint64_t ncols) { return mm && ncols > 4 && NExtended / (uint64_t)mi_multi_shards(mm) >= 64; };
+    auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, uint64_t *scratch, uint64_t scratchElems, Goldilocks::Element *root) {
+        mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
+        mi::check(mi_multi_lend(mm, 0, scratch, scratchElems * 8), "Starks::genProof (sharded commit: lend)");
+        mi::check(mi_multi_commit(mm, &mtree[t], src, ncols, srcDevice, N, NExtended, ncols, image, ncols, base, ncols, dev0, (uint64_t *)root),
+                  "Starks::genProof (sharded extendPol + merkelize)");
+        mi::check(mi_multi_tree_release_rows(mtree[t]), "Starks::genProof (sharded commit: release)"); // the openings read the rows from the image
+    };
+    if (sharded(cols(cm1_n))) {
+        commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns), root0.address());
+    } else {
+        lend(sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns));
+        mi::check(mi_lde_merkle_host_keep(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
+                                          cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
+        mi::check(mi_copy_d2h(c, root0.address(), d_nodes[0] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 1)");
+    }
     transcript.put(root0.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_1_LDE_AND_MERKLETREE);
     TimerStopAndLog(STARK_STEP_1);
@@ -465,10 +484,14 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     numCommited += starkInfo.puCtx.size() * 2;
     TimerStopAndLog(STARK_STEP_2_CALCULATEH1H2);
     TimerStart(STARK_STEP_2_LDE_AND_MERKLETREE);
-    lend(sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns));
-    mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
-    mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
-    mi::check(mi_copy_d2h(c, root1.address(), d_nodes[1] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 2)");
+    if (sharded(cols(cm2_n))) {
+        commitSharded(1, sec(cm2_n), dev0, cols(cm2_n), sec(cm2_2ns), nullptr, sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns), root1.address());
+    } else {
+        lend(sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns));
+        mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
+        mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
+        mi::check(mi_copy_d2h(c, root1.address(), d_nodes[1] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 2)");
+    }
     transcript.put(root1.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_2_LDE_AND_MERKLETREE);
     TimerStopAndLog(STARK_STEP_2);
@@ -513,10 +536,14 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     else perRowStep(m, params, 2);
     TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS_2);
     TimerStart(STARK_STEP_3_LDE_AND_MERKLETREE);
-    lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run
-    mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
-    mi::check(mi_merkle_build_dev(c, d_nodes[2], sec(cm3_2ns), cols(cm3_n), cols(cm3_n), NExtended), "Starks::genProof (stage 3: merkelize)");
-    mi::check(mi_copy_d2h(c, root2.address(), d_nodes[2] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 3)");
+    if (sharded(cols(cm3_n))) { // (scratch: cm1_n | cm2_n, their last reader has run)
+        commitSharded(2, sec(cm3_n), dev0, cols(cm3_n), sec(cm3_2ns), nullptr, sec(cm1_n), off(cm3_n) - off(cm1_n), root2.address());
+    } else {
+        lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run
+        mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
+        mi::check(mi_merkle_build_dev(c, d_nodes[2], sec(cm3_2ns), cols(cm3_n), cols(cm3_n), NExtended), "Starks::genProof (stage 3: merkelize)");
+        mi::check(mi_copy_d2h(c, root2.address(), d_nodes[2] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 3)");
+    }
     transcript.put(root2.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_3_LDE_AND_MERKLETREE);
     TimerStopAndLog(STARK_STEP_3);
@@ -644,7 +671,8 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         for (int t = 0; t < 4; t++) {
             views[t].height = NExtended;
             views[t].width = cols(s2[t]);
-            views[t].setDeviceTree(sec(s2[t]), d_nodes[t]);
+            if (mtree[t]) views[t].setMultiTree(sec(s2[t]), mtree[t]); // (the view owns the sharded tree and frees it)
+            else views[t].setDeviceTree(sec(s2[t]), d_nodes[t]);
         }
         // FRI's polynomials, step trees and opening buffers come out of the same remainder (the fold transforms in registers: no
         // NTT scratch is in use any more)

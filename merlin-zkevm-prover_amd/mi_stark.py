@@ -57,6 +57,8 @@ EXPORTS = [
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
     "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_get_host_pack_threads",
+    "mi_ctx_device", "mi_multi_lend", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_commit", "mi_multi_group_proofs",
+    "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_compile_micro", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
 ]
 
@@ -545,6 +547,85 @@ class ChelpersProgram:
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         P = self._params(pols.ctypes.data, const_pols.ctypes.data, n_const, challenges, publics, x.ctypes.data, x_stride, zhinv, q.ctypes.data, keep)
         _check(lib().mi_dbg_host_chelpers_run(self.h, ctypes.byref(P), _hp(rows), u64(rows.size)))
+
+
+class MultiTree:
+    """A tree committed by Multi.commit: rows and subtrees live on the shards."""
+
+    def __init__(self, multi, handle, root, n_ext, ncols):
+        self.multi, self.h, self.root, self.n_ext, self.ncols = multi, handle, root, n_ext, ncols
+        info = (u64 * 6)()
+        _check(lib().mi_multi_tree_info(self.h, info))
+        self.shards, self.rows_per_shard, self.cols_per_shard, self.rounds = (int(info[i]) for i in range(4))
+
+    def group_proofs(self, idx, with_values=True):
+        """-> [len(idx), ncols + 4 log2(n_ext)] host array: MerkleTreeGL::getGroupProof for every row of idx"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        stride = self.ncols + 4 * (self.n_ext - 1).bit_length()
+        out = np.zeros((idx.size, stride), dtype=np.uint64)
+        _check(lib().mi_multi_group_proofs(self.h, _hp(out), _hp(idx), u64(idx.size), ctypes.c_int(int(with_values))))
+        return out
+
+    def gather_rows(self, row0, nrows):
+        out = np.empty((nrows, self.ncols), dtype=np.uint64)
+        _check(lib().mi_multi_gather_rows(self.h, _hp(out), u64(row0), u64(nrows)))
+        return out
+
+    def leaf_digests(self, shard):
+        """level-0 digests of the shard's rows, as a host array [rows_per_shard, 4] (for checks)"""
+        L = lib()
+        L.mi_multi_tree_nodes.restype = ctypes.c_void_p
+        L.mi_multi_ctx.restype = ctypes.c_void_p
+        out = np.empty((self.rows_per_shard, 4), dtype=np.uint64)
+        _check(L.mi_copy_d2h(ctypes.c_void_p(L.mi_multi_ctx(self.multi.h, ctypes.c_int(shard))), _hp(out),
+                             ctypes.c_void_p(L.mi_multi_tree_nodes(self.h, ctypes.c_int(shard))), u64(out.size * 8)))
+        return out
+
+    def release_rows(self):
+        _check(lib().mi_multi_tree_release_rows(self.h))
+
+    def free(self):
+        if self.h:
+            lib().mi_multi_tree_free(self.h)
+            self.h = ctypes.c_void_p()
+
+
+class Multi:
+    """One process, several devices (csrc/multi.hip): the stage commit sharded over `devices` (a device may be named more than once:
+    logical shards on one GPU)."""
+
+    def __init__(self, devices):
+        devs = (ctypes.c_int * len(devices))(*devices)
+        self.h = ctypes.c_void_p()
+        self.devices = list(devices)
+        _check(lib().mi_multi_create(ctypes.byref(self.h), devs, ctypes.c_int(len(devices))))
+
+    def commit(self, src_ptr, n, n_ext, ncols, src_device=-1, src_pitch=None, image_ptr=None, image_pitch=None, base_ptr=None, base_pitch=None, image_device=0):
+        """src_ptr: address of the n x ncols row-major section (host memory when src_device < 0, else on that device) -> MultiTree"""
+        t = ctypes.c_void_p()
+        root = np.zeros(4, dtype=np.uint64)
+        _check(lib().mi_multi_commit(self.h, ctypes.byref(t), ctypes.c_void_p(src_ptr), u64(src_pitch or ncols), ctypes.c_int(src_device), u64(n), u64(n_ext), u64(ncols),
+                                     ctypes.c_void_p(image_ptr), u64(image_pitch or ncols), ctypes.c_void_p(base_ptr), u64(base_pitch or ncols), ctypes.c_int(image_device),
+                                     _hp(root)))
+        return MultiTree(self, t, root, n_ext, ncols)
+
+    def last_stats(self):
+        G = len(self.devices)
+        buf = np.zeros(G * (4 + G), dtype=np.float64)
+        wall = ctypes.c_double()
+        _check(lib().mi_multi_last_stats(self.h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(wall)))
+        rows = buf.reshape(G, 4 + G)
+        return {"wall_ms": wall.value,
+                "per_shard": [{"shard": g, "device": self.devices[g], "lde_ms": float(r[0]), "absorb_ms": float(r[1]), "exchange_wait_ms": float(r[2]),
+                               "host_pack_ms": float(r[3]), "bytes_sent_to_shard": [int(b) for b in r[4:]]} for g, r in enumerate(rows)]}
+
+    def set_pack_threads(self, threads):
+        _check(lib().mi_multi_set_pack_threads(self.h, ctypes.c_int(threads)))
+
+    def close(self):
+        if self.h:
+            lib().mi_multi_destroy(self.h)
+            self.h = ctypes.c_void_p()
 
 
 # ---- host debug hooks (same inline math as the kernels, run on the CPU; tests only)

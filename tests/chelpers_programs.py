@@ -159,7 +159,8 @@ def synthetic_program(rng, nrows, sections, n_const, n_chal, n_pub, passes=3, nt
 
 def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_ops=17986, next_shift=2, vc=4, long_lived=70, base_out=None,
                                   sec_weights=None, kind_weights=None, mean_len=4.6, ext_frac=0.09, run_ops=750, pool_scale=1.0, zipf=0.7, ll_generations=1,
-                                  ll_use=0.5, burst=None, shared_scale=1.0, partition=False, neighbour=0.0, class_p=(0.46, 0.29, 0.25)):
+                                  ll_use=0.5, burst=None, shared_scale=1.0, partition=False, neighbour=0.0, class_p=(0.46, 0.29, 0.25), pol3_frac=0.0,
+                                  pol3_secs=(0.0, 0.23, 0.77)):
     """A random valid step42ns program in the SHAPE of the zkEVM one (the real tables cannot travel to the GPU box): ~2 200
     constraint values, each a short base-field expression (on average 5.6 multiplications / additions / subtractions) over
     polynomial elements, shifted ("prime") elements, constants and numbers, every one folded into the running extension
@@ -184,7 +185,10 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
     runs as contiguous slices -- a state machine owns a range of columns -- so that every column is read somewhere and an operand is read
     by one or two kernels, as in the real program (2 167 distinct operands, each loaded by 2.0 kernels on average); neighbour = share of
     a partitioned run's picks that go to the PREVIOUS run's slices instead (constraints that tie two state machines together); class_p =
-    shares of multiplications / additions / subtractions among the base-field operations."""
+    shares of multiplications / additions / subtractions among the base-field operations; pol3_frac = share of the extension-valued
+    constraints that read EXTENSION-VALUED polynomials (three adjacent columns: the lookups' h1 / h2 of dimension 3 in cm2, the grand products
+    z and z' in cm3 -- opcodes 74, 75 / 44 / 41, 72: the real program has 316 such reads of 200 distinct polynomials, 600 staged words),
+    pol3_secs = which section they live in."""
     ops, args = [], []
     ACC = 0
     cls_of = lambda o: "add" if o <= 20 else "sub" if o <= 44 else "mul" if o <= 77 else "copy"
@@ -247,11 +251,17 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
         if kind == T1: return [temps.pop()]
         if kind == NUM: return [int(rng.integers(0, 1 << 64, dtype=np.uint64)) if rng.random() < 0.3 else int(rng.integers(0, 9))]
         if kind == CONST: return [zipf_pick(cur_pool["const"])]
-        if kind == CONSTS: return [zipf_pick(cur_pool["const"]), next_shift, nrows]
+        if kind == CONSTS: return [(int(rng.integers(0, n_const)) if pol3_frac else zipf_pick(cur_pool["const"])), next_shift, nrows]
         if kind == PUB: return [int(rng.integers(0, n_pub))]
         if kind == POL: return list(pick_part() if partition else zipf_pick(cur_pool["pol"]))
         if kind == POLS:
-            c, st = pick_part() if partition else zipf_pick(cur_pool["pols"])
+            if partition and pol3_frac:      # the real program's shifted reads hardly repeat (467 distinct in 540): a uniform pick inside the run's slice
+                w = np.asarray(sec_weights, dtype=np.float64)
+                w = np.array([wi if cur_pool["sec"][i] else 0.0 for i, wi in enumerate(w)])
+                lst = cur_pool["sec"][int(rng.choice(len(sections), p=w / w.sum()))]
+                c, st = lst[int(rng.integers(0, len(lst)))]
+            else:
+                c, st = pick_part() if partition else zipf_pick(cur_pool["pols"])
             return [c, next_shift, nrows, st]
         raise ValueError(kind)
 
@@ -331,7 +341,38 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
             out_cursor[0] += 1
             count += 1
             continue
-        if rng.random() < ext_frac:              # extension-valued constraint
+        is_ext = rng.random() < ext_frac
+        if is_ext and pol3_frac and rng.random() < pol3_frac:   # a constraint over extension-valued polynomials (grand-product shaped)
+            e1, e2 = 1 + eslot % 4, 1 + (eslot + 1) % 4
+            eslot += 2
+
+            def pol3():
+                w3 = np.array([pol3_secs[i] if (len(sections[i]) > 2 and sections[i][2] or sections[i][1]) >= 3 and i < len(pol3_secs) else 0.0 for i in range(len(sections))])
+                si = int(rng.choice(len(sections), p=w3 / w3.sum()))
+                off, stride = sections[si][0], sections[si][1]
+                cols = sections[si][2] if len(sections[si]) > 2 else stride
+                c = int(rng.integers(0, cols // 3)) * 3      # (316 reads of 200 distinct polynomials: close to uniform over the section)
+                return off + min(c, cols - 3), stride
+            c3, st3 = pol3()
+            push(59, [e1, cur, int(rng.integers(0, vc))])                   # e1 = value * challenge
+            if rng.random() < 0.42: push(74, [e2, c3, next_shift, nrows, st3, e1])   # e2 = z' * e1   (66 of the real program's 316 extension reads are shifted)
+            else: push(75, [e2, c3, st3, e1])                               # e2 = z * e1
+            c3b, st3b = pol3() if rng.random() < 0.7 else (c3, st3)
+            r = rng.random()
+            if r < 0.45: push(75, [e1, c3b, st3b, e1])                      # e1 = z * e1
+            elif r < 0.8: push(44, [e1, e1, c3b, st3b])                     # e1 = e1 - z
+            else: push(41, [e1, c3b, st3b, int(rng.integers(0, 9))])        # e1 = z - number
+            push(42, [e1, e2, e1])
+            n3 = 4
+            if rng.random() < 0.4:
+                c3c, st3c = pol3()
+                push(72, [e2, c3c, st3c, c3b, st3b])                        # e2 = h1 * z
+                push(17, [e1, e1, e2])
+                n3 += 2
+            push(17, [ACC, e1, ACC])
+            push(70, [ACC, vc, ACC])
+            count += n3 + 2
+        elif is_ext:                             # extension-valued constraint
             e1, e2 = 1 + eslot % 4, 1 + (eslot + 1) % 4
             eslot += 2
             push(59, [e1, cur, int(rng.integers(0, vc))])                   # e1 = value * challenge
@@ -360,9 +401,9 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
 # within 10 %: words moved through the kernel-boundary spill, Horner-chain steps, the (0.9 %) share of cm2 reads; NOT matched: operand
 # loads per row (-13 %) and distinct operands (-28 %) -- the real program reads extension-valued polynomials (three staged columns per
 # read) and more shifted constants than this generator's operation mix produces.
-ZKEVM_STEP42NS_FIT = dict(field_ops=17986, long_lived=5, sec_weights=[0.95448, 0.009, 0.048], kind_weights={CONST: 0.19, CONSTS: 0.028, POLS: 0.13, POL: 1.0},
-                          mean_len=5.1, ext_frac=0.06, run_ops=1197, pool_scale=1.0, zipf=0.289, ll_generations=2, ll_use=0.5, burst=[0.5, 97], shared_scale=0.6075,
-                          partition=True, neighbour=0.49, class_p=[0.56, 0.23, 0.21])
+ZKEVM_STEP42NS_FIT = dict(field_ops=17986, long_lived=4, sec_weights=[1.1065, 0.0012, 0.018], kind_weights={CONST: 0.17, CONSTS: 0.5, POLS: 0.10, POL: 1.0, NUM: 0.45},
+                          mean_len=5.733, ext_frac=0.065, run_ops=1592, pool_scale=1.0, zipf=0.5, ll_generations=2, ll_use=0.625, burst=[0.5, 78], shared_scale=0.4429,
+                          partition=True, neighbour=0.16807, class_p=[0.56, 0.23, 0.21], pol3_frac=1.0)
 # (re-fitted with the zkEVM's 218 constant polynomials -- ConstantPols::numPols(), pols_generated/constant_pols.hpp:689; r03 first fitted
 # against 360: operand loads per row are now -13 %, distinct operands -28 %)
 ZKEVM_STEP42NS_FIT_TOLERANCE = {"field_ops": 0.05, "live_words_rescheduled": 0.05, "kernels": 0.05, "estimated_valu_per_row": 0.05, "frac_reads_cm1": 0.05,

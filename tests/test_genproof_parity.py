@@ -146,3 +146,15 @@ def test_starks_genproof_with_per_row_steps_equals_the_oracle_prover(name, tmp_p
     so = sr.steps_library(inputs[1], str(tmp_path))
     got1, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(1,), steps_so=so)
     assert got1 == want, first_difference(got1, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,devices", [("zkevm_small", "0,0"), ("zkevm_14", "0,0,0,0"), ("recursive_12", "0,0"), ("zkevm_full_12", "0,0,0,0,0,0,0,0")])
+def test_starks_genproof_with_sharded_commits_equals_the_oracle_prover(name, devices, tmp_path):
+    """MI_STARK_DEVICES: the stage commits of Starks::genProof sharded over several devices from ONE process (csrc/multi.hip; here logical
+    shards on device 0): column-tile LDEs, peer exchange, row-sharded leaf hashing and subtrees, openings whose siblings come from the
+    shards -- and still the oracle prover's bytes."""
+    inputs = shaped_inputs(SHAPES[name])
+    want, _ = og.gen_proof(*inputs)
+    got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,), env=dict(os.environ, MI_STARK_DEVICES=devices))
+    assert got4 == want, first_difference(got4, want)

@@ -1,0 +1,126 @@
+"""One process, several devices (csrc/multi.hip): the stage commit sharded over G shards behind the C ABI -- the form a
+one-process Prover can use -- against the single-device path, on ONE GPU with G logical shards mapped to device 0 (peer copies
+degenerate to device copies; every other step is the code an 8-GPU node runs).  Root, every leaf digest, the openings (values and
+siblings) and the row-major image must equal the single-device result bit for bit, and the single-device result is the oracle's
+(tests/test_gpu_parity.py, tests/test_gpu_fullsize.py)."""
+import numpy as np
+import pytest
+
+import glo
+import mi_stark
+
+
+def single_device(ctx, trace, n, n_ext, ncols):
+    d_in = ctx.to_device(trace)
+    ext, nodes = ctx.empty(n_ext * ncols), ctx.empty((2 * n_ext - 1) * 4)
+    ctx.lde(ext, d_in, n_ext, n, ncols)
+    ctx.merkle_build(nodes, ext, ncols, n_ext)
+    ctx.sync()
+    return ext, nodes
+
+
+def test_multi_api_is_exported_and_refuses_without_a_gpu():
+    import ctypes
+    import torch
+    L = mi_stark.lib()
+    for s in ("mi_multi_create", "mi_multi_commit", "mi_multi_group_proofs", "mi_multi_last_stats"):
+        assert hasattr(L, s)
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        devs = (ctypes.c_int * 2)(0, 0)
+        assert L.mi_multi_create(ctypes.byref(h), devs, 2) == -1 and b"no CPU fallback" in L.mi_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ncols,G", [(10, 37, 2), (12, 665, 4), (13, 96, 8), (11, 6, 2), (14, 371, 8), (18, 665, 2), (18, 665, 4), (18, 665, 8)])
+def test_sharded_commit_from_host_equals_the_single_device_tree(log_n, ncols, G):
+    n, n_ext = 1 << log_n, 2 << log_n
+    trace = glo.splitmix64(0x5EED0500 + log_n, n * ncols).reshape(n, ncols)
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    want_nodes = ctx.to_host(nodes)
+    m = mi_stark.Multi([0] * G)
+    image = ctx.zeros(n_ext * ncols)
+    base = ctx.zeros(n * ncols)
+    ctx.sync()
+    t = m.commit(trace.ctypes.data, n, n_ext, ncols, image_ptr=image.data_ptr(), base_ptr=base.data_ptr())
+    assert [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+    assert t.shards == G and t.rows_per_shard == n_ext // G
+    # every leaf digest, shard by shard
+    for g in range(G):
+        assert np.array_equal(t.leaf_digests(g).reshape(-1), want_nodes[4 * g * t.rows_per_shard:4 * (g + 1) * t.rows_per_shard]), g
+    # the row-major image of the extension and the kept base-domain section
+    assert np.array_equal(ctx.to_host(image), ctx.to_host(ext))
+    assert np.array_equal(ctx.to_host(base), trace.reshape(-1))
+    # openings: first / last row of every shard and random rows
+    rng = np.random.default_rng(G)
+    idx = np.array(sorted({0, n_ext - 1} | {g * t.rows_per_shard for g in range(G)} | {(g + 1) * t.rows_per_shard - 1 for g in range(G)} |
+                          {int(v) for v in rng.integers(0, n_ext, size=24)}), dtype=np.uint64)
+    got = t.group_proofs(idx)
+    want = ctx.empty(idx.size * got.shape[1])
+    ctx.merkle_group_proofs(want, nodes, ext, n_ext, ncols, idx)
+    assert np.array_equal(got.reshape(-1), ctx.to_host(want))
+    for q, i in enumerate(idx[:6]):                                     # ... and the oracle accepts them against the root
+        assert glo.merkle_verify(t.root, got[q][:ncols], got[q][ncols:], int(i))
+    # siblings alone, after the row buffers went back
+    t.release_rows()
+    sib = t.group_proofs(idx, with_values=False)
+    assert np.array_equal(sib[:, ncols:], got[:, ncols:]) and not sib[:, :ncols].any()
+    st = m.last_stats()
+    assert len(st["per_shard"]) == G and all(s["absorb_ms"] > 0 for s in st["per_shard"]) and st["per_shard"][0]["lde_ms"] > 0   # (a shard may be dealt no columns)
+    sent = sum(sum(s["bytes_sent_to_shard"]) for s in st["per_shard"])
+    assert sent == 8 * n_ext * ncols * (G - 1) // G                     # every element leaves its shard for exactly (G - 1) / G of the rows
+    t.free(); m.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_sharded_commit_from_a_device_section_equals_the_single_device_tree():
+    """Stages 2-4 of a proof: the section is already on a device (the image), at a row pitch wider than itself."""
+    log_n, ncols, pitch, G = 12, 128, 200, 4
+    n, n_ext = 1 << log_n, 2 << log_n
+    wide = glo.splitmix64(0x5EED0600, n * pitch).reshape(n, pitch)
+    trace = np.ascontiguousarray(wide[:, 40:40 + ncols])
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    d_wide = ctx.to_device(wide)
+    image = ctx.zeros(n_ext * pitch)
+    ctx.sync()
+    m = mi_stark.Multi([0] * G)
+    t = m.commit(d_wide.data_ptr() + 8 * 40, n, n_ext, ncols, src_device=0, src_pitch=pitch, image_ptr=image.data_ptr() + 8 * 40, image_pitch=pitch)
+    assert [int(v) for v in t.root] == [int(v) for v in ctx.to_host(nodes)[-4:]]
+    img = ctx.to_host(image).reshape(n_ext, pitch)
+    assert np.array_equal(img[:, 40:40 + ncols].reshape(-1), ctx.to_host(ext)) and not img[:, :40].any() and not img[:, 40 + ncols:].any()
+    assert np.array_equal(t.gather_rows(n_ext // 2 - 3, 7).reshape(-1), ctx.to_host(ext).reshape(n_ext, ncols)[n_ext // 2 - 3:n_ext // 2 + 4].reshape(-1))
+    t.free(); m.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_two_shards_at_full_size_reproduce_the_verified_root():
+    """BASELINE configs[2] at full size (2^23 x 665 -> 2^24) through two logical shards on one GPU, the trace in pageable host memory:
+    the root must be the one tests/test_gpu_fullsize.py verifies against the oracle (bench.py's ROOT_2P23_X665), sampled openings must
+    verify against it, and the per-shard statistics must account for every byte that changed shards."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 300e9:
+        pytest.skip("needs the MI355X's 288 GiB")
+    import bench
+    log_n, ncols, G = 23, 665, 2
+    n, n_ext = 1 << log_n, 2 << log_n
+    ctx = mi_stark.Context(0)
+    host = torch.empty(n * ncols, dtype=torch.int64)                     # pageable, as a mapped pols file is
+    d = ctx.empty(n * ncols)
+    ctx.fill_synthetic_2d(d, n, ncols, ncols, 0, 0x5EED0003)             # bench.py's synthetic trace
+    host.copy_(d)
+    torch.cuda.synchronize()
+    del d
+    torch.cuda.empty_cache()
+    m = mi_stark.Multi([0] * G)
+    t = m.commit(host.data_ptr(), n, n_ext, ncols)
+    assert [int(v) for v in t.root] == bench.ROOT_2P23_X665
+    idx = np.array([0, 1, n_ext // 2 - 1, n_ext // 2, n_ext - 1, 12345678], dtype=np.uint64)
+    got = t.group_proofs(idx)
+    for q, i in enumerate(idx):
+        assert glo.merkle_verify(t.root, got[q][:ncols], got[q][ncols:], int(i))
+    st = m.last_stats()
+    assert sum(sum(s["bytes_sent_to_shard"]) for s in st["per_shard"]) == 8 * n_ext * ncols // 2
+    print(st)
+    t.free(); m.close(); ctx.close()

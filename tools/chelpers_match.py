@@ -101,7 +101,8 @@ def main():
         print("start %.4f" % best, {k: round(100 * v, 1) for k, v in bd.items()}, flush=True)
         knobs = [("mean_len", [0.85, 1.15]), ("pool_scale", [0.8, 1.25]), ("long_lived", [0.9, 1.1]), ("ll_generations", [-1, +1]), ("ll_use", [0.8, 1.25]),
                  ("ext_frac", [0.8, 1.25]), ("run_ops", [0.75, 1.33]), ("zipf", [0.85, 1.15]), ("sec0", [0.97, 1.03]), ("sec1", [0.7, 1.4]), ("sec2", [0.8, 1.25]),
-                 ("kCONST", [0.8, 1.25]), ("kCONSTS", [0.75, 1.33]), ("kPOLS", [0.75, 1.33]), ("shared_scale", [0.6, 1.5]), ("burst1", [0.9, 1.1]), ("neighbour", [0.7, 1.4])]
+                 ("kCONST", [0.8, 1.25]), ("kCONSTS", [0.6, 1.6]), ("kPOLS", [0.75, 1.33]), ("kNUM", [0.8, 1.25]), ("kT1", [0.85, 1.18]), ("shared_scale", [0.6, 1.5]),
+                 ("burst1", [0.9, 1.1]), ("neighbour", [0.7, 1.4]), ("pol3_frac", [0.7, 1.4])]
         for it in range(iters):
             improved = False
             for name, moves in knobs:
@@ -113,13 +114,15 @@ def main():
                         Q["sec_weights"][i] *= mv
                     elif name.startswith("k"):
                         kk = getattr(cp, name[1:])
-                        Q["kind_weights"][kk] *= mv
+                        Q["kind_weights"][kk] = Q["kind_weights"].get(kk, 1.0) * mv
                     elif name == "burst1":
                         Q["burst"] = [Q["burst"][0], max(1, int(round(Q["burst"][1] * mv)))]
                     elif name in ("ll_generations",):
                         Q[name] = max(1, Q[name] + mv)
                     elif name in ("long_lived", "run_ops"):
                         Q[name] = max(1, int(round(Q[name] * mv)))
+                    elif name == "pol3_frac":
+                        Q[name] = min(1.0, max(0.05, Q.get(name, 0.5) * mv))
                     else:
                         Q[name] = Q[name] * mv
                     sc, d = score(Q)
