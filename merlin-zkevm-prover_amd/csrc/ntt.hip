@@ -304,6 +304,134 @@ __global__ __launch_bounds__(16 << LOG_B) void k_ntt_pass(const NttPass a)
     }
 }
 
+// ---- persistent, double-buffered form of the radix-256 pass (the one LDE route DESIGN left open).
+// k_ntt_pass above: two 64 KB workgroups per CU, each loads -> syncs -> computes -> stores; the memory pipe idles while both compute and
+// the ALUs idle while both load, and how the two drift against each other is the ~40 ms between max(movement, arithmetic) and the
+// measured LDE (profiles/r03_pmc_ntt.txt).  Here ONE 512-thread workgroup per CU walks its share of the tiles with TWO tile buffers:
+// the next tile's 64 KB are requested with LDS-DMA loads (global_load_lds_dwordx4: no registers, no LDS-write instructions, the data
+// lands while the current tile is computed) at the top of an iteration and waited for -- one s_waitcnt vmcnt(0), by which time they
+// have had a whole tile's arithmetic to arrive -- just before the current tile's stores are issued, so load and compute phases overlap
+// by construction instead of by the luck of two workgroups' phases.  The LDS image is lane-linear per wave (4 rows x 256 B per
+// instruction), which is the layout the steps already use.  Only interior work qualifies (full 32-element tile rows, no zero-padded
+// input, 16-byte aligned source rows); everything else takes k_ntt_pass.
+template <bool INV>
+__global__ __launch_bounds__(512, 1) void k_ntt_pass_pers(const NttPass a)
+{
+    constexpr int LOG_R = 8, LOG_B = 5, B = 32, R = 256, RA = 16, RB = 16;
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    u64 *const tile0 = smem, *const tile1 = smem + R * B;
+    u64 *const w256 = smem + 2 * R * B;
+    u64 *const tw0 = w256 + 256, *const tw1 = tw0 + R; // [R] each: TJ == 1 (a tile row is 32 columns of one beta row)
+
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n = 1ull << a.log_n;
+    const uint64_t K = 1ull << a.log_K;
+    const uint64_t mK = n >> LOG_R;
+    if (tid < 256) w256[tid] = a.w256[tid];
+
+    auto locate = [&](uint64_t v, uint64_t &beta0, uint32_t &c0) { // virtual block id -> tile, XCD-aware as in k_ntt_pass (n_tiles and the grid are multiples of 8)
+        const uint64_t lt = (v & 7) * (a.n_tiles >> 3) + (v >> 3);
+        beta0 = lt / a.n_col_tiles;
+        c0 = (uint32_t)(lt % a.n_col_tiles) << 5;
+    };
+    // the inter-pass twiddle (and scale) of entry k1 = tid of a tile: the table reads are ISSUED with the tile's DMA and only consumed
+    // after the wait that retires both, so their latency hides behind a tile's arithmetic like the DMA's
+    struct TwRegs { u64 hi, lo, shi, slo; };
+    auto tw_issue = [&](uint64_t beta, TwRegs &r) {
+        r.hi = r.lo = r.shi = r.slo = 1;
+        if (a.unit_tw || tid >= 256) return;
+        const uint32_t k1 = tid;
+        const uint64_t ip = beta >> a.log_K, kappa = beta & (K - 1);
+        uint64_t ex = (ip * k1) << a.log_K;
+        if (INV) ex = (n - ex) & (n - 1);
+        r.hi = a.tw_hi[ex >> a.tw_lo_bits];
+        r.lo = a.tw_lo[ex & ((1ull << a.tw_lo_bits) - 1)];
+        if (a.apply_scale) {
+            const uint64_t ro = (((ip << LOG_R) + k1) << a.log_K) + kappa;
+            r.shi = a.sc_hi[ro >> a.sc_lo_bits];
+            r.slo = a.sc_lo[ro & ((1ull << a.sc_lo_bits) - 1)];
+        }
+    };
+    auto tw_finish = [&](u64 *tw, const TwRegs &r) {
+        if (a.unit_tw || tid >= 256) return;
+        u64 t = gl::mul(r.hi, r.lo); // (w^0 = hi[0] * lo[0] = 1 * 1)
+        if (a.apply_scale) t = gl::mul(t, gl::mul(r.shi, r.slo));
+        tw[tid] = t;
+    };
+    // a wave's instruction k fetches rows 4 w + 32 k .. + 3 of the tile: lane l -> row l / 16, 16-byte piece l % 16 = LDS bytes l * 16 on
+    auto issue = [&](u64 *tile, uint64_t beta0, uint32_t c0) {
+        const u64 *p = a.src + beta0 * a.src_pitch + c0 + (tid & 15) * 2 + (uint64_t)(tid >> 4) * mK * a.src_pitch;
+        const uint64_t rstride = 32 * mK * a.src_pitch;
+        u64 *wave_base = tile + (uint32_t)((tid >> 6) * 4) * B;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                             (__attribute__((address_space(3))) void *)(wave_base + k * 32 * B), 16, 0, 0);
+            p += rstride;
+        }
+    };
+
+    uint64_t v = blockIdx.x;
+    uint64_t beta0;
+    uint32_t c0;
+    TwRegs tr;
+    locate(v, beta0, c0);
+    tw_issue(beta0, tr);
+    issue(tile0, beta0, c0);
+    __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0): as an instruction the compiler sees (inline asm would leave it believing the loads pending) */
+    tw_finish(tw0, tr);
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */
+    __builtin_amdgcn_s_barrier();
+    for (uint32_t it = 0; v < a.n_tiles; it++, v += gridDim.x) {
+        u64 *tile = (it & 1) ? tile1 : tile0, *tile_n = (it & 1) ? tile0 : tile1;
+        u64 *tw = (it & 1) ? tw1 : tw0, *tw_n = (it & 1) ? tw0 : tw1;
+        const uint64_t vn = v + gridDim.x;
+        uint64_t bn = 0;
+        uint32_t cn = 0;
+        if (vn < a.n_tiles) { // the next tile: its table reads and its 64 KB request go out now and are waited for after this tile's arithmetic
+            locate(vn, bn, cn);
+            tw_issue(bn, tr);
+            issue(tile_n, bn, cn);
+        }
+        asm volatile("" ::: "memory");
+        // ---- step A (in place), step B, twiddle
+        tile_step_a<LOG_R, INV, LOG_B>(tile, w256, tid);
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */
+        __builtin_amdgcn_s_barrier();
+        const uint32_t b = tid & (B - 1), kap = tid >> LOG_B;
+        const uint32_t col = c0 + b;
+        u64 x[RB];
+        tile_step_b<LOG_R, INV, LOG_B>(tile, kap, b, x);
+        const uint64_t ip = beta0 >> a.log_K, kappa = beta0 & (K - 1);
+        const uint64_t qstride = ((uint64_t)RA << a.log_K) * a.dst_pitch;
+        const u64 *t = tw + kap;
+        if (a.unit_tw) {
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) x[kb] = NTT_CANON(x[kb]);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) x[kb] = NTT_MULW(x[kb], t[kb * RA]);
+            if (!a.weak_out) {
+#pragma unroll
+                for (int kb = 0; kb < RB; kb++) x[kb] = NTT_CANON(x[kb]);
+            }
+        }
+        // the next tile (and its table words) have had this tile's arithmetic to arrive; the previous tile's stores are long gone
+        __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0): as an instruction the compiler sees (inline asm would leave it believing the loads pending) */
+        if (vn < a.n_tiles) tw_finish(tw_n, tr);
+        {
+            const bool odd = b & 1;
+            const uint32_t col_e = col & ~1u;
+            u64 *q = a.dst + col_e + ((((ip << LOG_R) + kap) << a.log_K) + kappa) * a.dst_pitch;
+            store_pairs<RB>(q, qstride, x, odd, true, false);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */
+        __builtin_amdgcn_s_barrier(); // every wave has read this tile (its buffer is the target after next) and its share of the next has landed
+        beta0 = bn;
+        c0 = cn;
+    }
+}
+
 // ---- fused middle pass of extendPol: the LAST pass of INTT_N (radix r1, with the shift^k / N scale) and the FIRST
 // pass of NTT_Next on the zero-padded coefficients (radix r2 = blowup * r1) work on the same data: the INTT tile
 // (kappa, column tile) produces coefficients k = k1 * K1 + kappa, k1 < r1, K1 = N / r1, and the NTT's first pass
@@ -550,6 +678,21 @@ static int launch_pass(mi_ctx *ctx, NttPass &a, uint32_t log_r, bool inv)
     MI_REQUIRE(a.n_tiles < (1ull << 22), "NTT grid too large"); // 512 threads each: the grid must stay below 2^32 threads
     a.w256 = ctx->w256;
     const size_t lds = (((size_t)(1u << log_r) << log_b) + 256 + ((size_t)(1u << log_r) << tj_log)) * 8;
+    // the persistent double-buffered form (MI_NTT_PERSISTENT=1; A/B against the default in tools/pmc_ntt.sh): interior work only
+    static const int persistent = []() { const char *e = getenv("MI_NTT_PERSISTENT"); return e ? atoi(e) : 0; }();
+    const uint64_t grid_p = (uint64_t)ctx->cu_count & ~7ull;
+    if (persistent && log_r == 8 && log_b == 5 && tcp_log == 5 && tj_log == 0 && (a.ncols & 31) == 0 && a.in_valid_rows >= n && ((uintptr_t)a.src & 15) == 0 &&
+        (a.src_pitch & 1) == 0 && (a.n_tiles & 7) == 0 && a.n_tiles >= 4 * grid_p && grid_p >= 8) {
+        const size_t lds_p = ((size_t)2 * 256 * 32 + 256 + 2 * 256) * 8;
+        auto kf = k_ntt_pass_pers<false>;
+        auto ki = k_ntt_pass_pers<true>;
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        if (inv) hipLaunchKernelGGL(ki, dim3((unsigned)grid_p), dim3(512), lds_p, ctx->stream, a);
+        else hipLaunchKernelGGL(kf, dim3((unsigned)grid_p), dim3(512), lds_p, ctx->stream, a);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
     switch (log_r) {
     case 1: return launch_pass_r<1>(ctx, a, inv, lds, log_b);
     case 2: return launch_pass_r<2>(ctx, a, inv, lds, log_b);

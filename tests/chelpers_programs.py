@@ -401,9 +401,9 @@ def synthetic_program_zkevm_shape(rng, nrows, sections, n_const, n_pub, field_op
 # within 10 %: words moved through the kernel-boundary spill, Horner-chain steps, the (0.9 %) share of cm2 reads; NOT matched: operand
 # loads per row (-13 %) and distinct operands (-28 %) -- the real program reads extension-valued polynomials (three staged columns per
 # read) and more shifted constants than this generator's operation mix produces.
-ZKEVM_STEP42NS_FIT = dict(field_ops=17986, long_lived=4, sec_weights=[1.1065, 0.0012, 0.018], kind_weights={CONST: 0.17, CONSTS: 0.5, POLS: 0.10, POL: 1.0, NUM: 0.45},
-                          mean_len=5.733, ext_frac=0.065, run_ops=1592, pool_scale=1.0, zipf=0.5, ll_generations=2, ll_use=0.625, burst=[0.5, 78], shared_scale=0.4429,
-                          partition=True, neighbour=0.16807, class_p=[0.56, 0.23, 0.21], pol3_frac=1.0)
+ZKEVM_STEP42NS_FIT = dict(field_ops=17986, long_lived=4, sec_weights=[1.172829352735, 0.001, 0.027], kind_weights={CONST: 0.4, CONSTS: 1.0, POLS: 0.28, POL: 2.5, NUM: 0.35},
+                          mean_len=5.5, ext_frac=0.065, run_ops=1194, pool_scale=1.0, zipf=0.55, ll_generations=1, ll_use=0.625, burst=[0.5, 95], shared_scale=0.3,
+                          partition=True, neighbour=0.05, class_p=[0.56, 0.23, 0.21], pol3_frac=1.0)
 # (re-fitted with the zkEVM's 218 constant polynomials -- ConstantPols::numPols(), pols_generated/constant_pols.hpp:689; r03 first fitted
 # against 360: operand loads per row are now -13 %, distinct operands -28 %)
 ZKEVM_STEP42NS_FIT_TOLERANCE = {"field_ops": 0.05, "live_words_rescheduled": 0.05, "kernels": 0.05, "estimated_valu_per_row": 0.05, "frac_reads_cm1": 0.05,

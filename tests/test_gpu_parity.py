@@ -904,3 +904,15 @@ def test_element_wise_kernels_beyond_2pow32_elements(ctx):
     b = ctx.zeros(nrows * ncols)
     ctx.copy_2d(b, a, nrows, ncols, dst_pitch=ncols, src_pitch=ncols)
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_persistent_ntt_pass_matches_oracle():
+    """MI_NTT_PERSISTENT=1 selects the persistent double-buffered radix-256 pass (csrc/ntt.hip k_ntt_pass_pers; measured slower than the
+    default and therefore off: profiles/r04_pmc_ntt_persistent.txt).  It stays bit-exact against the oracle (LDE, INTT / NTT at sizes
+    where it is taken); the variable is read once per process, hence a child."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ntt_persistent_check.py")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MI_NTT_PERSISTENT="1"))
+    assert r.returncode == 0 and r.stdout.count("OK") == 6, r.stdout + r.stderr[-2000:]
