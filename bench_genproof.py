@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""bench_genproof.py -- BASELINE config 4 substitute: a Starks::genProof-shaped pass over a SYNTHETIC trace.
+"""LEGACY (round 2): superseded by bench_starks.py, which runs the same phases through the product's own `class Starks` (host/starks.hpp).
+Kept for tests/ministark.py (its Transcript helper) and the r02 profiles that name it; bench.py's batch-proof leg uses bench_starks.py.
+
+bench_genproof.py -- BASELINE config 4 substitute: a Starks::genProof-shaped pass over a SYNTHETIC trace.
 
 The real `genBatchProof` needs config/zkevm/* artefacts that are not in the reference tree ("hard
 parts"), so this driver runs every device-side phase of `Starks::genProof` (starks.cpp:9-403) on synthetic data of the

@@ -1,3 +1,5 @@
+// LEGACY (round 2): superseded by host/starks.hpp (class Starks with the reference's signatures).  Kept because tests/cpp/test_starkpil_flow.cpp
+// compares each device stage with the oracle through it; no new callers.
 // starks_device.hpp -- device-resident driver of the hot-path stages of Starks::genProof.
 //
 // The Level-0 shims let src/starkpil compile unchanged, but then every extendPol / merkelize moves its operands over PCIe
