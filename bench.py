@@ -87,7 +87,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(log_n, ncols):
+def cpu_baseline(log_n, ncols, trace_host=None):
     """CPU baseline on this node's host cores, on a bounded sample of the same workload (LDE + Merkle tree of a 2^log_n x ncols trace).
     The reference's CPU path (src/goldilocks: AVX2 + OpenMP) is an absent submodule, so what is timed is this repo's restatement of
     it, labelled as such:
@@ -126,7 +126,8 @@ def cpu_baseline(log_n, ncols):
 
     def run(L, extend, tree, n, label):
         n_ext = 2 * n
-        trace = synthetic(n)
+        # the benchmark's own trace when the caller still holds it on the host (the PCIe leg's copy: same seed, same values), else generated
+        trace = trace_host if (trace_host is not None and trace_host.shape == (n, ncols)) else synthetic(n)
         L.glo_set_num_threads(threads)
         cores = int(L.glo_num_threads())
         t0 = time.perf_counter()
@@ -172,7 +173,7 @@ def cpu_baseline(log_n, ncols):
     out["cpu_model"], out["nproc"], out["omp_threads"], out["cgroup_cpu_share"] = cpu_model(), os.cpu_count(), out["cores"], share
     Ln = glo.lib("avx2")
     out["naive"] = run(Ln, lambda t, ne, n: glo.extend_pol(t, ne, n, t.shape[1], flavour="avx2"),
-                       lambda e, rows: glo.merkletree(e, e.shape[1], rows, flavour="avx2"), 1 << max(min(log_n - 2, 18), 8),
+                       lambda e, rows: glo.merkletree(e, e.shape[1], rows, flavour="avx2"), 1 << max(min(log_n - 2, 16), 8),
                        "the CHECKER's scalar restatement (oracle/gl_oracle.c, gcc -O3 -mavx2 -fopenmp): not an optimised CPU path")
     return out
 
@@ -349,7 +350,7 @@ def main():
     ap.add_argument("--poseidon-variant", type=int, default=2)
     ap.add_argument("--cpu-log-n", type=int, default=23,
                     help="log2 rows of the CPU-baseline sample: 23 = the benchmark's own size (134 GB of host memory, about two minutes on 16 threads); "
-                         "the checker's scalar code runs on 2^18 rows at most")
+                         "the checker's scalar code runs on 2^16 rows at most")
     ap.add_argument("--no-genproof", action="store_true",
                     help="N = 1: skip the batch-proof leg (bench_starks.py --shape batch in a child process after this process has released its HBM)")
     ap.add_argument("--genproof-shape", default="batch", help="batch (zkEVM + c12a + recursive1 shapes, as genBatchProof) or zkevm")
@@ -559,6 +560,7 @@ def main():
     # ---- PCIe-inclusive leg (never `value`): the same step with the trace in (page-locked) HOST memory, streamed up in column
     # chunks behind the kernels by mi_lde_merkle_host; the extension and the tree stay resident, the root comes back
     pcie = None
+    host_keep = None
     if world == 1 and not exchange and args.pcie_steps > 0:
         try:
             t_a = time.perf_counter()
@@ -590,6 +592,8 @@ def main():
                             "mi_lde_merkle_host: column chunks of 32, 64, 64 ... columns, H2D of chunk k+1 (two copy streams) || LDE + leaf absorption of chunk k; extension + tree stay in HBM",
                     "h2d_note": "strided 2-D copies out of the row-major host trace run at 39 / 49 / 53 GB/s for 32 / 64 / 128 columns against 57 GB/s contiguous "
                                 "(profiles/r02_pcie_chunk_sweep.json): hence the host-side packing"}
+            if args.cpu_log_n == args.log_n and not args.no_cpu_baseline:
+                host_keep = host_trace          # the CPU baseline runs on this very trace (saves generating 44.6 GB a second time)
             del host_trace
         except Exception as e:  # a box without enough page-lockable host memory must not lose the headline number
             pcie = {"error": repr(e)}
@@ -644,7 +648,9 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/r03_pmc_leaf.json (round-3 rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, gfx950 x2 read correction; raw: profiles/r03_pmc_leaf_raw.txt)"
             out["valu"] = valu_roofline(perms, leaf_ms, pmc)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols)
+            th = host_keep.numpy().view(np.uint64).reshape(n, ncols) if host_keep is not None else None
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols, th)
+            th = host_keep = None
         else:
             out["cpu_baseline"] = None
         if world == 1 and not exchange and not args.no_genproof:

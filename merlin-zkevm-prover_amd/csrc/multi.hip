@@ -67,6 +67,21 @@ struct mi_multi {
     // next commit a region that is not live; the shard's row buffers, staging and NTT workspace are carved from it instead of allocated
     std::vector<u64 *> lent;
     std::vector<uint64_t> lent_elems;
+    // device buffers of freed trees, per shard: the next commit takes them back instead of allocating (tens of GB per shard and proof: a fresh
+    // allocation is wiped by the driver on the GPU's own bandwidth, DESIGN_HISTORY.md section 6)
+    struct Cached { u64 *p; uint64_t elems; };
+    std::vector<std::vector<Cached>> pool;
+    u64 *take(uint32_t g, uint64_t elems)
+    {
+        auto &v = pool[g];
+        size_t best = v.size();
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i].elems >= elems && (best == v.size() || v[i].elems < v[best].elems)) best = i;
+        if (best == v.size() || v[best].elems > 2 * elems + (1u << 20)) return nullptr; // nothing fits (or only something wastefully large)
+        u64 *p = v[best].p;
+        v.erase(v.begin() + best);
+        return p;
+    }
 };
 
 struct mi_multi_tree {
@@ -77,6 +92,7 @@ struct mi_multi_tree {
     std::vector<u64> roots_host;
     bool keep_rows = true;                      // ext / recv still hold the rows (openings read them)
     std::vector<char> rows_lent;                // per shard: ext / recv / stage live in a lent region (not freed here)
+    uint64_t e_ext = 0, e_recv = 0, e_stage = 0, e_nodes = 0; // elements of the buffers (for the pool)
 };
 
 #define MM_DEV(m, g) MI_HIP_CHECK(hipSetDevice((m)->dev[g]))
@@ -103,6 +119,7 @@ extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
     m->stats.resize(n_shards);
     m->lent.assign(n_shards, nullptr);
     m->lent_elems.assign(n_shards, 0);
+    m->pool.resize(n_shards);
     for (int g = 0; g < n_shards; g++) {
         mi_ctx *c = nullptr;
         int st = mi_ctx_create(&c, devices[g]);
@@ -143,6 +160,7 @@ extern "C" void mi_multi_destroy(mi_multi *m)
     for (size_t g = 0; g < m->ctx.size(); g++) {
         (void)hipSetDevice(m->dev[g]);
         if (g < m->cs.size()) { (void)hipStreamSynchronize(m->cs[g]); (void)hipStreamSynchronize(m->xs[g]); (void)hipStreamSynchronize(m->us[g]); }
+        if (g < m->pool.size()) for (auto &c : m->pool[g]) (void)hipFree(c.p);
         if (m->ctx[g]) { mi_ctx_set_stream(m->ctx[g], nullptr); mi_ctx_destroy(m->ctx[g]); }
         if (g < m->cs.size()) { (void)hipStreamDestroy(m->cs[g]); (void)hipStreamDestroy(m->xs[g]); (void)hipStreamDestroy(m->us[g]); }
     }
@@ -181,10 +199,11 @@ extern "C" void mi_multi_tree_free(mi_multi_tree *t)
         (void)hipSetDevice(m->dev[g]);
         (void)hipStreamSynchronize(m->cs[g]); (void)hipStreamSynchronize(m->xs[g]); (void)hipStreamSynchronize(m->us[g]);
         const bool lent = g < t->rows_lent.size() && t->rows_lent[g];
-        if (!lent && g < t->ext.size() && t->ext[g]) (void)hipFree(t->ext[g]);
-        if (!lent && g < t->recv.size() && t->recv[g]) (void)hipFree(t->recv[g]);
-        if (g < t->nodes.size() && t->nodes[g]) (void)hipFree(t->nodes[g]);
-        if (!lent && g < t->stage.size() && t->stage[g]) (void)hipFree(t->stage[g]);
+        auto back = [&](u64 *q, uint64_t elems) { if (q) m->pool[g].push_back({q, elems}); };
+        if (!lent && g < t->ext.size()) back(t->ext[g], t->e_ext);
+        if (!lent && g < t->recv.size()) back(t->recv[g], t->e_recv);
+        if (g < t->nodes.size()) back(t->nodes[g], t->e_nodes);
+        if (!lent && g < t->stage.size()) back(t->stage[g], t->e_stage);
     }
     if (t->roots) { (void)hipSetDevice(m->dev[0]); (void)hipFree(t->roots); }
     delete t;
@@ -200,9 +219,9 @@ extern "C" int mi_multi_tree_release_rows(mi_multi_tree *t)
         MM_DEV(m, g);
         MI_HIP_CHECK(hipStreamSynchronize(m->cs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->xs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->us[g]));
         if (!t->rows_lent[g]) {
-            if (t->ext[g]) MI_HIP_CHECK(hipFree(t->ext[g]));
-            if (t->recv[g]) MI_HIP_CHECK(hipFree(t->recv[g]));
-            if (t->stage[g]) MI_HIP_CHECK(hipFree(t->stage[g]));
+            if (t->ext[g]) m->pool[g].push_back({t->ext[g], t->e_ext});
+            if (t->recv[g]) m->pool[g].push_back({t->recv[g], t->e_recv});
+            if (t->stage[g]) m->pool[g].push_back({t->stage[g], t->e_stage});
         }
         t->ext[g] = t->recv[g] = t->stage[g] = nullptr;
     }
@@ -244,11 +263,20 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
     for (uint32_t g = 0; g < G; g++) {
         MM_DEV(m, g);
         auto alloc = [&](u64 **q, uint64_t elems) -> int {
+            if ((*q = m->take(g, std::max<uint64_t>(elems, 1)))) return MI_OK;
             hipError_t e = hipMalloc((void **)q, std::max<uint64_t>(elems, 1) * 8);
+            if (e != hipSuccess && !m->pool[g].empty()) { // make room: give the cached buffers back and try once more
+                (void)hipGetLastError();
+                for (auto &c : m->pool[g]) (void)hipFree(c.p);
+                m->pool[g].clear();
+                e = hipMalloc((void **)q, std::max<uint64_t>(elems, 1) * 8);
+            }
             if (e != hipSuccess) { mi_set_error("mi_multi_commit: shard %u cannot allocate %.2f GB: %s", g, elems * 8 / 1e9, hipGetErrorString(e)); return MI_ERR_NOMEM; }
             return MI_OK;
         };
         const uint64_t e_ext = (n_ext * p.per_rank + 31) & ~31ull, e_recv = G > 1 ? (p.rows_per_rank * G * p.per_rank + 31) & ~31ull : 0, e_stage = (NS * n * maxw + 31) & ~31ull;
+        t->e_ext = std::max<uint64_t>(n_ext * p.per_rank, 1); t->e_recv = std::max<uint64_t>(p.rows_per_rank * G * p.per_rank, 1); t->e_stage = std::max<uint64_t>(NS * n * maxw, 1);
+        t->e_nodes = std::max<uint64_t>((2 * p.rows_per_rank - 1) * 4, 1);
         const uint64_t e_ws = 4 * (n + 2 * n_ext) * maxw; // room for the tile's transforms (its compact ping-pong buffers)
         if (m->lent[g] && m->lent_elems[g] >= e_ext + e_recv + e_stage + e_ws) { // the row buffers, the staging and the transforms' workspace out of the lent region
             u64 *q = m->lent[g];
