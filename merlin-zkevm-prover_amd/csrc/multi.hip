@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <chrono>
 #include <emmintrin.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <thread>
 
@@ -148,7 +150,17 @@ extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); }
         }
     (void)hipGetLastError();
+    // host threads that pack tiles: the cores this process may actually use (a container's CPU quota is not in hardware_concurrency()), at most 64
     unsigned hw = std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = "";
+        unsigned long per = 0;
+        if (fscanf(f, "%31s %lu", q, &per) == 2 && strcmp(q, "max") != 0 && per) {
+            const unsigned long quota = (strtoul(q, nullptr, 10) + per - 1) / per;
+            if (quota >= 1 && (!hw || quota < hw)) hw = (unsigned)quota;
+        }
+        fclose(f);
+    }
     m->pack_threads = (int)std::max(1u, std::min(64u, hw ? hw : 16u));
     *out = m;
     return MI_OK;
@@ -394,9 +406,14 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
                     auto work = [=]() {
                         const uint64_t *s_ = src + r0 * src_pitch + c0;
                         u64 *d_ = hbuf + r0 * w;
-                        if (w % 8 == 0) {
+                        if (w % 8 == 0) { // 64-byte groups: unaligned loads, streaming stores (the staging is read next by the DMA engine, not by this core)
                             for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w)
-                                for (uint64_t j = 0; j < w; j += 2) _mm_stream_si128((__m128i *)(d_ + j), _mm_loadu_si128((const __m128i *)(s_ + j)));
+                                for (uint64_t j = 0; j < w; j += 8) {
+                                    const __m128i v0 = _mm_loadu_si128((const __m128i *)(s_ + j)), v1 = _mm_loadu_si128((const __m128i *)(s_ + j + 2));
+                                    const __m128i v2 = _mm_loadu_si128((const __m128i *)(s_ + j + 4)), v3 = _mm_loadu_si128((const __m128i *)(s_ + j + 6));
+                                    _mm_stream_si128((__m128i *)(d_ + j), v0); _mm_stream_si128((__m128i *)(d_ + j + 2), v1);
+                                    _mm_stream_si128((__m128i *)(d_ + j + 4), v2); _mm_stream_si128((__m128i *)(d_ + j + 6), v3);
+                                }
                             _mm_sfence();
                         } else {
                             for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w) memcpy(d_, s_, w * 8);

@@ -32,7 +32,8 @@ def test_multi_api_is_exported_and_refuses_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_n,ncols,G", [(10, 37, 2), (12, 665, 4), (13, 96, 8), (11, 6, 2), (14, 371, 8), (18, 665, 2), (18, 665, 4), (18, 665, 8)])
+@pytest.mark.parametrize("log_n,ncols,G", [(10, 37, 2), (12, 665, 4), (13, 96, 8), (11, 6, 2), (14, 371, 8), (18, 665, 2), (18, 665, 4), (18, 665, 8),
+                                           (9, 5, 8), (10, 9, 4), (12, 263, 2), (11, 64, 16), (10, 129, 1)])   # fewer columns than shards, one column over a tile, 16 shards, one shard
 def test_sharded_commit_from_host_equals_the_single_device_tree(log_n, ncols, G):
     n, n_ext = 1 << log_n, 2 << log_n
     trace = glo.splitmix64(0x5EED0500 + log_n, n * ncols).reshape(n, ncols)
