@@ -54,7 +54,7 @@ def valu_roofline(perms, leaf_ms, pmc):
            "unit": "permutations/s", "valu_instructions_per_permutation": instrs, "issue_mix": {"frac_2clk": f2, "frac_4clk": f4},
            "achieved_wave_instr_per_s": ach / 64.0 * instrs, "effective_clock_ghz_pmc": pmc.get("effective_clock_ghz"),
            "wave_time_split_pmc": pmc.get("wave_time_split"),
-           "source": "profiles/r03_pmc_leaf.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAIT_*, GRBM_GUI_ACTIVE), tools/valu_mix.py, tools/ubench_int3.hip"}
+           "source": "profiles/r0x_pmc_leaf.json, the newest (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAIT_*, GRBM_GUI_ACTIVE: tools/pmc_leaf.sh), tools/valu_mix.py, tools/ubench_int3.hip"}
     # what the ALGORITHM needs (tools/valu_floor.py: 472 modular multiplies at 4 partial products + a 5-instruction reduction, 8 full-round MDS
     # layers on 32-bit halves, the grouped partial rounds' 737 dot terms + 44 closings; no data movement) against what the compiler emitted
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -640,12 +640,13 @@ def main():
         out["roofline_lde"]["frac"] = out["roofline_lde"]["achieved"] / HBM_PEAK_GBS
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (they cannot run inside the
         # timed process); the committed summary of the same command is read back here when the workload matches
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_leaf.json")
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_leaf.json", "r03_pmc_leaf.json")) if os.path.exists(q)), "")
+        pmc_name = os.path.basename(pmc_path)
         if (world == 1 and args.log_n == 23 and ncols == 665 and args.leaf_mode == 1 and args.poseidon_variant == 2
                 and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))["kernels"]["k_linear_hash_rows_lines"]
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r03_pmc_leaf.json (round-3 rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, gfx950 x2 read correction; raw: profiles/r03_pmc_leaf_raw.txt)"
+            out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, gfx950 x2 read correction: tools/pmc_leaf.sh)" % pmc_name
             out["valu"] = valu_roofline(perms, leaf_ms, pmc)
         if world == 1 and not args.no_cpu_baseline:
             th = host_keep.numpy().view(np.uint64).reshape(n, ncols) if host_keep is not None else None
