@@ -71,8 +71,11 @@ def main():
                 if kind == 0:
                     ops, args = cp.synthetic_program(rng, nrows, secs, 7, 5, 4, passes=int(rng.integers(1, 4)))
                 else:
+                    # (r04: also constraints over extension-valued polynomials -- opcodes 74 / 75 / 44 / 41 / 72 -- and uniformly picked shifted reads)
+                    p3 = float(rng.choice([0.0, 0.5, 1.0]))
                     ops, args = cp.synthetic_program_zkevm_shape(rng, nrows, secs, 7, 4, field_ops=int(rng.integers(200, 2500)),
-                                                                 long_lived=int(rng.integers(0, 40)))
+                                                                 long_lived=int(rng.integers(0, 40)), pol3_frac=p3, ext_frac=0.3 if p3 else 0.09,
+                                                                 partition=bool(p3 and rng.random() < 0.5), sec_weights=[0.7, 0.2, 0.1] if p3 else None)
                 chal, pub, x, zh = glo.rand_fe(rng, 15), glo.rand_fe(rng, 4), glo.rand_fe(rng, nrows * 2), glo.rand_fe(rng, 4)
                 glo.chelpers_step42ns(ops, args, pols, cpols, 7, chal, pub, x, 2, zh, want, r0, nr)
                 dev = [ctx.to_device(a) for a in (pols, cpols, x)]
