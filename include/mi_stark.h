@@ -190,6 +190,9 @@ int mi_multi_gather_rows(mi_multi_tree *t, uint64_t *out_host, uint64_t row0, ui
 /* per shard of the last commit: lde_ms, absorb_ms, exchange_wait_ms (the compute stream stood still for the links), host_pack_ms, bytes
  * sent to shard 0 .. G-1: (4 + G) doubles per shard */
 int mi_multi_last_stats(const mi_multi *m, double *out, double *wall_ms);
+/* the dealing of columns to shards (no device needed): out = [rounds, columns per shard, rows per shard, then per round and shard (first
+ * global column, width)]; returns the words written, or minus the words needed */
+int64_t mi_multi_plan_debug(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards, uint64_t *out, uint64_t cap);
 
 /* ------------------------------------------------------------------ FRI
  * Replaces the fold loop of FRIProve::prove (friProve.cpp:44-108): pol holds 2^prev_bits cubic-extension

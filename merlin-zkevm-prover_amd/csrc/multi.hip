@@ -505,6 +505,22 @@ extern "C" int mi_multi_last_stats(const mi_multi *m, double *out, double *wall_
     return MI_OK;
 }
 
+// the dealing of columns to shards, without a device (tests compare it with shard.py's ShardPlan: the two forms run ONE plan): out receives
+// [rounds, per_rank, rows_per_rank] then, per round k and shard g, (first global column, width); returns the number of words written
+extern "C" int64_t mi_multi_plan_debug(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards, uint64_t *out, uint64_t cap)
+{
+    if (!out || !shards || !is_pow2(shards)) return -1;
+    Plan p;
+    p.init(n, n_ext, ncols, shards);
+    const uint64_t need = 3 + 2 * p.rounds() * shards;
+    if (cap < need) return -(int64_t)need;
+    out[0] = p.rounds(); out[1] = p.per_rank; out[2] = p.rows_per_rank;
+    uint64_t k2 = 3;
+    for (size_t k = 0; k < p.rounds(); k++)
+        for (uint32_t g = 0; g < shards; g++) { out[k2++] = p.c0(k, g); out[k2++] = p.width(k, g); }
+    return (int64_t)need;
+}
+
 extern "C" int mi_multi_tree_info(const mi_multi_tree *t, uint64_t out[6])
 {
     MI_REQUIRE(t && out, "null argument");

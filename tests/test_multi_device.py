@@ -31,6 +31,30 @@ def test_multi_api_is_exported_and_refuses_without_a_gpu():
         assert L.mi_multi_create(ctypes.byref(h), devs, 2) == -1 and b"no CPU fallback" in L.mi_last_error()
 
 
+def test_single_process_plan_is_the_torch_distributed_plan():
+    """csrc/multi.hip and shard.py are two forms of ONE plan: the same rounds, the same tile of every shard in every round,
+    for widths around every boundary (fewer columns than shards, one over a tile, the zkEVM's 665 / 128 / 371 / 6)."""
+    import ctypes
+    from shard import ShardPlan
+    L = mi_stark.lib()
+    L.mi_multi_plan_debug.restype = ctypes.c_int64
+    buf = np.zeros(4096, dtype=np.uint64)
+    for G in (1, 2, 4, 8, 16):
+        for ncols in list(range(5, 80)) + [96, 127, 128, 129, 255, 256, 257, 371, 664, 665, 666, 1024]:
+            n, n_ext = 1 << 12, 1 << 13
+            got = L.mi_multi_plan_debug(ctypes.c_uint64(n), ctypes.c_uint64(n_ext), ctypes.c_uint64(ncols), ctypes.c_uint32(G),
+                                        buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ctypes.c_uint64(buf.size))
+            assert got > 0
+            p = ShardPlan(n=n, n_ext=n_ext, ncols=ncols, world=G, rank=0)
+            assert (int(buf[0]), int(buf[1]), int(buf[2])) == (p.n_rounds, p.per_rank, p.rows_per_rank), (G, ncols)
+            k2 = 3
+            for k in range(p.n_rounds):
+                for g in range(G):
+                    c0, w = p.round_cols(k, g)
+                    assert int(buf[k2 + 1]) == w and (w == 0 or int(buf[k2]) == c0), (G, ncols, k, g)
+                    k2 += 2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_n,ncols,G", [(10, 37, 2), (12, 665, 4), (13, 96, 8), (11, 6, 2), (14, 371, 8), (18, 665, 2), (18, 665, 4), (18, 665, 8),
                                            (9, 5, 8), (10, 9, 4), (12, 263, 2), (11, 64, 16), (10, 129, 1)])   # fewer columns than shards, one column over a tile, 16 shards, one shard
