@@ -609,6 +609,10 @@ class Multi:
                                      _hp(root)))
         return MultiTree(self, t, root, n_ext, ncols)
 
+    def lend(self, shard, ptr, nbytes):
+        """the next commit carves shard `shard`'s row buffers, staging and NTT workspace out of [ptr, ptr + nbytes) (device memory of that shard)"""
+        _check(lib().mi_multi_lend(self.h, ctypes.c_int(shard), ctypes.c_void_p(ptr), u64(nbytes)))
+
     def last_stats(self):
         G = len(self.devices)
         buf = np.zeros(G * (4 + G), dtype=np.float64)

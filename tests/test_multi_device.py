@@ -149,3 +149,43 @@ def test_two_shards_at_full_size_reproduce_the_verified_root():
     assert sum(sum(s["bytes_sent_to_shard"]) for s in st["per_shard"]) == 8 * n_ext * ncols // 2
     print(st)
     t.free(); m.close(); ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big_enough", [True, False])
+def test_a_lent_region_serves_the_shard_and_is_returned(big_enough):
+    """mi_multi_lend: a caller that plans a device's HBM (Starks: the image fills device 0, which is also shard 0) hands the next commit a
+    region that is not live; the shard's row buffers, staging and NTT workspace come out of it (nothing is allocated for that shard) and
+    the region is the caller's again after mi_multi_tree_release_rows.  A region that is too small is ignored (the shard allocates)."""
+    import torch
+    log_n, ncols, G = 14, 160, 2
+    n, n_ext = 1 << log_n, 2 << log_n
+    trace = glo.splitmix64(0x5EED0700, n * ncols).reshape(n, ncols)
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    want_root = [int(v) for v in ctx.to_host(nodes)[-4:]]
+    m = mi_stark.Multi([0] * G)
+    per_rank = 80
+    need = n_ext * per_rank + (n_ext // G) * G * per_rank + 2 * n * 32 + 4 * (n + 2 * n_ext) * 32 + 256
+    region = ctx.zeros(need if big_enough else need // 8)
+    region[:] = 0x7777
+    ctx.sync()
+    free_before = torch.cuda.mem_get_info()[0]
+    m.lend(0, region.data_ptr(), region.numel() * 8)
+    t = m.commit(trace.ctypes.data, n, n_ext, ncols)
+    assert [int(v) for v in t.root] == want_root
+    idx = np.array([0, 5, n_ext // 2 - 1, n_ext // 2, n_ext - 1], dtype=np.uint64)
+    got = t.group_proofs(idx)
+    for q, i in enumerate(idx):
+        assert glo.merkle_verify(t.root, got[q][:ncols], got[q][ncols:], int(i))
+    used = bool((ctx.to_host(region[:1024]) != 0x7777).any())
+    assert used == big_enough                                            # the lent region was written iff it was large enough to serve
+    t.release_rows()
+    region[:] = 1                                                       # ours again: overwriting it must not disturb the subtrees
+    ctx.sync()
+    sib = t.group_proofs(idx, with_values=False)
+    assert np.array_equal(sib[:, ncols:], got[:, ncols:])
+    t2 = m.commit(trace.ctypes.data, n, n_ext, ncols)                    # (the lend was for ONE commit: this one allocates or reuses its pool)
+    assert [int(v) for v in t2.root] == want_root and bool((ctx.to_host(region[:1024]) == 1).all())
+    t.free(); t2.free(); m.close(); ctx.close()
+    assert free_before > 0
