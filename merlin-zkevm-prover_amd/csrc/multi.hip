@@ -289,7 +289,7 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
         const uint64_t e_ext = (n_ext * p.per_rank + 31) & ~31ull, e_recv = G > 1 ? (p.rows_per_rank * G * p.per_rank + 31) & ~31ull : 0, e_stage = (NS * n * maxw + 31) & ~31ull;
         t->e_ext = std::max<uint64_t>(n_ext * p.per_rank, 1); t->e_recv = std::max<uint64_t>(p.rows_per_rank * G * p.per_rank, 1); t->e_stage = std::max<uint64_t>(NS * n * maxw, 1);
         t->e_nodes = std::max<uint64_t>((2 * p.rows_per_rank - 1) * 4, 1);
-        const uint64_t e_ws = 4 * (n + 2 * n_ext) * maxw; // room for the tile's transforms (its compact ping-pong buffers)
+        const uint64_t e_ws = (2 * n + n_ext) * maxw + 4096; // the tile's transforms (launch_lde into a compact window: INTT intermediate + one n_ext ping-pong buffer [+ coefficients when the middle pass is not fused])
         if (m->lent[g] && m->lent_elems[g] >= e_ext + e_recv + e_stage + e_ws) { // the row buffers, the staging and the transforms' workspace out of the lent region
             u64 *q = m->lent[g];
             t->ext[g] = q; q += e_ext;

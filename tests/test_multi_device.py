@@ -166,7 +166,7 @@ def test_a_lent_region_serves_the_shard_and_is_returned(big_enough):
     want_root = [int(v) for v in ctx.to_host(nodes)[-4:]]
     m = mi_stark.Multi([0] * G)
     per_rank = 80
-    need = n_ext * per_rank + (n_ext // G) * G * per_rank + 2 * n * 32 + 4 * (n + 2 * n_ext) * 32 + 256
+    need = n_ext * per_rank + (n_ext // G) * G * per_rank + 2 * n * 32 + (2 * n + n_ext) * 32 + 8192   # row buffers + staging + the transforms' workspace (multi.hip)
     region = ctx.zeros(need if big_enough else need // 8)
     region[:] = 0x7777
     ctx.sync()
