@@ -427,7 +427,7 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
                 MI_HIP_CHECK(hipEventRecord(m->hstage_sent[hs][g], m->us[g]));
                 m->hstage_user[hs] = (int)g;
             } else {
-                MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, src + c0, src_pitch * 8, w * 8, n, hipMemcpyDeviceToDevice, m->us[g]));
+                MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, src + c0, src_pitch * 8, w * 8, n, hipMemcpyDefault, m->us[g]));
             }
             MI_HIP_CHECK(hipEventRecord(ev_up[g * NS + slot], m->us[g]));
             // ---- LDE of the tile
@@ -442,7 +442,7 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
             // ---- exchange stream: the section itself and the whole extended tile into the row-major image (if asked), my tile's rows to their owners
             if (base) {
                 MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_up[g * NS + slot], 0));
-                MI_HIP_CHECK(hipMemcpy2DAsync(base + c0, base_pitch * 8, st, w * 8, w * 8, n, hipMemcpyDeviceToDevice, m->xs[g]));
+                MI_HIP_CHECK(hipMemcpy2DAsync(base + c0, base_pitch * 8, st, w * 8, w * 8, n, hipMemcpyDefault, m->xs[g]));
             }
             MI_HIP_CHECK(hipEventRecord(ev_based[g * NS + slot], m->xs[g]));
             MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_lde[g][k], 0));
@@ -452,7 +452,7 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
                 MI_TRY(copy_dd(m, t->recv[q] + p.recv_off(k, g), (int)q, t->ext[g] + p.ext_base(k) + (uint64_t)q * cnt, (int)g, cnt * 8, m->xs[g]));
                 m->stats[g].bytes_to[q] += cnt * 8;
             }
-            if (image) MI_HIP_CHECK(hipMemcpy2DAsync(image + c0, image_pitch * 8, t->ext[g] + p.ext_base(k), w * 8, w * 8, n_ext, hipMemcpyDeviceToDevice, m->xs[g]));
+            if (image) MI_HIP_CHECK(hipMemcpy2DAsync(image + c0, image_pitch * 8, t->ext[g] + p.ext_base(k), w * 8, w * 8, n_ext, hipMemcpyDefault, m->xs[g]));
             MI_HIP_CHECK(hipEventRecord(ev_sent[g][k], m->xs[g]));
         }
         if (k > 0) MI_TRY(absorb_round(k - 1));
