@@ -102,7 +102,7 @@ def main():
         knobs = [("mean_len", [0.85, 1.15]), ("pool_scale", [0.8, 1.25]), ("long_lived", [0.9, 1.1]), ("ll_generations", [-1, +1]), ("ll_use", [0.8, 1.25]),
                  ("ext_frac", [0.8, 1.25]), ("run_ops", [0.75, 1.33]), ("zipf", [0.85, 1.15]), ("sec0", [0.97, 1.03]), ("sec1", [0.7, 1.4]), ("sec2", [0.8, 1.25]),
                  ("kCONST", [0.8, 1.25]), ("kCONSTS", [0.6, 1.6]), ("kPOLS", [0.75, 1.33]), ("kNUM", [0.8, 1.25]), ("kT1", [0.85, 1.18]), ("shared_scale", [0.6, 1.5]),
-                 ("burst1", [0.9, 1.1]), ("neighbour", [0.7, 1.4]), ("pol3_frac", [0.7, 1.4])]
+                 ("burst1", [0.9, 1.1]), ("neighbour", [0.7, 1.4]), ("pol3_frac", [0.7, 1.4]), ("pols_global", [0.85, 1.15])]
         for it in range(iters):
             improved = False
             for name, moves in knobs:
@@ -121,7 +121,7 @@ def main():
                         Q[name] = max(1, Q[name] + mv)
                     elif name in ("long_lived", "run_ops"):
                         Q[name] = max(1, int(round(Q[name] * mv)))
-                    elif name == "pol3_frac":
+                    elif name in ("pol3_frac", "pols_global"):
                         Q[name] = min(1.0, max(0.05, Q.get(name, 0.5) * mv))
                     else:
                         Q[name] = Q[name] * mv
