@@ -326,28 +326,43 @@ int glo_chelpers_stepbase(const uint64_t *ops, uint64_t nops, const uint64_t *ar
     uint64_t maxarg = 0;
     for (uint64_t k = 0; k < nargs; k++)
         if (args[k] < (1u << 20) && args[k] > maxarg) maxarg = args[k];
-    uint64_t *tmp1 = (uint64_t *)calloc(maxarg + 1, sizeof(uint64_t));
-    uint64_t *tmp3 = (uint64_t *)calloc(3 * (maxarg + 1), sizeof(uint64_t));
     chp_env e = {pols, const_pols, challenges, publics, x, NULL, numpols, x_stride, 1, NULL, pols};
     int bad = 0;
-    for (uint64_t r = 0; r < nrows && !bad; r++) {
-        const uint64_t i = rows[r];
-        uint64_t ia = 0;
-        for (uint64_t kk = 0; kk < nops && !bad; kk++) {
-            const int *f = ops[kk] == 115 ? G115 : NULL;
-            if (f) {
-                for (; *f >= 0 && !bad; f++) {
-                    const int n = chp_stepbase_op((uint64_t)*f, args, ia, i, tmp1, tmp3, &e);
-                    if (n < 0) bad = -1; else ia += (uint64_t)n;
+    /* Rows are independent but for one thing: a row may store into the NEXT row's cell (cases 101-114), which that row's own evaluation
+     * stores too -- with the same value (the generator emits both; the product relies on it as well: DESIGN_HISTORY.md "base-domain steps").
+     * Many rows (a whole proof of the oracle prover, tests/oracle_genproof.py) are therefore walked by all threads, each with its own
+     * temporaries; a few rows stay on one thread in the given order. */
+    const int parallel = nrows >= 4096;
+#pragma omp parallel if (parallel)
+    {
+        uint64_t *tmp1 = (uint64_t *)calloc(maxarg + 1, sizeof(uint64_t));
+        uint64_t *tmp3 = (uint64_t *)calloc(3 * (maxarg + 1), sizeof(uint64_t));
+        int mybad = 0;
+#pragma omp for schedule(static)
+        for (uint64_t r = 0; r < nrows; r++) {
+            if (mybad) continue;
+            const uint64_t i = rows[r];
+            uint64_t ia = 0;
+            for (uint64_t kk = 0; kk < nops && !mybad; kk++) {
+                const int *f = ops[kk] == 115 ? G115 : NULL;
+                if (f) {
+                    for (; *f >= 0 && !mybad; f++) {
+                        const int n = chp_stepbase_op((uint64_t)*f, args, ia, i, tmp1, tmp3, &e);
+                        if (n < 0) mybad = -1; else ia += (uint64_t)n;
+                    }
+                } else {
+                    const int n = chp_stepbase_op(ops[kk], args, ia, i, tmp1, tmp3, &e);
+                    if (n < 0) mybad = -1; else ia += (uint64_t)n;
                 }
-            } else {
-                const int n = chp_stepbase_op(ops[kk], args, ia, i, tmp1, tmp3, &e);
-                if (n < 0) bad = -1; else ia += (uint64_t)n;
             }
+            if (!mybad && ia != nargs) mybad = -2;
         }
-        if (!bad && ia != nargs) bad = -2;
+        if (mybad) {
+#pragma omp critical
+            bad = mybad;
+        }
+        free(tmp1);
+        free(tmp3);
     }
-    free(tmp1);
-    free(tmp3);
     return bad;
 }

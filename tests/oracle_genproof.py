@@ -53,13 +53,33 @@ class OracleStarks:
         return self.pol(int(self.si["exp2pol"][str(exp_id)]))
 
 
+_FAST = [False]
+
+
 def _tree(src, ncols, nrows):
+    """fast: the hand-vectorised restatement of oracle/cpu_baseline_avx2.c (6 x the checker's permutation; itself checked bit for bit against
+    the checker by tests/test_cpu_baseline.py) -- for the larger shapes, where the scalar tree alone would take a minute"""
+    if _FAST[0] and ncols > 4:
+        L = glo.lib("baseline")
+        nodes = np.zeros((2 * nrows - 1) * 4, dtype=np.uint64)
+        L.glb_merkletree(glo.ptr(nodes), glo.ptr(glo.A(src).reshape(-1)), u64(ncols), u64(nrows))
+        return nodes
     return glo.merkletree(src, ncols, nrows)
 
 
-def gen_proof(si, progs, const_n, const_tree, witness, publics):
+def _extend(src, n_ext, n, ncols):
+    if _FAST[0]:
+        L = glo.lib("baseline")
+        out = np.zeros(n_ext * ncols, dtype=np.uint64)
+        L.glb_extend_pol(glo.ptr(out), glo.ptr(glo.A(src).reshape(-1)), u64(n_ext), u64(n), u64(ncols))
+        return out
+    return glo.extend_pol(src, n_ext, n, ncols).reshape(-1)
+
+
+def gen_proof(si, progs, const_n, const_tree, witness, publics, fast=False):
     """-> (zkin text, debug dictionary).  progs: {"step2prev" | "step3prev" | "step3" | "step42ns" | "step52ns": (ops, args)}; a missing
-    program is a stage without expressions (the step computes nothing)."""
+    program is a stage without expressions (the step computes nothing).  fast: trees and extensions through the vectorised restatement."""
+    _FAST[0] = bool(fast)
     st = OracleStarks(si, const_n, const_tree)
     L = glo.lib()
     N, NE, nbits, nbits_ext = st.N, st.NE, st.nbits, st.nbits_ext
@@ -82,7 +102,7 @@ def gen_proof(si, progs, const_n, const_tree, witness, publics):
 
     def commit(src_sec, dst_sec):
         w = cols[src_sec]
-        sec(dst_sec)[:] = glo.extend_pol(sec(src_sec), NE, N, w).reshape(-1) if w else 0
+        sec(dst_sec)[:] = _extend(sec(src_sec), NE, N, w) if w else 0
         return _tree(sec(dst_sec), w, NE)
 
     # ---- 1 (starks.cpp:48-61)

@@ -17,8 +17,16 @@ STEP_ID = {"step2prev": 20, "step3prev": 30, "step3": 31, "step42ns": 42, "step5
 vp = ctypes.c_void_p
 
 
-def const_tree_image(const_n, n_const, nbits, nbits_ext):
+def const_tree_image(const_n, n_const, nbits, nbits_ext, fast=False):
     n, ne = 1 << nbits, 1 << nbits_ext
+    if fast:                       # the vectorised restatement (checked against the checker: tests/test_cpu_baseline.py), for the larger shapes
+        import ctypes
+        L = glo.lib("baseline")
+        c2 = np.zeros(ne * n_const, dtype=np.uint64)
+        L.glb_extend_pol(glo.ptr(c2), glo.ptr(glo.A(const_n).reshape(-1)), ctypes.c_uint64(ne), ctypes.c_uint64(n), ctypes.c_uint64(n_const))
+        nodes = np.zeros((2 * ne - 1) * 4, dtype=np.uint64)
+        L.glb_merkletree(glo.ptr(nodes), glo.ptr(c2), ctypes.c_uint64(n_const), ctypes.c_uint64(ne))
+        return np.concatenate([np.array([n_const, ne], dtype=np.uint64), c2, nodes])
     c2 = glo.extend_pol(glo.A(const_n).reshape(n, n_const), ne, n, n_const)
     nodes = glo.merkletree(c2, n_const, ne)
     return np.concatenate([np.array([n_const, ne], dtype=np.uint64), c2.reshape(-1), nodes])

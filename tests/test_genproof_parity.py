@@ -49,14 +49,14 @@ def mini_inputs(nbits, n_queries):
     return si, progs, const_n, sr.const_tree_image(const_n, 3, nbits, nbits + 1), ms.witness(n), ms.PUBLICS.copy()
 
 
-def shaped_inputs(argv):
+def shaped_inputs(argv, fast=False):
     import bench_starks as b
     a = b.parse(argv)
     si, progs, secs, off, cols = b.shape(a)
     n = 1 << a.log_n
     witness = glo.splitmix64(0x5EED0104, n * cols["cm1_n"])
     const_n = glo.splitmix64(0x5EED0204, n * a.n_const)
-    tree = sr.const_tree_image(const_n, a.n_const, a.log_n, a.log_n + a.ext_bits)
+    tree = sr.const_tree_image(const_n, a.n_const, a.log_n, a.log_n + a.ext_bits, fast=fast)
     return si, progs, const_n, tree, witness, np.arange(1, 9, dtype=np.uint64)
 
 
@@ -157,4 +157,23 @@ def test_starks_genproof_with_sharded_commits_equals_the_oracle_prover(name, dev
     inputs = shaped_inputs(SHAPES[name])
     want, _ = og.gen_proof(*inputs)
     got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,), env=dict(os.environ, MI_STARK_DEVICES=devices))
+    assert got4 == want, first_difference(got4, want)
+
+
+def test_fast_oracle_prover_is_the_oracle_prover():
+    """The larger parity case below lets the oracle prover build its trees and extensions with the vectorised restatement
+    (oracle/cpu_baseline_avx2.c); on a shape both finish quickly the two give the same bytes."""
+    inputs = shaped_inputs(SHAPES["zkevm_small"])
+    assert og.gen_proof(*inputs)[0] == og.gen_proof(*inputs, fast=True)[0]
+    assert np.array_equal(inputs[3], shaped_inputs(SHAPES["zkevm_small"], fast=True)[3])
+
+
+@pytest.mark.gpu
+def test_starks_genproof_equals_the_oracle_prover_at_2p16_rows_full_zkevm_shape(tmp_path):
+    """Every count of the zkEVM (665 / 128 / 371 / 265 columns, 218 constants, 1 768 evaluations, 21 lookups, 30 grand products, 128 queries,
+    the five programs at their real sizes) at 2^16 rows -> 2^17: the largest shape the oracle prover finishes inside a test (about a
+    minute of CPU), byte for byte."""
+    inputs = shaped_inputs(["--log-n", "16"], fast=True)
+    want, _ = og.gen_proof(*inputs, fast=True)
+    got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,))
     assert got4 == want, first_difference(got4, want)
