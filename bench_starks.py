@@ -221,6 +221,16 @@ def shape(args):
     return si, progs, secs, off, cols
 
 
+def tiled_witness(si, n, w1):
+    """host/starks.hpp's rule for keeping cm1_n tile-major in the image (one device, device steps): no lookup or grand-product operand
+    is a witness column read by stride.  The base-domain programs are compiled for that layout (mi_chelpers_set_tiled_section)."""
+    if os.environ.get("MI_STARK_TILED_WITNESS", "1")[:1] == "0" or n < 64 or w1 == 0 or len(os.environ.get("MI_STARK_DEVICES", "").split(",")) > 1:
+        return False
+    ids = [c[k] for c in si["puCtx"] for k in ("fExpId", "tExpId", "numId", "denId")]
+    ids += [c[k] for ctx in ("peCtx", "ciCtx") for c in si[ctx] for k in ("numId", "denId")]
+    return all(si["varPolMap"][int(si["exp2pol"][str(e)])]["section"] != "cm1_n" for e in ids)
+
+
 def compiled_programs(args, shard=None):
     """The five programs through mi_chelpers_compile + the native build with the in-tree code-object cache (no GPU needed): what
     Starks does on first use, done ahead so that the GPU box finds every kernel in the cache."""
@@ -231,6 +241,8 @@ def compiled_programs(args, shard=None):
     for name, (ops, ar) in progs.items():
         base = name in ("step2prev", "step3prev", "step3")
         p = mi_stark.ChelpersProgram(None, ops, ar, sections=secs[name], n_const=args.n_const, nrows_ext=n if base else ne, step=STEP_ID[name])
+        if base and tiled_witness(si, n, cols["cm1_n"]):
+            p.set_tiled_section(off["cm1_n"])
         if shard is not None:
             p.precompile_shard(*shard)
         else:

@@ -151,6 +151,10 @@ int mi_lde_merkle_host(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext
  * the trace itself (canonical) -- what the base-domain steps of stages 2 and 3 read (starks.cpp:66-90,150-210 over p_cm1_n). */
 int mi_lde_merkle_host_keep(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base, uint64_t base_pitch,
                             const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
+/* The same with the base-domain section kept TILE-MAJOR (n x ncols, n a multiple of 64; see mi_chelpers_set_tiled_section): the layout
+ * the compiled base-domain steps read in place.  Costs what the row-major copy costs and hides behind the upload like it. */
+int mi_lde_merkle_host_keep_tiled(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base_tiled,
+                                  const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
 int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister: page-lock a host range for DMA */
 int mi_host_unregister(mi_ctx *ctx, void *p);
 
@@ -354,6 +358,18 @@ int mi_set_chelpers_min_words(mi_ctx *ctx, uint64_t words);
  * estimated VALU instructions per kernel (0 = 25 000).  Afterwards mi_chelpers_run_dev runs the compiled kernels instead of the
  * interpreter; results are the same field elements.  Requires shifts < 64 and power-of-two section row counts. */
 int mi_chelpers_build_native(mi_chelpers_prog *prog, const char *cache_dir, uint64_t chunk_cost);
+/* A section the caller keeps TILE-MAJOR in HBM -- [tile of 64 rows][column][row in tile], element (row, col) at
+ * (row / 64 * ncols + col) * 64 + row % 64, canonical values (mi_tile_major_dev, mi_lde_merkle_host_keep_tiled write it) -- instead of
+ * row-major: the generated kernels read it in place, a lane per row and 512 contiguous bytes per operand and wave, and the per-batch
+ * tile-major copy of that section (k_chp_transpose: a read and a write of the whole section per step) is not made.  For a section every
+ * base-domain step reads but nothing writes or reads by stride: the witness cm1_n (host/starks.hpp; starks.cpp:66-210 read it three
+ * times).  Call after mi_chelpers_compile and before mi_chelpers_build_native / _precompile_shard / _lower_stats; one section per
+ * program, named by its offset; the program then runs through the compiled kernels only, over rows from a multiple of 64. */
+int mi_chelpers_set_tiled_section(mi_chelpers_prog *prog, uint64_t section_offset);
+/* dst (tile-major as above, nrows x ncols_total) <- src (row-major, src_pitch words per row, ncols columns), placed at column col0 of
+ * the tiles; nrows a multiple of 64; values canonicalised. */
+int mi_tile_major_dev(mi_ctx *ctx, uint64_t *dst, uint64_t ncols_total, uint64_t col0, const uint64_t *src, uint64_t src_pitch,
+                      uint64_t nrows, uint64_t ncols);
 /* What the native backend makes of the program, without compiling anything: out = kernels, instructions evaluated as
  * Horner-chain accumulator steps, chain pieces, estimated VALU instructions per row, chain coefficients (+- C^e), per-piece
  * constants, folded (polynomial - evaluation) leaves, temporary words moved through the spill per row, polynomial elements

@@ -497,12 +497,14 @@ extern "C" int mi_get_host_pack_threads(mi_ctx *c)
     return effective_pack_threads(c);
 }
 
+// base_pitch == 0: the base-domain section is kept tile-major (mi_lde_merkle_host_keep_tiled)
 static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base, uint64_t base_pitch,
                                 const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
 {
     if (n == 0 || ncols == 0) return MI_OK;
     MI_REQUIRE(nodes && ext && trace_host, "null buffer");
-    MI_REQUIRE(!base || base_pitch >= ncols, "pitch smaller than ncols");
+    MI_REQUIRE(!base || base_pitch == 0 || base_pitch >= ncols, "pitch smaller than ncols");
+    MI_REQUIRE(!base || base_pitch != 0 || n % 64 == 0, "a tile-major section has a multiple of 64 rows");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
     MI_REQUIRE(ext_pitch >= ncols, "pitch smaller than ncols");
     if (chunk_cols == 0) chunk_cols = 64;
@@ -670,7 +672,8 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
     for (uint64_t k = 0; k < n_chunks; k++) {
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k % NS][s], 0));
         MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k % NS], cws[k], n_ext, n, cws[k]));
-        if (base) MI_TRY(launch_copy_2d(c, (u64 *)base + c0s[k], base_pitch, st[k % NS], cws[k], n, cws[k])); // the base-domain section stays too
+        if (base && base_pitch) MI_TRY(launch_copy_2d(c, (u64 *)base + c0s[k], base_pitch, st[k % NS], cws[k], n, cws[k])); // the base-domain section stays too
+        else if (base) MI_TRY(launch_tile_major(c, (u64 *)base, ncols, c0s[k], st[k % NS], cws[k], n, cws[k]));
         MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k % NS], c->stream));
         MI_TRY(absorb(k));
         // enqueued after this chunk's kernels (the copy call may block the host), but its only dependency -- the LDE of chunk
@@ -696,6 +699,25 @@ extern "C" int mi_lde_merkle_host_keep(mi_ctx *c, uint64_t *nodes, uint64_t *ext
     CTX_OK(c);
     MI_REQUIRE(base, "null buffer");
     return lde_merkle_host_impl(c, nodes, ext, ext_pitch, base, base_pitch, trace_host, n, n_ext, ncols, chunk_cols);
+}
+
+extern "C" int mi_lde_merkle_host_keep_tiled(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base_tiled,
+                                             const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+{
+    CTX_OK(c);
+    MI_REQUIRE(base_tiled, "null buffer");
+    return lde_merkle_host_impl(c, nodes, ext, ext_pitch, base_tiled, 0, trace_host, n, n_ext, ncols, chunk_cols);
+}
+
+extern "C" int mi_tile_major_dev(mi_ctx *c, uint64_t *dst, uint64_t ncols_total, uint64_t col0, const uint64_t *src, uint64_t src_pitch,
+                                 uint64_t nrows, uint64_t ncols)
+{
+    CTX_OK(c);
+    if (nrows == 0 || ncols == 0) return MI_OK;
+    MI_REQUIRE(dst && src, "null buffer");
+    MI_REQUIRE(nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
+    MI_REQUIRE(src_pitch >= ncols && col0 + ncols <= ncols_total, "columns outside the section");
+    return launch_tile_major(c, (u64 *)dst, ncols_total, col0, (const u64 *)src, src_pitch, nrows, ncols);
 }
 
 extern "C" int mi_set_host_pack_threads(mi_ctx *c, int threads)

@@ -1092,6 +1092,22 @@ extern "C" int mi_chelpers_build_native(mi_chelpers_prog *p, const char *cache_d
     return chp::native_build(p, cache_dir, chunk_cost, 0, 1);
 }
 
+// A section the caller keeps tile-major in HBM (include/mi_stark.h): the generated kernels read it in place.
+extern "C" int mi_chelpers_set_tiled_section(mi_chelpers_prog *p, uint64_t section_offset)
+{
+    if (!p) return MI_ERR_INVALID;
+    MI_REQUIRE(!p->native, "mi_chelpers_set_tiled_section comes before mi_chelpers_build_native");
+    HostSection *hit = nullptr;
+    for (HostSection &S : p->sections) {
+        MI_REQUIRE(!S.tiled || (S.role == 0 && S.offset == section_offset), "one tile-major section per program");
+        if (S.role == 0 && S.offset == section_offset) hit = &S;
+    }
+    MI_REQUIRE(hit, "no declared section starts at this offset");
+    MI_REQUIRE(hit->nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
+    hit->tiled = true;
+    return MI_OK;
+}
+
 // Parallel builds: process `shard` of `nshards` compiles every nshards-th kernel into the cache and keeps nothing; a final
 // mi_chelpers_build_native then finds every kernel in the cache.
 extern "C" int mi_chelpers_precompile_shard(mi_chelpers_prog *p, const char *cache_dir, uint64_t chunk_cost, uint32_t shard, uint32_t nshards)
@@ -1111,6 +1127,7 @@ extern "C" int mi_dbg_host_chelpers_run_lowered(const mi_chelpers_prog *p, const
 {
     MI_TRY(check_params(p, a, 0, 0));
     MI_REQUIRE(rows || nrows == 0, "null row list");
+    for (const HostSection &S : p->sections) MI_REQUIRE(!S.tiled, "the host executors read row-major sections");
     return chp::native_host_run(p, a, rows, nrows, chunk_cost);
 }
 
@@ -1184,6 +1201,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     if (p->native) return chp::native_run(c, p, a, row0, nrows);
     MI_REQUIRE(!p->stores_pols, "the base-domain steps run through the compiled kernels: call mi_chelpers_build_native first");
     MI_REQUIRE(p->dev, "program was compiled without a context");
+    for (const HostSection &S : p->sections) MI_REQUIRE(!S.tiled, "a program with a tile-major section runs through the compiled kernels: call mi_chelpers_build_native first");
     if (nrows == 0) return MI_OK;
     MI_REQUIRE(a->n_const == p->n_const, "number of constant polynomials differs from what the program was compiled for");
     MI_REQUIRE(row0 + nrows <= p->nrows_ext, "rows beyond the extended domain the program was compiled for");
@@ -1270,6 +1288,7 @@ extern "C" int mi_dbg_host_chelpers_run(const mi_chelpers_prog *p, const mi_chel
 {
     MI_TRY(check_params(p, a, 0, 0));
     MI_REQUIRE(rows || nrows == 0, "null row list");
+    for (const HostSection &S : p->sections) MI_REQUIRE(!S.tiled, "the host executors read row-major sections");
     std::vector<u64> chal(p->max_chal * 3 + 1), pub(p->max_pub + 1), zh(a->n_zhinv + 1), ev(p->max_eval * 3 + 1);
     for (uint64_t i = 0; i < p->max_eval * 3; i++) ev[i] = gl::canon(a->evals[i]);
     for (uint64_t i = 0; i < p->max_chal * 3; i++) chal[i] = gl::canon(a->challenges[i]);

@@ -181,7 +181,9 @@ struct HostTmp {
 
 } // namespace chp
 
-struct HostSection { uint64_t offset, ncols, nrows; uint32_t col0; int role; }; // role 0: section of pols, 1: constant polynomials, 2: x
+// role 0: section of pols, 1: constant polynomials, 2: x, 3 / 4: xDivXSubXi / xDivXSubWXi.  tiled: the section already lies in HBM as
+// [tile of 64 rows][column][row in tile] (mi_chelpers_set_tiled_section): the generated kernels read it in place, nothing is copied
+struct HostSection { uint64_t offset, ncols, nrows; uint32_t col0; int role; bool tiled = false; };
 struct mi_chelpers_prog {
     std::vector<chp::DInstr> host; // the translated program, operands in place (host debug executor)
     std::vector<chp::GInstr> gpu;  // the same program over staged columns (kernel)

@@ -282,7 +282,8 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
             if (!(lk == K_POL || lk == K_POL3 || lk == K_CONST || lk == K_X)) return false;
             uint32_t col, sh;
             int dim;
-            return resolve_pol(P, lk, m.folded >= 0 ? H[m.folded].a : (m.yside == 0 ? H[i].b : H[i].a), col, dim, sh) != nullptr;
+            const HostSection *S = resolve_pol(P, lk, m.folded >= 0 ? H[m.folded].a : (m.yside == 0 ? H[i].b : H[i].a), col, dim, sh);
+            return S && !S->tiled; // (the linear kernel fetches along the rows of a row-major section)
         };
         for (size_t i = 0; i < n; i++) cand += is_lin(i);
         uint32_t lin_min = LIN_MIN_TERMS;
@@ -471,7 +472,7 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
             if (!S) continue; // reported by the generator
             MI_REQUIRE(S->ncols <= 2048, "sections wider than 2048 columns are not supported by the tile-major copy");
             for (int j = 0; j < dim; j++) {
-                N->sec_slab_mask[S - P->sections.data()] |= 1u << ((col + j - S->col0) / 64);
+                if (!S->tiled) N->sec_slab_mask[S - P->sections.data()] |= 1u << ((col + j - S->col0) / 64);
                 chunk_ops.insert(((uint64_t)(col + j) << 8) | sh);
                 all_ops.insert(((uint64_t)(col + j) << 8) | sh);
             }
@@ -552,7 +553,7 @@ struct Gen {
         recent[expr] = {name, cur_group};
         return group_loads[expr] = name;
     }
-    std::set<uint32_t> shifts;
+    std::set<uint32_t> shifts, xshifts; // row shifts read from the tile-major copy / from the section kept tile-major (0 included)
     bool uses_zh = false;
     std::vector<uint8_t> canon; // per temp word: known canonical
     char buf[256];
@@ -603,10 +604,12 @@ struct Gen {
             return MI_ERR_INVALID;
         }
         const bool three = pdim == 3;
-        if (sh) shifts.insert(sh);
+        if (S->tiled) xshifts.insert(sh); // read in place: X<shift>, columns counted from the section's first
+        else if (sh) shifts.insert(sh);
         v.dim = three ? 3 : 1;
         for (int j = 0; j < v.dim; j++) {
-            snprintf(buf, sizeof buf, "T%u[%llu]", sh, (unsigned long long)(col + j) * 64);
+            if (S->tiled) snprintf(buf, sizeof buf, "X%u[%llu]", sh, (unsigned long long)(col - S->col0 + j) * 64);
+            else snprintf(buf, sizeof buf, "T%u[%llu]", sh, (unsigned long long)(col + j) * 64);
             v.e[j] = load(buf);
         }
         return MI_OK;
@@ -691,6 +694,9 @@ struct Gen {
         V a, b;
         MI_TRY(operand(ak, d.a, a));
         if (cls == C_STOREP) { // params.pols[off + row' * stride] = a, row' = row or (row + shift) mod n (out = the polynomial memory here)
+            for (const HostSection &S : P->sections)
+                MI_REQUIRE(!(S.tiled && S.role == 0 && d.b.off >= S.offset && d.b.off < S.offset + S.ncols),
+                           "the program stores into the section declared tile-major (it is read in place, row-major stores would corrupt it)");
             body += "  if (row < row_end) { ";
             if (dk == K_DPOLS) {
                 MI_REQUIRE(d.b.mod && (d.b.mod & (d.b.mod - 1)) == 0, "shifted-row destination: the modulus must be a power of two");
@@ -858,7 +864,7 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
     char line[1024];
     snprintf(line, sizeof line,
              "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(%u, %u))) void chelpers_chunk(const u64 *__restrict__ tiled, u64 *__restrict__ spill, "
-             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin)\n{\n"
+             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin, const u64 *__restrict__ xsec)\n{\n"
              "  const u32 lane = threadIdx.x;\n  const u64 tile = blockIdx.x;\n  const u64 row = row_base + tile * 64 + lane;\n"
              "  const u64 *__restrict__ T0 = tiled + tile * %lluULL + lane;\n  u64 *__restrict__ S = spill + tile * %lluULL + lane;\n",
              waves, waves, (unsigned long long)N->sc * 64, (unsigned long long)N->nw * 64);
@@ -867,6 +873,15 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
         snprintf(line, sizeof line, "  const u64 *__restrict__ T%u = tiled + (tile + ((lane + %uu) >> 6)) * %lluULL + ((lane + %uu) & 63u);\n", s, s,
                  (unsigned long long)N->sc * 64, s);
         src += line;
+    }
+    for (const HostSection &S : P->sections) {
+        if (!S.tiled) continue;
+        // the section kept tile-major: tile = row / 64 of the whole section (row_base is a multiple of 64), rows wrap at its end
+        for (uint32_t s : g.xshifts) {
+            snprintf(line, sizeof line, "  const u64 *__restrict__ X%u = xsec + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + ((lane + %uu) & 63u);\n", s, s,
+                     (unsigned long long)(S.nrows / 64 - 1), (unsigned long long)S.ncols * 64, s);
+            src += line;
+        }
     }
     if (g.uses_zh) {
         snprintf(line, sizeof line, "  const u64 zh = cst[%u + (u32)(row & zmask)];\n", N->zh_off);
@@ -1087,6 +1102,22 @@ __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ s
         if (c0 + cc < ncols) dst[(uint64_t)cc * 64] = t[l][cc];
 }
 
+} // namespace chp
+
+int launch_tile_major(mi_ctx *ctx, u64 *dst, uint64_t ncols_total, uint64_t col0, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols)
+{
+    MI_REQUIRE(nrows % 64 == 0 && nrows / 64 < (1ull << 31), "a tile-major section has a multiple of 64 rows");
+    MI_REQUIRE(ncols_total < (1ull << 32), "section too wide");
+    for (uint64_t c0 = 0; c0 < ncols; c0 += 2048) { // (one launch carries a 32-bit mask of 64-column slabs)
+        const uint64_t w = std::min<uint64_t>(2048, ncols - c0);
+        hipLaunchKernelGGL(chp::k_chp_transpose, dim3((unsigned)(nrows / 64), (unsigned)((w + 63) / 64)), dim3(256), 0, ctx->stream, src + c0, src_pitch, (uint32_t)w,
+                           ~0ull, dst, (uint32_t)ncols_total, (uint32_t)(col0 + c0), (uint64_t)0, 0xffffffffu);
+        MI_HIP_CHECK(hipGetLastError());
+    }
+    return MI_OK;
+}
+
+namespace chp {
 
 // sums of polynomial elements times constants, straight from the row-major sections (see "linear terms" above).  One wave per
 // tile of 64 rows; per slab of LIN_COLS columns: 64 x LIN_COLS elements are fetched along the rows (128-byte runs) and turned
@@ -1271,6 +1302,9 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     u64 *out = P->stores_pols ? (u64 *)a->pols : (u64 *)(P->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
     uint32_t zmask = (uint32_t)(n_zh - 1);
     const uint64_t row_end = row0 + nrows;
+    const u64 *xsec = nullptr;
+    for (const HostSection &S : P->sections)
+        if (S.tiled) MI_REQUIRE(row0 % 64 == 0 && is_pow2(S.nrows) && S.nrows >= 64, "a program with a tile-major section runs over rows from a multiple of 64");
     for (uint64_t b0 = row0; b0 < row_end; b0 += batch) {
         const uint64_t rows = std::min(batch, row_end - b0), tiles = (rows + 63) / 64;
         LinSections ls = {};
@@ -1285,6 +1319,7 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             else { MI_REQUIRE(a->xdivw, "null xDivXSubWXi"); ptr = (const u64 *)a->xdivw; pitch = 3; }
             MI_REQUIRE(is_pow2(S.nrows), "section row counts must be powers of two");
             ls.ptr[si] = ptr; ls.pitch[si] = pitch; ls.row_mask[si] = S.nrows - 1;
+            if (S.tiled) { xsec = ptr; continue; } // read in place
             if (!N->sec_slab_mask[si]) continue;
             hipLaunchKernelGGL(k_chp_transpose, dim3((unsigned)(tiles + 1), (unsigned)((S.ncols + 63) / 64)), dim3(256), 0, c->stream, ptr, pitch,
                                (uint32_t)S.ncols, S.nrows - 1, c->chelpers_tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
@@ -1306,7 +1341,7 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             u64 *spill = c->chelpers_spill, *outp = out;
             uint64_t row_base = b0, rend = row_end;
             const u64 *linp = c->chelpers_lin;
-            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp};
+            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &xsec};
             MI_HIP_CHECK(hipModuleLaunchKernel(C.fn, (unsigned)tiles, 1, 1, 64, 1, 1, 0, c->stream, args, nullptr));
         }
     }

@@ -178,3 +178,5 @@ int launch_fill_synthetic(mi_ctx *ctx, u64 *out, uint64_t count, u64 seed);
 int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t nrows, uint64_t ncols, uint64_t global_cols,
                              uint64_t col0, u64 seed);
 int launch_copy_2d(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols);
+// row-major [nrows x ncols] at src_pitch -> columns [col0, col0 + ncols) of the tile-major section dst = [nrows / 64][ncols_total][64], canonical
+int launch_tile_major(mi_ctx *ctx, u64 *dst, uint64_t ncols_total, uint64_t col0, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols);

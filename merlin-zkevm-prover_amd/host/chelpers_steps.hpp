@@ -29,6 +29,7 @@ struct StarkMirror
     uint64_t N = 0, NExtended = 0, nBits = 0, nBitsExt = 0, nPublics = 0, nEvals = 0;
     struct Sec { uint64_t offset, cols; };
     Sec cmN[4] = {}, cm2ns[4] = {}; // cm1_n cm2_n cm3_n tmpExp_n / cm1_2ns .. cm4_2ns
+    bool tiledWitness = false;      // cm1_n lies tile-major in the image (host/starks.hpp): the base-domain steps read it in place
     uint64_t qOffset = 0, fOffset = 0;
     uint64_t *d_constN = nullptr, *d_const2ns = nullptr, nConst = 0;
     uint64_t *d_xn = nullptr, *d_x2ns = nullptr, *d_xdiv = nullptr, *d_xdivw = nullptr;
@@ -71,6 +72,8 @@ inline std::vector<mi_chelpers_section> stepSections(const StarkMirror *m, int s
 }
 inline void buildStepProgram(const StarkMirror *m, int step, mi_chelpers_prog *prog)
 {
+    if (isBaseStep(step) && m->tiledWitness && m->cmN[0].cols)
+        check(mi_chelpers_set_tiled_section(prog, m->cmN[0].offset), "Steps (the witness section is tile-major)");
     const char *backend = std::getenv("MI_CHELPERS_BACKEND"); // "interpreter": the extended-domain steps through the SIMT interpreter (A/B)
     if (isBaseStep(step) || !backend || std::string(backend) != "interpreter")
         check(mi_chelpers_build_native(prog, m->cacheDir.empty() ? nullptr : m->cacheDir.c_str(), 0), "Steps (compile the program)");

@@ -412,6 +412,27 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     for (uint64_t i = 0; i < m.zhinv.size(); i++) m.zhinv[i] = Goldilocks::toU64(zi.zhInv(i));
     m.progs = &progs;
     if (const char *e = std::getenv("MI_CHELPERS_CACHE")) m.cacheDir = e;
+    // more than one device (MI_STARK_DEVICES, csrc/multi.hip): the commit of a stage is sharded over them -- each device extends column
+    // tiles (stage 1: uploaded over ITS OWN PCIe link) and hashes the leaves and the subtree of its rows -- while the row-major extension
+    // still lands in this device's image, where the constraint evaluation reads it.  The shard on this device works in the same dead
+    // regions the single-device path lends as scratch.
+    mi_multi *mm = mi::multi();
+    auto sharded = [&](uint64_t ncols) { return mm && ncols > 4 && NExtended / (uint64_t)mi_multi_shards(mm) >= 64; };
+    // The witness TILE-MAJOR in the image ([64 rows][column][row in tile], mi_lde_merkle_host_keep_tiled): the three base-domain steps read
+    // nearly every column of cm1_n (the zkEVM's: 497 / 647 / 553 of 665), and from a row-major section each of them first makes a tile-major
+    // copy of it (a read and a write of 44.6 GB); kept tile-major -- written that way behind the upload, where the row-major copy was written
+    // -- they read it in place.  Only the steps read cm1_n on the device; should a lookup or grand-product operand be a witness column
+    // itself (read by stride, polRef), the section stays row-major.  MI_STARK_TILED_WITNESS=0: row-major as before.
+    {
+        const char *e = std::getenv("MI_STARK_TILED_WITNESS");
+        bool ok = deviceSteps && !(e && e[0] == '0') && N >= 64 && cols(cm1_n) > 0 && !sharded(cols(cm1_n));
+        auto inWitness = [&](uint64_t idPol) { const PolRef r = polRef(idPol); return r.offset >= off(cm1_n) && r.offset < off(cm1_n) + N * cols(cm1_n); };
+        for (auto &x : starkInfo.puCtx) ok = ok && !inWitness(exp2pol(x.fExpId)) && !inWitness(exp2pol(x.tExpId));
+        for (auto &x : starkInfo.puCtx) ok = ok && !inWitness(exp2pol(x.numId)) && !inWitness(exp2pol(x.denId));
+        for (auto &x : starkInfo.peCtx) ok = ok && !inWitness(exp2pol(x.numId)) && !inWitness(exp2pol(x.denId));
+        for (auto &x : starkInfo.ciCtx) ok = ok && !inWitness(exp2pol(x.numId)) && !inWitness(exp2pol(x.denId));
+        m.tiledWitness = ok;
+    }
     mi::currentMirror() = &m;
 
     transcript.put(&publicInputs[0], starkInfo.nPublics);
@@ -434,14 +455,8 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     //--------------------------------
     TimerStart(STARK_STEP_1);
     TimerStart(STARK_STEP_1_LDE_AND_MERKLETREE);
-    // more than one device (MI_STARK_DEVICES, csrc/multi.hip): the commit of a stage is sharded over them -- each device extends column
-    // tiles (stage 1: uploaded over ITS OWN PCIe link) and hashes the leaves and the subtree of its rows -- while the row-major extension
-    // still lands in this device's image, where the constraint evaluation reads it.  The shard on this device works in the same dead
-    // regions the single-device path lends as scratch.
-    mi_multi *mm = mi::multi();
     mi_multi_tree *mtree[4] = {};
     const int dev0 = mi_ctx_device(c);
-    auto sharded = [&](uint64_t ncols) { return mm && ncols > 4 && NExtended / (uint64_t)mi_multi_shards(mm) >= 64; };
     auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, uint64_t *scratch, uint64_t scratchElems, Goldilocks::Element *root) {
         mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
         mi::check(mi_multi_lend(mm, 0, scratch, scratchElems * 8), "Starks::genProof (sharded commit: lend)");
@@ -453,8 +468,12 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns), root0.address());
     } else {
         lend(sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns));
-        mi::check(mi_lde_merkle_host_keep(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
-                                          cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
+        if (m.tiledWitness)
+            mi::check(mi_lde_merkle_host_keep_tiled(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
+                                                    cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
+        else
+            mi::check(mi_lde_merkle_host_keep(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
+                                              cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
         mi::check(mi_copy_d2h(c, root0.address(), d_nodes[0] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 1)");
     }
     transcript.put(root0.address(), HASH_SIZE);

@@ -56,7 +56,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
-    "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_get_host_pack_threads",
+    "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_get_host_pack_threads",
     "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_commit", "mi_multi_group_proofs",
     "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_compile_micro", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
@@ -200,6 +200,15 @@ class Context:
         """lde_merkle_host, and the uploaded base-domain section stays in `base` (device, n x ncols) as well."""
         _check(lib().mi_lde_merkle_host_keep(self.h, _dp(nodes), _dp(ext), u64(ext_pitch or ncols), _dp(base), u64(base_pitch or ncols),
                                              ctypes.c_void_p(host_trace_ptr), u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
+
+    def lde_merkle_host_keep_tiled(self, nodes, ext, base_tiled, host_trace_ptr, n, n_ext, ncols, ext_pitch=None, chunk_cols=0):
+        """lde_merkle_host_keep with the base-domain section kept TILE-MAJOR ([n / 64][ncols][64]: ChelpersProgram.set_tiled_section)."""
+        _check(lib().mi_lde_merkle_host_keep_tiled(self.h, _dp(nodes), _dp(ext), u64(ext_pitch or ncols), _dp(base_tiled),
+                                                   ctypes.c_void_p(host_trace_ptr), u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
+
+    def tile_major(self, dst, ncols_total, col0, src, nrows, ncols, src_pitch=None):
+        """dst (tile-major, nrows x ncols_total) <- src (row-major device tensor) at column col0 of the tiles, canonical."""
+        _check(lib().mi_tile_major_dev(self.h, _dp(dst), u64(ncols_total), u64(col0), _dp(src), u64(src_pitch or ncols), u64(nrows), u64(ncols)))
 
     def lend_workspace(self, buf):
         """NTT / LDE scratch out of a caller-owned device tensor (None: back to the context's own workspace)."""
@@ -443,6 +452,10 @@ class ChelpersProgram:
         _check(lib().mi_chelpers_stats(self.h, _hp(st)))
         self.stats = {k: int(v) for k, v in zip(self.STAT_NAMES, st)}
         return self
+
+    def set_tiled_section(self, offset):
+        """The section at this offset lies tile-major in HBM and is read in place (before build_native / precompile_shard)."""
+        _check(lib().mi_chelpers_set_tiled_section(self.h, u64(offset)))
 
     NATIVE_STAT_NAMES = ("kernels", "code_bytes", "build_ms", "cache_hits", "estimated_valu_per_row", "spill_words_moved_per_row",
                          "horner_chain_steps", "constant_words")

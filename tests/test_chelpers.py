@@ -568,6 +568,87 @@ def test_base_step_program_on_gpu_matches_oracle(seed, tmp_path):
     ctx.close()
 
 
+def _tile_major(a, nrows, ncols):
+    """[nrows x ncols] row-major -> [nrows / 64][ncols][64], canonical (include/mi_stark.h: mi_chelpers_set_tiled_section)."""
+    return (np.asarray(a, dtype=np.uint64).reshape(nrows // 64, 64, ncols) % np.uint64(glo.P)).transpose(0, 2, 1).reshape(-1).copy()
+
+
+def test_tiled_section_is_declared_before_the_build_and_never_stored_into(tmp_path):
+    """mi_chelpers_set_tiled_section: an offset that names no section, a second section, a call after the build and a program that stores
+    into the section are refused; the kernels of a program with such a section compile; the host executors (row-major) refuse it."""
+    import mi_stark
+    nrows = 256
+    ops, args, pols, cpols, chal, pub, x, sections = _base_case(5, nrows)
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=sections, n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3)
+    with pytest.raises(mi_stark.MiStarkError, match="no declared section starts at this offset"):
+        prog.set_tiled_section(17)
+    prog.set_tiled_section(0)
+    prog.set_tiled_section(0)
+    with pytest.raises(mi_stark.MiStarkError, match="one tile-major section per program"):
+        prog.set_tiled_section(nrows * 40)
+    with pytest.raises(mi_stark.MiStarkError, match="host executors read row-major"):
+        prog.run_base_host(pols.copy(), cpols, 7, chal, pub, x, 2, np.arange(4))
+    for shard in (0, 1):
+        prog.precompile_shard(shard, 2, cache_dir=str(tmp_path), chunk_cost=2500)
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=2500)["cache_hits"] >= 2
+    with pytest.raises(mi_stark.MiStarkError, match="comes before mi_chelpers_build_native"):
+        prog.set_tiled_section(0)
+    prog.close()
+    # the output area declared as a read section and tile-major: the program's stores land in it
+    out_sec = (nrows * 52, 120, nrows)
+    prog = mi_stark.ChelpersProgram(None, ops, args, sections=sections + [out_sec], n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3)
+    prog.set_tiled_section(nrows * 52)
+    with pytest.raises(mi_stark.MiStarkError, match="stores into the section declared tile-major"):
+        prog.build_native(cache_dir=str(tmp_path), chunk_cost=2500)
+    prog.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_base_step_program_reads_a_tile_major_section_in_place(seed, tmp_path):
+    """The witness kept tile-major (host/starks.hpp): mi_tile_major_dev writes [tile][column][64 rows]; a base-domain program compiled
+    with that section declared tile-major reads it in place -- shifted rows across tile borders and around the section's end included --
+    and writes the oracle's polynomial elements, in one batch and in many, from row 0 and from a later multiple of 64."""
+    import mi_stark
+    import torch
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 12
+    ops, args, pols, cpols, chal, pub, x, sections = _base_case(seed, nrows)
+    want = pols.copy()
+    glo.chelpers_stepbase(ops, args, want, cpols, 7, chal, pub, x, 2, np.arange(nrows))
+    tiled = pols.copy()
+    tiled[:nrows * 40] = _tile_major(pols[:nrows * 40], nrows, 40)
+    # the kernel that writes the layout: whole section, and in column chunks at a pitch
+    d_rm = ctx.to_device(pols[:nrows * 40])
+    d_tm = torch.zeros(nrows * 40, dtype=torch.int64, device="cuda")
+    ctx.tile_major(d_tm, 40, 0, d_rm, nrows, 40)
+    assert np.array_equal(ctx.to_host(d_tm), tiled[:nrows * 40])
+    d_tm2 = torch.zeros(nrows * 40, dtype=torch.int64, device="cuda")
+    for c0, w in ((0, 8), (8, 24), (32, 8)):
+        chunk = ctx.to_device(np.ascontiguousarray(pols[:nrows * 40].reshape(nrows, 40)[:, c0:c0 + w]))
+        ctx.tile_major(d_tm2, 40, c0, chunk, nrows, w)
+    assert np.array_equal(ctx.to_host(d_tm2), tiled[:nrows * 40])
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=sections, n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3PREV)
+    prog.set_tiled_section(0)
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=2500)["kernels"] >= 2
+    d_c, d_x = ctx.to_device(cpols), ctx.to_device(x)
+    for batch in (0, 512):
+        ctx.set_chelpers_batch_rows(batch)
+        d_pols = ctx.to_device(tiled)
+        prog.run_base(d_pols, d_c, 7, chal, pub, d_x, 2, 0, nrows)
+        got = ctx.to_host(d_pols)
+        assert np.array_equal(got[nrows * 40:], want[nrows * 40:]) and np.array_equal(got[:nrows * 40], tiled[:nrows * 40]), batch
+    d_pols = ctx.to_device(tiled)                  # rows [1024, 4096) only
+    prog.run_base(d_pols, d_c, 7, chal, pub, d_x, 2, 1024, nrows - 1024)
+    part = pols.copy()
+    glo.chelpers_stepbase(ops, args, part, cpols, 7, chal, pub, x, 2, np.arange(1024, nrows))
+    assert np.array_equal(ctx.to_host(d_pols)[nrows * 40:], part[nrows * 40:])
+    with pytest.raises(mi_stark.MiStarkError, match="rows from a multiple of 64"):
+        prog.run_base(d_pols, d_c, 7, chal, pub, d_x, 2, 5, 64)
+    prog.close()
+    ctx.close()
+
+
 def _fit_stats():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
