@@ -119,6 +119,7 @@ struct NativeProg {
     struct LinTermW *d_lin_terms = nullptr;   // rewritten per run: the coefficients are constants of the running proof
     LinSlabD *d_lin_slabs = nullptr;
     std::vector<uint32_t> sec_slab_mask;      // per section: 64-column slabs the generated kernels read (tile-major copy)
+    std::vector<uint32_t> sec_inplace_mask;   // per section: slabs the kernels read so little of that they read it in place (row-major, a sector per lane)
     uint32_t sc = 0, nw = 0;                     // staged columns per tile, temp words per row
     uint32_t pub_off = 0, ev_off = 0, zh_off = 0, coef_off = 0, k_off = 0, cst_words = 0; // word offsets into the constants table (challenges first)
     double compile_s = 0;
@@ -451,6 +452,8 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
     }
     // ---- which 64-column slabs of every section the generated kernels read: only those go into the tile-major copy
     N->sec_slab_mask.assign(P->sections.size(), 0);
+    N->sec_inplace_mask.assign(P->sections.size(), 0);
+    std::map<std::pair<size_t, uint32_t>, uint32_t> slab_loads; // (section, slab) -> operand loads per row out of it, all kernels
     std::set<uint64_t> chunk_ops, all_ops; // (staged column, shift) read by the current kernel / by any: what CSE leaves of the operand reads
     size_t chunk_of = 0;
     for (size_t i = 0; i < n; i++) {
@@ -472,14 +475,27 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
             if (!S) continue; // reported by the generator
             MI_REQUIRE(S->ncols <= 2048, "sections wider than 2048 columns are not supported by the tile-major copy");
             for (int j = 0; j < dim; j++) {
-                if (!S->tiled) N->sec_slab_mask[S - P->sections.data()] |= 1u << ((col + j - S->col0) / 64);
-                chunk_ops.insert(((uint64_t)(col + j) << 8) | sh);
+                const size_t si = S - P->sections.data();
+                const uint32_t slab = (col + j - S->col0) / 64;
+                if (!S->tiled) N->sec_slab_mask[si] |= 1u << slab;
+                if (chunk_ops.insert(((uint64_t)(col + j) << 8) | sh).second) slab_loads[{si, slab}]++;
                 all_ops.insert(((uint64_t)(col + j) << 8) | sh);
             }
         }
     }
     N->operand_loads += chunk_ops.size();
     N->operand_distinct = all_ops.size();
+    // A slab the kernels load only a few elements of per row is not worth its copy (64 columns read and written: 1 KiB per row; the
+    // zkEVM's step52ns left FOUR polynomial elements to the generated kernel -- the rest are linear terms -- and paid 16 ms of copies for
+    // them): those elements are read in place, one 64-byte sector per lane and load.
+    uint32_t inplace_max = 8;
+    if (const char *e = getenv("MI_CHELPERS_INPLACE_MAX")) inplace_max = (uint32_t)std::max(0, atoi(e));
+    for (const auto &kv : slab_loads) {
+        const HostSection &S = P->sections[kv.first.first];
+        if (S.tiled || S.role > 1 || kv.second > inplace_max) continue;
+        N->sec_inplace_mask[kv.first.first] |= 1u << kv.first.second;
+        N->sec_slab_mask[kv.first.first] &= ~(1u << kv.first.second);
+    }
     return MI_OK;
 }
 
@@ -605,10 +621,15 @@ struct Gen {
         }
         const bool three = pdim == 3;
         if (S->tiled) xshifts.insert(sh); // read in place: X<shift>, columns counted from the section's first
-        else if (sh) shifts.insert(sh);
+        else if (sh) shifts.insert(sh);   // (a T<shift> no load names is dropped by the compiler)
         v.dim = three ? 3 : 1;
         for (int j = 0; j < v.dim; j++) {
-            if (S->tiled) snprintf(buf, sizeof buf, "X%u[%llu]", sh, (unsigned long long)(col - S->col0 + j) * 64);
+            const uint32_t sc = col - S->col0 + j; // column of the section
+            if (S->tiled) snprintf(buf, sizeof buf, "X%u[%llu]", sh, (unsigned long long)sc * 64);
+            else if ((N->sec_inplace_mask[S - P->sections.data()] >> (sc / 64)) & 1) // in place, row-major (role 0: the polynomial area, 1: the constants)
+                snprintf(buf, sizeof buf, "%s[%lluULL + ((row + %uu) & %lluULL) * %lluULL]", S->role == 0 ? "pols" : "cpols",
+                         (unsigned long long)((S->role == 0 ? S->offset : 0) + sc), sh, (unsigned long long)(S->nrows - 1),
+                         (unsigned long long)(S->role == 0 ? S->ncols : P->n_const));
             else snprintf(buf, sizeof buf, "T%u[%llu]", sh, (unsigned long long)(col + j) * 64);
             v.e[j] = load(buf);
         }
@@ -864,7 +885,7 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
     char line[1024];
     snprintf(line, sizeof line,
              "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(%u, %u))) void chelpers_chunk(const u64 *__restrict__ tiled, u64 *__restrict__ spill, "
-             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin, const u64 *__restrict__ xsec)\n{\n"
+             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin, const u64 *__restrict__ xsec, const u64 *__restrict__ pols, const u64 *__restrict__ cpols)\n{\n"
              "  const u32 lane = threadIdx.x;\n  const u64 tile = blockIdx.x;\n  const u64 row = row_base + tile * 64 + lane;\n"
              "  const u64 *__restrict__ T0 = tiled + tile * %lluULL + lane;\n  u64 *__restrict__ S = spill + tile * %lluULL + lane;\n",
              waves, waves, (unsigned long long)N->sc * 64, (unsigned long long)N->nw * 64);
@@ -1341,7 +1362,8 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             u64 *spill = c->chelpers_spill, *outp = out;
             uint64_t row_base = b0, rend = row_end;
             const u64 *linp = c->chelpers_lin;
-            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &xsec};
+            const u64 *polsp = (const u64 *)a->pols, *cpolsp = (const u64 *)a->const_pols;
+            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &xsec, &polsp, &cpolsp};
             MI_HIP_CHECK(hipModuleLaunchKernel(C.fn, (unsigned)tiles, 1, 1, 64, 1, 1, 0, c->stream, args, nullptr));
         }
     }

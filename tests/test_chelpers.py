@@ -544,10 +544,12 @@ def test_base_step_tables_agree_with_the_reference_and_its_programs_match_the_or
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12])
-def test_base_step_program_on_gpu_matches_oracle(seed, tmp_path):
+@pytest.mark.parametrize("seed,inplace_max", [(11, None), (12, None), (11, "0"), (12, "64")])
+def test_base_step_program_on_gpu_matches_oracle(seed, inplace_max, tmp_path, monkeypatch):
     """The compiled kernels of a base-domain program write the same polynomial elements as the oracle, in one batch and in many;
     the interpreter has no store form and says so."""
+    if inplace_max is not None:      # operands through the tile-major copy only / read in place wherever a section allows it
+        monkeypatch.setenv("MI_CHELPERS_INPLACE_MAX", inplace_max)
     import mi_stark
     ctx = mi_stark.Context(0)
     nrows = 1 << 12

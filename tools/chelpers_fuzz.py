@@ -31,6 +31,7 @@ def main():
             sections = [(o, w, nrows) for o, w in secs]
             cc = int(rng.choice([0, 1500, 4000, 9000]))
             os.environ["MI_CHELPERS_LIN_MIN"] = str(int(rng.choice([1, 256])))
+            os.environ["MI_CHELPERS_INPLACE_MAX"] = str(int(rng.choice([0, 3, 8, 64])))   # slabs read in place / through the tile-major copy
             ctx.set_chelpers_batch_rows(int(rng.choice([0, 64, 512])))
             r0 = int(rng.integers(0, nrows // 2))
             nr = int(rng.integers(1, nrows - r0 + 1))
@@ -91,8 +92,8 @@ def main():
             ok = [bool(np.array_equal(o, want)) for o in outs]
             if not all(ok):
                 bad += 1
-            print("seed %d kind %d rows %d [%d,+%d) chunk_cost %d lin_min %s: interpreter %s native %s  (%.0f s)" %
-                  (seed, kind, nrows, r0, nr, cc, os.environ["MI_CHELPERS_LIN_MIN"], ok[0], ok[1], time.time() - t0), flush=True)
+            print("seed %d kind %d rows %d [%d,+%d) chunk_cost %d lin_min %s inplace_max %s: interpreter %s native %s  (%.0f s)" %
+                  (seed, kind, nrows, r0, nr, cc, os.environ["MI_CHELPERS_LIN_MIN"], os.environ["MI_CHELPERS_INPLACE_MAX"], ok[0], ok[1], time.time() - t0), flush=True)
     print("fuzz: %d programs, %d mismatches" % (count, bad))
     ctx.close()
     sys.exit(1 if bad else 0)
