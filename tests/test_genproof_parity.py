@@ -11,6 +11,7 @@ CPU side (-m "not gpu"): the oracle prover's proof of the mini STARK is accepted
 and a tampered witness is not -- so the checker is not just self-consistent."""
 import json
 import os
+import time
 import sys
 
 import numpy as np
@@ -173,7 +174,13 @@ def test_starks_genproof_equals_the_oracle_prover_at_2p16_rows_full_zkevm_shape(
     """Every count of the zkEVM (665 / 128 / 371 / 265 columns, 218 constants, 1 768 evaluations, 21 lookups, 30 grand products, 128 queries,
     the five programs at their real sizes) at 2^16 rows -> 2^17: the largest shape the oracle prover finishes inside a test (about a
     minute of CPU), byte for byte."""
-    inputs = shaped_inputs(["--log-n", "16"], fast=True)
+    log_n = int(os.environ.get("MI_PARITY_LOG_N", "16"))          # a one-off at a larger size: profiles/r04_genproof_parity_large.txt
+    t0 = time.time()
+    inputs = shaped_inputs(["--log-n", str(log_n)], fast=True)
+    t1 = time.time()
     want, _ = og.gen_proof(*inputs, fast=True)
+    t2 = time.time()
     got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,))
+    print("full zkEVM shape at 2^%d rows: inputs %.0f s, oracle prover %.0f s, Starks::genProof (child process, incl. compiling) %.0f s, zkin.json %d bytes, equal: %s"
+          % (log_n, t1 - t0, t2 - t1, time.time() - t2, len(want), got4 == want))
     assert got4 == want, first_difference(got4, want)
