@@ -46,6 +46,7 @@ inline StarkMirror *&currentMirror()
 }
 
 inline bool isBaseStep(int step) { return step == MI_CHELPERS_STEP2PREV || step == MI_CHELPERS_STEP3PREV || step == MI_CHELPERS_STEP3; }
+constexpr int MI_STEP_KEY_TRACED = 0x10000, MI_STEP_KEY_TILED = 0x20000; // flags in the first half of a program-cache key
 
 inline StarkMirror *mirrorOf(StepsParams &params)
 {
@@ -110,7 +111,8 @@ inline void runStepProgram(StarkMirror *m, int step, const mi_chelpers_prog *pro
 inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, StepsParams &params, uint64_t nrows)
 {
     StarkMirror *m = mirrorOf(params);
-    mi_chelpers_prog *&prog = (*m->progs)[{step, (const void *)ops}];
+    // (a base-domain program is compiled for the layout of the witness section: one entry per layout)
+    mi_chelpers_prog *&prog = (*m->progs)[{step | (isBaseStep(step) && m->tiledWitness ? MI_STEP_KEY_TILED : 0), (const void *)ops}];
     if (!prog) {
         const std::vector<mi_chelpers_section> secs = stepSections(m, step);
         const bool base = isBaseStep(step);

@@ -211,10 +211,12 @@ public:
     // step's tables in place (the reference's tables are constants of the binary and never change)
     void forgetProgram(int step, const void *opsTable)
     {
-        auto it = progs.find({step, opsTable});
-        if (it == progs.end()) return;
-        if (it->second) mi_chelpers_free(mi::ctx(), it->second);
-        progs.erase(it);
+        for (int key : {step, step | mi::MI_STEP_KEY_TILED}) {
+            auto it = progs.find({key, opsTable});
+            if (it == progs.end()) continue;
+            if (it->second) mi_chelpers_free(mi::ctx(), it->second);
+            progs.erase(it);
+        }
     }
 
     // device image of the last proof's polynomial area (valid until the next genProof of any Starks): for checks after the fact.
@@ -322,7 +324,8 @@ inline mi_chelpers_prog *Starks::tracedProgram(mi::StarkMirror &m, Steps *steps,
     static const int ids[5] = {MI_CHELPERS_STEP2PREV, MI_CHELPERS_STEP3PREV, MI_CHELPERS_STEP3, MI_CHELPERS_STEP42NS, MI_CHELPERS_STEP52NS};
     const int step = ids[which];
     const bool base = which <= 2;
-    const std::pair<int, const void *> key = {step | 0x10000, (const void *)&typeid(*steps)}; // per Steps class: one per proving key
+    const std::pair<int, const void *> key = {step | mi::MI_STEP_KEY_TRACED | (base && m.tiledWitness ? mi::MI_STEP_KEY_TILED : 0),
+                                              (const void *)&typeid(*steps)}; // per Steps class (one per proving key) and witness layout
     if (emptySteps.count(key)) return nullptr;
     mi_chelpers_prog *&prog = progs[key];
     if (!prog) {
