@@ -30,6 +30,11 @@ def main():
     import bench
     n, ne, w = 1 << a.log_n, 2 << a.log_n, a.ncols
     A, B = mi_stark.Context(0), mi_stark.Context(0)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()      # a context enqueues on the stream that is current when use_torch_stream() is called
+    with torch.cuda.stream(sa):
+        A.use_torch_stream()
+    with torch.cuda.stream(sb):
+        B.use_torch_stream()
     trace = A.empty(n * w)
     A.fill_synthetic_2d(trace, n, w, w, 0, 0x5EED0003)
     ext, nodes = A.empty(ne * w), A.empty((2 * ne - 1) * 4)
