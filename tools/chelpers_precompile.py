@@ -36,6 +36,7 @@ STARKS_CONFIGS = [
     ["--log-n", "12", "--ext-bits", "3", "--qdeg", "7", "--widths", "18", "0", "39", "--tmpexp", "14", "--n-const", "52", "--n-evals", "118",
      "--n-queries", "43", "--n-lookups", "0", "0", "--n-products", "1", "--fri-steps", "15", "11", "7", "4", "--field-ops", "0", "201", "1761", "3483", "463"],
     ["--log-n", "12"],                                      # the zkEVM's full widths, counts and program sizes at 2^12 rows
+    ["--log-n", "16"],                                      # ... and at 2^16 (tests/test_genproof_parity.py's largest)
 ]
 
 
@@ -45,9 +46,13 @@ def precompile_starks(jobs, only):
         if only >= 0 and ci != only:
             continue
         t0 = time.time()
-        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench_starks.py")] + argv + ["--precompile", str(s), str(jobs)]) for s in range(jobs)]
-        if any(p.wait() for p in procs):
-            raise SystemExit("a precompile shard of bench_starks.py failed")
+        # both layouts of the witness section: tile-major (one device) and row-major (MI_STARK_DEVICES, MI_STARK_TILED_WITNESS=0, a STARK
+        # whose lookups read witness columns): the base-domain programs' kernels differ, the others are found in the cache the second time
+        for tiled in ("1", "0"):
+            env = dict(os.environ, MI_STARK_TILED_WITNESS=tiled)
+            procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench_starks.py")] + argv + ["--precompile", str(s), str(jobs)], env=env) for s in range(jobs)]
+            if any(p.wait() for p in procs):
+                raise SystemExit("a precompile shard of bench_starks.py failed")
         st = bench_starks.compiled_programs(bench_starks.parse(argv))
         print("precompiled bench_starks", argv or "(default)", {k: (v["kernels"], v["cache_hits"], v["code_bytes"]) for k, v in st.items()},
               "%.1f s" % (time.time() - t0), flush=True)
