@@ -61,6 +61,18 @@ def shaped_inputs(argv, fast=False):
     return si, progs, const_n, tree, witness, np.arange(1, 9, dtype=np.uint64)
 
 
+_ORACLE = {}
+
+
+def shaped_case(name):
+    """(inputs, the oracle prover's zkin) of a named shape, once per session: three GPU tests prove each shape (one device, per-row steps,
+    sharded commits) against the same CPU proof."""
+    if name not in _ORACLE:
+        inputs = shaped_inputs(SHAPES[name])
+        _ORACLE[name] = (inputs, og.gen_proof(*inputs)[0])
+    return _ORACLE[name]
+
+
 def first_difference(a, b):
     """where two zkin texts part, as a key path: for the failure message."""
     ja, jb = json.loads(a), json.loads(b)
@@ -131,8 +143,7 @@ def test_starks_genproof_equals_the_oracle_prover_mini_stark(nbits, n_queries, t
 def test_starks_genproof_equals_the_oracle_prover_shaped_starks(name, tmp_path):
     """bench_starks.py's synthetic STARKs at sizes the oracle finishes in seconds: lookups of both dimensions, grand products of the three
     kinds, evaluations of committed / constant / quotient polynomials at xi and w xi, blow-up 2 and 8, a stage without columns."""
-    inputs = shaped_inputs(SHAPES[name])
-    want, _ = og.gen_proof(*inputs)
+    inputs, want = shaped_case(name)
     got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,))
     assert got4 == want, first_difference(got4, want)
 
@@ -142,8 +153,7 @@ def test_starks_genproof_equals_the_oracle_prover_shaped_starks(name, tmp_path):
 def test_starks_genproof_with_per_row_steps_equals_the_oracle_prover(name, tmp_path):
     """nrowsStepBatch = 1 as the reference proves c12a / recursive1 / recursive2 (prover.cpp:577,611): the tables written out as generated
     per-row C++, recorded by host/steps_tracer.hpp and run on the device; the same bytes as the oracle prover over the tables."""
-    inputs = shaped_inputs(SHAPES[name])
-    want, _ = og.gen_proof(*inputs)
+    inputs, want = shaped_case(name)
     so = sr.steps_library(inputs[1], str(tmp_path))
     got1, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(1,), steps_so=so)
     assert got1 == want, first_difference(got1, want)
@@ -155,8 +165,7 @@ def test_starks_genproof_with_sharded_commits_equals_the_oracle_prover(name, dev
     """MI_STARK_DEVICES: the stage commits of Starks::genProof sharded over several devices from ONE process (csrc/multi.hip; here logical
     shards on device 0): column-tile LDEs, peer exchange, row-sharded leaf hashing and subtrees, openings whose siblings come from the
     shards -- and still the oracle prover's bytes."""
-    inputs = shaped_inputs(SHAPES[name])
-    want, _ = og.gen_proof(*inputs)
+    inputs, want = shaped_case(name)
     got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,), env=dict(os.environ, MI_STARK_DEVICES=devices))
     assert got4 == want, first_difference(got4, want)
 
