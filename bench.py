@@ -295,12 +295,28 @@ def single_process_main(args):
     dt, root, st = run(trace.data_ptr(), 0, args.steps, args.warmup)
     pcie = None
     if args.pcie_steps > 0:
-        host = torch.empty(n * ncols, dtype=torch.int64)
+        # the host trace page-locked (what Starks does with the witness section of pAddress when several devices are configured): each
+        # shard's DMA engines read its tiles in place -- "strided" --, then the same buffer through the host-packed form (what a pageable
+        # trace takes) for the A/B
+        host = torch.empty(n * ncols, dtype=torch.int64, pin_memory=not args.pcie_pageable)
         host.copy_(trace)
         torch.cuda.synchronize()
-        dt_h, root_h, st_h = run(host.data_ptr(), -1, args.pcie_steps, 1)
-        pcie = {"ms_per_step": 1e3 * dt_h, "value": n * ncols / dt_h, "unit": "field-elements/s", "root_matches": root_h == root, "per_shard": st_h["per_shard"],
-                "path": "trace in pageable host memory; every shard's tiles packed by host threads and sent over that shard's own PCIe link"}
+        legs = {}
+        for name, mode in (("auto", 1 if (args.logical_shards and not args.pcie_pageable) else -1), ("packed", 0)):  # (logical shards share a link: auto would pack)
+            m.set_upload_mode(mode)
+            dt_h, root_h, st_h = run(host.data_ptr(), -1, args.pcie_steps, 1)
+            legs[name] = {"upload": m.last_upload_mode(), "ms_per_step": 1e3 * dt_h, "value": n * ncols / dt_h, "unit": "field-elements/s", "root_matches": root_h == root,
+                          "per_shard": st_h["per_shard"]}
+            if legs[name]["upload"] == "packed":
+                break
+        m.set_upload_mode(-1)
+        pcie = dict(legs["auto"])
+        pcie["host_memory"] = "pageable" if args.pcie_pageable else "page-locked"
+        pcie["path"] = ("strided: every shard's DMA engines read its column tiles out of the page-locked trace over that shard's own PCIe link (no host thread in the data path)"
+                        if pcie["upload"] == "strided" else "packed: every shard's tiles packed by host threads into page-locked staging and sent over that shard's own PCIe link")
+        if "packed" in legs:
+            pcie["packed_ab"] = {k: legs["packed"][k] for k in ("ms_per_step", "value", "root_matches")}
+            pcie["packed_ab"]["host_pack_ms_per_shard"] = [s_["host_pack_ms"] for s_ in legs["packed"]["per_shard"]]
         del host
     out = {"metric": "goldilocks_field_elements_per_s_lde_merkleize_2^%d_rows" % args.log_n, "value": n * ncols / dt, "unit": "field-elements/s", "n_gpus": G,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "strong" if G > 1 else "none", "vs_baseline": None,

@@ -155,7 +155,7 @@ int mi_lde_merkle_host_keep(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_
  * the compiled base-domain steps read in place.  Costs what the row-major copy costs and hides behind the upload like it. */
 int mi_lde_merkle_host_keep_tiled(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base_tiled,
                                   const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
-int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister: page-lock a host range for DMA */
+int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister (portable: every device may read it): page-lock a host range for DMA */
 int mi_host_unregister(mi_ctx *ctx, void *p);
 
 /* ------------------------------------------------------------------ one process, several devices (csrc/multi.hip)
@@ -173,9 +173,15 @@ void mi_multi_destroy(mi_multi *m);
 int mi_multi_shards(const mi_multi *m);
 mi_ctx *mi_multi_ctx(mi_multi *m, int shard);
 int mi_multi_set_pack_threads(mi_multi *m, int threads); /* host threads that pack a tile for its upload (default min(64, hardware threads)) */
-/* src: the n x ncols row-major base-domain section at row pitch src_pitch (elements): HOST memory when src_device < 0 (pageable is fine:
- * host threads pack each tile into page-locked staging and it crosses the PCIe link of the shard that extends it), else memory of that
- * device.  image / base (either may be NULL; on device image_device): receive the whole extension (n_ext x ncols at row pitch
+/* How a HOST source reaches the shards: -1 (default) = a page-locked source (mi_host_register, hipHostMalloc) is read in place by each
+ * device's own DMA engines, strided 2-D copies over that device's PCIe link and no host thread in the data path, when the shards sit on
+ * at least two devices; a pageable source, or shards sharing one device, is packed by host threads into page-locked staging.  0 / 1 force the packed / the strided form (1 on a pageable source: the commit refuses).
+ * The environment's MI_MULTI_UPLOAD=packed|strided overrides it (A/B runs). */
+int mi_multi_set_upload_mode(mi_multi *m, int mode);
+int mi_multi_last_upload_mode(const mi_multi *m); /* the last commit: -1 device source, 0 host-packed, 1 strided DMA out of the page-locked source */
+/* src: the n x ncols row-major base-domain section at row pitch src_pitch (elements): HOST memory when src_device < 0 (page-locked: read
+ * in place by the DMA engines of the shard that extends the tile; pageable is fine too: host threads pack each tile into page-locked
+ * staging and it crosses that shard's PCIe link), else memory of that device.  image / base (either may be NULL; on device image_device): receive the whole extension (n_ext x ncols at row pitch
  * image_pitch) and the section itself (n x ncols at base_pitch), row-major -- what a caller that evaluates constraints on one device
  * keeps.  root: 4 words (host).  The call returns when everything has arrived.  *out: the sharded tree, for the openings. */
 int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t *src, uint64_t src_pitch, int src_device, uint64_t n, uint64_t n_ext,

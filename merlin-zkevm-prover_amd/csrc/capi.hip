@@ -728,11 +728,14 @@ extern "C" int mi_set_host_pack_threads(mi_ctx *c, int threads)
     return MI_OK;
 }
 
+// page-locking works on whole pages: the range is widened to the pages that cover it (all of them hold the caller's bytes), so that a
+// section in the middle of a malloc'ed area (pAddress + an offset) can be named as it is
 extern "C" int mi_host_register(mi_ctx *c, void *p, uint64_t bytes)
 {
     CTX_OK(c);
     MI_REQUIRE(p && bytes, "null range");
-    MI_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    const uintptr_t a = (uintptr_t)p & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+    MI_HIP_CHECK(hipHostRegister((void *)a, e - a, hipHostRegisterPortable)); // every device of a multi-device commit reads it over its own link
     return MI_OK;
 }
 
@@ -740,7 +743,7 @@ extern "C" int mi_host_unregister(mi_ctx *c, void *p)
 {
     CTX_OK(c);
     MI_REQUIRE(p, "null pointer");
-    MI_HIP_CHECK(hipHostUnregister(p));
+    MI_HIP_CHECK(hipHostUnregister((void *)((uintptr_t)p & ~(uintptr_t)4095)));
     return MI_OK;
 }
 

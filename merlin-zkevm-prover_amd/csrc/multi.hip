@@ -56,7 +56,10 @@ struct mi_multi {
     uint32_t G = 0;
     std::vector<int> dev;
     std::vector<mi_ctx *> ctx;
-    std::vector<hipStream_t> cs, xs, us; // compute, exchange, upload
+    std::vector<hipStream_t> cs, xs, us, us2; // compute, exchange, upload (us2: the lower rows of a strided upload -- a second DMA engine)
+    std::vector<hipEvent_t> ev_us2;           // per shard: us2's half of the current tile is up
+    int upload_mode = -1;                     // -1 auto (page-locked source -> strided DMA, pageable -> host-packed), 0 packed, 1 strided
+    int last_upload = -1;                     // what the last commit did: -1 device source, 0 host-packed staging, 1 strided DMA from the page-locked source
     int pack_threads = 16;
     static constexpr int HS = 3;         // page-locked staging ring of the host uploads (shared by the shards: the host packs one tile at a time)
     u64 *hstage[HS] = {};
@@ -127,10 +130,15 @@ extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
         int st = mi_ctx_create(&c, devices[g]);
         if (st != MI_OK) { mi_multi_destroy(m); return st; }
         m->ctx.push_back(c);
-        hipStream_t s[3];
-        for (int i = 0; i < 3; i++)
+        hipStream_t s[4];
+        for (int i = 0; i < 4; i++)
             if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) { mi_set_error("mi_multi_create: cannot create a stream"); mi_multi_destroy(m); return MI_ERR_HIP; }
-        m->cs.push_back(s[0]); m->xs.push_back(s[1]); m->us.push_back(s[2]);
+        m->cs.push_back(s[0]); m->xs.push_back(s[1]); m->us.push_back(s[2]); m->us2.push_back(s[3]);
+        {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { mi_set_error("mi_multi_create: cannot create an event"); mi_multi_destroy(m); return MI_ERR_HIP; }
+            m->ev_us2.push_back(e);
+        }
         mi_ctx_set_stream(c, s[0]);
         for (int i = 0; i < mi_multi::HS; i++) {
             hipEvent_t e = nullptr;
@@ -172,9 +180,12 @@ extern "C" void mi_multi_destroy(mi_multi *m)
     for (size_t g = 0; g < m->ctx.size(); g++) {
         (void)hipSetDevice(m->dev[g]);
         if (g < m->cs.size()) { (void)hipStreamSynchronize(m->cs[g]); (void)hipStreamSynchronize(m->xs[g]); (void)hipStreamSynchronize(m->us[g]); }
+        if (g < m->us2.size()) (void)hipStreamSynchronize(m->us2[g]);
         if (g < m->pool.size()) for (auto &c : m->pool[g]) (void)hipFree(c.p);
         if (m->ctx[g]) { mi_ctx_set_stream(m->ctx[g], nullptr); mi_ctx_destroy(m->ctx[g]); }
         if (g < m->cs.size()) { (void)hipStreamDestroy(m->cs[g]); (void)hipStreamDestroy(m->xs[g]); (void)hipStreamDestroy(m->us[g]); }
+        if (g < m->us2.size()) (void)hipStreamDestroy(m->us2[g]);
+        if (g < m->ev_us2.size() && m->ev_us2[g]) (void)hipEventDestroy(m->ev_us2[g]);
     }
     for (int i = 0; i < mi_multi::HS; i++) {
         if (m->hstage[i]) (void)hipHostFree(m->hstage[i]);
@@ -191,6 +202,19 @@ extern "C" int mi_multi_set_pack_threads(mi_multi *m, int threads)
     m->pack_threads = threads;
     return MI_OK;
 }
+// How a HOST source reaches the shards.  -1 (default): a page-locked source (hipHostMalloc / hipHostRegister: mi_host_register) is read by
+// each device's own DMA engines as strided 2-D copies straight out of the caller's trace -- no host thread touches the data, G links run
+// at once -- when the shards sit on at least two devices; a pageable source (the DMA engines cannot read it) and shards that share one
+// device (one link: contiguous copies are faster) are packed by host threads into page-locked staging.  0 / 1 force a form (1 on a
+// pageable source is refused by the commit).
+extern "C" int mi_multi_set_upload_mode(mi_multi *m, int mode)
+{
+    MI_REQUIRE(m && mode >= -1 && mode <= 1, "bad argument");
+    m->upload_mode = mode;
+    return MI_OK;
+}
+// what the last commit did with its source: -1 device source, 0 host-packed staging, 1 strided DMA from the page-locked source
+extern "C" int mi_multi_last_upload_mode(const mi_multi *m) { return m ? m->last_upload : -1; }
 
 // The NEXT commit carves shard `shard`'s row buffers, staging and NTT workspace from [ptr, ptr + bytes) (memory of that shard's device)
 // instead of allocating them; the region is the caller's again when the commit returns and mi_multi_tree_release_rows has been called
@@ -309,7 +333,25 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
     MM_DEV(m, 0);
     MI_HIP_CHECK(hipMalloc((void **)&t->roots, (2 * G - 1) * 4 * 8));
     const bool from_host = src_device < 0;
+    bool strided = false; // host source read by the devices' DMA engines in place
     if (from_host) {
+        hipPointerAttribute_t at;
+        const uint64_t last = (n - 1) * src_pitch + ncols - 1;
+        bool locked = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+        if (locked) { hipPointerAttribute_t a2; locked = hipPointerGetAttributes(&a2, src + last) == hipSuccess && a2.type == hipMemoryTypeHost; }
+        (void)hipGetLastError(); // a pageable pointer is "invalid value" to the query, not an error of this call
+        int mode = m->upload_mode;
+        if (const char *e = getenv("MI_MULTI_UPLOAD")) mode = !strcmp(e, "packed") ? 0 : !strcmp(e, "strided") ? 1 : mode;
+        MI_REQUIRE(mode != 1 || locked, "strided upload asked for a source that is not page-locked (mi_host_register it, or leave the mode at -1)");
+        // auto: in place when the shards sit on at least two devices -- G links at the strided rate (39.5 GB/s each at 32 columns) beat one
+        // host's packing threads (55 GB/s on 16 cores out of a page-locked trace, measured); logical shards on ONE device share one link,
+        // where the packed form's contiguous copies are the faster (1.07 s against 1.40 s per zkEVM step: profiles/r04_sp4_upload_ab.json)
+        bool two_devices = false;
+        for (uint32_t g = 1; g < G; g++) two_devices = two_devices || m->dev[g] != m->dev[0];
+        strided = mode == 1 || (mode == -1 && locked && two_devices);
+    }
+    m->last_upload = from_host ? (strided ? 1 : 0) : -1;
+    if (from_host && !strided) {
         const uint64_t need = n * maxw * 8;
         if (m->hstage_bytes < need) {
             for (int i = 0; i < mi_multi::HS; i++) {
@@ -392,7 +434,17 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
             // ---- the tile's base-domain columns onto shard g's device
             MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], ev_consumed[g * NS + slot], 0));
             MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], ev_based[g * NS + slot], 0));
-            if (from_host) {
+            if (from_host && strided) {
+                // the tile's columns straight out of the caller's page-locked trace: rows of 8 w bytes at the trace's pitch, upper and lower
+                // rows on two streams (two DMA engines of THIS device; profiles/r02_pcie_chunk_sweep.json: 39.5 GB/s per link at 32 columns)
+                const uint64_t half = n / 2;
+                MI_HIP_CHECK(hipStreamWaitEvent(m->us2[g], ev_consumed[g * NS + slot], 0));
+                MI_HIP_CHECK(hipStreamWaitEvent(m->us2[g], ev_based[g * NS + slot], 0));
+                MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, src + c0, src_pitch * 8, w * 8, n - half, hipMemcpyHostToDevice, m->us[g]));
+                if (half) MI_HIP_CHECK(hipMemcpy2DAsync(st + (n - half) * w, w * 8, src + (n - half) * src_pitch + c0, src_pitch * 8, w * 8, half, hipMemcpyHostToDevice, m->us2[g]));
+                MI_HIP_CHECK(hipEventRecord(m->ev_us2[g], m->us2[g]));
+                MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], m->ev_us2[g], 0));
+            } else if (from_host) {
                 const int hs = hs_next++ % mi_multi::HS;
                 const auto t0 = std::chrono::steady_clock::now();
                 if (m->hstage_user[hs] >= 0) MI_HIP_CHECK(hipEventSynchronize(m->hstage_sent[hs][m->hstage_user[hs]])); // the copy that last read this slot is done
@@ -477,7 +529,7 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
     MI_HIP_CHECK(hipMemcpyAsync(t->roots_host.data(), t->roots, (2 * G - 1) * 32, hipMemcpyDeviceToHost, m->cs[0]));
     for (uint32_t g = 0; g < G; g++) {
         MM_DEV(m, g);
-        MI_HIP_CHECK(hipStreamSynchronize(m->us[g])); MI_HIP_CHECK(hipStreamSynchronize(m->xs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->cs[g]));
+        MI_HIP_CHECK(hipStreamSynchronize(m->us[g])); MI_HIP_CHECK(hipStreamSynchronize(m->us2[g])); MI_HIP_CHECK(hipStreamSynchronize(m->xs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->cs[g]));
     }
     for (int i = 0; i < 4; i++) root[i] = t->roots_host[(2 * G - 2) * 4 + i];
     for (const Timed &x : timed) {

@@ -192,6 +192,7 @@ public:
     ~Starks()
     {
         if (!pConstPols) return; // nothing was set up (config.generateProof() false)
+        if (witnessLocked) (void)mi_host_unregister(mi::ctx(), mem + off(cm1_n));
         for (auto &p : progs) if (p.second) mi_chelpers_free(mi::ctx(), p.second);
         if (d_constN) mi_dev_free(mi::ctx(), d_constN);
         delete pConstPols;
@@ -225,7 +226,7 @@ public:
     uint64_t lateOffsets[3] = {0, 0, 0};
 
 private:
-    bool ownsConstants = false;
+    bool ownsConstants = false, witnessLocked = false;
     void init()
     {
         pConstPols = new ConstantPolsStarks(pConstPolsAddress, constPolsSize, starkInfo.nConstants);
@@ -244,6 +245,17 @@ private:
         // the proof's HBM now, not inside the first genProof: like the reference, which allocates pAddress when the prover starts
         // (prover.cpp:99-120).  273 GB of fresh device memory take the driver 5.7 s; a later, larger Starks grows the arena once more.
         mi::arena().reserve(starkInfo.mapTotalN + 4 * treeElems + scratchElems);
+        // Several devices (MI_STARK_DEVICES): the witness section of pAddress is page-locked ONCE, here -- like pAddress itself it lives as
+        // long as the prover (prover.cpp:99-120) --, so that every device's DMA engines read their column tiles of stage 1 straight out of
+        // it over their own PCIe link (csrc/multi.hip "strided"); pageable, the tiles are packed by host threads first, and eight links
+        // wait for one socket's memory bandwidth.  MI_STARK_REGISTER_WITNESS=0 leaves it pageable; a refusal (RLIMIT_MEMLOCK) is not fatal.
+        const char *rw = std::getenv("MI_STARK_REGISTER_WITNESS");
+        if (mi::multi() && !(rw && rw[0] == '0') && cols(cm1_n) && pAddress) {
+            TimerStart(STARK_PAGE_LOCK_WITNESS);
+            if (mi_host_register(mi::ctx(), mem + off(cm1_n), N * cols(cm1_n) * 8) == MI_OK) witnessLocked = true;
+            else zklog.warning("Starks: the witness section could not be page-locked (" + std::string(mi_last_error()) + "): stage 1 packs its tiles on the host");
+            TimerStopAndLog(STARK_PAGE_LOCK_WITNESS);
+        }
     }
     // genProof lends sections that are not live as LDE / NTT / FRI scratch and re-plans the base-domain part from stage 4 on (see the
     // header): that is only sound for pil-stark's section order with every section starting where the previous one ends.  The reference

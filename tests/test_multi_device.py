@@ -99,6 +99,62 @@ def test_sharded_commit_from_host_equals_the_single_device_tree(log_n, ncols, G)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ncols,G,pitch_extra", [(12, 665, 4, 0), (13, 96, 8, 0), (14, 371, 2, 24), (10, 9, 4, 3), (16, 128, 8, 0)])
+def test_a_page_locked_host_source_is_read_in_place_by_the_shards_dma(log_n, ncols, G, pitch_extra):
+    """A page-locked witness (mi_host_register: what Starks does with pAddress's cm1_n when MI_STARK_DEVICES names several devices) is not
+    packed by host threads: each shard's DMA engines read its tile's columns out of the caller's rows (strided 2-D copies, two streams per
+    shard).  Same root, digests and image as the packed form and as one device; a pageable source still takes the packed form, and
+    forcing the strided form on it is refused."""
+    n, n_ext, pitch = 1 << log_n, 2 << log_n, ncols + pitch_extra
+    raw = np.zeros(n * pitch + 2048, dtype=np.uint64)                    # (page-locking works on whole pages: a page-aligned range inside one array)
+    skip = (-raw.ctypes.data % 4096) // 8 + (5 if pitch_extra else 0)    # ... or not: mi_host_register widens the range to whole pages
+    buf = raw[skip:skip + (n * pitch + 511) // 512 * 512]
+    view = buf[:n * pitch].reshape(n, pitch)
+    view[:, :ncols] = glo.splitmix64(0x5EED0600 + log_n, n * ncols).reshape(n, ncols)
+    view[:, ncols:] = 0xDEAD                                            # never read
+    trace = np.ascontiguousarray(view[:, :ncols])
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    want_nodes = ctx.to_host(nodes)
+    m = mi_stark.Multi([0] * G)
+    image, base = ctx.zeros(n_ext * ncols), ctx.zeros(n * ncols)
+    ctx.sync()
+    # pageable: packed
+    t = m.commit(buf.ctypes.data, n, n_ext, ncols, src_pitch=pitch)
+    assert m.last_upload_mode() == "packed" and [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+    t.free()
+    m.set_upload_mode(1)
+    with pytest.raises(mi_stark.MiStarkError, match="not page-locked"):
+        m.commit(buf.ctypes.data, n, n_ext, ncols, src_pitch=pitch)
+    m.set_upload_mode(-1)
+    ctx.host_register(buf.ctypes.data, buf.nbytes)
+    try:
+        t = m.commit(buf.ctypes.data, n, n_ext, ncols, src_pitch=pitch)  # auto: logical shards share ONE device and its one link -> packed
+        assert m.last_upload_mode() == "packed" and [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+        t.free()
+        m.set_upload_mode(1)                                            # ... what shards on two or more devices take by themselves
+        t = m.commit(buf.ctypes.data, n, n_ext, ncols, src_pitch=pitch, image_ptr=image.data_ptr(), base_ptr=base.data_ptr())
+        assert m.last_upload_mode() == "strided"
+        assert [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+        for g in range(G):
+            assert np.array_equal(t.leaf_digests(g).reshape(-1), want_nodes[4 * g * t.rows_per_shard:4 * (g + 1) * t.rows_per_shard]), g
+        assert np.array_equal(ctx.to_host(image), ctx.to_host(ext)) and np.array_equal(ctx.to_host(base), trace.reshape(-1))
+        st = m.last_stats()
+        assert all(s["host_pack_ms"] == 0 for s in st["per_shard"])     # no host thread touched the data
+        t.free()
+        m.set_upload_mode(0)                                            # the packed form out of the same page-locked source (A/B runs)
+        t = m.commit(buf.ctypes.data, n, n_ext, ncols, src_pitch=pitch)
+        assert m.last_upload_mode() == "packed" and [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+        t.free()
+    finally:
+        ctx.host_unregister(buf.ctypes.data)
+    d = ctx.to_device(trace)                                            # a device source says so
+    t = m.commit(d.data_ptr(), n, n_ext, ncols, src_device=0)
+    assert m.last_upload_mode() == "device" and [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+    t.free(); m.close(); ctx.close()
+
+
+@pytest.mark.gpu
 def test_sharded_commit_from_a_device_section_equals_the_single_device_tree():
     """Stages 2-4 of a proof: the section is already on a device (the image), at a row pitch wider than itself."""
     log_n, ncols, pitch, G = 12, 128, 200, 4
