@@ -192,6 +192,14 @@ int mi_multi_group_proofs(mi_multi_tree *t, uint64_t *proofs, const uint64_t *id
 /* the NEXT commit carves shard `shard`'s row buffers, staging and NTT workspace from [ptr, ptr + bytes) (memory of that shard's device, not
  * live for the duration of the commit) instead of allocating them: for a caller whose own plan fills the device (host/starks.hpp) */
 int mi_multi_lend(mi_multi *m, int shard, void *ptr, uint64_t bytes);
+/* the NEXT commit also leaves shard q's own rows [q R, (q + 1) R) of the extension and the halo_rows rows after them (wrapping at n_ext:
+ * the shifted reads of a constraint program, starks.cpp:240) row-major at row pitch `pitch` in imgs[q] -- the start of a FULL-HEIGHT
+ * section (n_ext x pitch) in memory of shard q's device, of which only those rows are written -- for every non-null imgs[q] (G entries):
+ * what a row-sharded constraint evaluation on that device reads (host/chelpers_steps.hpp: step42ns over its rows on every device) */
+int mi_multi_set_row_images(mi_multi *m, uint64_t *const *imgs, uint64_t pitch, uint64_t halo_rows);
+int mi_multi_set_device(mi_multi *m, int shard); /* the calling thread's current device := the shard's (to drive mi_multi_ctx(m, shard) directly) */
+int mi_multi_copy(mi_multi *m, void *dst, int dst_shard, const void *src, int src_shard, uint64_t bytes); /* behind the work queued on src_shard's context */
+int mi_multi_sync(mi_multi *m, int shard); /* wait for the shard's context */
 int mi_multi_tree_release_rows(mi_multi_tree *t); /* give the shards' row buffers back, keep the subtrees (siblings can still be opened) */
 void mi_multi_tree_free(mi_multi_tree *t);
 int mi_multi_tree_info(const mi_multi_tree *t, uint64_t out[6]); /* shards, rows per shard, columns per shard, rounds, columns, rows */
@@ -412,6 +420,9 @@ void *mi_dev_alloc(mi_ctx *ctx, uint64_t bytes);
 int mi_dev_free(mi_ctx *ctx, void *p);
 int mi_copy_h2d(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int mi_dev_zero(mi_ctx *ctx, void *p, uint64_t bytes); /* zeros, enqueued on the context's stream */
+/* a column window: host rows of `width` words at row pitch src_pitch -> device rows at row pitch dst_pitch (words) */
+int mi_copy_h2d_2d(mi_ctx *ctx, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch, uint64_t width, uint64_t rows);
 /* Selects the Poseidon code path: 2 (default) = full rounds with the MDS on 32-bit halves (v_mad_u64_u32) and the
  * 22 partial rounds in the grouped optimised form (dot products with 64-bit constants, tools/gen_poseidon_sparse.py);
  * 0 = naive rounds throughout, MDS on 32-bit halves; 1 = naive rounds, MDS on 22-bit limbs (v_mad_u32_u24).

@@ -921,6 +921,27 @@ extern "C" int mi_copy_h2d(mi_ctx *c, void *dst, const void *src, uint64_t bytes
     return MI_OK;
 }
 
+// zeros, enqueued on the context's stream
+extern "C" int mi_dev_zero(mi_ctx *c, void *p, uint64_t bytes)
+{
+    CTX_OK(c);
+    if (!bytes) return MI_OK;
+    MI_REQUIRE(p, "null buffer");
+    MI_HIP_CHECK(hipMemsetAsync(p, 0, bytes, c->stream));
+    return MI_OK;
+}
+
+// host rows of `width` words at pitch src_pitch -> device rows at pitch dst_pitch (a column window of a row-major section); returns when done
+extern "C" int mi_copy_h2d_2d(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch, uint64_t width, uint64_t rows)
+{
+    CTX_OK(c);
+    if (!width || !rows) return MI_OK;
+    MI_REQUIRE(dst && src && dst_pitch >= width && src_pitch >= width, "bad 2-D copy");
+    MI_HIP_CHECK(hipMemcpy2DAsync(dst, dst_pitch * 8, src, src_pitch * 8, width * 8, rows, hipMemcpyHostToDevice, c->stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return MI_OK;
+}
+
 extern "C" int mi_copy_d2h(mi_ctx *c, void *dst, const void *src, uint64_t bytes)
 {
     CTX_OK(c);

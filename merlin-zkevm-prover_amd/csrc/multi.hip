@@ -72,6 +72,11 @@ struct mi_multi {
     // next commit a region that is not live; the shard's row buffers, staging and NTT workspace are carved from it instead of allocated
     std::vector<u64 *> lent;
     std::vector<uint64_t> lent_elems;
+    // mi_multi_set_row_images: the NEXT commit also leaves, on every shard that names one, the shard's OWN rows of the extension (and the
+    // `halo` rows after them, wrapping at n_ext) in row-major form at their place in a full-height section -- what a row-sharded
+    // constraint evaluation reads on that device (host/chelpers_steps.hpp)
+    std::vector<u64 *> row_img;
+    uint64_t row_img_pitch = 0, row_img_halo = 0;
     // device buffers of freed trees, per shard: the next commit takes them back instead of allocating (tens of GB per shard and proof: a fresh
     // allocation is wiped by the driver on the GPU's own bandwidth, DESIGN_HISTORY.md section 6)
     struct Cached { u64 *p; uint64_t elems; };
@@ -79,6 +84,7 @@ struct mi_multi {
     u64 *take(uint32_t g, uint64_t elems)
     {
         auto &v = pool[g];
+        if (getenv("MI_MULTI_NO_POOL")) return nullptr; // (debugging: every buffer a fresh allocation)
         size_t best = v.size();
         for (size_t i = 0; i < v.size(); i++)
             if (v[i].elems >= elems && (best == v.size() || v[i].elems < v[best].elems)) best = i;
@@ -103,6 +109,7 @@ struct mi_multi_tree {
 #define MM_DEV(m, g) MI_HIP_CHECK(hipSetDevice((m)->dev[g]))
 
 extern "C" void mi_multi_destroy(mi_multi *m);
+static int copy_dd(const mi_multi *m, void *dst, int gd, const void *src, int gs, uint64_t bytes, hipStream_t s);
 
 extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
 {
@@ -227,6 +234,43 @@ extern "C" int mi_multi_lend(mi_multi *m, int shard, void *ptr, uint64_t bytes)
     return MI_OK;
 }
 
+// The NEXT commit also writes shard q's rows [q R, (q + 1) R) of the extension, and the halo_rows rows that follow them (wrapping at
+// n_ext: the shifted reads of a constraint program, starks.cpp:240 "(i + next) % NExtended"), row-major at row pitch `pitch` into
+// imgs[q] -- the START of a FULL-HEIGHT section (n_ext x pitch) in device memory of shard q's device, of which only those rows are
+// written -- for every q with a non-null imgs[q].  With 288 GB a device the full-height layout is affordable and keeps the evaluator's
+// addressing that of the one-device image.  One-shot, like mi_multi_lend.
+extern "C" int mi_multi_set_row_images(mi_multi *m, uint64_t *const *imgs, uint64_t pitch, uint64_t halo_rows)
+{
+    MI_REQUIRE(m, "null argument");
+    m->row_img.assign(m->G, nullptr);
+    if (imgs) for (uint32_t g = 0; g < m->G; g++) m->row_img[g] = (u64 *)imgs[g];
+    m->row_img_pitch = pitch;
+    m->row_img_halo = halo_rows;
+    return MI_OK;
+}
+// the calling thread's current device := shard's device (for a caller that drives mi_multi_ctx(m, shard) itself: kernels are launched on
+// the current device).  The caller switches back to its own device (shard 0's, by host/mi_runtime.hpp's convention) afterwards.
+extern "C" int mi_multi_set_device(mi_multi *m, int shard)
+{
+    MI_REQUIRE(m && shard >= 0 && (uint32_t)shard < m->G, "bad shard");
+    MM_DEV(m, shard);
+    return MI_OK;
+}
+// bytes from src (device memory of src_shard's device) to dst (of dst_shard's), behind the work queued on src_shard's context
+extern "C" int mi_multi_copy(mi_multi *m, void *dst, int dst_shard, const void *src, int src_shard, uint64_t bytes)
+{
+    MI_REQUIRE(m && dst && src && dst_shard >= 0 && (uint32_t)dst_shard < m->G && src_shard >= 0 && (uint32_t)src_shard < m->G, "bad argument");
+    MM_DEV(m, src_shard);
+    return copy_dd(m, dst, dst_shard, src, src_shard, bytes, m->cs[src_shard]);
+}
+extern "C" int mi_multi_sync(mi_multi *m, int shard)
+{
+    MI_REQUIRE(m && shard >= 0 && (uint32_t)shard < m->G, "bad shard");
+    MM_DEV(m, shard);
+    MI_HIP_CHECK(hipStreamSynchronize(m->cs[shard]));
+    return MI_OK;
+}
+
 extern "C" void mi_multi_tree_free(mi_multi_tree *t)
 {
     if (!t) return;
@@ -295,6 +339,8 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
     constexpr int NS = 2; // device staging buffers per shard
     t->ext.assign(G, nullptr); t->recv.assign(G, nullptr); t->nodes.assign(G, nullptr); t->stage.assign(G, nullptr);
     t->rows_lent.assign(G, 0);
+    struct RowImgGuard { mi_multi *m; ~RowImgGuard() { m->row_img.clear(); m->row_img_pitch = m->row_img_halo = 0; } } rowimgguard{m}; // one-shot
+    MI_REQUIRE(m->row_img.empty() || (m->row_img_pitch >= ncols && m->row_img_halo <= n_ext / m->G), "row images: pitch smaller than ncols or halo larger than a shard");
     struct LendGuard { mi_multi *m; ~LendGuard() { for (uint32_t g = 0; g < m->G; g++) if (m->lent[g]) { (void)hipSetDevice(m->dev[g]); (void)mi_ctx_lend_workspace(m->ctx[g], nullptr, 0); m->lent[g] = nullptr; m->lent_elems[g] = 0; } } } lendguard{m};
     for (uint32_t g = 0; g < G; g++) {
         MM_DEV(m, g);
@@ -505,6 +551,15 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
                 m->stats[g].bytes_to[q] += cnt * 8;
             }
             if (image) MI_HIP_CHECK(hipMemcpy2DAsync(image + c0, image_pitch * 8, t->ext[g] + p.ext_base(k), w * 8, w * 8, n_ext, hipMemcpyDefault, m->xs[g]));
+            for (uint32_t q = 0; q < G && !m->row_img.empty(); q++) { // shard q's own rows (+ halo) of the tile, row-major, into its full-height section
+                u64 *ri = m->row_img[q];
+                if (!ri) continue;
+                const u64 *tile = t->ext[g] + p.ext_base(k);
+                const uint64_t r0 = (uint64_t)q * p.rows_per_rank, r1 = (r0 + p.rows_per_rank) % n_ext, pt = m->row_img_pitch;
+                MI_HIP_CHECK(hipMemcpy2DAsync(ri + r0 * pt + c0, pt * 8, tile + r0 * w, w * 8, w * 8, p.rows_per_rank, hipMemcpyDefault, m->xs[g]));
+                if (m->row_img_halo) MI_HIP_CHECK(hipMemcpy2DAsync(ri + r1 * pt + c0, pt * 8, tile + r1 * w, w * 8, w * 8, m->row_img_halo, hipMemcpyDefault, m->xs[g]));
+                m->stats[g].bytes_to[q] += q == g ? 0 : (p.rows_per_rank + m->row_img_halo) * w * 8;
+            }
             MI_HIP_CHECK(hipEventRecord(ev_sent[g][k], m->xs[g]));
         }
         if (k > 0) MI_TRY(absorb_round(k - 1));

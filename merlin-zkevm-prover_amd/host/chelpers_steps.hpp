@@ -10,6 +10,8 @@
 // 367-388.
 #ifndef MI_CHELPERS_STEPS_HPP
 #define MI_CHELPERS_STEPS_HPP
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -37,6 +39,20 @@ struct StarkMirror
     // programs of this proving key, by (step, address of the opcode table): translated and compiled on first use, kept by the Starks
     std::map<std::pair<int, const void *>, mi_chelpers_prog *> *progs = nullptr;
     std::string cacheDir;
+    // Row-sharded step42ns / step52ns (several devices, host/starks.hpp): shard g >= 1 evaluates rows [row0, row0 + rows) of the extended
+    // domain on ITS device, over a full-height mirror of the extended sections of which the stage commits left its own rows and the halo
+    // after them (mi_multi_set_row_images), its own extension of the constant polynomials, its own x_2ns and x / (x - xi) tables; the q /
+    // f rows come back into this image.  The rows before rowShards[0].row0 stay with this device.  Empty: everything here.
+    struct RowShard
+    {
+        int shard = 0;                  // index into the mi_multi
+        uint64_t *d_mem = nullptr;      // VIRTUAL base: d_mem + offset is that device's copy of element `offset` (valid in the extended sections only)
+        uint64_t *d_const2ns = nullptr, *d_x2ns = nullptr, *d_xdiv = nullptr, *d_xdivw = nullptr;
+        uint64_t row0 = 0, rows = 0;
+        std::map<std::pair<int, const void *>, mi_chelpers_prog *> *progs = nullptr; // that shard's programs (a program is loaded on one device)
+    };
+    std::vector<RowShard> rowShards;
+    mi_multi *multi = nullptr;
 };
 // one proof in flight per process (prover.cpp:187-260): the image of the running genProof
 inline StarkMirror *&currentMirror()
@@ -79,6 +95,7 @@ inline void buildStepProgram(const StarkMirror *m, int step, mi_chelpers_prog *p
     if (isBaseStep(step) || !backend || std::string(backend) != "interpreter")
         check(mi_chelpers_build_native(prog, m->cacheDir.empty() ? nullptr : m->cacheDir.c_str(), 0), "Steps (compile the program)");
 }
+inline bool isRowShardedStep(const StarkMirror *m, int step) { return !m->rowShards.empty() && (step == MI_CHELPERS_STEP42NS || step == MI_CHELPERS_STEP52NS); }
 // a translated program over rows [0, nrows) of its domain, on the device image
 inline void runStepProgram(StarkMirror *m, int step, const mi_chelpers_prog *prog, StepsParams &params, uint64_t nrows)
 {
@@ -104,7 +121,46 @@ inline void runStepProgram(StarkMirror *m, int step, const mi_chelpers_prog *pro
         p.xdivw = m->d_xdivw;
         p.f = m->d_mem + m->fOffset;
     }
-    check(mi_chelpers_run_dev(ctx(), prog, &p, 0, nrows), "Steps (run the program)");
+    const uint64_t mine = (isRowShardedStep(m, step)) ? std::min<uint64_t>(nrows, m->rowShards[0].row0) : nrows;
+    check(mi_chelpers_run_dev(ctx(), prog, &p, 0, mine), "Steps (run the program)");
+}
+// step42ns / step52ns on the other devices: shard S's rows through ITS program over ITS mirror, then its q / f rows into this device's image
+inline void runRowShard(StarkMirror *m, int step, const StarkMirror::RowShard &S, const mi_chelpers_prog *prog, StepsParams &params, uint64_t nrows)
+{
+    if (S.row0 >= nrows) return;
+    mi_chelpers_params p = {};
+    p.pols = S.d_mem;
+    p.const_pols = S.d_const2ns;
+    p.n_const = m->nConst;
+    p.challenges = (const uint64_t *)params.challenges.address();
+    p.n_challenges = params.challenges.degree();
+    p.publics = (const uint64_t *)params.publicInputs;
+    p.n_publics = m->nPublics;
+    p.x = S.d_x2ns;
+    p.x_stride = 1;
+    uint64_t outOffset = m->qOffset;
+    if (step == MI_CHELPERS_STEP42NS) {
+        p.zhinv = m->zhinv.data();
+        p.n_zhinv = m->zhinv.size();
+        p.q = S.d_mem + m->qOffset;
+    } else {
+        p.evals = (const uint64_t *)params.evals.address();
+        p.n_evals = m->nEvals;
+        p.xdiv = S.d_xdiv;
+        p.xdivw = S.d_xdivw;
+        p.f = S.d_mem + m->fOffset;
+        outOffset = m->fOffset;
+    }
+    const uint64_t rows = std::min(S.rows, nrows - S.row0);
+    check(mi_multi_set_device(m->multi, S.shard), "Steps (row shard: device)");
+    check(mi_chelpers_run_dev(mi_multi_ctx(m->multi, S.shard), prog, &p, S.row0, rows), "Steps (row shard: run the program)");
+    check(mi_multi_copy(m->multi, m->d_mem + outOffset + 3 * S.row0, 0, S.d_mem + outOffset + 3 * S.row0, S.shard, rows * 3 * 8), "Steps (row shard: result rows home)");
+    check(mi_multi_set_device(m->multi, 0), "Steps (row shard: device)");
+    if (const char *log = std::getenv("MI_STARK_ROW_SHARD_LOG")) // tests: which rows left this device
+        if (FILE *f = std::fopen(log, "a")) {
+            std::fprintf(f, "step%dns shard %d device %d rows %llu %llu\n", step, S.shard, mi_ctx_device(mi_multi_ctx(m->multi, S.shard)), (unsigned long long)S.row0, (unsigned long long)(S.row0 + rows));
+            std::fclose(f);
+        }
 }
 
 // One constraint program, given as the reference's tables, over rows [0, nrows) of its domain, on the device image of params.pols.
@@ -119,6 +175,25 @@ inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const 
         check(mi_chelpers_compile(ctx(), &prog, step, ops, nops, args, nargs, secs.data(), secs.size(), m->nConst, base ? m->N : m->NExtended),
               "Steps::step*_parser_first_avx (translate the program)");
         buildStepProgram(m, step, prog);
+    }
+    if (isRowShardedStep(m, step)) {
+        // the other devices first (their launches return at once), this device's rows beside them, then everybody's q rows are home
+        for (const StarkMirror::RowShard &S : m->rowShards) {
+            mi_chelpers_prog *&sp = (*S.progs)[{step, (const void *)ops}];
+            if (!sp) {
+                const std::vector<mi_chelpers_section> secs = stepSections(m, step);
+                check(mi_multi_set_device(m->multi, S.shard), "Steps (row shard: device)");
+                check(mi_chelpers_compile(mi_multi_ctx(m->multi, S.shard), &sp, step, ops, nops, args, nargs, secs.data(), secs.size(), m->nConst, m->NExtended),
+                      "Steps::step*_parser_first_avx (row shard: translate the program)");
+                buildStepProgram(m, step, sp);
+                check(mi_multi_set_device(m->multi, 0), "Steps (row shard: device)");
+            }
+            runRowShard(m, step, S, sp, params, nrows);
+        }
+        runStepProgram(m, step, prog, params, nrows);
+        for (const StarkMirror::RowShard &S : m->rowShards) check(mi_multi_sync(m->multi, S.shard), "Steps (row shard: sync)");
+        check(mi_multi_set_device(m->multi, 0), "Steps (row shard: device)");
+        return;
     }
     runStepProgram(m, step, prog, params, nrows);
 }

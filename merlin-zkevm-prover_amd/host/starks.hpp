@@ -193,6 +193,15 @@ public:
     {
         if (!pConstPols) return; // nothing was set up (config.generateProof() false)
         if (witnessLocked) (void)mi_host_unregister(mi::ctx(), mem + off(cm1_n));
+        if (mi_multi *mm = mi::multi()) {
+            for (size_t g = 1; g < rowMem.size(); g++) {
+                (void)mi_multi_set_device(mm, (int)g);
+                mi_ctx *cg = mi_multi_ctx(mm, (int)g);
+                for (auto &p : rowMem[g].progs) if (p.second) mi_chelpers_free(cg, p.second);
+                for (uint64_t *q : {rowMem[g].ext, rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv}) if (q) mi_dev_free(cg, q);
+            }
+            (void)mi_multi_set_device(mm, 0);
+        }
         for (auto &p : progs) if (p.second) mi_chelpers_free(mi::ctx(), p.second);
         if (d_constN) mi_dev_free(mi::ctx(), d_constN);
         delete pConstPols;
@@ -218,6 +227,14 @@ public:
             if (it->second) mi_chelpers_free(mi::ctx(), it->second);
             progs.erase(it);
         }
+        for (size_t g = 1; g < rowMem.size(); g++) {
+            auto it = rowMem[g].progs.find({step, opsTable});
+            if (it == rowMem[g].progs.end()) continue;
+            (void)mi_multi_set_device(mi::multi(), (int)g);
+            if (it->second) mi_chelpers_free(mi_multi_ctx(mi::multi(), (int)g), it->second);
+            rowMem[g].progs.erase(it);
+            (void)mi_multi_set_device(mi::multi(), 0);
+        }
     }
 
     // device image of the last proof's polynomial area (valid until the next genProof of any Starks): for checks after the fact.
@@ -227,6 +244,18 @@ public:
 
 private:
     bool ownsConstants = false, witnessLocked = false;
+    // Row-sharded step42ns (several devices): what shard g >= 1 keeps on ITS device from proof to proof -- a full-height mirror of the
+    // image's extended part [cm1_2ns, end) of which the stage commits fill its own rows and the halo after them (157 GB of address range
+    // at zkEVM size on a device that holds little else; 20 GB of it ever written), the constant polynomials and room for their extension
+    // and x_2ns --, and its compiled programs.
+    struct RowShardMem
+    {
+        uint64_t *ext = nullptr, *constN = nullptr, *const2ns = nullptr, *x2ns = nullptr, *xdiv = nullptr; // xdiv: xDivXSubXi | xDivXSubWXi
+        std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
+    };
+    std::vector<RowShardMem> rowMem; // by shard; [0] unused (shard 0 is this device and its image)
+    bool rowSharded = false;
+    uint64_t *rowBase(int g) const { return rowMem[g].ext - starkInfo.mapOffsets.section[cm1_2ns]; } // virtual: + an extended section's offset = that device's copy
     void init()
     {
         pConstPols = new ConstantPolsStarks(pConstPolsAddress, constPolsSize, starkInfo.nConstants);
@@ -255,6 +284,39 @@ private:
             if (mi_host_register(mi::ctx(), mem + off(cm1_n), N * cols(cm1_n) * 8) == MI_OK) witnessLocked = true;
             else zklog.warning("Starks: the witness section could not be page-locked (" + std::string(mi_last_error()) + "): stage 1 packs its tiles on the host");
             TimerStopAndLog(STARK_PAGE_LOCK_WITNESS);
+        }
+        // Row-sharded step42ns: on by default when MI_STARK_DEVICES names DISTINCT devices (MI_STARK_ROW_SHARDED=0 / 1 overrides: logical
+        // shards on one device rehearse it at sizes where G mirrors fit beside the image)
+        if (mi_multi *mm = mi::multi()) {
+            const int G = mi_multi_shards(mm);
+            bool distinct = true;
+            for (int a = 0; a < G; a++)
+                for (int b = a + 1; b < G; b++) distinct = distinct && mi_ctx_device(mi_multi_ctx(mm, a)) != mi_ctx_device(mi_multi_ctx(mm, b));
+            const char *rs = std::getenv("MI_STARK_ROW_SHARDED");
+            const uint64_t halo = 1ULL << (starkInfo.starkStruct.nBitsExt - starkInfo.starkStruct.nBits);
+            rowSharded = (rs ? rs[0] == '1' : distinct) && NExtended / (uint64_t)G >= 64 && halo <= NExtended / (uint64_t)G;
+            if (rowSharded) {
+                TimerStart(STARK_ROW_SHARD_SETUP);
+                rowMem.resize(G);
+                const uint64_t extElems = starkInfo.mapTotalN - off(cm1_2ns);
+                for (int g = 1; g < G; g++) {
+                    mi::check(mi_multi_set_device(mm, g), "Starks::Starks (row shards: device)");
+                    mi_ctx *cg = mi_multi_ctx(mm, g);
+                    RowShardMem &R = rowMem[g];
+                    R.ext = (uint64_t *)mi_dev_alloc(cg, extElems * 8);
+                    R.x2ns = (uint64_t *)mi_dev_alloc(cg, NExtended * 8);
+                    R.xdiv = (uint64_t *)mi_dev_alloc(cg, 6 * NExtended * 8);
+                    if (starkInfo.nConstants) {
+                        R.constN = (uint64_t *)mi_dev_alloc(cg, starkInfo.nConstants * N * 8);
+                        R.const2ns = (uint64_t *)mi_dev_alloc(cg, starkInfo.nConstants * NExtended * 8);
+                    }
+                    if (!R.ext || !R.x2ns || !R.xdiv || (starkInfo.nConstants && (!R.constN || !R.const2ns))) mi::fail("Starks::Starks (row shards: device memory)");
+                    if (starkInfo.nConstants)
+                        mi::check(mi_copy_h2d(cg, R.constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (row shards: constant polynomials h2d)");
+                }
+                mi::check(mi_multi_set_device(mm, 0), "Starks::Starks (row shards: device)");
+                TimerStopAndLog(STARK_ROW_SHARD_SETUP);
+            }
         }
     }
     // genProof lends sections that are not live as LDE / NTT / FRI scratch and re-plans the base-domain part from stage 4 on (see the
@@ -416,6 +478,13 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         const uint64_t atLeast = 16 * 2 * (N + NExtended);
         mi::check(mi_ctx_lend_workspace(c, elems >= atLeast ? p : nullptr, elems * 8), "Starks::genProof (lend workspace)");
     };
+    // The computed base-domain sections start every proof as ZEROS.  Every column of them is extended and committed, written or not
+    // (starks.cpp:133,214); a real starkinfo leaves none unwritten, but a map with a column no step stores into (the synthetic shapes
+    // have them) must not commit what the PREVIOUS proof's stage-4 plan left there -- the region is scratch between proofs.  Zeros are
+    // what the reference's calloc'ed pAddress holds in a column nothing writes (prover.cpp:113).  52 GB at zkEVM size: 17 ms of HBM
+    // writes on this stream, beside a stage 1 that is bound by the PCIe link.
+    mi::check(mi_dev_zero(c, sec(cm2_n), (off(cm1_2ns) - off(cm2_n)) * 8), "Starks::genProof (zero the computed base-domain sections)");
+    lend(nullptr, 0); // whatever the previous proof lent last (the tail of ITS stage-4 plan: inside what are live sections again now) is not this proof's
     mi::StarkMirror m;
     m.hostPols = mem; m.d_mem = d_mem; m.N = N; m.NExtended = NExtended; m.nBits = nBits; m.nBitsExt = nBitsExt;
     m.nPublics = starkInfo.nPublics; m.nEvals = nEvals;
@@ -475,9 +544,29 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, uint64_t *scratch, uint64_t scratchElems, Goldilocks::Element *root) {
         mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
         mi::check(mi_multi_lend(mm, 0, scratch, scratchElems * 8), "Starks::genProof (sharded commit: lend)");
+        if (rowSharded) { // every other shard keeps its own rows of this extension (+ the rows its shifted reads reach) on its device, for step42ns
+            std::vector<uint64_t *> imgs(rowMem.size(), nullptr);
+            for (size_t g = 1; g < rowMem.size(); g++) imgs[g] = rowBase((int)g) + (image - d_mem);
+            mi::check(mi_multi_set_row_images(mm, imgs.data(), ncols, 1ULL << extendBits), "Starks::genProof (sharded commit: row images)");
+        }
         mi::check(mi_multi_commit(mm, &mtree[t], src, ncols, srcDevice, N, NExtended, ncols, image, ncols, base, ncols, dev0, (uint64_t *)root),
                   "Starks::genProof (sharded extendPol + merkelize)");
         mi::check(mi_multi_tree_release_rows(mtree[t]), "Starks::genProof (sharded commit: release)"); // the openings read the rows from the image
+        lend(scratch, scratchElems); // ... and the region serves this context's transforms until the next stage, as on the one-device path
+    };
+    // a section whose commit is NOT sharded (at most 4 columns: linear_hash copies such rows) still has to reach the row shards: their rows
+    // (+ halo, wrapping) out of this image, contiguous because whole rows of a section are
+    auto mirrorRows = [&](eSection e) {
+        if (!rowSharded || !cols(e)) return;
+        mi::check(mi_ctx_sync(c), "Starks::genProof (row shards: sync)");
+        const uint64_t R = NExtended / rowMem.size(), halo = 1ULL << extendBits, w = cols(e);
+        for (size_t g = 1; g < rowMem.size(); g++) {
+            const uint64_t r0 = g * R, r1 = (r0 + R) % NExtended;
+            mi::check(mi_multi_copy(mm, rowBase((int)g) + off(e) + r0 * w, (int)g, sec(e) + r0 * w, 0, R * w * 8), "Starks::genProof (row shards: rows of an unsharded section)");
+            mi::check(mi_multi_copy(mm, rowBase((int)g) + off(e) + r1 * w, (int)g, sec(e) + r1 * w, 0, halo * w * 8), "Starks::genProof (row shards: halo of an unsharded section)");
+        }
+        mi::check(mi_multi_sync(mm, 0), "Starks::genProof (row shards: sync)");
+        mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     };
     if (sharded(cols(cm1_n))) {
         commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns), root0.address());
@@ -490,6 +579,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
             mi::check(mi_lde_merkle_host_keep(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
                                               cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
         mi::check(mi_copy_d2h(c, root0.address(), d_nodes[0] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 1)");
+        mirrorRows(cm1_2ns);
     }
     transcript.put(root0.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_1_LDE_AND_MERKLETREE);
@@ -525,6 +615,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
         mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
         mi::check(mi_copy_d2h(c, root1.address(), d_nodes[1] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 2)");
+        mirrorRows(cm2_2ns);
     }
     transcript.put(root1.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_2_LDE_AND_MERKLETREE);
@@ -577,6 +668,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
         mi::check(mi_merkle_build_dev(c, d_nodes[2], sec(cm3_2ns), cols(cm3_n), cols(cm3_n), NExtended), "Starks::genProof (stage 3: merkelize)");
         mi::check(mi_copy_d2h(c, root2.address(), d_nodes[2] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 3)");
+        mirrorRows(cm3_2ns);
     }
     transcript.put(root2.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_3_LDE_AND_MERKLETREE);
@@ -611,6 +703,20 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     uint64_t *rest = scratchElems ? d_late + lateUsed : d_mem + poolUsed;
     const uint64_t restElems = scratchElems ? scratchElems - lateUsed : poolElems - poolUsed;
     lend(rest, restElems);
+    if (rowSharded && parserSteps) { // the other devices extend the constants and build x_2ns for themselves, beside this one (launches return at once)
+        const uint64_t R = NExtended / rowMem.size();
+        for (size_t g = 1; g < rowMem.size(); g++) {
+            mi::check(mi_multi_set_device(mm, (int)g), "Starks::genProof (row shards: device)");
+            mi_ctx *cg = mi_multi_ctx(mm, (int)g);
+            if (nConst) mi::check(mi_lde_dev(cg, rowMem[g].const2ns, nConst, rowMem[g].constN, nConst, NExtended, N, nConst), "Starks::genProof (row shards: constant polynomials, extended)");
+            mi::check(mi_geom_seq_dev(cg, rowMem[g].x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))), "Starks::genProof (row shards: x_2ns)");
+            mi::StarkMirror::RowShard S;
+            S.shard = (int)g; S.d_mem = rowBase((int)g); S.d_const2ns = rowMem[g].const2ns; S.d_x2ns = rowMem[g].x2ns; S.d_xdiv = rowMem[g].xdiv; S.d_xdivw = rowMem[g].xdiv + 3 * NExtended; S.row0 = g * R; S.rows = R; S.progs = &rowMem[g].progs;
+            m.rowShards.push_back(S);
+        }
+        m.multi = mm;
+        mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
+    }
     if (nConst) mi::check(mi_lde_dev(c, m.d_const2ns, nConst, d_constN, nConst, NExtended, N, nConst), "Starks::genProof (constant polynomials, extended)");
     mi::check(mi_geom_seq_dev(c, m.d_x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))),
               "Starks::genProof (x_2ns)"); // starks.hpp:155-160
@@ -633,6 +739,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     mi::check(mi_ntt_dev(c, sec(cm4_2ns), qDim * qDeg, qq2, qDim * qDeg, NExtended, qDim * qDeg, 0), "Starks::genProof (NTT of the q chunks)");
     TimerStopAndLog(STARK_STEP_4_CALCULATE_EXPS_2NS_NTT);
     TimerStart(STARK_STEP_4_MERKLETREE);
+    if (!m.rowShards.empty()) mirrorRows(cm4_2ns); // step52ns reads the quotient chunks at its rows
     mi::check(mi_merkle_build_dev(c, d_nodes[3], sec(cm4_2ns), cols(cm4_2ns), cols(cm4_2ns), NExtended), "Starks::genProof (stage 4: merkelize)");
     mi::check(mi_copy_d2h(c, root3.address(), d_nodes[3] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 4)");
     transcript.put(root3.address(), HASH_SIZE);
@@ -685,6 +792,13 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     else for (uint64_t i = 0; i < nEvals; i++) transcript.put(evals[i], 3);
     transcript.getField(challenges[5]); // v1
     transcript.getField(challenges[6]); // v2
+    for (const mi::StarkMirror::RowShard &S : m.rowShards) { // the other devices build their own tables (full height: addressing as here), beside this one
+        mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (row shards: device)");
+        mi_ctx *cg = mi_multi_ctx(mm, S.shard);
+        mi::check(mi_x_div_x_sub_dev(cg, S.d_xdiv, S.d_x2ns, NExtended, (const uint64_t *)xi), "Starks::genProof (row shards: xDivXSubXi)");
+        mi::check(mi_x_div_x_sub_dev(cg, S.d_xdivw, S.d_x2ns, NExtended, (const uint64_t *)wxi), "Starks::genProof (row shards: xDivXSubWXi)");
+    }
+    if (!m.rowShards.empty()) mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, NExtended, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");    // :350-365
     mi::check(mi_x_div_x_sub_dev(c, m.d_xdivw, m.d_x2ns, NExtended, (const uint64_t *)wxi), "Starks::genProof (xDivXSubWXi)");
     TimerStopAndLog(STARK_STEP_5_XDIVXSUB);

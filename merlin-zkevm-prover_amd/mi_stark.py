@@ -52,12 +52,12 @@ EXPORTS = [
     "mi_merkle_group_proofs_dev",
     "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev", "mi_calculate_z_batch_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
-    "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h",
+    "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_2d", "mi_dev_zero",
     "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
     "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_get_host_pack_threads",
-    "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
+    "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
     "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_compile_micro", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
 ]
@@ -638,6 +638,11 @@ class Multi:
 
     def set_pack_threads(self, threads):
         _check(lib().mi_multi_set_pack_threads(self.h, ctypes.c_int(threads)))
+
+    def set_row_images(self, ptrs, pitch, halo_rows):
+        """the next commit also leaves every shard's own rows (+ halo_rows after them, wrapping) row-major in ptrs[shard] (0 / None: not for that shard)"""
+        arr = (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(p or None) for p in ptrs])
+        _check(lib().mi_multi_set_row_images(self.h, arr, u64(pitch), u64(halo_rows)))
 
     def set_upload_mode(self, mode):
         """-1 auto (page-locked host source -> strided DMA per device link, pageable -> host-packed staging), 0 packed, 1 strided"""

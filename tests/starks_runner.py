@@ -74,10 +74,24 @@ def gen_proof_on_device(si, progs, const_n, const_tree, witness, publics, workdi
         arrays["ops_" + name], arrays["args_" + name] = glo.A(ops), glo.A(ar)
     np.savez(os.path.join(workdir, "parity.inputs.npz"), **arrays)
     cmd = [sys.executable, os.path.abspath(__file__), workdir, ",".join(str(b) for b in batches)] + ([steps_so] if steps_so else [])
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    # a child that stops making progress is reported with the stacks of its threads (MI_TEST_CHILD_TIMEOUT seconds; default 1200), not waited for
+    limit = float((env or os.environ).get("MI_TEST_CHILD_TIMEOUT", "1200"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        so, se = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        bt = ""
+        try:
+            bt = subprocess.run(["/opt/rocm/bin/rocgdb", "-p", str(proc.pid), "-batch", "-ex", "thread apply all bt 14"], capture_output=True, text=True, timeout=120).stdout[-6000:]
+        except Exception as e:  # no debugger here: the timeout itself is the report
+            bt = "(no backtrace: %s)" % e
+        proc.kill()
+        so, se = proc.communicate()
+        raise RuntimeError("Starks::genProof child made no progress for %.0f s; stacks:\n%s\nstderr tail:\n%s" % (limit, bt, se[-1500:]))
+    r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
     if r.returncode != 0:
         raise RuntimeError("Starks::genProof child failed (rc %d):\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-4000:]))
-    return [open(os.path.join(workdir, "zkin.%d.json" % b)).read() for b in batches]
+    return [open(os.path.join(workdir, "zkin.%d.%d.json" % (i, b))).read() for i, b in enumerate(batches)]
 
 
 def _child(workdir, batches, steps_so):
@@ -102,9 +116,9 @@ def _child(workdir, batches, steps_so):
         L.mis_set_tables(h, ctypes.c_int(STEP_ID[name]), vp(ops.ctypes.data), ctypes.c_uint64(ops.size), vp(ar.ctypes.data), ctypes.c_uint64(ar.size))
     if steps_so is not None and L.mis_load_steps(h, steps_so.encode()) != 0:
         raise SystemExit("cannot load the generated Steps library")
-    for b in batches:
+    for i, b in enumerate(batches):
         L.mis_gen_proof(h, vp(publics.ctypes.data), ctypes.c_uint64(b), b"", b"")
-        open(os.path.join(workdir, "zkin.%d.json" % b), "w").write(L.mis_zkin(h).decode())
+        open(os.path.join(workdir, "zkin.%d.%d.json" % (i, b)), "w").write(L.mis_zkin(h).decode())
     L.mis_destroy(h)
 
 

@@ -166,8 +166,30 @@ def test_starks_genproof_with_sharded_commits_equals_the_oracle_prover(name, dev
     shards on device 0): column-tile LDEs, peer exchange, row-sharded leaf hashing and subtrees, openings whose siblings come from the
     shards -- and still the oracle prover's bytes."""
     inputs, want = shaped_case(name)
-    got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,), env=dict(os.environ, MI_STARK_DEVICES=devices))
+    got4, again = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 4), env=dict(os.environ, MI_STARK_DEVICES=devices))
     assert got4 == want, first_difference(got4, want)
+    assert again == want, first_difference(again, want)                 # (the second proof takes its shard buffers from the pool)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,devices", [("zkevm_small", "0,0"), ("zkevm_14", "0,0,0,0"), ("recursive_12", "0,0,0,0"), ("zkevm_full_12", "0,0,0,0,0,0,0,0")])
+def test_starks_genproof_with_row_sharded_step42ns_equals_the_oracle_prover(name, devices, tmp_path):
+    """MI_STARK_ROW_SHARDED (the default when MI_STARK_DEVICES names distinct devices; forced here on logical shards of device 0): every
+    shard but the first evaluates step42ns and step52ns over ITS rows of the extended domain -- from a full-height mirror on its device
+    of which the stage commits wrote only those rows and the halo its shifted reads reach (blow-up 2: two rows; recursive_12: eight, and
+    the last shard's wrap to row 0), its own extension of the constants, its own x_2ns and x / (x - xi) tables, through its own compiled
+    programs -- and sends its q and f rows home.  Still the oracle prover's bytes, twice (the second proof reuses the shards' memory and programs)."""
+    inputs, want = shaped_case(name)
+    log = str(tmp_path / "row_shards.log")
+    got4, again = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 4),
+                                         env=dict(os.environ, MI_STARK_DEVICES=devices, MI_STARK_ROW_SHARDED="1", MI_STARK_ROW_SHARD_LOG=log))
+    assert got4 == want, first_difference(got4, want)
+    assert again == want, first_difference(again, want)
+    G = len(devices.split(","))
+    n_ext = 1 << inputs[0]["starkStruct"]["nBitsExt"]
+    lines = open(log).read().split("\n")[:-1]
+    assert len(lines) == 2 * 2 * (G - 1)                                 # both steps, every shard but this device's, in both proofs
+    assert sorted(set(lines)) == sorted("step%dns shard %d device 0 rows %d %d" % (st, g, g * n_ext // G, (g + 1) * n_ext // G) for g in range(1, G) for st in (42, 52))
 
 
 def test_fast_oracle_prover_is_the_oracle_prover():

@@ -155,6 +155,44 @@ def test_a_page_locked_host_source_is_read_in_place_by_the_shards_dma(log_n, nco
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ncols,G,halo,pitch_extra", [(10, 37, 2, 2, 0), (12, 128, 4, 8, 5), (11, 665, 8, 2, 0), (9, 9, 4, 128, 0)])
+def test_row_images_hold_every_shards_own_rows_and_halo(log_n, ncols, G, halo, pitch_extra):
+    """mi_multi_set_row_images: beside the tree, the commit leaves on every shard that asks for it the shard's own rows of the extension and
+    the `halo` rows after them (the last shard's wrap to row 0) row-major at their place in a full-height section -- what the row-sharded
+    step42ns reads on that device (host/chelpers_steps.hpp) -- and nothing else; one-shot."""
+    n, n_ext, pitch = 1 << log_n, 2 << log_n, ncols + pitch_extra
+    trace = glo.splitmix64(0x5EED0700 + log_n, n * ncols).reshape(n, ncols)
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    want = ctx.to_host(ext).reshape(n_ext, ncols)
+    m = mi_stark.Multi([0] * G)
+    SENT = 0x5A5A5A5A5A5A5A5A
+    imgs = [None] + [ctx.zeros(n_ext * pitch).fill_(SENT) for _ in range(1, G)]   # (shard 0 is the caller's device: it has the whole image)
+    ctx.sync()
+    m.set_row_images([0] + [t_.data_ptr() for t_ in imgs[1:]], pitch, halo)
+    t = m.commit(trace.ctypes.data, n, n_ext, ncols)
+    assert [int(v) for v in t.root] == [int(v) for v in ctx.to_host(nodes)[-4:]]
+    R = n_ext // G
+    for g in range(1, G):
+        got = ctx.to_host(imgs[g]).reshape(n_ext, pitch)
+        rows = np.zeros(n_ext, dtype=bool)
+        rows[g * R:(g + 1) * R] = True
+        rows[[(r % n_ext) for r in range((g + 1) * R, (g + 1) * R + halo)]] = True
+        assert np.array_equal(got[rows][:, :ncols], want[rows]), g
+        assert (got[~rows] == SENT).all() and (got[:, ncols:] == SENT).all(), g
+    t.free()
+    t = m.commit(trace.ctypes.data, n, n_ext, ncols)                      # one-shot: the next commit writes no row images
+    before = [ctx.to_host(x) for x in imgs[1:]]
+    for x in imgs[1:]:
+        x.fill_(0)
+    ctx.sync()
+    t.free()
+    t = m.commit(trace.ctypes.data, n, n_ext, ncols)
+    assert all(not ctx.to_host(x).any() for x in imgs[1:]) and len(before) == G - 1
+    t.free(); m.close(); ctx.close()
+
+
+@pytest.mark.gpu
 def test_sharded_commit_from_a_device_section_equals_the_single_device_tree():
     """Stages 2-4 of a proof: the section is already on a device (the image), at a row pitch wider than itself."""
     log_n, ncols, pitch, G = 12, 128, 200, 4
