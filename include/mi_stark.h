@@ -235,6 +235,11 @@ int mi_q_split_dev(mi_ctx *ctx, uint64_t *qq2, const uint64_t *qq1, uint64_t n, 
 int mi_evmap_dev(mi_ctx *ctx, uint64_t *evals /* device, n_evals*3 */, uint64_t n_evals, uint64_t n,
                  unsigned ext_bits, const uint64_t *const *pol_ptr, const uint32_t *pol_dim,
                  const uint64_t *pol_stride, const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev);
+/* the same sums over rows [row0, row0 + nrows) of the base domain only (lev / lpev still indexed by the absolute row): a row shard's
+ * share -- the shares of a partition of [0, n) add up (in F_p^3) to mi_evmap_dev's evaluations */
+int mi_evmap_range_dev(mi_ctx *ctx, uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const uint64_t *const *pol_ptr,
+                       const uint32_t *pol_dim, const uint64_t *pol_stride, const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev,
+                       uint64_t row0, uint64_t nrows);
 /* element-wise inverse of n cubic-extension elements (Polinomial::batchInverse[Parallel],
  * polinomial.hpp:612-720); res == src allowed; inverse of 0 is 0 */
 int mi_batch_inverse3_dev(mi_ctx *ctx, uint64_t *res, const uint64_t *src, uint64_t n);

@@ -789,7 +789,19 @@ extern "C" int mi_evmap_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, uint64
     if (n_evals == 0) return MI_OK;
     MI_REQUIRE(evals && pol_ptr && pol_dim && pol_stride && prime && lev && lpev, "null buffer");
     return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
-                        prime, (const u64 *)lev, (const u64 *)lpev);
+                        prime, (const u64 *)lev, (const u64 *)lpev, 0, n);
+}
+
+// the partial sums over rows [row0, row0 + nrows) of the base domain (a row shard's share; the shares add up to mi_evmap_dev's result)
+extern "C" int mi_evmap_range_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits,
+                                  const uint64_t *const *pol_ptr, const uint32_t *pol_dim, const uint64_t *pol_stride,
+                                  const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev, uint64_t row0, uint64_t nrows)
+{
+    CTX_OK(c);
+    if (n_evals == 0 || nrows == 0) return MI_OK;
+    MI_REQUIRE(evals && pol_ptr && pol_dim && pol_stride && prime && lev && lpev, "null buffer");
+    return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
+                        prime, (const u64 *)lev, (const u64 *)lpev, row0, nrows);
 }
 
 extern "C" int mi_batch_inverse3_dev(mi_ctx *c, uint64_t *res, const uint64_t *src, uint64_t n)

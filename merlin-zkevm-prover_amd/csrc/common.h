@@ -162,7 +162,7 @@ int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, u
 int launch_fri_transpose(mi_ctx *ctx, u64 *aux, const u64 *pol, uint64_t degree, unsigned tbits);
 int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg);
 int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,
-                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev);
+                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev, uint64_t row0, uint64_t nrows);
 int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n);
 int launch_calculate_h1h2(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uint64_t h2_stride, const u64 *f, uint64_t f_stride, const u64 *t,
                           uint64_t t_stride, unsigned dim, uint64_t n);

@@ -175,14 +175,14 @@ struct EvDesc {
 
 __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial, const EvDesc *__restrict__ desc,
                                                        uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
-                                                       const u64 *__restrict__ lev, const u64 *__restrict__ lpev)
+                                                       const u64 *__restrict__ lev, const u64 *__restrict__ lpev, uint64_t row0)
 {
     // LEv / LpEv of 64 rows at a time through LDS: the same three words for every lane, which as vector loads cost an address-path slot
     // each (12 a four-row step against 4 for the polynomial values: the kernel was bound there, not by HBM or issue)
     constexpr uint32_t CH = 64, LW = CH * 3 + 2; // (+2: the two tables' rows fall into different banks)
     __shared__ u64 sL[2][LW];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint64_t k0 = (uint64_t)blockIdx.y * rows_per_slice;
+    const uint64_t k0 = row0 + (uint64_t)blockIdx.y * rows_per_slice; // rows [row0, n) of the base domain (row0 > 0: a row shard's partial sums)
     uint64_t k1 = k0 + rows_per_slice;
     if (k1 > n) k1 = n;
     const bool active = i < n_evals;
@@ -246,10 +246,12 @@ __global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, c
     o[0] = acc.v[0]; o[1] = acc.v[1]; o[2] = acc.v[2];
 }
 
-int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,
-                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev)
+int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, unsigned ext_bits, const u64 *const *pol_ptr,
+                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev, uint64_t row0, uint64_t nrows)
 {
     if (n_evals == 0) return MI_OK;
+    MI_REQUIRE(row0 + nrows <= n_total && nrows > 0, "rows outside the base domain");
+    const uint64_t n = nrows; // the slices below cover [row0, row0 + nrows)
     MI_REQUIRE(n_evals < (1u << 24), "too many evaluations");
     std::vector<EvDesc> d(n_evals);
     for (uint64_t i = 0; i < n_evals; i++) {
@@ -268,8 +270,8 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned
     MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // d is a stack-lifetime host buffer
     const unsigned gx = (unsigned)((n_evals + 255) / 256);
-    hipLaunchKernelGGL(k_evmap_partial, dim3(gx, n_slices), dim3(256), 0, ctx->stream, partial, ddesc, (uint32_t)n_evals, n,
-                       (uint32_t)ext_bits, rows_per_slice, lev, lpev);
+    hipLaunchKernelGGL(k_evmap_partial, dim3(gx, n_slices), dim3(256), 0, ctx->stream, partial, ddesc, (uint32_t)n_evals, row0 + nrows,
+                       (uint32_t)ext_bits, rows_per_slice, lev, lpev, row0);
     hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, partial, ddesc, (uint32_t)n_evals, n_slices);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;

@@ -198,7 +198,7 @@ public:
                 (void)mi_multi_set_device(mm, (int)g);
                 mi_ctx *cg = mi_multi_ctx(mm, (int)g);
                 for (auto &p : rowMem[g].progs) if (p.second) mi_chelpers_free(cg, p.second);
-                for (uint64_t *q : {rowMem[g].ext, rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv}) if (q) mi_dev_free(cg, q);
+                for (uint64_t *q : {rowMem[g].ext, rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv, rowMem[g].lev}) if (q) mi_dev_free(cg, q);
             }
             (void)mi_multi_set_device(mm, 0);
         }
@@ -250,7 +250,7 @@ private:
     // and x_2ns --, and its compiled programs.
     struct RowShardMem
     {
-        uint64_t *ext = nullptr, *constN = nullptr, *const2ns = nullptr, *x2ns = nullptr, *xdiv = nullptr; // xdiv: xDivXSubXi | xDivXSubWXi
+        uint64_t *ext = nullptr, *constN = nullptr, *const2ns = nullptr, *x2ns = nullptr, *xdiv = nullptr, *lev = nullptr; // xdiv: xDivXSubXi | xDivXSubWXi; lev: LEv | LpEv | partial evals
         std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
     };
     std::vector<RowShardMem> rowMem; // by shard; [0] unused (shard 0 is this device and its image)
@@ -306,11 +306,12 @@ private:
                     R.ext = (uint64_t *)mi_dev_alloc(cg, extElems * 8);
                     R.x2ns = (uint64_t *)mi_dev_alloc(cg, NExtended * 8);
                     R.xdiv = (uint64_t *)mi_dev_alloc(cg, 6 * NExtended * 8);
+                    R.lev = (uint64_t *)mi_dev_alloc(cg, (6 * N + 3 * starkInfo.evMap.size() + 16) * 8);
                     if (starkInfo.nConstants) {
                         R.constN = (uint64_t *)mi_dev_alloc(cg, starkInfo.nConstants * N * 8);
                         R.const2ns = (uint64_t *)mi_dev_alloc(cg, starkInfo.nConstants * NExtended * 8);
                     }
-                    if (!R.ext || !R.x2ns || !R.xdiv || (starkInfo.nConstants && (!R.constN || !R.const2ns))) mi::fail("Starks::Starks (row shards: device memory)");
+                    if (!R.ext || !R.x2ns || !R.xdiv || !R.lev || (starkInfo.nConstants && (!R.constN || !R.const2ns))) mi::fail("Starks::Starks (row shards: device memory)");
                     if (starkInfo.nConstants)
                         mi::check(mi_copy_h2d(cg, R.constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (row shards: constant polynomials h2d)");
                 }
@@ -782,8 +783,49 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
             }
             prime[i] = ev.prime ? 1 : 0;
         }
-        mi::check(mi_evmap_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev), "Starks::genProof (evmap)");
-        mi::check(mi_copy_d2h(c, evals.address(), d_evals, nEvals * 3 * 8), "Starks::genProof (evals d2h)");
+        if (m.rowShards.empty()) {
+            mi::check(mi_evmap_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev), "Starks::genProof (evmap)");
+            mi::check(mi_copy_d2h(c, evals.address(), d_evals, nEvals * 3 * 8), "Starks::genProof (evals d2h)");
+        } else {
+            // row shards: a device's rows of the extension hold every 2^extendBits-th row the sums run over, so each device sums ITS base-domain
+            // rows [g N/G, (g + 1) N/G) -- from its mirror, its constants and its slice of LEv / LpEv (75 MB at zkEVM size, sent across) --
+            // and the G shares of 3 nEvals words are added here, in F_p^3
+            const uint64_t G = rowMem.size(), nk = N / G;
+            mi::check(mi_ctx_sync(c), "Starks::genProof (evmap shards: LEv / LpEv ready)");
+            std::vector<std::vector<Goldilocks::Element>> share(G, std::vector<Goldilocks::Element>(nEvals * 3));
+            for (const mi::StarkMirror::RowShard &S : m.rowShards) {
+                uint64_t *lg = rowMem[S.shard].lev, *lpg = lg + 3 * N;
+                const uint64_t k0 = S.shard * nk;
+                mi::check(mi_multi_copy(mm, lg + 3 * k0, S.shard, lev + 3 * k0, 0, nk * 3 * 8), "Starks::genProof (evmap shards: LEv slice)");
+                mi::check(mi_multi_copy(mm, lpg + 3 * k0, S.shard, lpev + 3 * k0, 0, nk * 3 * 8), "Starks::genProof (evmap shards: LpEv slice)");
+            }
+            mi::check(mi_multi_sync(mm, 0), "Starks::genProof (evmap shards: slices sent)");
+            for (const mi::StarkMirror::RowShard &S : m.rowShards) {
+                std::vector<const uint64_t *> pg(nEvals);
+                for (uint64_t i = 0; i < nEvals; i++) {
+                    const EvMap &ev = starkInfo.evMap[i];
+                    pg[i] = ev.type == EvMap::eType::_const ? S.d_const2ns + ev.id : S.d_mem + (ptr[i] - d_mem);
+                }
+                uint64_t *lg = rowMem[S.shard].lev, *lpg = lg + 3 * N, *eg = lg + 6 * N;
+                mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (evmap shards: device)");
+                mi::check(mi_evmap_range_dev(mi_multi_ctx(mm, S.shard), eg, nEvals, N, (unsigned)extendBits, pg.data(), dim.data(), stride.data(), prime.data(), lg, lpg, S.shard * nk, nk),
+                          "Starks::genProof (evmap shards)");
+            }
+            mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (evmap shards: device)");
+            mi::check(mi_evmap_range_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev, 0, nk), "Starks::genProof (evmap, this device's rows)");
+            mi::check(mi_copy_d2h(c, share[0].data(), d_evals, nEvals * 3 * 8), "Starks::genProof (evals d2h)");
+            for (const mi::StarkMirror::RowShard &S : m.rowShards) {
+                mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (evmap shards: device)");
+                mi::check(mi_copy_d2h(mi_multi_ctx(mm, S.shard), share[S.shard].data(), rowMem[S.shard].lev + 6 * N, nEvals * 3 * 8), "Starks::genProof (evmap shards: share d2h)");
+            }
+            mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (evmap shards: device)");
+            for (uint64_t i = 0; i < nEvals; i++)
+                for (int d = 0; d < 3; d++) {
+                    Goldilocks::Element a = share[0][3 * i + d];
+                    for (uint64_t g = 1; g < G; g++) a = a + share[g][3 * i + d];
+                    evals[i][d] = a;
+                }
+        }
     }
     TimerStopAndLog(STARK_STEP_5_EVMAP);
     TimerStart(STARK_STEP_5_XDIVXSUB);

@@ -50,7 +50,7 @@ EXPORTS = [
     "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_transcript_put", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
     "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
     "mi_merkle_group_proofs_dev",
-    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev", "mi_calculate_z_batch_dev",
+    "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_evmap_range_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev", "mi_calculate_z_batch_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_2d", "mi_dev_zero",
     "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
@@ -290,13 +290,18 @@ class Context:
     def q_split(self, qq2, qq1, n, n_ext, qdeg):
         _check(lib().mi_q_split_dev(self.h, _dp(qq2), _dp(qq1), u64(n), u64(n_ext), ctypes.c_uint(qdeg)))
 
-    def evmap(self, evals, pols, prime, lev, lpev, n, ext_bits):
-        """pols: list of (tensor, offset_elems, dim, stride)"""
+    def evmap(self, evals, pols, prime, lev, lpev, n, ext_bits, row0=None, nrows=None):
+        """pols: list of (tensor, offset_elems, dim, stride); row0 / nrows: only the partial sums over those rows of the base domain"""
         k = len(pols)
         ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() + 8 * off for (t, off, _, _) in pols])
         dims = np.array([d for (_, _, d, _) in pols], dtype=np.uint32)
         strides = np.array([s for (_, _, _, s) in pols], dtype=np.uint64)
         pr = np.ascontiguousarray(prime, dtype=np.uint8)
+        if row0 is not None:
+            _check(lib().mi_evmap_range_dev(self.h, _dp(evals), u64(k), u64(n), ctypes.c_uint(ext_bits), ptrs,
+                                            dims.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _hp(strides),
+                                            pr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dp(lev), _dp(lpev), u64(row0), u64(nrows)))
+            return
         _check(lib().mi_evmap_dev(self.h, _dp(evals), u64(k), u64(n), ctypes.c_uint(ext_bits), ptrs,
                                   dims.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _hp(strides),
                                   pr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _dp(lev), _dp(lpev)))

@@ -178,7 +178,7 @@ def test_starks_genproof_with_row_sharded_step42ns_equals_the_oracle_prover(name
     shard but the first evaluates step42ns and step52ns over ITS rows of the extended domain -- from a full-height mirror on its device
     of which the stage commits wrote only those rows and the halo its shifted reads reach (blow-up 2: two rows; recursive_12: eight, and
     the last shard's wrap to row 0), its own extension of the constants, its own x_2ns and x / (x - xi) tables, through its own compiled
-    programs -- and sends its q and f rows home.  Still the oracle prover's bytes, twice (the second proof reuses the shards' memory and programs)."""
+    programs -- and sends its q and f rows home; the evaluation map is summed per device over its rows and the shares added.  Still the oracle prover's bytes, twice (the second proof reuses the shards' memory and programs)."""
     inputs, want = shaped_case(name)
     log = str(tmp_path / "row_shards.log")
     got4, again = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 4),

@@ -723,7 +723,16 @@ def test_evmap_matches_oracle(ctx):
     prime = [0, 1, 0, 1, 1, 0, 1]
     ev = ctx.empty(len(pols_d) * 3)
     ctx.evmap(ev, pols_d, prime, ctx.to_device(lev), ctx.to_device(lpev), n, ext_bits)
-    assert np.array_equal(ctx.to_host(ev).reshape(-1, 3), glo.evmap(pols_h, prime, lev, lpev, n, ext_bits))
+    want = glo.evmap(pols_h, prime, lev, lpev, n, ext_bits)
+    assert np.array_equal(ctx.to_host(ev).reshape(-1, 3), want)
+    # row shards' shares (mi_evmap_range_dev): the partial sums of a ragged partition of the rows add up, in F_p^3, to the evaluations
+    P = (1 << 64) - (1 << 32) + 1
+    total = np.zeros((len(pols_d), 3), dtype=object)
+    for row0, nrows in ((0, 1), (1, 1023), (1024, 2048), (3072, 1000), (4072, 24)):
+        part = ctx.zeros(len(pols_d) * 3)
+        ctx.evmap(part, pols_d, prime, ctx.to_device(lev), ctx.to_device(lpev), n, ext_bits, row0=row0, nrows=nrows)
+        total = (total + ctx.to_host(part).reshape(-1, 3).astype(object)) % P
+    assert np.array_equal(total.astype(np.uint64), want)
 
 
 def test_genproof_shaped_flow_small():
