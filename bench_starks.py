@@ -17,6 +17,7 @@ low-water mark), the plan, the checks.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -345,7 +346,7 @@ def run(args):
     batch = 1 if args.per_row_steps else 4
     plan = L.mis_hbm_plan_bytes(h)
     L.mis_phase_timer(1)
-    walls, inner = [], []
+    walls, inner, digests = [], [], []
     for it in range(args.proofs):
         L.mis_phase_timer(1)                                 # (resets the low-water mark)
         t0 = time.perf_counter()
@@ -354,6 +355,7 @@ def run(args):
         two = (ctypes.c_double * 2)()
         L.mis_last_wall_ms(h, two)
         inner.append((two[0], two[1]))
+        digests.append(hashlib.sha256(L.mis_zkin(h)).hexdigest())  # (after the clock: the proof's zkin text)
         print("genProof %d: %.1f ms" % (it, walls[-1]), file=sys.stderr, flush=True)
     buf = ctypes.create_string_buffer(1 << 16)
     L.mis_phase_times(buf, ctypes.c_uint64(len(buf)))
@@ -363,6 +365,8 @@ def run(args):
 
     # ------------------------------------------------------------------ checks (oracle), after the clock
     checks = {}
+    if len(digests) > 1:  # same witness, same publics: every proof of the run is the same text (nothing of a proof leaks into the next one)
+        checks["consecutive_proofs_identical"] = "%d/%d" % (sum(d_ == digests[0] for d_ in digests), len(digests))
     U = lambda x: np.array(x, dtype=object).astype(np.uint64)
     steps = fri_steps(nbits_ext, args.fri_steps)
     tr = glo.Transcript()
