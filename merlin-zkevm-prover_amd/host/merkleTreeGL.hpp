@@ -21,6 +21,9 @@ class MerkleTreeGL
     uint64_t *d_source = nullptr, *d_nodes = nullptr; // HBM copies
     bool d_source_borrowed = false, d_nodes_borrowed = false;
     mi_multi_tree *multiTree = nullptr;               // set: the nodes are subtrees on several devices
+    mi_multi *shardMulti = nullptr;                   // with shardSources: the rows of other shards are read on their devices
+    std::vector<const uint64_t *> shardSources;
+    uint64_t rowsPerShard = 0;
     void releaseDevice()
     {
         if (multiTree) mi_multi_tree_free(multiTree);
@@ -86,6 +89,13 @@ public:
         d_source = dev_source;
         d_source_borrowed = true;
         multiTree = tree;
+        shardSources.clear();
+    }
+    // ... and when this device's image holds only ITS rows of the section (row-sharded evaluation, host/starks.hpp): row idx lives on shard
+    // idx / rowsPerShard, at sources[shard] + idx * width in that device's memory (sources[0] unused: shard 0 is this device)
+    void setShardSources(mi_multi *mm, const std::vector<const uint64_t *> &sources, uint64_t rowsPerShard_)
+    {
+        shardMulti = mm; shardSources = sources; rowsPerShard = rowsPerShard_;
     }
     uint64_t *deviceNodes() { return d_nodes; }
     uint64_t *deviceSource() { return d_source; }
@@ -131,6 +141,15 @@ public:
             mi::check(mi_copy_d2h(c, proofs, d_out, nq * stride * 8), "MerkleTreeGL::getGroupProofs (d2h)");
             mi::devFree(d_out);
             for (uint64_t q = 0; q < nq; q++) std::memcpy((uint64_t *)proofs + q * stride + width, &sib[q * stride + width], (stride - width) * 8);
+            bool away = false;
+            for (uint64_t q = 0; q < nq && !shardSources.empty(); q++) { // rows another device holds: their values from there
+                const uint64_t g = idx[q] / rowsPerShard;
+                if (g == 0 || g >= shardSources.size() || !shardSources[g]) continue;
+                mi::check(mi_multi_set_device(shardMulti, (int)g), "MerkleTreeGL::getGroupProofs (row of another device)");
+                mi::check(mi_copy_d2h(mi_multi_ctx(shardMulti, (int)g), (uint64_t *)proofs + q * stride, shardSources[g] + idx[q] * width, width * 8), "MerkleTreeGL::getGroupProofs (row of another device)");
+                away = true;
+            }
+            if (away) mi::check(mi_multi_set_device(shardMulti, 0), "MerkleTreeGL::getGroupProofs (device)");
             return;
         }
         if (d_nodes && d_source) {

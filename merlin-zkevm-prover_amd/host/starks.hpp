@@ -240,6 +240,23 @@ public:
     // device image of the last proof's polynomial area (valid until the next genProof of any Starks): for checks after the fact.
     // lateOffsets: where the stage-4 re-plan put the extended constant polynomials, xDivXSubXi and xDivXSubWXi (elements from the image's start)
     const uint64_t *deviceImage() const { return mi::arena().base; }
+    // n elements of the last proof's image from element `offset` (inside one row): from the device that holds the row when the extension is
+    // row-sharded (checks after the fact)
+    void peekImage(uint64_t offset, uint64_t n, uint64_t *out)
+    {
+        if (ownRowsOnly)
+            for (eSection e : {cm1_2ns, cm2_2ns, cm3_2ns})
+                if (cols(e) && offset >= off(e) && offset < off(e) + cols(e) * NExtended) {
+                    const uint64_t g = (offset - off(e)) / cols(e) / (NExtended / rowMem.size());
+                    if (g == 0) break;
+                    mi_multi *mm = mi::multi();
+                    mi::check(mi_multi_set_device(mm, (int)g), "Starks::peekImage (device)");
+                    mi::check(mi_copy_d2h(mi_multi_ctx(mm, (int)g), out, rowBase((int)g) + offset, n * 8), "Starks::peekImage (row of another device)");
+                    mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
+                    return;
+                }
+        mi::check(mi_copy_d2h(mi::ctx(), out, deviceImage() + offset, n * 8), "Starks::peekImage");
+    }
     uint64_t lateOffsets[3] = {0, 0, 0};
 
 private:
@@ -254,7 +271,7 @@ private:
         std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
     };
     std::vector<RowShardMem> rowMem; // by shard; [0] unused (shard 0 is this device and its image)
-    bool rowSharded = false;
+    bool rowSharded = false, ownRowsOnly = false; // ownRowsOnly (per proof): this device's image holds only ITS rows (+ halo) of cm1..3_2ns
     uint64_t *rowBase(int g) const { return rowMem[g].ext - starkInfo.mapOffsets.section[cm1_2ns]; } // virtual: + an extended section's offset = that device's copy
     void init()
     {
@@ -542,12 +559,18 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStart(STARK_STEP_1_LDE_AND_MERKLETREE);
     mi_multi_tree *mtree[4] = {};
     const int dev0 = mi_ctx_device(c);
+    // Row shards active (several devices, the table steps): NOBODY on this device reads another shard's rows of the extension any more --
+    // step42ns, step52ns and evmap take this device's rows, the openings fetch a row's values from the device that holds it -- so the
+    // commits no longer send the whole extension here (seven links into one device: 137 GB per zkEVM-size proof, the sharded commit's
+    // longest transfer): this device, like the others, receives its own rows and the halo.
+    ownRowsOnly = rowSharded && parserSteps;
     auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, uint64_t *scratch, uint64_t scratchElems, Goldilocks::Element *root) {
         mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
         mi::check(mi_multi_lend(mm, 0, scratch, scratchElems * 8), "Starks::genProof (sharded commit: lend)");
         if (rowSharded) { // every other shard keeps its own rows of this extension (+ the rows its shifted reads reach) on its device, for step42ns
             std::vector<uint64_t *> imgs(rowMem.size(), nullptr);
             for (size_t g = 1; g < rowMem.size(); g++) imgs[g] = rowBase((int)g) + (image - d_mem);
+            if (ownRowsOnly) { imgs[0] = image; image = nullptr; }
             mi::check(mi_multi_set_row_images(mm, imgs.data(), ncols, 1ULL << extendBits), "Starks::genProof (sharded commit: row images)");
         }
         mi::check(mi_multi_commit(mm, &mtree[t], src, ncols, srcDevice, N, NExtended, ncols, image, ncols, base, ncols, dev0, (uint64_t *)root),
@@ -861,7 +884,14 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         for (int t = 0; t < 4; t++) {
             views[t].height = NExtended;
             views[t].width = cols(s2[t]);
-            if (mtree[t]) views[t].setMultiTree(sec(s2[t]), mtree[t]); // (the view owns the sharded tree and frees it)
+            if (mtree[t]) {
+                views[t].setMultiTree(sec(s2[t]), mtree[t]); // (the view owns the sharded tree and frees it)
+                if (ownRowsOnly) {
+                    std::vector<const uint64_t *> srcs(rowMem.size(), nullptr);
+                    for (size_t g = 1; g < rowMem.size(); g++) srcs[g] = rowBase((int)g) + off(s2[t]);
+                    views[t].setShardSources(mm, srcs, NExtended / rowMem.size());
+                }
+            }
             else views[t].setDeviceTree(sec(s2[t]), d_nodes[t]);
         }
         // FRI's polynomials, step trees and opening buffers come out of the same remainder (the fold transforms in registers: no

@@ -132,7 +132,8 @@ const char *mis_proof(void *hv) { return ((Handle *)hv)->proof.c_str(); }
 int mis_peek(void *hv, uint64_t offset, uint64_t n, uint64_t *out)
 {
     Handle *h = (Handle *)hv;
-    return mi_copy_d2h(mi::ctx(), out, h->starks->deviceImage() + offset, n * 8);
+    h->starks->peekImage(offset, n, out);
+    return 0;
 }
 void mis_late_offsets(void *hv, uint64_t out[3])
 {
