@@ -255,6 +255,14 @@ public:
                     mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
                     return;
                 }
+        if (constRowsOnly && offset >= lateOffsets[0] && offset < lateOffsets[0] + starkInfo.nConstants * NExtended &&
+            (offset - lateOffsets[0]) / starkInfo.nConstants >= NExtended / rowMem.size()) { // a row of the extended constants this device did not fetch
+            mi_multi *mm = mi::multi();
+            mi::check(mi_multi_set_device(mm, 1), "Starks::peekImage (device)");
+            mi::check(mi_copy_d2h(mi_multi_ctx(mm, 1), out, rowMem[1].const2ns + (offset - lateOffsets[0]), n * 8), "Starks::peekImage (constants on a peer)");
+            mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
+            return;
+        }
         mi::check(mi_copy_d2h(mi::ctx(), out, deviceImage() + offset, n * 8), "Starks::peekImage");
     }
     uint64_t lateOffsets[3] = {0, 0, 0};
@@ -269,8 +277,10 @@ private:
     {
         uint64_t *ext = nullptr, *constN = nullptr, *const2ns = nullptr, *x2ns = nullptr, *xdiv = nullptr, *lev = nullptr; // xdiv: xDivXSubXi | xDivXSubWXi; lev: LEv | LpEv | partial evals
         std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
+        bool tablesReady = false; // const2ns and x2ns are computed (once per Starks: they belong to the proving key)
     };
     std::vector<RowShardMem> rowMem; // by shard; [0] unused (shard 0 is this device and its image)
+    bool constRowsOnly = false; // (per proof) the extended constants on this device: only its rows (+ halo), fetched from a peer's resident copy
     bool rowSharded = false, ownRowsOnly = false; // ownRowsOnly (per proof): this device's image holds only ITS rows (+ halo) of cm1..3_2ns
     uint64_t *rowBase(int g) const { return rowMem[g].ext - starkInfo.mapOffsets.section[cm1_2ns]; } // virtual: + an extended section's offset = that device's copy
     void init()
@@ -732,8 +742,11 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         for (size_t g = 1; g < rowMem.size(); g++) {
             mi::check(mi_multi_set_device(mm, (int)g), "Starks::genProof (row shards: device)");
             mi_ctx *cg = mi_multi_ctx(mm, (int)g);
-            if (nConst) mi::check(mi_lde_dev(cg, rowMem[g].const2ns, nConst, rowMem[g].constN, nConst, NExtended, N, nConst), "Starks::genProof (row shards: constant polynomials, extended)");
-            mi::check(mi_geom_seq_dev(cg, rowMem[g].x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))), "Starks::genProof (row shards: x_2ns)");
+            if (!rowMem[g].tablesReady) { // constants of the proving key: extended ONCE and kept (a device that holds 20 GB of a proof has the room)
+                if (nConst) mi::check(mi_lde_dev(cg, rowMem[g].const2ns, nConst, rowMem[g].constN, nConst, NExtended, N, nConst), "Starks::genProof (row shards: constant polynomials, extended)");
+                mi::check(mi_geom_seq_dev(cg, rowMem[g].x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))), "Starks::genProof (row shards: x_2ns)");
+                rowMem[g].tablesReady = true;
+            }
             mi::StarkMirror::RowShard S;
             S.shard = (int)g; S.d_mem = rowBase((int)g); S.d_const2ns = rowMem[g].const2ns; S.d_x2ns = rowMem[g].x2ns; S.d_xdiv = rowMem[g].xdiv; S.d_xdivw = rowMem[g].xdiv + 3 * NExtended; S.row0 = g * R; S.rows = R; S.progs = &rowMem[g].progs;
             m.rowShards.push_back(S);
@@ -741,7 +754,20 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         m.multi = mm;
         mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     }
-    if (nConst) mi::check(mi_lde_dev(c, m.d_const2ns, nConst, d_constN, nConst, NExtended, N, nConst), "Starks::genProof (constant polynomials, extended)");
+    constRowsOnly = false;
+    if (nConst && ownRowsOnly && !m.rowShards.empty()) {
+        // this device's image is planned to the last byte and cannot keep the extended constants from proof to proof; the other devices
+        // can and do, and of all it would compute here (68 ms at zkEVM size) this device reads only its own rows and the halo: they come
+        // across from the others' resident copies, a slice from each (seven links at once: 3.6 GB)
+        const uint64_t need = NExtended / rowMem.size() + (1ULL << extendBits), G1 = rowMem.size() - 1, per = (need + G1 - 1) / G1;
+        for (size_t g = 1; g < rowMem.size(); g++) {
+            const uint64_t r0 = (g - 1) * per, r1 = std::min(need, r0 + per);
+            if (r0 < r1) mi::check(mi_multi_copy(mm, m.d_const2ns + r0 * nConst, 0, rowMem[g].const2ns + r0 * nConst, (int)g, (r1 - r0) * nConst * 8), "Starks::genProof (constant polynomials: this device's rows from a peer)");
+        }
+        for (size_t g = 1; g < rowMem.size(); g++) mi::check(mi_multi_sync(mm, (int)g), "Starks::genProof (constant polynomials: rows arrived)");
+        mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
+        constRowsOnly = true;
+    } else if (nConst) mi::check(mi_lde_dev(c, m.d_const2ns, nConst, d_constN, nConst, NExtended, N, nConst), "Starks::genProof (constant polynomials, extended)");
     mi::check(mi_geom_seq_dev(c, m.d_x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))),
               "Starks::genProof (x_2ns)"); // starks.hpp:155-160
     transcript.getField(challenges[4]); // gamma
