@@ -255,6 +255,17 @@ public:
                     mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
                     return;
                 }
+        if (ownRowsOnly && rowMem.size() > 1)
+            for (int t = 1; t <= 2; t++) // xDivXSubXi / xDivXSubWXi: every device filled the rows it evaluates
+                if (offset >= lateOffsets[t] && offset < lateOffsets[t] + 3 * NExtended) {
+                    const uint64_t g = (offset - lateOffsets[t]) / 3 / (NExtended / rowMem.size());
+                    if (g == 0) break;
+                    mi_multi *mm = mi::multi();
+                    mi::check(mi_multi_set_device(mm, (int)g), "Starks::peekImage (device)");
+                    mi::check(mi_copy_d2h(mi_multi_ctx(mm, (int)g), out, rowMem[g].xdiv + (t - 1) * 3 * NExtended + (offset - lateOffsets[t]), n * 8), "Starks::peekImage (x / (x - xi) on a peer)");
+                    mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
+                    return;
+                }
         if (constRowsOnly && offset >= lateOffsets[0] && offset < lateOffsets[0] + starkInfo.nConstants * NExtended &&
             (offset - lateOffsets[0]) / starkInfo.nConstants >= NExtended / rowMem.size()) { // a row of the extended constants this device did not fetch
             mi_multi *mm = mi::multi();
@@ -886,12 +897,14 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     for (const mi::StarkMirror::RowShard &S : m.rowShards) { // the other devices build their own tables (full height: addressing as here), beside this one
         mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (row shards: device)");
         mi_ctx *cg = mi_multi_ctx(mm, S.shard);
-        mi::check(mi_x_div_x_sub_dev(cg, S.d_xdiv, S.d_x2ns, NExtended, (const uint64_t *)xi), "Starks::genProof (row shards: xDivXSubXi)");
-        mi::check(mi_x_div_x_sub_dev(cg, S.d_xdivw, S.d_x2ns, NExtended, (const uint64_t *)wxi), "Starks::genProof (row shards: xDivXSubWXi)");
+        // (element-wise: a device fills the rows it evaluates, at their place in the full-height tables)
+        mi::check(mi_x_div_x_sub_dev(cg, S.d_xdiv + 3 * S.row0, S.d_x2ns + S.row0, S.rows, (const uint64_t *)xi), "Starks::genProof (row shards: xDivXSubXi)");
+        mi::check(mi_x_div_x_sub_dev(cg, S.d_xdivw + 3 * S.row0, S.d_x2ns + S.row0, S.rows, (const uint64_t *)wxi), "Starks::genProof (row shards: xDivXSubWXi)");
     }
     if (!m.rowShards.empty()) mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
-    mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, NExtended, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");    // :350-365
-    mi::check(mi_x_div_x_sub_dev(c, m.d_xdivw, m.d_x2ns, NExtended, (const uint64_t *)wxi), "Starks::genProof (xDivXSubWXi)");
+    const uint64_t xdivRows = m.rowShards.empty() ? NExtended : m.rowShards[0].row0; // row shards: this device's rows only
+    mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, xdivRows, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");    // :350-365
+    mi::check(mi_x_div_x_sub_dev(c, m.d_xdivw, m.d_x2ns, xdivRows, (const uint64_t *)wxi), "Starks::genProof (xDivXSubWXi)");
     TimerStopAndLog(STARK_STEP_5_XDIVXSUB);
     TimerStart(STARK_STEP_5_CALCULATE_EXPS);
     if (nrowsStepBatch == 4) steps->step52ns_parser_first_avx(params, NExtended, nrowsStepBatch);
