@@ -242,8 +242,10 @@ extern "C" int mi_multi_lend(mi_multi *m, int shard, void *ptr, uint64_t bytes)
 extern "C" int mi_multi_set_row_images(mi_multi *m, uint64_t *const *imgs, uint64_t pitch, uint64_t halo_rows)
 {
     MI_REQUIRE(m, "null argument");
+    m->row_img.clear();
+    if (!imgs) { m->row_img_pitch = m->row_img_halo = 0; return MI_OK; } // (takes the request back)
     m->row_img.assign(m->G, nullptr);
-    if (imgs) for (uint32_t g = 0; g < m->G; g++) m->row_img[g] = (u64 *)imgs[g];
+    for (uint32_t g = 0; g < m->G; g++) m->row_img[g] = (u64 *)imgs[g];
     m->row_img_pitch = pitch;
     m->row_img_halo = halo_rows;
     return MI_OK;

@@ -192,6 +192,19 @@ def test_starks_genproof_with_row_sharded_step42ns_equals_the_oracle_prover(name
     assert sorted(set(lines)) == sorted("step%dns shard %d device 0 rows %d %d" % (st, g, g * n_ext // G, (g + 1) * n_ext // G) for g in range(1, G) for st in (42, 52))
 
 
+@pytest.mark.gpu
+def test_row_sharded_and_per_row_proofs_alternate_on_one_starks(tmp_path):
+    """One Starks, several devices configured, proofs of both kinds in turn: the table steps (row shards active: this device's image holds
+    only ITS rows of the extension, the others are opened from the devices that hold them) and recorded per-row steps (everything on this
+    device: the commits send the whole extension here again).  Each proof must not see what the other kind left in the image."""
+    inputs, want = shaped_case("zkevm_small")
+    so = sr.steps_library(inputs[1], str(tmp_path))
+    got = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 1, 4, 1), steps_so=so,
+                                 env=dict(os.environ, MI_STARK_DEVICES="0,0,0,0", MI_STARK_ROW_SHARDED="1"))
+    for i, g in enumerate(got):
+        assert g == want, (i, first_difference(g, want))
+
+
 def test_fast_oracle_prover_is_the_oracle_prover():
     """The larger parity case below lets the oracle prover build its trees and extensions with the vectorised restatement
     (oracle/cpu_baseline_avx2.c); on a shape both finish quickly the two give the same bytes."""
