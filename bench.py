@@ -383,6 +383,7 @@ def main():
     ap.add_argument("--lde-fuse", type=int, default=1, help="0 = separate last-INTT / first-NTT passes (A/B only)")
     ap.add_argument("--leaf-mode", type=int, default=1, help="1 = line-aligned leaf fetch (default), 0 = per-block loads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-process-leg", action="store_true", help="N > 1: skip the extra leg that runs the same step once more from ONE process over the same devices")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the N > 1 code path (tile-by-tile LDE, streaming leaf absorption, subtree) on a one-rank "
                          "communicator, to rehearse it at full size on a single GPU")
@@ -614,6 +615,70 @@ def main():
         except Exception as e:  # a box without enough page-lockable host memory must not lose the headline number
             pcie = {"error": repr(e)}
 
+    # ---- N > 1: the same step ONCE MORE from ONE process over the same N devices (csrc/multi.hip: mi_multi_commit, the form a one-process
+    # Prover links; bench.py --single-process) -- so that a run on a real multi-GPU node measures both forms of the plan.  Never `value`.
+    # The ranks give their buffers back and wait on the CPU (a gloo group: an RCCL barrier would spin on the GPUs the child is using); the
+    # child has a hard time limit; whatever goes wrong here becomes an "error" string and nothing else.
+    single_process = None
+    if dist is not None and (world > 1 or args.force_exchange) and not args.no_single_process_leg:
+        cpu_group = None
+        try:
+            import datetime
+            cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
+        except Exception as e:
+            single_process = {"error": "gloo group: " + repr(e)}
+        if cpu_group is not None:
+            try:
+                trace = root = None
+                bufs.clear()
+                gc.collect()
+                torch.cuda.empty_cache()
+                dist.barrier(group=cpu_group)
+            except Exception as e:
+                single_process = {"error": "before the child: " + repr(e)}
+            if rank == 0 and single_process is None:
+                try:
+                    import subprocess
+                    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", "2", "--warmup", "1", "--pcie-steps", "0",
+                           "--log-n", str(args.log_n), "--cols", str(ncols)]
+                    t_c0 = time.perf_counter()
+                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                    if r.returncode != 0:
+                        single_process = {"error": "child exited %d" % r.returncode, "stderr_tail": r.stderr[-800:]}
+                    else:
+                        j = json.loads(r.stdout.strip().splitlines()[-1])
+                        single_process = {"what": "the same step from ONE process over the same devices (mi_multi_commit; python bench.py --gpus %d --single-process): what a one-process Prover links" % world,
+                                          "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "root_matches": j["root"] == root_host,
+                                          "per_shard": j["per_rank"], "comm": j["comm"], "child_wall_s": time.perf_counter() - t_c0}
+                except Exception as e:
+                    single_process = {"error": repr(e)}
+                # ... and one Starks::genProof at the same size with MI_STARK_DEVICES naming the same devices: sharded commits, row-sharded
+                # step42ns / step52ns / evmap (host/starks.hpp) -- the batch-proof path on N devices, with its oracle checks
+                try:
+                    devs = os.environ.get("MI_BENCH_LEG_DEVICES") or ",".join(str(d_) for d_ in range(world))   # (the override: a one-GPU box rehearsing the plumbing)
+                    if len(devs.split(",")) > 1:
+                        env = dict(os.environ, MI_STARK_DEVICES=devs)
+                        if len(set(devs.split(","))) == 1:
+                            env["MI_STARK_ROW_SHARDED"] = "1"
+                        cmd = [sys.executable, os.path.join(ROOT, "bench_starks.py"), "--log-n", str(args.log_n), "--proofs", "2", "--check-rows", "8"]
+                        t_c0 = time.perf_counter()
+                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+                        if r.returncode != 0:
+                            gp = {"error": "child exited %d" % r.returncode, "stderr_tail": r.stderr[-800:]}
+                        else:
+                            j = json.loads(r.stdout.strip().splitlines()[-1])
+                            gp = {"what": "Starks::genProof (synthetic zkEVM-shaped STARK, 2^%d rows) with MI_STARK_DEVICES=%s: stage commits sharded, step42ns / step52ns / evmap row-sharded" % (args.log_n, devs),
+                                  "ms": j["value"], "genproof_wall_ms": j["genproof_wall_ms"], "phase_ms": j["phase_ms"], "checks": j["checks"], "hbm_device0": j["hbm"],
+                                  "child_wall_s": time.perf_counter() - t_c0}
+                        single_process = dict(single_process or {}, genproof=gp)
+                except Exception as e:
+                    single_process = dict(single_process or {}, genproof={"error": repr(e)})
+            try:
+                dist.barrier(group=cpu_group)
+            except Exception as e:
+                if rank == 0 and single_process is not None:
+                    single_process["after_the_child"] = repr(e)
+
     if rank == 0:
         K = max(args.steps, 1)
         ms_per_step = 1e3 * elapsed / K
@@ -641,7 +706,7 @@ def main():
             "leaf_rows_checked": (verify or {}).get("leaf_rows_checked", 0),
             "verify": verify,
             "root_matches_regression_constant": (root_host == ROOT_2P23_X665) if (args.log_n == 23 and ncols == 665) else None,
-            "comm": comm, "per_rank": per_rank, "sharded_verify": sharded_verify,
+            "comm": comm, "per_rank": per_rank, "sharded_verify": sharded_verify, "single_process": single_process,
             "pcie_inclusive": pcie,
             "value_pcie_inclusive": (pcie or {}).get("value"),
             "roofline": {"kernel": "k_linear_hash_rows_lines" if args.leaf_mode else "k_linear_hash_rows", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
