@@ -624,6 +624,11 @@ def main():
         cpu_group = None
         try:
             import datetime
+            import socket
+            try:
+                socket.gethostbyname(socket.gethostname())
+            except Exception:   # a container whose hostname does not resolve: gloo finds its interface by that name; this is one node, loopback will do
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
         except Exception as e:
             single_process = {"error": "gloo group: " + repr(e)}
