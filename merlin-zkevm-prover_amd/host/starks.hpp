@@ -100,6 +100,35 @@ inline Arena &arena()
     static Arena a;
     return a;
 }
+// The same on the OTHER devices of a row-sharded proof (shard g >= 1): the full-height mirror of the image's extended part.  One per
+// process and device, shared by every Starks of the prover (zkEVM, c12a, recursive1, recursive2 live side by side: prover.cpp:128-132) --
+// a proof fills it anew, one proof is in flight -- and sized for the largest of them; what belongs to a proving key (its constants and
+// their extension) stays with its Starks.
+struct ShardArena
+{
+    uint64_t *base = nullptr;
+    uint64_t elems = 0;
+    uint64_t *reserve(mi_multi *mm, int g, uint64_t want)
+    {
+        if (want <= elems) return base;
+        check(mi_multi_set_device(mm, g), "Starks (row-shard mirror: device)");
+        mi_ctx *c = mi_multi_ctx(mm, g);
+        if (base) mi_dev_free(c, base);
+        base = (uint64_t *)mi_dev_alloc(c, want * 8);
+        if (!base) {
+            std::fprintf(stderr, "mi_stark: the row-shard mirror on shard %d needs %.1f GB of that device's memory\n", g, want * 8 / 1e9);
+            fail("Starks (row-shard mirror)");
+        }
+        elems = want;
+        check(mi_multi_set_device(mm, 0), "Starks (row-shard mirror: device)");
+        return base;
+    }
+};
+inline ShardArena &shardArena(int g)
+{
+    static ShardArena a[64];
+    return a[g];
+}
 } // namespace mi
 
 class Starks
@@ -198,7 +227,7 @@ public:
                 (void)mi_multi_set_device(mm, (int)g);
                 mi_ctx *cg = mi_multi_ctx(mm, (int)g);
                 for (auto &p : rowMem[g].progs) if (p.second) mi_chelpers_free(cg, p.second);
-                for (uint64_t *q : {rowMem[g].ext, rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv, rowMem[g].lev}) if (q) mi_dev_free(cg, q);
+                for (uint64_t *q : {rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv, rowMem[g].lev}) if (q) mi_dev_free(cg, q); // (the mirror is the process's)
             }
             (void)mi_multi_set_device(mm, 0);
         }
@@ -341,7 +370,8 @@ private:
                     mi::check(mi_multi_set_device(mm, g), "Starks::Starks (row shards: device)");
                     mi_ctx *cg = mi_multi_ctx(mm, g);
                     RowShardMem &R = rowMem[g];
-                    R.ext = (uint64_t *)mi_dev_alloc(cg, extElems * 8);
+                    R.ext = mi::shardArena(g).reserve(mm, g, extElems); // (re-read at every proof: a later, larger Starks may move it)
+                    mi::check(mi_multi_set_device(mm, g), "Starks::Starks (row shards: device)");
                     R.x2ns = (uint64_t *)mi_dev_alloc(cg, NExtended * 8);
                     R.xdiv = (uint64_t *)mi_dev_alloc(cg, 6 * NExtended * 8);
                     R.lev = (uint64_t *)mi_dev_alloc(cg, (6 * N + 3 * starkInfo.evMap.size() + 16) * 8);
@@ -585,6 +615,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     // commits no longer send the whole extension here (seven links into one device: 137 GB per zkEVM-size proof, the sharded commit's
     // longest transfer): this device, like the others, receives its own rows and the halo.
     ownRowsOnly = rowSharded && parserSteps;
+    for (size_t g = 1; g < rowMem.size(); g++) rowMem[g].ext = mi::shardArena((int)g).reserve(mm, (int)g, starkInfo.mapTotalN - off(cm1_2ns));
     auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, uint64_t *scratch, uint64_t scratchElems, Goldilocks::Element *root) {
         mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
         mi::check(mi_multi_lend(mm, 0, scratch, scratchElems * 8), "Starks::genProof (sharded commit: lend)");
