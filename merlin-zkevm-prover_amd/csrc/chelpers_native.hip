@@ -571,6 +571,35 @@ struct Gen {
     }
     std::set<uint32_t> shifts, xshifts; // row shifts read from the tile-major copy / from the section kept tile-major (0 included)
     bool uses_zh = false;
+    // Stores into params.pols at the row itself (the base-domain steps): a lane owns a row, so a store is 64 eight-byte writes a pitch
+    // apart -- one 64-byte sector touched per word (measured: 19 of step3's 95 ms, 11 of step3prev's 47).  The words a kernel stores are
+    // mostly ADJACENT columns (a step's outputs are laid out in the order it computes them), so they wait in LDS ([slot][row], 65-word
+    // slot pitch) and the epilogue writes each run of adjacent columns row by row: runs of 8 L bytes instead of L scattered words.
+    struct LdsStore { uint64_t off; uint32_t stride; };
+    std::vector<LdsStore> lds_stores;
+    uint32_t lds_cap = 0, lds_slots = 0; // cap 0: stores go straight to memory; lds_slots: the most slots in use at a time (the array's size)
+    // the staged words out to memory: every run of adjacent columns, row by row (one wave per workgroup: the barriers order its LDS traffic).
+    // Called when the slots are full and at the end of the kernel.
+    void flush_lds(std::string &dst)
+    {
+        if (lds_stores.empty()) return;
+        lds_slots = std::max<uint32_t>(lds_slots, (uint32_t)lds_stores.size());
+        char ln[640];
+        dst += "  __syncthreads();\n";
+        for (size_t s0 = 0; s0 < lds_stores.size();) {
+            size_t s1 = s0 + 1;
+            while (s1 < lds_stores.size() && lds_stores[s1].stride == lds_stores[s0].stride && lds_stores[s1].off == lds_stores[s1 - 1].off + 1) s1++;
+            const unsigned L = (unsigned)(s1 - s0);
+            snprintf(ln, sizeof ln,
+                     "  for (u32 i = lane; i < %uu; i += 64u) { const u32 rr = i / %uu, j = i - rr * %uu; const u64 grow = row_base + tile * 64 + rr; "
+                     "if (grow < row_end) out[%lluULL + j + grow * %uULL] = LS[(%uu + j) * 65u + rr]; }\n",
+                     64u * L, L, L, (unsigned long long)lds_stores[s0].off, lds_stores[s0].stride, (unsigned)s0);
+            dst += ln;
+            s0 = s1;
+        }
+        dst += "  __syncthreads();\n";
+        lds_stores.clear();
+    }
     std::vector<uint8_t> canon; // per temp word: known canonical
     char buf[256];
 
@@ -718,6 +747,15 @@ struct Gen {
             for (const HostSection &S : P->sections)
                 MI_REQUIRE(!(S.tiled && S.role == 0 && d.b.off >= S.offset && d.b.off < S.offset + S.ncols),
                            "the program stores into the section declared tile-major (it is read in place, row-major stores would corrupt it)");
+            if (dk != K_DPOLS && (uint32_t)a.dim <= lds_cap) {
+                if (lds_stores.size() + (size_t)a.dim > lds_cap) flush_lds(body); // the slots are full: out they go, the slots start over
+                for (int j = 0; j < a.dim; j++) {
+                    snprintf(buf, sizeof buf, "  LS[%uu * 65u + lane] = ", (unsigned)lds_stores.size());
+                    body += buf + (a.c[j] ? a.e[j] : "gl::canon(" + a.e[j] + ")") + ";\n";
+                    lds_stores.push_back({d.b.off + (uint64_t)j, d.b.stride});
+                }
+                return MI_OK;
+            }
             body += "  if (row < row_end) { ";
             if (dk == K_DPOLS) {
                 MI_REQUIRE(d.b.mod && (d.b.mod & (d.b.mod - 1)) == 0, "shifted-row destination: the modulus must be a power of two");
@@ -866,6 +904,12 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
         if (const char *e = getenv("MI_CHELPERS_GROUP_COST")) group_cost = (uint64_t)atoll(e);   // experiments
         if (const char *e = getenv("MI_CHELPERS_GROUP_LOADS")) group_loads = (size_t)atoll(e);
         if (const char *e = getenv("MI_CHELPERS_REUSE_WINDOW")) g.reuse_window = (uint32_t)atoi(e);
+        {   // LDS-staged stores: as many slots as leave every wave the kernel is compiled for its share of the CU's 160 KB
+            unsigned w_ = std::max(1u, std::min(4u, 512u / (2 * N->nw + 64)));
+            if (const char *e = getenv("MI_CHELPERS_WAVES")) w_ = std::max(1, std::min(8, atoi(e)));
+            const char *e = getenv("MI_CHELPERS_LDS_STORES");
+            g.lds_cap = (e && e[0] == '0') ? 0u : std::min(32u, (160u * 1024u / (w_ * 4u)) / (65u * 8u));
+        }
         for (size_t i = C.i0; i < C.i1; i++) {
             MI_TRY(g.instr(i));
             acc += cost_of(P->host[i], N->marks[i], P->host);
@@ -890,6 +934,12 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
              "  const u64 *__restrict__ T0 = tiled + tile * %lluULL + lane;\n  u64 *__restrict__ S = spill + tile * %lluULL + lane;\n",
              waves, waves, (unsigned long long)N->sc * 64, (unsigned long long)N->nw * 64);
     src += line;
+    std::string lds_tail;
+    g.flush_lds(lds_tail); // (what is still staged at the end of the kernel; fixes lds_slots)
+    if (g.lds_slots) {
+        snprintf(line, sizeof line, "  __shared__ u64 LS[%uu];\n", g.lds_slots * 65u);
+        src += line;
+    }
     for (uint32_t s : g.shifts) {
         snprintf(line, sizeof line, "  const u64 *__restrict__ T%u = tiled + (tile + ((lane + %uu) >> 6)) * %lluULL + ((lane + %uu) & 63u);\n", s, s,
                  (unsigned long long)N->sc * 64, s);
@@ -935,6 +985,7 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
         snprintf(line, sizeof line, g.canon[w] ? "  S[%llu] = t%u;\n" : "  S[%llu] = gl::canon(t%u);\n", (unsigned long long)w * 64, w);
         src += line;
     }
+    src += lds_tail;
     src += "}\n";
     return MI_OK;
 }
