@@ -638,6 +638,9 @@ def main():
                 bufs.clear()
                 gc.collect()
                 torch.cuda.empty_cache()
+                ctx.close()      # the library's own workspace and staging too (the proof below plans 284 of device 0's 309 GB)
+                ctx = None
+                torch.cuda.synchronize()
                 dist.barrier(group=cpu_group)
             except Exception as e:
                 single_process = {"error": "before the child: " + repr(e)}
