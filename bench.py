@@ -87,6 +87,40 @@ def cpu_model():
     return "unknown"
 
 
+T_PROCESS0 = time.perf_counter()
+
+
+def run_child(cmd, timeout_s, env=None):
+    """A child leg under a HARD wall limit: its own process group, killed as a group at the limit, and never waited for longer than a few
+    seconds after that (a process stuck in the driver does not die on SIGKILL until the GPU lets go of it: the contract line must not wait
+    for it).  -> (returncode or None, stdout, stderr, note)"""
+    import signal
+    import subprocess
+    import tempfile
+    if timeout_s < 5:
+        return None, "", "", "skipped: %.0f s left of the leg budget" % timeout_s
+    fo, fe = tempfile.TemporaryFile(mode="w+"), tempfile.TemporaryFile(mode="w+")   # (files, not pipes: nothing to drain while polling)
+    p = subprocess.Popen(cmd, stdout=fo, stderr=fe, env=env, start_new_session=True)
+    t0 = time.perf_counter()
+    note = ""
+    while p.poll() is None:
+        if time.perf_counter() - t0 > timeout_s:
+            note = "killed at its %.0f s limit" % timeout_s
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            t_k = time.perf_counter()
+            while p.poll() is None and time.perf_counter() - t_k < 10:
+                time.sleep(0.2)
+            if p.poll() is None:
+                note += " and still not gone 10 s later (abandoned)"
+            break
+        time.sleep(0.2)
+    fo.seek(0), fe.seek(0)
+    return p.returncode, fo.read(), fe.read(), note
+
+
 def cpu_baseline(log_n, ncols, trace_host=None):
     """CPU baseline on this node's host cores, on a bounded sample of the same workload (LDE + Merkle tree of a 2^log_n x ncols trace).
     The reference's CPU path (src/goldilocks: AVX2 + OpenMP) is an absent submodule, so what is timed is this repo's restatement of
@@ -184,6 +218,7 @@ def proof_kernel_rooflines(stats_csv, proofs_in_profile, zk):
     bytes per proof from the shape (Merkle 8 h w + 32 (2h - 1), LDE 8 N c + 8 Next c, NTT 16 n c; a constraint program
     reads each declared section once per row).  zk: the shape's sizes."""
     import csv
+    import re
     N, NE = zk["n"], zk["n_ext"]
     w = zk["widths"]                                        # cm1, cm2, cm3, cm4_2ns, tmpExp, constants
     fam = {"leaf_hashing": ("k_linear_hash_rows_lines",), "ntt_passes": ("k_ntt_pass", "k_lde_mid"), "constraint_kernels": ("chelpers_chunk",),
@@ -192,7 +227,10 @@ def proof_kernel_rooflines(stats_csv, proofs_in_profile, zk):
     calls = {k: 0 for k in fam}
     for row in csv.DictReader(open(stats_csv)):
         for k, pats in fam.items():
-            if any(row["Name"].lstrip("void ").startswith(p_) or (p_ + "(") in row["Name"] or (p_ + "<") in row["Name"] for p_ in pats):
+            # the demangled name without its return type and namespaces, up to the template / argument list: matched EXACTLY (a prefix match
+            # would count k_ntt_pass_pers -- the opt-in persistent pass -- in k_ntt_pass's family)
+            base = re.split(r"[<(]", row["Name"].removeprefix("void ").strip(), maxsplit=1)[0].split("::")[-1].strip()
+            if base in pats:
                 ns[k] += float(row["TotalDurationNs"])
                 calls[k] += int(row["Calls"])
     committed = [w["cm1"], w["cm2"], w["cm3"], w["cm4"]]
@@ -226,14 +264,15 @@ def genproof_leg(shape):
     released its HBM, a child runs bench_starks.py -- Starks::genProof of the product class (host/starks.hpp) over the synthetic zkEVM-shaped
     STARK at full size, then (shape 'batch') c12a's and recursive1's shapes, as genBatchProof's three calls (prover.cpp:541,577,611) -- and its
     JSON is merged into this line.  A child: one proof's plan is 273 of the device's 309 GB, and the arena is a process-wide singleton."""
-    import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "bench_starks.py"), "--shape", shape, "--proofs", "2", "--check-rows", "4"]
+    # the whole default command must print its line inside MI_BENCH_WALL_BUDGET_S (default 560 s) of its start: the child gets what is left
+    limit = min(400.0, float(os.environ.get("MI_BENCH_WALL_BUDGET_S", "560")) - (time.perf_counter() - T_PROCESS0) - 5.0)
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    rc, so, se, note = run_child(cmd, limit)
     wall = time.perf_counter() - t0
-    if r.returncode != 0:
-        return {"error": "bench_starks.py exited %d" % r.returncode, "stderr_tail": r.stderr[-1500:]}
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    if rc != 0:
+        return {"error": "bench_starks.py: %s" % (note or "exited %s" % rc), "timeout_s": limit, "stderr_tail": se[-1500:]}
+    j = json.loads(so.strip().splitlines()[-1])
     zk = j["starks"]["zkevm"] if "starks" in j else {"genproof_ms": j["value"], "phase_ms": j["phase_ms"], "hbm": j["hbm"], "checks": j["checks"],
                                                      "genproof_wall_ms": j["genproof_wall_ms"], "setup_s": j["setup_s"], "workload": j["config"]["workload"],
                                                      "field_ops_per_row": j["config"]["field_ops_per_row"], "flow": j["flow"], "peak_hbm_gb": j["hbm"]["peak_hbm_gb"]}
@@ -325,6 +364,7 @@ def single_process_main(args):
                       "rows_ext": n_ext, "parallelism": "single process, %d shards on devices %s: column-tile LDE -> hipMemcpyPeerAsync exchange -> row-shard streaming Merkle" % (G, devices)},
            "root": root, "root_matches_regression_constant": (root == ROOT_2P23_X665) if (args.log_n == 23 and ncols == 665) else None,
            "comm": {"backend": "hipMemcpyPeerAsync / hipMemcpyAsync inside one process (csrc/multi.hip)", "shards": G, "devices": devices, "logical_shards_on_one_device": bool(args.logical_shards)},
+           "peer_access": m.peer_access(),
            "per_rank": [{"rank": s["shard"], "device": s["device"], "lde_ms": s["lde_ms"], "absorb_ms": s["absorb_ms"], "exchange_wait_ms": s["exchange_wait_ms"],
                          "bytes_sent_to_peer": s["bytes_sent_to_shard"]} for s in st["per_shard"]],
            "pcie_inclusive": pcie, "value_pcie_inclusive": (pcie or {}).get("value"), "roofline": None, "cpu_baseline": None}
@@ -511,7 +551,7 @@ def main():
         root = lde_merkle_sharded(plan, Ops, dist, trace, bufs, always_exchange=exchange)
     import gc
     gc.collect()
-    gc.disable()     # no collector pauses inside the timed region (bench_genproof.py met a 35-55 ms one)
+    gc.disable()     # no collector pauses inside the timed region (an earlier script met a 35-55 ms one)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -645,19 +685,26 @@ def main():
             except Exception as e:
                 single_process = {"error": "before the child: " + repr(e)}
             if rank == 0 and single_process is None:
+                # Both legs together get MI_BENCH_LEG_BUDGET_S (default 150 s) of wall time, each child what is left of it, killed as a process
+                # group at its limit and never waited for beyond that (run_child): the contract line below is printed inside the driver's
+                # limit whatever these never-yet-run-on-hardware paths do on first contact.
+                leg_budget = float(os.environ.get("MI_BENCH_LEG_BUDGET_S", "150"))
+                t_legs0 = time.perf_counter()
+                left = lambda: leg_budget - (time.perf_counter() - t_legs0)
+                legs = {"budget_s": leg_budget}
                 try:
-                    import subprocess
                     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", "2", "--warmup", "1", "--pcie-steps", "0",
                            "--log-n", str(args.log_n), "--cols", str(ncols)]
                     t_c0 = time.perf_counter()
-                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
-                    if r.returncode != 0:
-                        single_process = {"error": "child exited %d" % r.returncode, "stderr_tail": r.stderr[-800:]}
+                    legs["commit_timeout_s"] = lim = min(left(), 0.55 * leg_budget)
+                    rc, so, se, note = run_child(cmd, lim)
+                    if rc != 0:
+                        single_process = {"error": "child: %s" % (note or "exited %s" % rc), "stderr_tail": se[-800:]}
                     else:
-                        j = json.loads(r.stdout.strip().splitlines()[-1])
+                        j = json.loads(so.strip().splitlines()[-1])
                         single_process = {"what": "the same step from ONE process over the same devices (mi_multi_commit; python bench.py --gpus %d --single-process): what a one-process Prover links" % world,
                                           "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "root_matches": j["root"] == root_host,
-                                          "per_shard": j["per_rank"], "comm": j["comm"], "child_wall_s": time.perf_counter() - t_c0}
+                                          "per_shard": j["per_rank"], "comm": j["comm"], "peer_access": j.get("peer_access"), "child_wall_s": time.perf_counter() - t_c0}
                 except Exception as e:
                     single_process = {"error": repr(e)}
                 # ... and one Starks::genProof at the same size with MI_STARK_DEVICES naming the same devices: sharded commits, row-sharded
@@ -670,17 +717,20 @@ def main():
                             env["MI_STARK_ROW_SHARDED"] = "1"
                         cmd = [sys.executable, os.path.join(ROOT, "bench_starks.py"), "--log-n", str(args.log_n), "--proofs", "2", "--check-rows", "8"]
                         t_c0 = time.perf_counter()
-                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-                        if r.returncode != 0:
-                            gp = {"error": "child exited %d" % r.returncode, "stderr_tail": r.stderr[-800:]}
+                        legs["genproof_timeout_s"] = lim = left()
+                        rc, so, se, note = run_child(cmd, lim, env=env)
+                        if rc != 0:
+                            gp = {"error": "child: %s" % (note or "exited %s" % rc), "stderr_tail": se[-800:]}
                         else:
-                            j = json.loads(r.stdout.strip().splitlines()[-1])
+                            j = json.loads(so.strip().splitlines()[-1])
                             gp = {"what": "Starks::genProof (synthetic zkEVM-shaped STARK, 2^%d rows) with MI_STARK_DEVICES=%s: stage commits sharded, step42ns / step52ns / evmap row-sharded" % (args.log_n, devs),
                                   "ms": j["value"], "genproof_wall_ms": j["genproof_wall_ms"], "phase_ms": j["phase_ms"], "checks": j["checks"], "hbm_device0": j["hbm"],
-                                  "child_wall_s": time.perf_counter() - t_c0}
+                                  "peer_access": j.get("peer_access"), "child_wall_s": time.perf_counter() - t_c0}
                         single_process = dict(single_process or {}, genproof=gp)
                 except Exception as e:
                     single_process = dict(single_process or {}, genproof={"error": repr(e)})
+                legs["wall_s"] = time.perf_counter() - t_legs0
+                single_process = dict(single_process or {}, legs=legs)
             try:
                 dist.barrier(group=cpu_group)
             except Exception as e:

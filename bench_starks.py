@@ -446,6 +446,16 @@ def run(args):
                    "fits_one_gpu": bool(total_hbm - min_free < total_hbm)},
            "setup_s": {"inputs": t_inputs, "starks_ctor_incl_const_upload": t_create, "per_row_steps_library_build": t_steps_lib},
            "checks": checks, "dtype": "u64", "data": "synthetic"}
+    # several devices (MI_STARK_DEVICES): what the driver answered about direct access between them -- a pair without it stages its
+    # exchange through the host, and a reader of this line should not have to guess that from the times
+    mat = (ctypes.c_int * 256)()
+    warn = ctypes.create_string_buffer(2048)
+    bad = ctypes.c_int(0)
+    G = int(L.mis_peer_access(mat, warn, ctypes.c_uint64(2048), ctypes.byref(bad)))
+    if G:
+        out["peer_access"] = {"devices": os.environ.get("MI_STARK_DEVICES"), "matrix": [[int(mat[a * G + b]) for b in range(G)] for a in range(G)],
+                              "indirect_pairs": int(bad.value), "warning": warn.value.decode(), "legend": "2 same device, 1 peer access enabled, 0 not possible, -1 enabling failed"}
+        out["n_gpus"] = len(set(os.environ.get("MI_STARK_DEVICES", "").split(",")))
     L.mis_destroy(h)
     return out
 

@@ -168,9 +168,14 @@ int mi_host_unregister(mi_ctx *ctx, void *p);
  * subtree roots are hashed on shard 0.  Result: the single-device tree, node for node. */
 typedef struct mi_multi mi_multi;
 typedef struct mi_multi_tree mi_multi_tree;
-int mi_multi_create(mi_multi **out, const int *devices, int n_shards /* a power of two */);
+int mi_multi_create(mi_multi **out, const int *devices, int n_shards /* a power of two, at most 16 */);
 void mi_multi_destroy(mi_multi *m);
 int mi_multi_shards(const mi_multi *m);
+/* What the driver answered when mi_multi_create asked for direct (xGMI) access between the shards' devices: out (G x G ints, may be
+ * NULL) [a * G + b] = 2 same device, 1 peer access enabled, 0 the devices cannot reach each other directly, -1 enabling it failed.
+ * Returns the number of ordered pairs that are neither 1 nor 2 (their exchanges are staged through host memory by the runtime);
+ * warning (optional, warning_cap bytes) receives the sentence mi_multi_create printed about them, "" when every pair is direct. */
+int mi_multi_peer_access(const mi_multi *m, int *out, char *warning, uint64_t warning_cap);
 mi_ctx *mi_multi_ctx(mi_multi *m, int shard);
 int mi_multi_set_pack_threads(mi_multi *m, int threads); /* host threads that pack a tile for its upload (default min(64, hardware threads)) */
 /* How a HOST source reaches the shards: -1 (default) = a page-locked source (mi_host_register, hipHostMalloc) is read in place by each

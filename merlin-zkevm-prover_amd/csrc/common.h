@@ -87,7 +87,7 @@ struct mi_ctx {
     u64 *small = nullptr; // 4 KiB device scratch for host-pointer single hashes
     u64 *pinned = nullptr; // 4 KiB of page-locked host memory: the few words an entry point hands back (a hash, a flag) are copied
                            // through it -- pageable async copies go through the runtime's staging pool, whose housekeeping after a
-                           // few dozen of them stalled a later launch by ~40 ms (seen in bench_genproof.py's FRI phase)
+                           // few dozen of them stalled a later launch by ~40 ms (seen in an earlier benchmark's FRI phase)
     // grow-only device scratch of the entry points that need a few hundred MB per call (plookup tables, evaluation partials): kept
     // for the life of the context -- memory that goes back to the driver, also through the stream-ordered pool, is wiped in the
     // background and slows down whatever runs next ("released and fresh device memory")

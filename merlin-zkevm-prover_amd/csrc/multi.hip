@@ -68,6 +68,12 @@ struct mi_multi {
     int hstage_user[HS] = {-1, -1, -1};      // the shard whose upload last read the slot
     std::vector<Stats> stats;
     double last_wall_ms = 0;
+    // what hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess answered per ordered pair of shards (row a, column b: a's device reaching
+    // b's memory): 2 same device, 1 peer access enabled, 0 the devices cannot reach each other directly, -1 enabling it failed.  A pair
+    // that is not 1 or 2 moves its exchange through host memory (the runtime stages the copies) or, for the kernels that write a peer's
+    // row image, cannot run at all: `warnings` says so in words, mi_multi_create prints it, the commit refuses kernels across such a pair.
+    std::vector<int> peer;
+    std::string warnings;
     // mi_multi_lend: a caller that plans a device's HBM (host/starks.hpp: the proof's image fills the device that also is shard 0) hands the
     // next commit a region that is not live; the shard's row buffers, staging and NTT workspace are carved from it instead of allocated
     std::vector<u64 *> lent;
@@ -114,6 +120,7 @@ static int copy_dd(const mi_multi *m, void *dst, int gd, const void *src, int gs
 extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
 {
     MI_REQUIRE(out && devices && n_shards >= 1 && is_pow2((uint64_t)n_shards), "the number of shards must be a power of two");
+    MI_REQUIRE(n_shards <= MI_MAX_SLABS, "at most 16 shards (one leaf-hash launch absorbs one column window per shard)");
     *out = nullptr;
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have == 0) {
@@ -153,18 +160,39 @@ extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
             m->hstage_sent[i].push_back(e);
         }
     }
-    // every pair of distinct devices talks directly (xGMI): without peer access the runtime would stage the copies through the host
+    // every pair of distinct devices talks directly (xGMI): without peer access the runtime would stage the copies through the host.
+    // What the driver answers is RECORDED (mi_multi_peer_access) and a missing link is said aloud: a node whose devices cannot reach each
+    // other still computes the right root, several times slower, and nobody should have to find that out from a profile.
+    m->peer.assign((size_t)n_shards * n_shards, 2);
     for (int a = 0; a < n_shards; a++)
         for (int b = 0; b < n_shards; b++) {
             if (devices[a] == devices[b]) continue;
+            int &cell = m->peer[(size_t)a * n_shards + b];
             int can = 0;
-            (void)hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
-            if (!can) continue;
+            hipError_t e = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+            if (e != hipSuccess || !can) {
+                (void)hipGetLastError();
+                cell = 0;
+                char w[160];
+                snprintf(w, sizeof w, "device %d cannot access device %d directly (hipDeviceCanAccessPeer: %s); ", devices[a], devices[b], e != hipSuccess ? hipGetErrorString(e) : "no");
+                if (m->warnings.find(w) == std::string::npos) m->warnings += w;
+                continue;
+            }
             (void)hipSetDevice(devices[a]);
-            hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); }
+            e = hipDeviceEnablePeerAccess(devices[b], 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); cell = 1; continue; }
+            (void)hipGetLastError();
+            cell = -1;
+            char w[200];
+            snprintf(w, sizeof w, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s; ", devices[a], devices[b], hipGetErrorString(e));
+            if (m->warnings.find(w) == std::string::npos) m->warnings += w;
         }
     (void)hipGetLastError();
+    if (!m->warnings.empty()) {
+        m->warnings += "exchanges over such a pair are staged through host memory by the runtime";
+        fprintf(stderr, "mi_stark: WARNING (mi_multi_create): %s\n", m->warnings.c_str());
+    }
+    (void)hipSetDevice(devices[0]);
     // host threads that pack tiles: the cores this process may actually use (a container's CPU quota is not in hardware_concurrency()), at most 64
     unsigned hw = std::thread::hardware_concurrency();
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -202,6 +230,20 @@ extern "C" void mi_multi_destroy(mi_multi *m)
 }
 
 extern "C" int mi_multi_shards(const mi_multi *m) { return m ? (int)m->G : 0; }
+// The peer-access matrix recorded by mi_multi_create: out[a * G + b] for shard a's device reaching shard b's memory -- 2 same device,
+// 1 enabled, 0 no direct access, -1 enabling failed.  Returns the number of pairs that are neither 1 nor 2; warning (optional) receives
+// the sentence mi_multi_create printed about them ("" when every pair is direct).
+extern "C" int mi_multi_peer_access(const mi_multi *m, int *out, char *warning, uint64_t warning_cap)
+{
+    if (!m) return -1;
+    int bad = 0;
+    for (size_t i = 0; i < m->peer.size(); i++) {
+        if (out) out[i] = m->peer[i];
+        bad += m->peer[i] != 1 && m->peer[i] != 2;
+    }
+    if (warning && warning_cap) snprintf(warning, warning_cap, "%s", m->warnings.c_str());
+    return bad;
+}
 extern "C" mi_ctx *mi_multi_ctx(mi_multi *m, int shard) { return (m && shard >= 0 && (uint32_t)shard < m->G) ? m->ctx[shard] : nullptr; }
 extern "C" int mi_multi_set_pack_threads(mi_multi *m, int threads)
 {
@@ -326,7 +368,12 @@ static int copy_dd(const mi_multi *m, void *dst, int gd, const void *src, int gs
 extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t *src, uint64_t src_pitch, int src_device, uint64_t n, uint64_t n_ext,
                                uint64_t ncols, uint64_t *image, uint64_t image_pitch, uint64_t *base, uint64_t base_pitch, int image_device, uint64_t root[4])
 {
-    MI_REQUIRE(m && out && src && root, "null argument");
+    MI_REQUIRE(m, "null argument");
+    // mi_multi_lend and mi_multi_set_row_images arm ONE commit: they are disarmed however this call ends, also by a refused argument
+    // (a later commit, possibly of another stage, must not carve its buffers out of a region its caller considers live again)
+    struct RowImgGuard { mi_multi *m; ~RowImgGuard() { m->row_img.clear(); m->row_img_pitch = m->row_img_halo = 0; } } rowimgguard{m};
+    struct LendGuard { mi_multi *m; ~LendGuard() { for (uint32_t g = 0; g < m->G; g++) if (m->lent[g]) { (void)hipSetDevice(m->dev[g]); (void)mi_ctx_lend_workspace(m->ctx[g], nullptr, 0); m->lent[g] = nullptr; m->lent_elems[g] = 0; } } } lendguard{m};
+    MI_REQUIRE(out && src && root, "null argument");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n && ncols > 4, "sizes: powers of two, more than 4 columns (linear_hash copies shorter rows)");
     MI_REQUIRE(n_ext % m->G == 0 && n_ext / m->G >= 2, "too few rows for this many shards");
     const auto t_begin = std::chrono::steady_clock::now();
@@ -341,9 +388,7 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
     constexpr int NS = 2; // device staging buffers per shard
     t->ext.assign(G, nullptr); t->recv.assign(G, nullptr); t->nodes.assign(G, nullptr); t->stage.assign(G, nullptr);
     t->rows_lent.assign(G, 0);
-    struct RowImgGuard { mi_multi *m; ~RowImgGuard() { m->row_img.clear(); m->row_img_pitch = m->row_img_halo = 0; } } rowimgguard{m}; // one-shot
     MI_REQUIRE(m->row_img.empty() || (m->row_img_pitch >= ncols && m->row_img_halo <= n_ext / m->G), "row images: pitch smaller than ncols or halo larger than a shard");
-    struct LendGuard { mi_multi *m; ~LendGuard() { for (uint32_t g = 0; g < m->G; g++) if (m->lent[g]) { (void)hipSetDevice(m->dev[g]); (void)mi_ctx_lend_workspace(m->ctx[g], nullptr, 0); m->lent[g] = nullptr; m->lent_elems[g] = 0; } } } lendguard{m};
     for (uint32_t g = 0; g < G; g++) {
         MM_DEV(m, g);
         auto alloc = [&](u64 **q, uint64_t elems) -> int {

@@ -7,6 +7,7 @@
 #ifndef GOLDILOCKS_BASE_FIELD
 #define GOLDILOCKS_BASE_FIELD
 #include <cassert>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -35,9 +36,11 @@ inline thread_local MiFieldRecorder *mi_field_recorder = nullptr;
 // set while ANY thread has a recorder installed and tested first: in -fPIC objects (libmi_starks.so, a generated Steps library) a
 // thread_local costs a __tls_get_addr call, which an ordinary run -- MI_STEPS_ON_HOST's row loops, any host code on these headers -- must
 // not pay per field operation; a plain global is one load through the GOT.  (Both variables must unify across shared objects: a Steps
-// library is loaded RTLD_GLOBAL after the library that records it, INTEGRATION.md.)
-inline bool mi_field_recording = false;
-#define MI_FIELD_RECORDER() (__builtin_expect(mi_field_recording, 0) ? mi_field_recorder : (MiFieldRecorder *)nullptr)
+// library is loaded RTLD_GLOBAL after the library that records it, INTEGRATION.md.)  A COUNT of installed recorders, not a flag: two
+// threads may trace at once (two Starks built in parallel), and the first to finish must not switch the other's recording off -- the
+// relaxed load is still one plain load.
+inline std::atomic<int> mi_field_recording{0};
+#define MI_FIELD_RECORDER() (__builtin_expect(mi_field_recording.load(std::memory_order_relaxed) != 0, 0) ? mi_field_recorder : (MiFieldRecorder *)nullptr)
 struct MiFieldScope
 {
     MiFieldRecorder *const r;

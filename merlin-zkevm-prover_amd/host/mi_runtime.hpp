@@ -17,13 +17,35 @@ inline mi_ctx *&ctx_slot()
     std::fprintf(stderr, "mi_stark: %s failed: %s\n", where, mi_last_error());
     std::exit(-1); // exitProcess() without the 5 s grace sleep
 }
-// One context per process (one process per GPU); device taken from MI_STARK_DEVICE or the current device.
+// MI_STARK_DEVICES ("0,1,2,3": shard g on that device) parsed strictly: digits and commas only -- atoi would read "a,b" as devices 0,0.
+inline int parseDevices(int *devs, int cap)
+{
+    const char *e = std::getenv("MI_STARK_DEVICES");
+    if (!e || !*e) return 0;
+    int n = 0;
+    for (const char *p = e; *p;) {
+        if (*p < '0' || *p > '9' || n >= cap) {
+            std::fprintf(stderr, "mi_stark: MI_STARK_DEVICES=\"%s\" is not a comma-separated list of at most %d device numbers\n", e, cap);
+            std::exit(-1);
+        }
+        long v = 0;
+        while (*p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); if (v > 1023) v = 1023; p++; }
+        devs[n++] = (int)v;
+        if (*p == ',') { p++; if (!*p) { std::fprintf(stderr, "mi_stark: MI_STARK_DEVICES=\"%s\" ends in a comma\n", e); std::exit(-1); } }
+        else if (*p) { std::fprintf(stderr, "mi_stark: MI_STARK_DEVICES=\"%s\" is not a comma-separated list of device numbers\n", e); std::exit(-1); }
+    }
+    return n;
+}
+// One context per process (one process per GPU); device taken from MI_STARK_DEVICE, else the first entry of MI_STARK_DEVICES (shard 0
+// shares the device of the proof's image: host/starks.hpp lends it regions of that image), else the current device.
 inline mi_ctx *ctx()
 {
     mi_ctx *&c = ctx_slot();
     if (!c) {
         const char *d = std::getenv("MI_STARK_DEVICE");
-        if (mi_ctx_create(&c, d ? std::atoi(d) : -1) != MI_OK) fail("mi_ctx_create");
+        int devs[64];
+        const int n = parseDevices(devs, 64);
+        if (mi_ctx_create(&c, d ? std::atoi(d) : n > 1 ? devs[0] : -1) != MI_OK) fail("mi_ctx_create");
     }
     return c;
 }
@@ -32,22 +54,25 @@ inline void check(int status, const char *where)
     if (status != MI_OK) fail(where);
 }
 // More than one device for the stage commits (csrc/multi.hip): MI_STARK_DEVICES = "0,1,2,3" -- shard g on that device, a power of two of
-// them, the first one the device of ctx() (where the proof's image lives); a device may be named twice (logical shards: how a one-GPU box
-// rehearses the path).  Unset or one entry: nullptr, everything runs on ctx()'s device.
+// them (at most 16), the first one the device of ctx() (where the proof's image lives: checked); a device may be named twice (logical
+// shards: how a one-GPU box rehearses the path).  Unset or one entry: nullptr, everything runs on ctx()'s device.
 inline mi_multi *multi()
 {
     static mi_multi *m = nullptr;
     static bool tried = false;
     if (!tried) {
         tried = true;
-        const char *e = std::getenv("MI_STARK_DEVICES");
-        int devs[64], n = 0;
-        for (const char *p = e; p && *p && n < 64;) {
-            devs[n++] = std::atoi(p);
-            while (*p && *p != ',') p++;
-            if (*p == ',') p++;
+        int devs[64];
+        const int n = parseDevices(devs, 64);
+        if (n > 1) {
+            // shard 0 works in regions of the image (mi_multi_lend) and is "home" for every device switch: it must be the image's device
+            if (devs[0] != mi_ctx_device(ctx())) {
+                std::fprintf(stderr, "mi_stark: MI_STARK_DEVICES starts with device %d but the proof's image lives on device %d (MI_STARK_DEVICE): "
+                                     "the first shard must share the image's device\n", devs[0], mi_ctx_device(ctx()));
+                std::exit(-1);
+            }
+            if (mi_multi_create(&m, devs, n) != MI_OK) fail("mi_multi_create (MI_STARK_DEVICES)");
         }
-        if (n > 1 && mi_multi_create(&m, devs, n) != MI_OK) fail("mi_multi_create (MI_STARK_DEVICES)");
     }
     return m;
 }

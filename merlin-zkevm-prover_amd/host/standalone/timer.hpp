@@ -1,6 +1,6 @@
 // timer.hpp (standalone stand-in) -- TimerStart / TimerStopAndLog with the reference's phase names (timer.hpp:19-30).  Here the
 // phases are timed with HIP events on the library's stream (the work is asynchronous to the host) and collected in a table that
-// bench_genproof.py / tests read: mi::phaseTimes().
+// bench_starks.py / tests read: mi::phaseTimes().
 #ifndef TIMER_HPP
 #define TIMER_HPP
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// starks_capi.cpp -> libmi_starks.so: class Starks (host/starks.hpp) behind a C ABI, for callers that are not C++ (bench_genproof.py,
+// starks_capi.cpp -> libmi_starks.so: class Starks (host/starks.hpp) behind a C ABI, for callers that are not C++ (bench_starks.py,
 // the tests): build a Starks over in-memory or on-disk constants, register the constraint programs' tables, run genProof, read the
 // proof as zkin / proof JSON text, the phase times, the free-HBM low-water mark, and -- for checks after the fact -- any range of
 // the device image of the polynomial area.  Errors follow the host classes: message on stderr, exit(-1) (the reference's convention).
@@ -149,4 +149,14 @@ uint64_t mis_phase_times(char *buf, uint64_t cap)
     return s.size() + 1;
 }
 uint64_t mis_min_free_bytes(void) { return mi::phaseTimer().minFree; }
+// MI_STARK_DEVICES: the shards and what the driver said about direct access between their devices (mi_multi_peer_access); returns the
+// number of shards, 0 when the proof runs on one device
+int mis_peer_access(int *matrix, char *warning, uint64_t warning_cap, int *indirect_pairs)
+{
+    mi_multi *mm = mi::multi();
+    if (!mm) return 0;
+    const int bad = mi_multi_peer_access(mm, matrix, warning, warning_cap);
+    if (indirect_pairs) *indirect_pairs = bad;
+    return mi_multi_shards(mm);
+}
 }

@@ -299,12 +299,11 @@ inline bool traceStep(const TraceLayout &L, Call call, ZhInvAt zhinvAt, std::vec
         };
         window(false);
         MiFieldRecorder *before = mi_field_recorder;
-        const bool recordingBefore = mi_field_recording;
         mi_field_recorder = &rec;
-        mi_field_recording = true;
+        mi_field_recording.fetch_add(1, std::memory_order_relaxed); // (a count: another thread may be tracing too)
         call(rows[t]);
         mi_field_recorder = before;
-        mi_field_recording = recordingBefore;
+        mi_field_recording.fetch_sub(1, std::memory_order_relaxed);
         rec.finish();
         if (rec.error.empty() && rec.ops.empty() && !window(true))
             rec.error = "steps tracer: the function recorded nothing but changed params.pols: its arithmetic does not go through Goldilocks:: / Goldilocks3:: "

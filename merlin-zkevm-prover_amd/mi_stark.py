@@ -57,7 +57,7 @@ EXPORTS = [
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
     "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_get_host_pack_threads",
-    "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
+    "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_peer_access", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
     "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_compile_micro", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
 ]
@@ -640,6 +640,15 @@ class Multi:
         return {"wall_ms": wall.value,
                 "per_shard": [{"shard": g, "device": self.devices[g], "lde_ms": float(r[0]), "absorb_ms": float(r[1]), "exchange_wait_ms": float(r[2]),
                                "host_pack_ms": float(r[3]), "bytes_sent_to_shard": [int(b) for b in r[4:]]} for g, r in enumerate(rows)]}
+
+    def peer_access(self):
+        """what the driver answered about direct access between the shards' devices: matrix[a][b] = 2 same device, 1 enabled, 0 not
+        possible, -1 enabling failed; `indirect_pairs` of them are staged through the host, `warning` says which"""
+        G = len(self.devices)
+        mat = (ctypes.c_int * (G * G))()
+        warn = ctypes.create_string_buffer(2048)
+        bad = int(lib().mi_multi_peer_access(self.h, mat, warn, u64(2048)))
+        return {"matrix": [[int(mat[a * G + b]) for b in range(G)] for a in range(G)], "indirect_pairs": bad, "warning": warn.value.decode()}
 
     def set_pack_threads(self, threads):
         _check(lib().mi_multi_set_pack_threads(self.h, ctypes.c_int(threads)))

@@ -14,7 +14,6 @@
 #include "friProve.hpp"
 #include "build_const_tree.hpp"
 #include "proof2zkinStark.hpp"
-#include "starks_device.hpp"
 #include <fstream>
 #include "../../oracle/gl_oracle.h"
 
@@ -76,231 +75,6 @@ int main()
     transcript.getField(ch);
     glo_transcript_get_field(&otr, och);
     EXPECT(same(ch, och, 3), "Transcript challenge == oracle");
-
-    // ---- the same stages through the device-resident driver (host/starks_device.hpp): host trace streamed in, the
-    // extension, the trees, q_2ns and cm4_2ns stay in HBM; roots, openings and (here, for the check) sections come back
-    {
-        const uint64_t c2 = 9, nConst = 5;
-        StarksDevice sd(nBits, nBitsExt, {nCols, c2, 3});
-        Goldilocks::Element r[HASH_SIZE];
-        sd.commitStage(0, cm1_n.data(), r);
-        EXPECT(same(r, &want_nodes[want_nodes.size() - 4], 4), "StarksDevice::commitStage(0) root == oracle");
-        std::vector<Goldilocks::Element> back(NExtended * nCols);
-        mi::check(mi_copy_d2h(mi::ctx(), back.data(), sd.section(0), back.size() * 8), "d2h");
-        EXPECT(same(back.data(), want_2ns.data(), back.size()), "StarksDevice: resident cm1_2ns == oracle");
-        std::vector<Goldilocks::Element> cm2_n(N * c2), cm3_n(N * 3);
-        for (uint64_t i = 0; i < cm2_n.size(); i++) cm2_n[i] = Goldilocks::fromU64(splitmix(21, i));
-        for (uint64_t i = 0; i < cm3_n.size(); i++) cm3_n[i] = Goldilocks::fromU64(splitmix(22, i));
-        sd.commitStage(1, cm2_n.data(), r);
-        sd.commitStage(2, cm3_n.data(), r);
-        std::vector<uint64_t> w3(NExtended * 3), n3((2 * NExtended - 1) * 4);
-        glo_extend_pol(w3.data(), (const uint64_t *)cm3_n.data(), NExtended, N, 3);
-        glo_merkletree(n3.data(), w3.data(), 3, NExtended);
-        EXPECT(same(r, &n3[n3.size() - 4], 4), "StarksDevice::commitStage(2) (3 columns: copied leaves) root == oracle");
-        {   // openings straight from the resident tree
-            uint64_t idx[3] = {0, 777, NExtended - 1};
-            std::vector<Goldilocks::Element> pr(3 * (nCols + nBitsExt * 4)), wp(nCols + nBitsExt * 4);
-            sd.getGroupProofs(0, pr.data(), idx, 3);
-            bool ok = true;
-            for (int q = 0; q < 3; q++) {
-                glo_merkle_group_proof((uint64_t *)wp.data(), want_nodes.data(), (const uint64_t *)want_2ns.data(), NExtended, nCols, idx[q]);
-                ok = ok && same(&pr[q * wp.size()], wp.data(), wp.size());
-            }
-            EXPECT(ok, "StarksDevice::getGroupProofs == oracle");
-        }
-        // step 4: a small constraint program over the three sections (offsets relative to the polynomial area), then q -> cm4
-        const uint64_t o1 = sd.sectionOffset(0), o2 = sd.sectionOffset(1), o3 = sd.sectionOffset(2);
-        // tmp1[0] = cm1[3] * cm2[1];  tmp1[1] = tmp1[0] + const[2];  tmp3[0] = tmp1[1] + challenge 1;
-        // tmp3[1] = cm3 (as ext element) * tmp3[0];  tmp3[0] = x_2ns * tmp3[1];  tmp1[2] = cm1'[5] (row + 2);  tmp3[0] = tmp1[2] + tmp3[0];  q = zhInv * tmp3[0]
-        const uint64_t ops[] = {50, 3, 14, 75, 68, 80, 12, 69};
-        const uint64_t args[] = {0, o1 + 3, nCols, o2 + 1, c2,   1, 0, 2,   0, 1, 1,   1, o3, 3, 0,   0, 1,   2, o1 + 5, 2, NExtended, nCols,   0, 2, 0,   0};
-        std::vector<Goldilocks::Element> cpols(NExtended * nConst), chal(2 * 3), pub(1);
-        for (uint64_t i = 0; i < cpols.size(); i++) cpols[i] = Goldilocks::fromU64(splitmix(23, i));
-        for (uint64_t i = 0; i < chal.size(); i++) chal[i] = Goldilocks::fromU64(splitmix(24, i));
-        pub[0] = Goldilocks::fromU64(5);
-        sd.setStep42nsProgram(ops, sizeof(ops) / 8, args, sizeof(args) / 8, cpols.data(), nConst);
-        sd.step42ns(chal.data(), 2, pub.data(), 1);
-        // oracle: same program over a host copy of the polynomial area
-        std::vector<uint64_t> area(o3 + NExtended * 3), w2(NExtended * c2), x2ns(NExtended), zh(2), wq_(NExtended * 3), gq(NExtended * 3);
-        glo_extend_pol(w2.data(), (const uint64_t *)cm2_n.data(), NExtended, N, c2);
-        std::memcpy(&area[o1], want_2ns.data(), NExtended * nCols * 8);
-        std::memcpy(&area[o2], w2.data(), w2.size() * 8);
-        std::memcpy(&area[o3], w3.data(), w3.size() * 8);
-        glo_geom_seq(x2ns.data(), NExtended, 49, glo_w((unsigned)nBitsExt));
-        glo_zhinv(zh.data(), (unsigned)nBits, (unsigned)nBitsExt);
-        int st = glo_chelpers_step42ns(ops, sizeof(ops) / 8, args, sizeof(args) / 8, area.data(), (const uint64_t *)cpols.data(), nConst,
-                                       (const uint64_t *)chal.data(), (const uint64_t *)pub.data(), x2ns.data(), 1, zh.data(), 2, wq_.data(), 0, NExtended);
-        mi::check(mi_copy_d2h(mi::ctx(), gq.data(), sd.section(4), gq.size() * 8), "d2h");
-        EXPECT(st == 0 && same(gq.data(), wq_.data(), gq.size()), "StarksDevice::step42ns (constraint program on the GPU) == oracle interpreter");
-        sd.commitQ(r);
-        std::vector<uint64_t> q1(NExtended * 3), q2(NExtended * 6), c4(NExtended * 6), n4((2 * NExtended - 1) * 4);
-        glo_ntt(q1.data(), wq_.data(), NExtended, 3, 1);
-        glo_q_split(q2.data(), q1.data(), N, 2);
-        glo_ntt(c4.data(), q2.data(), NExtended, 6, 0);
-        glo_merkletree(n4.data(), c4.data(), 6, NExtended);
-        EXPECT(same(r, &n4[n4.size() - 4], 4), "StarksDevice::commitQ (INTT, split, NTT, tree) root == oracle");
-        // step 5: a small FRI-polynomial program over cm1..cm4 (zkevm.chelpers.step52ns opcodes), interpreter and compiled kernels
-        //   tmp = cm1[3]*c5; tmp += cm2[1]; tmp = tmp*c5 + cm3[0..2]; tmp1 = tmp*c5; tmp2 = cm1[7] - evals[1]; tmp = tmp2*c6;
-        //   tmp = tmp*c6 + (cm4[0..2] - evals[2]); tmp = tmp*c6 + (const[4] - evals[0]); tmp *= xDivXSubXi; tmp = tmp1 + tmp; f = tmp
-        const uint64_t o4 = sd.sectionOffset(3);
-        const uint64_t ops52[] = {0, 10, 17, 3, 11, 4, 20, 19, 5, 8, 15};
-        const uint64_t args52[] = {o1 + 3, nCols,   o2 + 1, c2,   o3, 3,   o1 + 7, nCols, 1,   o4, 6, 2,   4, 0};
-        std::vector<Goldilocks::Element> chal7(7 * 3), ev(3 * 3), xi(3), wxi(3);
-        for (uint64_t i = 0; i < chal7.size(); i++) chal7[i] = Goldilocks::fromU64(splitmix(25, i));
-        for (uint64_t i = 0; i < ev.size(); i++) ev[i] = Goldilocks::fromU64(splitmix(26, i));
-        for (uint64_t i = 0; i < 3; i++) { xi[i] = Goldilocks::fromU64(splitmix(27, i)); wxi[i] = Goldilocks::fromU64(splitmix(28, i)); }
-        sd.setStep52nsProgram(ops52, sizeof(ops52) / 8, args52, sizeof(args52) / 8);
-        std::vector<uint64_t> area52(o4 + NExtended * 6), xd(NExtended * 3), xdw(NExtended * 3), wf(NExtended * 3), gf(NExtended * 3);
-        std::memcpy(area52.data(), area.data(), area.size() * 8);
-        std::memcpy(&area52[o4], c4.data(), c4.size() * 8);
-        auto x_div_x_sub = [&](std::vector<uint64_t> &out, const Goldilocks::Element *z) { // x / (x - z), starks.cpp:350-365
-            std::vector<uint64_t> den(NExtended * 3);
-            for (uint64_t k = 0; k < NExtended; k++) {
-                den[3 * k] = glo_sub(x2ns[k], Goldilocks::toU64(z[0]));
-                den[3 * k + 1] = glo_sub(0, Goldilocks::toU64(z[1]));
-                den[3 * k + 2] = glo_sub(0, Goldilocks::toU64(z[2]));
-            }
-            glo_batch_inverse3(out.data(), den.data(), NExtended);
-            for (uint64_t k = 0; k < NExtended * 3; k++) out[k] = glo_mul(out[k], x2ns[k / 3]);
-        };
-        x_div_x_sub(xd, xi.data());
-        x_div_x_sub(xdw, wxi.data());
-        st = glo_chelpers_step52ns(ops52, sizeof(ops52) / 8, args52, sizeof(args52) / 8, area52.data(), (const uint64_t *)cpols.data(), nConst,
-                                   (const uint64_t *)chal7.data(), (const uint64_t *)ev.data(), xd.data(), xdw.data(), wf.data(), 0, NExtended);
-        uint64_t *d_f = sd.step52ns(chal7.data(), 7, ev.data(), 3, xi.data(), wxi.data());
-        mi::check(mi_copy_d2h(mi::ctx(), gf.data(), d_f, gf.size() * 8), "d2h");
-        EXPECT(st == 0 && same(gf.data(), wf.data(), gf.size()), "StarksDevice::step52ns (FRI-polynomial program, interpreter) == oracle interpreter");
-        // the same two programs compiled to gfx950 kernels (hiprtc): same q, same f
-        sd.buildNative(nullptr);
-        sd.step42ns(chal.data(), 2, pub.data(), 1);
-        mi::check(mi_copy_d2h(mi::ctx(), gq.data(), sd.section(4), gq.size() * 8), "d2h");
-        EXPECT(same(gq.data(), wq_.data(), gq.size()), "StarksDevice::step42ns after buildNative (compiled kernels) == oracle interpreter");
-        d_f = sd.step52ns(chal7.data(), 7, ev.data(), 3, xi.data(), wxi.data());
-        std::fill(gf.begin(), gf.end(), 0);
-        mi::check(mi_copy_d2h(mi::ctx(), gf.data(), d_f, gf.size() * 8), "d2h");
-        EXPECT(same(gf.data(), wf.data(), gf.size()), "StarksDevice::step52ns after buildNative (compiled kernels) == oracle interpreter");
-        // step 5, evaluations (starks.cpp:300-332) from the resident sections
-        {
-            std::vector<StarksDevice::EvMapEntry> evMap = {{false, 0, 3, 1, false}, {false, 1, 1, 1, true}, {false, 2, 0, 3, false}, {false, 3, 3, 3, true},
-                                                           {true, 0, 2, 1, false}, {false, 0, 36, 1, true}, {true, 0, 4, 1, true}};
-            std::vector<Goldilocks::Element> ev(evMap.size() * 3);
-            sd.calculateEvals(evMap, xi.data(), ev.data());
-            uint64_t xis_[3], wxis_[3];
-            const uint64_t sinv = glo_inv(49), wN = glo_w((unsigned)nBits);
-            for (int d = 0; d < 3; d++) { xis_[d] = glo_mul(Goldilocks::toU64(xi[d]), sinv); wxis_[d] = glo_mul(glo_mul(Goldilocks::toU64(xi[d]), wN), sinv); }
-            std::vector<uint64_t> l0(N * 3), l1(N * 3), lev(N * 3), lpev(N * 3), wev(evMap.size() * 3);
-            glo_geom_seq3(l0.data(), N, xis_); glo_geom_seq3(l1.data(), N, wxis_);
-            glo_ntt(lev.data(), l0.data(), N, 3, 1); glo_ntt(lpev.data(), l1.data(), N, 3, 1);
-            const uint64_t soff[4] = {o1, o2, o3, o4}, sw[4] = {nCols, c2, 3, 6};
-            std::vector<const uint64_t *> pp; std::vector<uint32_t> pd; std::vector<uint64_t> ps; std::vector<uint8_t> pr;
-            for (auto &e : evMap) {
-                pp.push_back(e.isConst ? (const uint64_t *)cpols.data() + e.column : &area52[soff[e.section] + e.column]);
-                pd.push_back((uint32_t)e.dim); ps.push_back(e.isConst ? nConst : sw[e.section]); pr.push_back(e.prime);
-            }
-            glo_evmap(wev.data(), evMap.size(), N, 1, pp.data(), pd.data(), ps.data(), pr.data(), lev.data(), lpev.data());
-            EXPECT(same(ev.data(), wev.data(), wev.size()), "StarksDevice::calculateEvals (LEv, LpEv, evmap over resident sections) == oracle");
-        }
-        // FRI over the resident f_2ns with the resident trees lent as MerkleTreeGL views == FRIProve::prove over host copies
-        {
-            StarkInfo si;
-            si.starkStruct.nBits = nBits; si.starkStruct.nBitsExt = nBitsExt; si.starkStruct.nQueries = 7;
-            for (uint64_t bts : {13, 8, 4}) si.starkStruct.steps.push_back(StepStruct{bts});
-            Transcript tr;
-            tr.put(r, HASH_SIZE);
-            MerkleTreeGL constTree(NExtended, nConst, cpols.data());
-            constTree.merkelize();
-            FRIProof pa(1ULL << 4, FIELD_EXTENSION, si.starkStruct.steps.size(), 5, 3), pb(1ULL << 4, FIELD_EXTENSION, si.starkStruct.steps.size(), 5, 3);
-            sd.friProve(pa, tr, si, &constTree);
-            // host-side twin: trees from host copies of the same sections (area52), the FRI polynomial from the host copy gf
-            std::vector<std::vector<Goldilocks::Element>> hs(4);
-            MerkleTreeGL *tw[5] = {nullptr, nullptr, nullptr, nullptr, &constTree};
-            const uint64_t soff[4] = {o1, o2, o3, o4}, sw[4] = {nCols, c2, 3, 6};
-            for (int t = 0; t < 4; t++) {
-                hs[t].resize(NExtended * sw[t]);
-                std::memcpy(hs[t].data(), &area52[soff[t]], hs[t].size() * 8);
-                tw[t] = new MerkleTreeGL(NExtended, sw[t], hs[t].data());
-                tw[t]->merkelize();
-            }
-            std::vector<Goldilocks::Element> fh(gf.size());
-            std::memcpy(fh.data(), gf.data(), gf.size() * 8);
-            Polinomial friPolH(fh.data(), NExtended, 3, 3, "friPol");
-            FRIProve::prove(pb, tw, tr, friPolH, nBitsExt, si);
-            const std::string ja = pa.proofs.proof2json(), jb = pb.proofs.proof2json();
-            EXPECT(ja == jb && ja.size() > 1000, "StarksDevice::friProve (resident f_2ns, resident trees) == FRIProve::prove over host copies");
-            for (int t = 0; t < 4; t++) delete tw[t];
-        }
-    }
-
-    // ---- stages 2 and 3 with the base domain resident (starks.cpp:66-221): witness up once; step2prev-numbered program -> compressed
-    // lookup columns in tmpExp_n; plookup h1 / h2 into cm2_n; commit; step3prev program -> num / den; grand product z into cm3_n;
-    // step3 program; commit.  The oracle does the same on a host copy of the area.
-    {
-        const uint64_t c1 = 4, c2 = 8, c3 = 3, cT = 15, nConstN = 2;
-        StarksDevice sd(nBits, nBitsExt, {c1, c2, c3});
-        std::vector<Goldilocks::Element> constN(N * nConstN), w1(N * c1), chal(4 * 3), pub(1);
-        for (uint64_t i = 0; i < constN.size(); i++) constN[i] = Goldilocks::fromU64(splitmix(31, i));
-        for (uint64_t i = 0; i < chal.size(); i++) chal[i] = Goldilocks::fromU64(splitmix(32, i));
-        pub[0] = Goldilocks::fromU64(9);
-        for (uint64_t i = 0; i < N; i++) { // column 0: a table with repeated rows; 1: a permutation of it; 2: lookups with repetition; 3: noise
-            w1[i * c1] = Goldilocks::fromU64(splitmix(33, i >> 2));
-            w1[i * c1 + 3] = Goldilocks::fromU64(splitmix(34, i));
-        }
-        for (uint64_t i = 0; i < N; i++) {
-            w1[i * c1 + 1] = w1[((i * 5 + 3) & (N - 1)) * c1];
-            w1[i * c1 + 2] = w1[((i * i + 7) & (N - 1)) * c1];
-        }
-        sd.enableBaseDomain(cT, constN.data(), nConstN);
-        sd.loadStage(0, w1.data());
-        const uint64_t o1 = sd.baseOffset(0), o2 = sd.baseOffset(1), o3 = sd.baseOffset(2), oT = sd.baseOffset(3);
-        // step2prev: f' = cm1[1] * u + defVal -> tmpExp[0..2];  t' = cm1[0] * u + defVal -> tmpExp[3..5]      (challenges 0, 1)
-        const uint64_t ops2[] = {62, 90, 62, 90};
-        const uint64_t args2[] = {0, o1 + 1, c1, 0,   oT + 0, cT, 0, 1,   1, o1 + 0, c1, 0,   oT + 3, cT, 1, 1};
-        // step3prev: num = (f' + gamma) + beta -> tmpExp[6..8];  den = (t' + gamma) + beta -> tmpExp[9..11]   (challenges 2, 3)
-        const uint64_t ops3p[] = {20, 90, 20, 90};
-        const uint64_t args3p[] = {0, oT + 0, cT, 2,   oT + 6, cT, 0, 3,   1, oT + 3, cT, 2,   oT + 9, cT, 1, 3};
-        // step3: (z * z) * (z * z) -> tmpExp[12..14]
-        const uint64_t ops3[] = {72, 98};
-        const uint64_t args3[] = {0, o3, c3, o3, c3,   oT + 12, cT, 0, 0};
-        sd.setBaseProgram(MI_CHELPERS_STEP2PREV, ops2, sizeof(ops2) / 8, args2, sizeof(args2) / 8);
-        sd.setBaseProgram(MI_CHELPERS_STEP3PREV, ops3p, sizeof(ops3p) / 8, args3p, sizeof(args3p) / 8);
-        sd.setBaseProgram(MI_CHELPERS_STEP3, ops3, sizeof(ops3) / 8, args3, sizeof(args3) / 8);
-        Goldilocks::Element r1[HASH_SIZE], r2[HASH_SIZE], r3[HASH_SIZE];
-        sd.commitStageResident(0, r1);
-        sd.stepBase(MI_CHELPERS_STEP2PREV, chal.data(), 4, pub.data(), 1);
-        sd.calculateH1H2(o2 + 0, c2, o2 + 3, c2, oT + 0, cT, oT + 3, cT, 3);          // the compressed lookup, dim 3
-        sd.calculateH1H2(o2 + 6, c2, o2 + 7, c2, o1 + 2, c1, o1 + 0, c1, 1);          // a lookup straight on witness columns, dim 1
-        sd.commitStageResident(1, r2);
-        sd.stepBase(MI_CHELPERS_STEP3PREV, chal.data(), 4, pub.data(), 1);
-        const bool closes = sd.calculateZ(o3, c3, oT + 6, cT, oT + 9, cT);
-        sd.stepBase(MI_CHELPERS_STEP3, chal.data(), 4, pub.data(), 1);
-        sd.commitStageResident(2, r3);
-        // oracle
-        std::vector<uint64_t> area(oT + N * cT, 0), xn(N), rows(N);
-        std::memcpy(&area[o1], w1.data(), w1.size() * 8);
-        glo_geom_seq(xn.data(), N, 1, glo_w((unsigned)nBits));
-        for (uint64_t i = 0; i < N; i++) rows[i] = i;
-        auto run = [&](const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs) {
-            return glo_chelpers_stepbase(ops, nops, args, nargs, area.data(), (const uint64_t *)constN.data(), nConstN, (const uint64_t *)chal.data(),
-                                         (const uint64_t *)pub.data(), xn.data(), 1, rows.data(), N);
-        };
-        int st = run(ops2, sizeof(ops2) / 8, args2, sizeof(args2) / 8);
-        int64_t bad = glo_calculate_h1h2(&area[o2], c2, &area[o2 + 3], c2, &area[oT], cT, &area[oT + 3], cT, 3, N);
-        bad |= glo_calculate_h1h2(&area[o2 + 6], c2, &area[o2 + 7], c2, &area[o1 + 2], c1, &area[o1], c1, 1, N);
-        st |= run(ops3p, sizeof(ops3p) / 8, args3p, sizeof(args3p) / 8);
-        const int wcloses = glo_calculate_z(&area[o3], c3, &area[oT + 6], cT, &area[oT + 9], cT, N);
-        st |= run(ops3, sizeof(ops3) / 8, args3, sizeof(args3) / 8);
-        std::vector<uint64_t> got(area.size()); // every column of the four sections is written by the flow
-        mi::check(mi_copy_d2h(mi::ctx(), got.data(), sd.baseSection(0), got.size() * 8), "d2h");
-        EXPECT(st == 0 && bad == 0 && same(got.data(), area.data(), area.size()), "StarksDevice: step2prev -> calculateH1H2 (dim 3, dim 1) -> step3prev -> calculateZ -> step3 on the device == oracle");
-        EXPECT(closes == (wcloses != 0) && closes, "StarksDevice::calculateZ closes (the lookup columns are permutations of each other)");
-        // the stage-2 / stage-3 roots: the device extended what it computed itself
-        std::vector<uint64_t> e2(NExtended * c2), t2((2 * NExtended - 1) * 4), e3(NExtended * c3), t3((2 * NExtended - 1) * 4);
-        glo_extend_pol(e2.data(), &area[o2], NExtended, N, c2);
-        glo_merkletree(t2.data(), e2.data(), c2, NExtended);
-        glo_extend_pol(e3.data(), &area[o3], NExtended, N, c3);
-        glo_merkletree(t3.data(), e3.data(), c3, NExtended);
-        EXPECT(same(r2, &t2[t2.size() - 4], 4) && same(r3, &t3[t3.size() - 4], 4), "StarksDevice::commitStageResident(1), (2) roots == oracle");
-    }
 
     // ---- the same two operations through the Polinomial shim, the way starks.cpp:106-126,179-185 calls them (host views)
     {

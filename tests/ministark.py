@@ -1,6 +1,6 @@
 """A complete small STARK, end to end (TEST INFRASTRUCTURE).
 
-The reference's full proof run (BASELINE config 4) needs inputs that are not in the tree, and `bench_genproof.py` runs the device phases
+The reference's full proof run (BASELINE config 4) needs inputs that are not in the tree, and an earlier benchmark script ran the device phases
 on programs that are shaped like the zkEVM's but do not describe a satisfiable system -- its q is not a low-degree polynomial and no
 verifier would accept the result.  This module closes that gap at small size: an AIR with a real witness, its two constraint programs
 written in the reference's own opcode formats (step42ns, step52ns), a PROVER that strings the product's device entry points together in
@@ -342,12 +342,63 @@ def fri_steps(nbits_ext):
     return steps
 
 
+class Transcript:
+    """transcript.cpp:4-87 -- host state machine, every permutation on the GPU (mi_poseidon_hash_full_result): the mini prover's transcript."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.state = np.zeros(4, dtype=np.uint64)
+        self.pending = np.zeros(8, dtype=np.uint64)
+        self.out = np.zeros(12, dtype=np.uint64)
+        self.pending_cursor = 0
+        self.out_cursor = 0
+
+    def _update(self):
+        self.out = self.ctx.hash_full_result(np.concatenate([self.pending, self.state]))
+        self.out_cursor = 12
+        self.pending[:] = 0
+        self.pending_cursor = 0
+        self.state = self.out[:4].copy()
+
+    def put(self, vals):
+        for v in np.asarray(vals, dtype=np.uint64).ravel():
+            self.pending[self.pending_cursor] = v
+            self.pending_cursor += 1
+            self.out_cursor = 0
+            if self.pending_cursor == 8:
+                self._update()
+
+    def get_fields1(self):
+        if self.out_cursor == 0:
+            self._update()
+        r = int(self.out[(12 - self.out_cursor) % 12])
+        self.out_cursor -= 1
+        return r
+
+    def get_field(self):
+        return np.array([self.get_fields1() for _ in range(3)], dtype=np.uint64)
+
+    def get_permutations(self, n, nbits):
+        nfields = (n * nbits - 1) // 63 + 1
+        fields = [self.get_fields1() for _ in range(nfields)]
+        res, cur_field, cur_bit = [], 0, 0
+        for _ in range(n):
+            a = 0
+            for j in range(nbits):
+                if (fields[cur_field] >> cur_bit) & 1:
+                    a += 1 << j
+                cur_bit += 1
+                if cur_bit == 63:
+                    cur_bit, cur_field = 0, cur_field + 1
+            res.append(a)
+        return np.array(res, dtype=np.uint64)
+
+
 # ------------------------------------------------------------------ prover: the product's device entry points in genProof's order
 def prove(ctx, nbits, n_queries=12, native=False, cache_dir=None, tamper=None):
     """Returns the proof (host data only).  native: the constraint programs through the compiled-kernel backend.  The polynomial area is
     ONE device buffer in the reference's memory map (Layout), the programs address it by absolute offsets."""
     import mi_stark
-    from bench_genproof import Transcript
     L = glo.lib()
     nbits_ext = nbits + 1
     N, NE = 1 << nbits, 1 << nbits_ext

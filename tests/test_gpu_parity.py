@@ -735,24 +735,6 @@ def test_evmap_matches_oracle(ctx):
     assert np.array_equal(total.astype(np.uint64), want)
 
 
-def test_genproof_shaped_flow_small():
-    """bench_genproof.py at 2^12 rows: every device phase of Starks::genProof in order (step 4 through the constraint-program
-    interpreter), with the transcript on the host, and its built-in checks (q rows against the oracle interpreter, Merkle
-    paths, FRI fold relation on the openings, evmap spot check, the stage-2 lookups' sortedness, the stage-3 products' recurrence)."""
-    import json, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench_genproof.py"), "--log-n", "12", "--widths", "37", "9", "20",
-                        "--n-evals", "24", "--n-queries", "16", "--check-queries", "16", "--n-const", "11", "--chelpers-field-ops", "1500",
-                        "--chelpers52-field-ops", "700"],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["checks"] == {"step42ns_rows_match_oracle": True, "step52ns_rows_match_oracle": True, "step0_merkle_paths_verify": True, "fri_merkle_paths_verify": True,
-                             "fri_fold_relation_on_openings": True, "evmap_spot_check": True, "h1h2_is_f_u_t_sorted_along_t": True,
-                             "grand_product_recurrence_on_sampled_rows": True}
-    assert out["config"]["fri_steps_bits"] == [13, 8, 3]
-
-
 def _device_ops(ctx):
     from shard import device_ops
     return device_ops(ctx)

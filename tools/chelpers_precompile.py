@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fill the in-tree code-object cache (merlin-zkevm-prover_amd/_chelpers_cache/) with the compiled constraint programs of
-bench_genproof.py's default configuration and of the small configuration the GPU test uses.  Needs no GPU: hiprtc cross-compiles
+bench_starks.py's default (zkEVM-shaped) configuration and of the configurations the GPU tests prove.  Needs no GPU: hiprtc cross-compiles
 gfx950.  A proving key's programs are compiled once; the GPU box then loads the code objects instead of spending its minutes in the
 compiler (about 10 s per 25 000-instruction kernel).  The kernels of a program are compiled by --jobs processes in parallel (each
 takes every jobs-th kernel: mi_chelpers_precompile_shard)."""
@@ -13,13 +13,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "merlin-zkevm-prover_amd"))
-
-CONFIGS = [
-    [],
-    ["--log-n", "12", "--widths", "37", "9", "20", "--n-evals", "24", "--n-queries", "16", "--check-queries", "16", "--n-const", "11",
-     "--chelpers-field-ops", "1500", "--chelpers52-field-ops", "700"],
-]
-
 
 # bench_starks.py (class Starks end to end): the default zkEVM-shaped STARK and the small one the GPU test runs
 STARKS_CONFIGS = [
@@ -61,40 +54,9 @@ def precompile_starks(jobs, only):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--jobs", type=int, default=min(8, os.cpu_count() or 1))
-    ap.add_argument("--shard", type=int, default=-1, help="internal: run one shard of one configuration")
-    ap.add_argument("--config", type=int, default=-1)
-    ap.add_argument("--only", type=int, default=-1, help="precompile only this configuration")
-    ap.add_argument("--extra", nargs=argparse.REMAINDER, default=[], help="further bench_genproof.py arguments for every configuration")
-    ap.add_argument("--starks-only", type=int, default=None, help="only the bench_starks.py configuration with this index (-1: all of them)")
+    ap.add_argument("--starks-only", type=int, default=-1, help="only the bench_starks.py configuration with this index (-1: all of them)")
     a = ap.parse_args()
-    if a.starks_only is not None:
-        precompile_starks(a.jobs, a.starks_only)
-        return
-    for c in CONFIGS:
-        c.extend(a.extra)
-    import bench_genproof
-    if a.shard >= 0:
-        args = bench_genproof.arg_parser().parse_args(CONFIGS[a.config])
-        *_, prog, _, _, prog52, _ = bench_genproof.chelpers_programs(args, None, (a.shard, a.jobs))
-        return
-    for ci, argv in enumerate(CONFIGS):
-        t0 = time.time()
-        if a.only >= 0 and ci != a.only:
-            continue
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--jobs", str(a.jobs), "--shard", str(s), "--config", str(ci)] +
-                                  (["--extra"] + a.extra if a.extra else []))
-                 for s in range(a.jobs)]
-        bad = [p.wait() for p in procs]
-        if any(bad):
-            raise SystemExit("a precompile shard failed")
-        args = bench_genproof.arg_parser().parse_args(argv)
-        *_, prog, _, _, prog52, native = bench_genproof.chelpers_programs(args, None, True)      # everything is in the cache now
-        print("precompiled", argv or "(default)", {k: (v["kernels"], v["cache_hits"], v["code_bytes"]) for k, v in native.items()},
-              "%.1f s" % (time.time() - t0), flush=True)
-        prog.close()
-        prog52.close()
-    if a.shard < 0 and a.only < 0:
-        precompile_starks(a.jobs, -1)
+    precompile_starks(a.jobs, a.starks_only)
 
 
 if __name__ == "__main__":
