@@ -452,7 +452,17 @@ def run(args):
     warn = ctypes.create_string_buffer(2048)
     bad = ctypes.c_int(0)
     G = int(L.mis_peer_access(mat, warn, ctypes.c_uint64(2048), ctypes.byref(bad)))
+    L.mis_image_backed_bytes.restype = ctypes.c_uint64
+    sp = ctypes.c_int(0)
+    out["hbm"]["image_backed_gb"] = int(L.mis_image_backed_bytes(ctypes.byref(sp))) / 1e9
+    out["hbm"]["image_is_a_sparse_address_range"] = bool(sp.value)
+    chk = (ctypes.c_uint64 * 4)()
+    ctypes.CDLL(os.path.join(ROOT, "merlin-zkevm-prover_amd", "libmi_stark.so")).mi_multi_check_stats(chk)
+    if chk[0]:
+        out["multi_check"] = {"checks": int(chk[1]), "unknown_pointers": int(chk[2]), "violations": int(chk[3])}
     if G:
+        out["row_sharded"] = os.environ.get("MI_STARK_ROW_SHARDED")
+        out["device_groups"] = os.environ.get("MI_MULTI_GROUP_SAME_DEVICE", "0") == "1"
         out["peer_access"] = {"devices": os.environ.get("MI_STARK_DEVICES"), "matrix": [[int(mat[a * G + b]) for b in range(G)] for a in range(G)],
                               "indirect_pairs": int(bad.value), "warning": warn.value.decode(), "legend": "2 same device, 1 peer access enabled, 0 not possible, -1 enabling failed"}
         out["n_gpus"] = len(set(os.environ.get("MI_STARK_DEVICES", "").split(",")))

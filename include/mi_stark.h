@@ -169,6 +169,12 @@ int mi_host_unregister(mi_ctx *ctx, void *p);
 typedef struct mi_multi mi_multi;
 typedef struct mi_multi_tree mi_multi_tree;
 int mi_multi_create(mi_multi **out, const int *devices, int n_shards /* a power of two, at most 16 */);
+/* group_same_device != 0: the shards that name one physical device form a GROUP -- one set of streams, one tile ring, staging and NTT
+ * workspace, shared per-context pools, everything ordered by the one stream -- so that a one-GPU box can rehearse eight shards at the
+ * full 2^23 rows (8 x 36 GB of per-shard buffers do not fit beside the proof).  With one shard per device it changes nothing.
+ * mi_multi_create takes the choice from MI_MULTI_GROUP_SAME_DEVICE=1. */
+int mi_multi_create2(mi_multi **out, const int *devices, int n_shards, int group_same_device);
+int mi_multi_lead(const mi_multi *m, int shard); /* the first shard of this shard's device group (itself when ungrouped) */
 void mi_multi_destroy(mi_multi *m);
 int mi_multi_shards(const mi_multi *m);
 /* What the driver answered when mi_multi_create asked for direct (xGMI) access between the shards' devices: out (G x G ints, may be
@@ -202,6 +208,22 @@ int mi_multi_lend(mi_multi *m, int shard, void *ptr, uint64_t bytes);
  * section (n_ext x pitch) in memory of shard q's device, of which only those rows are written -- for every non-null imgs[q] (G entries):
  * what a row-sharded constraint evaluation on that device reads (host/chelpers_steps.hpp: step42ns over its rows on every device) */
 int mi_multi_set_row_images(mi_multi *m, uint64_t *const *imgs, uint64_t pitch, uint64_t halo_rows);
+/* the NEXT commit is TRANSIENT: a row image for EVERY shard (mi_multi_set_row_images, no whole-extension image), no row values will be
+ * opened from its tree.  A tile's rows are then written ONCE, by a kernel of the extending shard, straight into each owner's row image
+ * and absorbed there at the image's pitch (no contiguous windows: half the bytes on the links); the extended tiles live in a ring of
+ * two.  Per device group it takes mi_multi_transient_need(...) elements (21.5 GB at 2^23 x 665 and 8 shards against 36.5 GB): lent to the
+ * group's leader (mi_multi_lend) or from its pool.  What a row-sharded Starks::genProof asks for (host/starks.hpp). */
+int mi_multi_set_transient(mi_multi *m, int on);
+uint64_t mi_multi_transient_need(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards);
+/* MI_MULTI_CHECK=1 (environment, read once): logical-shard discipline.  Every device range the library allocates for a shard
+ * (mi_dev_alloc and mi_vmm_reserve through that shard's context, the buffers of csrc/multi.hip) is entered with its shard; an entry
+ * point then refuses (MI_ERR_INVALID, the reason on stderr) a device pointer that belongs to ANOTHER shard than the one its context
+ * works for, a compiled program run for two shards, an event recorded on another group's stream; operands that legitimately cross
+ * (mi_multi_copy, row images, a device source) are declared by the call that takes them.  So that a one-GPU rehearsal, where every
+ * shard is device 0 and every pointer is valid everywhere, fails where an eight-GPU node would.  out: [enabled, checks made, pointers
+ * nobody entered (they pass), violations].  mi_multi_own enters (bytes > 0) or withdraws a range a caller allocated itself. */
+int mi_multi_check_stats(uint64_t out[4]);
+int mi_multi_own(const void *p, uint64_t bytes, int shard, const char *what);
 int mi_multi_set_device(mi_multi *m, int shard); /* the calling thread's current device := the shard's (to drive mi_multi_ctx(m, shard) directly) */
 int mi_multi_copy(mi_multi *m, void *dst, int dst_shard, const void *src, int src_shard, uint64_t bytes); /* behind the work queued on src_shard's context */
 int mi_multi_sync(mi_multi *m, int shard); /* wait for the shard's context */
@@ -427,6 +449,16 @@ int mi_fill_synthetic_2d_dev(mi_ctx *ctx, uint64_t *out, uint64_t out_pitch, uin
 int mi_copy_2d_dev(mi_ctx *ctx, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch,
                    uint64_t nrows, uint64_t ncols);
 void *mi_dev_alloc(mi_ctx *ctx, uint64_t bytes);
+/* Sparse device memory (HIP virtual-memory management).  A row-sharded proof addresses FULL-HEIGHT sections on every device but a device
+ * touches only its own rows of them (20 of 157 GB at zkEVM size): mi_vmm_reserve takes the address range (no memory), mi_vmm_back puts
+ * physical memory under [offset, offset + bytes) (widened to 2 MiB boundaries; idempotent; fresh memory is not zeroed),
+ * mi_vmm_allow_peer lets another device's kernels reach what is backed so far, mi_vmm_free unmaps and releases everything.  An access
+ * outside a backed part faults. */
+int mi_vmm_reserve(mi_ctx *ctx, uint64_t bytes, void **base);
+int mi_vmm_back(mi_ctx *ctx, void *base, uint64_t offset, uint64_t bytes);
+int mi_vmm_allow_peer(mi_ctx *ctx, void *base, int peer_device);
+int mi_vmm_backed_bytes(mi_ctx *ctx, void *base, uint64_t *bytes);
+int mi_vmm_free(mi_ctx *ctx, void *base);
 int mi_dev_free(mi_ctx *ctx, void *p);
 int mi_copy_h2d(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int mi_copy_d2h(mi_ctx *ctx, void *dst, const void *src, uint64_t bytes);

@@ -29,6 +29,78 @@ extern "C" int mi_device_count(void)
     return n;
 }
 
+
+// ------------------------------------------------------------------ MI_MULTI_CHECK: logical ownership of device address ranges
+#include <atomic>
+namespace {
+struct OwnRange { uintptr_t hi; int shard; std::string what; };
+std::mutex g_own_mu;
+std::map<uintptr_t, OwnRange> g_own; // by start address
+std::atomic<uint64_t> g_own_checks{0}, g_own_unknown{0}, g_own_violations{0};
+int g_check_state = -1; // -1 not read yet, 0 off, 1 on
+int g_own_lead[64]; // device groups (csrc/multi.hip): shards of one group share buffers legitimately; identity until mi_own_set_leaders
+bool g_own_lead_set = false;
+}
+void mi_own_set_leaders(const uint32_t *lead, uint32_t n)
+{
+    std::lock_guard<std::mutex> lock(g_own_mu);
+    for (uint32_t i = 0; i < 64; i++) g_own_lead[i] = i < n ? (int)lead[i] : (int)i;
+    g_own_lead_set = true;
+}
+bool mi_check_on()
+{
+    if (g_check_state < 0) {
+        const char *e = getenv("MI_MULTI_CHECK");
+        g_check_state = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_check_state == 1;
+}
+void mi_own_add(const void *p, uint64_t bytes, int shard, const char *what)
+{
+    if (!mi_check_on() || !p || !bytes) return;
+    std::lock_guard<std::mutex> lock(g_own_mu);
+    g_own[(uintptr_t)p] = OwnRange{(uintptr_t)p + bytes, shard, what ? what : ""};
+}
+void mi_own_del(const void *p)
+{
+    if (!mi_check_on() || !p) return;
+    std::lock_guard<std::mutex> lock(g_own_mu);
+    g_own.erase((uintptr_t)p);
+}
+int mi_own_check(int shard, const void *p, const char *what)
+{
+    if (!p) return MI_OK;
+    g_own_checks.fetch_add(1, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lock(g_own_mu);
+    auto it = g_own.upper_bound((uintptr_t)p);
+    if (it == g_own.begin()) { g_own_unknown.fetch_add(1, std::memory_order_relaxed); return MI_OK; }
+    --it;
+    if ((uintptr_t)p >= it->second.hi) { g_own_unknown.fetch_add(1, std::memory_order_relaxed); return MI_OK; }
+    if (it->second.shard == shard) return MI_OK;
+    if (g_own_lead_set && shard >= 0 && shard < 64 && it->second.shard >= 0 && it->second.shard < 64 && g_own_lead[shard] == g_own_lead[it->second.shard]) return MI_OK; // one device group
+    g_own_violations.fetch_add(1, std::memory_order_relaxed);
+    mi_set_error("MI_MULTI_CHECK: %s was handed %p, which lies in \"%s\" of logical shard %d, while working for shard %d (on a real multi-GPU node: memory of another device)",
+                 what, p, it->second.what.c_str(), it->second.shard, shard);
+    fprintf(stderr, "mi_stark: %s\n", mi_last_error());
+    return MI_ERR_INVALID;
+}
+// [enabled, checks made, pointers nobody entered (passed), violations]
+extern "C" int mi_multi_check_stats(uint64_t out[4])
+{
+    if (!out) return MI_ERR_INVALID;
+    out[0] = mi_check_on() ? 1 : 0;
+    out[1] = g_own_checks.load(); out[2] = g_own_unknown.load(); out[3] = g_own_violations.load();
+    return MI_OK;
+}
+// a caller that allocates device memory itself for a shard (host/starks.hpp's arenas come through mi_dev_alloc / mi_vmm_reserve and need
+// not call this) enters the range; bytes == 0 withdraws it
+extern "C" int mi_multi_own(const void *p, uint64_t bytes, int shard, const char *what)
+{
+    if (!p) return MI_ERR_INVALID;
+    if (bytes) mi_own_add(p, bytes, shard, what); else mi_own_del(p);
+    return MI_OK;
+}
+
 // every entry point: reject a null context, take the context lock, make its device current
 #define CTX_OK(ctx)                                                   \
     if (!(ctx)) {                                                     \
@@ -40,20 +112,20 @@ extern "C" int mi_device_count(void)
 
 int mi_scratch(mi_ctx *c, uint64_t bytes, void **p)
 {
-    if (c->scratch_bytes < bytes) {
+    if (c->pool->scratch_bytes < bytes) {
         MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // earlier users are done with the old buffer
-        if (c->scratch) MI_HIP_CHECK(hipFree(c->scratch));
-        c->scratch = nullptr;
-        c->scratch_bytes = 0;
+        if (c->pool->scratch) MI_HIP_CHECK(hipFree(c->pool->scratch));
+        c->pool->scratch = nullptr;
+        c->pool->scratch_bytes = 0;
         const uint64_t want = (bytes + (1ull << 20) - 1) & ~((1ull << 20) - 1);
-        hipError_t e = hipMalloc((void **)&c->scratch, want);
+        hipError_t e = hipMalloc((void **)&c->pool->scratch, want);
         if (e != hipSuccess) {
             mi_set_error("cannot allocate %llu bytes of device scratch: %s", (unsigned long long)want, hipGetErrorString(e));
             return MI_ERR_NOMEM;
         }
-        c->scratch_bytes = want;
+        c->pool->scratch_bytes = want;
     }
-    *p = c->scratch;
+    *p = c->pool->scratch;
     return MI_OK;
 }
 
@@ -112,14 +184,14 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     else if (c->workspace) (void)hipFree(c->workspace);
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
-    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->own_pool.scratch) (void)hipFree(c->own_pool.scratch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
-    if (c->chelpers_stage) (void)hipFree(c->chelpers_stage);
-    if (c->chelpers_cst) (void)hipFree(c->chelpers_cst);
-    if (c->chelpers_tiled) (void)hipFree(c->chelpers_tiled);
-    if (c->chelpers_spill) (void)hipFree(c->chelpers_spill);
-    if (c->chelpers_lin) (void)hipFree(c->chelpers_lin);
+    if (c->own_pool.chelpers_stage) (void)hipFree(c->own_pool.chelpers_stage);
+    if (c->own_pool.chelpers_cst) (void)hipFree(c->own_pool.chelpers_cst);
+    if (c->own_pool.chelpers_tiled) (void)hipFree(c->own_pool.chelpers_tiled);
+    if (c->own_pool.chelpers_spill) (void)hipFree(c->own_pool.chelpers_spill);
+    if (c->own_pool.chelpers_lin) (void)hipFree(c->own_pool.chelpers_lin);
     if (c->stage) (void)hipFree(c->stage);
     for (int i = 0; i < 3; i++) {
         if (c->pack_stage[i]) (void)hipHostFree(c->pack_stage[i]);
@@ -265,6 +337,8 @@ extern "C" int mi_ntt_dev(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, const ui
                           uint64_t ncols, int inverse)
 {
     CTX_OK(c);
+    MI_OWN(c, dst);
+    MI_OWN(c, src);
     MI_REQUIRE((dst && src) || n == 0 || ncols == 0, "null buffer");
     return launch_ntt(c, (u64 *)dst, dst_pitch, (const u64 *)src, src_pitch, n, ncols, inverse);
 }
@@ -273,6 +347,8 @@ extern "C" int mi_lde_dev(mi_ctx *c, uint64_t *out, uint64_t out_pitch, const ui
                           uint64_t n, uint64_t ncols)
 {
     CTX_OK(c);
+    MI_OWN(c, out);
+    MI_OWN(c, in);
     MI_REQUIRE((out && in) || n == 0 || ncols == 0, "null buffer");
     return launch_lde(c, (u64 *)out, out_pitch, (const u64 *)in, in_pitch, n_ext, n, ncols);
 }
@@ -329,6 +405,8 @@ extern "C" int mi_lde(mi_ctx *c, uint64_t *out, const uint64_t *in, uint64_t n_e
 extern "C" int mi_poseidon_permute_dev(mi_ctx *c, uint64_t *out, const uint64_t *in, uint64_t count)
 {
     CTX_OK(c);
+    MI_OWN(c, out);
+    MI_OWN(c, in);
     MI_REQUIRE((out && in) || count == 0, "null buffer");
     return launch_permute(c, (u64 *)out, (const u64 *)in, count);
 }
@@ -393,6 +471,8 @@ extern "C" int mi_linear_hash_rows_dev(mi_ctx *c, uint64_t *digests, const uint6
                                        uint64_t nrows)
 {
     CTX_OK(c);
+    MI_OWN(c, digests);
+    MI_OWN(c, src);
     MI_REQUIRE((digests && (src || ncols == 0)) || nrows == 0, "null buffer");
     MI_REQUIRE(pitch >= ncols, "pitch smaller than ncols");
     return launch_linear_hash_rows(c, (u64 *)digests, (const u64 *)src, pitch, ncols, nrows);
@@ -404,6 +484,8 @@ extern "C" int mi_linear_hash_absorb_dev(mi_ctx *c, uint64_t *digests, uint32_t 
     CTX_OK(c);
     MI_REQUIRE(nrows == 0 || nwindows == 0 || (digests && bases && pitches && widths), "null buffer");
     for (uint32_t i = 0; i < nwindows && nrows; i++) MI_REQUIRE(bases[i] || widths[i] == 0, "null column window");
+    MI_OWN(c, digests);
+    for (uint32_t i = 0; i < nwindows && nrows; i++) MI_OWN(c, bases[i]);
     return launch_linear_hash_absorb(c, (u64 *)digests, nwindows, (const u64 *const *)bases, pitches, widths, nrows, first != 0,
                                      final != 0);
 }
@@ -425,6 +507,7 @@ extern "C" int mi_poseidon_linear_hash(mi_ctx *c, uint64_t out[4], const uint64_
 extern "C" int mi_merkle_levels_dev(mi_ctx *c, uint64_t *nodes, uint64_t nleaves)
 {
     CTX_OK(c);
+    MI_OWN(c, nodes);
     if (nleaves == 0) return MI_OK;
     MI_REQUIRE(nodes, "null buffer");
     return launch_merkle_levels(c, (u64 *)nodes, nleaves);
@@ -434,6 +517,8 @@ extern "C" int mi_merkle_build_dev(mi_ctx *c, uint64_t *nodes, const uint64_t *s
                                    uint64_t nrows)
 {
     CTX_OK(c);
+    MI_OWN(c, nodes);
+    MI_OWN(c, src);
     if (nrows == 0) return MI_OK; // merkletree() returns immediately on zero rows
     MI_REQUIRE(nodes && (src || ncols == 0), "null buffer");
     MI_REQUIRE(is_pow2(nrows), "number of rows must be a power of two");
@@ -462,6 +547,9 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
                                           uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx, uint64_t nq)
 {
     CTX_OK(c);
+    MI_OWN(c, proofs);
+    MI_OWN(c, nodes);
+    MI_OWN(c, src);
     if (nq == 0) return MI_OK;
     MI_REQUIRE(proofs && (nodes || src) && (src || width == 0) && idx, "null buffer"); // width 0: sibling paths only; nodes NULL: row values only
     for (uint64_t q = 0; q < nq; q++) MI_REQUIRE(idx[q] < height, "query index out of range");
@@ -690,6 +778,8 @@ extern "C" int mi_lde_merkle_host(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uin
                                   uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
 {
     CTX_OK(c);
+    MI_OWN(c, nodes);
+    MI_OWN(c, ext);
     return lde_merkle_host_impl(c, nodes, ext, ext_pitch, nullptr, 0, trace_host, n, n_ext, ncols, chunk_cols);
 }
 
@@ -697,6 +787,9 @@ extern "C" int mi_lde_merkle_host_keep(mi_ctx *c, uint64_t *nodes, uint64_t *ext
                                        const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
 {
     CTX_OK(c);
+    MI_OWN(c, nodes);
+    MI_OWN(c, ext);
+    MI_OWN(c, base);
     MI_REQUIRE(base, "null buffer");
     return lde_merkle_host_impl(c, nodes, ext, ext_pitch, base, base_pitch, trace_host, n, n_ext, ncols, chunk_cols);
 }
@@ -705,6 +798,9 @@ extern "C" int mi_lde_merkle_host_keep_tiled(mi_ctx *c, uint64_t *nodes, uint64_
                                              const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
 {
     CTX_OK(c);
+    MI_OWN(c, nodes);
+    MI_OWN(c, ext);
+    MI_OWN(c, base_tiled);
     MI_REQUIRE(base_tiled, "null buffer");
     return lde_merkle_host_impl(c, nodes, ext, ext_pitch, base_tiled, 0, trace_host, n, n_ext, ncols, chunk_cols);
 }
@@ -713,6 +809,8 @@ extern "C" int mi_tile_major_dev(mi_ctx *c, uint64_t *dst, uint64_t ncols_total,
                                  uint64_t nrows, uint64_t ncols)
 {
     CTX_OK(c);
+    MI_OWN(c, dst);
+    MI_OWN(c, src);
     if (nrows == 0 || ncols == 0) return MI_OK;
     MI_REQUIRE(dst && src, "null buffer");
     MI_REQUIRE(nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
@@ -752,6 +850,8 @@ extern "C" int mi_fri_fold_dev(mi_ctx *c, uint64_t *out, const uint64_t *pol, un
                                unsigned nbits_ext, const uint64_t x[3])
 {
     CTX_OK(c);
+    MI_OWN(c, out);
+    MI_OWN(c, pol);
     MI_REQUIRE(out && pol && x, "null buffer");
     const u64 xe[3] = {x[0], x[1], x[2]};
     MI_REQUIRE(cur_bits <= 40, "bad FRI step sizes");
@@ -762,6 +862,8 @@ extern "C" int mi_fri_fold_range_dev(mi_ctx *c, uint64_t *out, const uint64_t *p
                                      unsigned nbits_ext, const uint64_t x[3], uint64_t g0, uint64_t g_count)
 {
     CTX_OK(c);
+    MI_OWN(c, out);
+    MI_OWN(c, pol);
     MI_REQUIRE(out && pol && x, "null buffer");
     const u64 xe[3] = {x[0], x[1], x[2]};
     return launch_fri_fold(c, (u64 *)out, (const u64 *)pol, prev_bits, cur_bits, nbits_ext, xe, g0, g_count);
@@ -770,6 +872,8 @@ extern "C" int mi_fri_fold_range_dev(mi_ctx *c, uint64_t *out, const uint64_t *p
 extern "C" int mi_fri_transpose_dev(mi_ctx *c, uint64_t *aux, const uint64_t *pol, uint64_t degree, unsigned tbits)
 {
     CTX_OK(c);
+    MI_OWN(c, aux);
+    MI_OWN(c, pol);
     MI_REQUIRE((aux && pol) || degree == 0, "null buffer");
     return launch_fri_transpose(c, (u64 *)aux, (const u64 *)pol, degree, tbits);
 }
@@ -777,6 +881,8 @@ extern "C" int mi_fri_transpose_dev(mi_ctx *c, uint64_t *aux, const uint64_t *po
 extern "C" int mi_q_split_dev(mi_ctx *c, uint64_t *qq2, const uint64_t *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg)
 {
     CTX_OK(c);
+    MI_OWN(c, qq2);
+    MI_OWN(c, qq1);
     MI_REQUIRE(qq2 && qq1, "null buffer");
     return launch_q_split(c, (u64 *)qq2, (const u64 *)qq1, n, n_ext, qdeg);
 }
@@ -788,6 +894,8 @@ extern "C" int mi_evmap_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, uint64
     CTX_OK(c);
     if (n_evals == 0) return MI_OK;
     MI_REQUIRE(evals && pol_ptr && pol_dim && pol_stride && prime && lev && lpev, "null buffer");
+    MI_OWN(c, evals); MI_OWN(c, lev); MI_OWN(c, lpev);
+    for (uint64_t i = 0; i < n_evals; i++) MI_OWN(c, pol_ptr[i]);
     return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
                         prime, (const u64 *)lev, (const u64 *)lpev, 0, n);
 }
@@ -800,6 +908,8 @@ extern "C" int mi_evmap_range_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, 
     CTX_OK(c);
     if (n_evals == 0 || nrows == 0) return MI_OK;
     MI_REQUIRE(evals && pol_ptr && pol_dim && pol_stride && prime && lev && lpev, "null buffer");
+    MI_OWN(c, evals); MI_OWN(c, lev); MI_OWN(c, lpev);
+    for (uint64_t i = 0; i < n_evals; i++) MI_OWN(c, pol_ptr[i]);
     return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
                         prime, (const u64 *)lev, (const u64 *)lpev, row0, nrows);
 }
@@ -807,6 +917,8 @@ extern "C" int mi_evmap_range_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, 
 extern "C" int mi_batch_inverse3_dev(mi_ctx *c, uint64_t *res, const uint64_t *src, uint64_t n)
 {
     CTX_OK(c);
+    MI_OWN(c, res);
+    MI_OWN(c, src);
     MI_REQUIRE((res && src) || n == 0, "null buffer");
     return launch_batch_inverse3(c, (u64 *)res, (const u64 *)src, n);
 }
@@ -815,6 +927,10 @@ extern "C" int mi_calculate_h1h2_dev(mi_ctx *c, uint64_t *h1, uint64_t h1_stride
                                      uint64_t f_stride, const uint64_t *t, uint64_t t_stride, unsigned dim, uint64_t n)
 {
     CTX_OK(c);
+    MI_OWN(c, h1);
+    MI_OWN(c, h2);
+    MI_OWN(c, f);
+    MI_OWN(c, t);
     MI_REQUIRE((h1 && h2 && f && t) || n == 0, "null buffer");
     return launch_calculate_h1h2(c, (u64 *)h1, h1_stride, (u64 *)h2, h2_stride, (const u64 *)f, f_stride, (const u64 *)t, t_stride, dim, n);
 }
@@ -823,6 +939,9 @@ extern "C" int mi_calculate_z_dev(mi_ctx *c, uint64_t *z, uint64_t z_stride, con
                                   uint64_t den_stride, uint64_t n, int *closes)
 {
     CTX_OK(c);
+    MI_OWN(c, z);
+    MI_OWN(c, num);
+    MI_OWN(c, den);
     MI_REQUIRE((z && num && den) || n == 0, "null buffer");
     return launch_calculate_z(c, (u64 *)z, z_stride, (const u64 *)num, num_stride, (const u64 *)den, den_stride, n, closes);
 }
@@ -832,12 +951,14 @@ extern "C" int mi_calculate_z_batch_dev(mi_ctx *c, unsigned nprod, uint64_t *con
 {
     CTX_OK(c);
     MI_REQUIRE(nprod == 0 || (z && z_stride && num && num_stride && den && den_stride), "null argument array");
+    for (unsigned i = 0; i < nprod; i++) { MI_OWN(c, z[i]); MI_OWN(c, num[i]); MI_OWN(c, den[i]); }
     return launch_calculate_z_batch(c, nprod, (u64 *const *)z, z_stride, (const u64 *const *)num, num_stride, (const u64 *const *)den, den_stride, n, closes);
 }
 
 extern "C" int mi_geom_seq_dev(mi_ctx *c, uint64_t *out, uint64_t n, uint64_t start, uint64_t ratio)
 {
     CTX_OK(c);
+    MI_OWN(c, out);
     MI_REQUIRE(out || n == 0, "null buffer");
     return launch_geom_seq(c, (u64 *)out, n, start, ratio);
 }
@@ -845,6 +966,7 @@ extern "C" int mi_geom_seq_dev(mi_ctx *c, uint64_t *out, uint64_t n, uint64_t st
 extern "C" int mi_geom_seq3_dev(mi_ctx *c, uint64_t *out, uint64_t n, const uint64_t ratio[3])
 {
     CTX_OK(c);
+    MI_OWN(c, out);
     MI_REQUIRE((out || n == 0) && ratio, "null buffer");
     const u64 r[3] = {ratio[0], ratio[1], ratio[2]};
     return launch_geom_seq3(c, (u64 *)out, n, r);
@@ -853,6 +975,8 @@ extern "C" int mi_geom_seq3_dev(mi_ctx *c, uint64_t *out, uint64_t n, const uint
 extern "C" int mi_x_div_x_sub_dev(mi_ctx *c, uint64_t *out, const uint64_t *x, uint64_t n, const uint64_t xi[3])
 {
     CTX_OK(c);
+    MI_OWN(c, out);
+    MI_OWN(c, x);
     MI_REQUIRE(((out && x) || n == 0) && xi, "null buffer");
     const u64 e[3] = {xi[0], xi[1], xi[2]};
     return launch_x_div_x_sub(c, (u64 *)out, (const u64 *)x, n, e);
@@ -879,6 +1003,7 @@ extern "C" int mi_zhinv(mi_ctx *c, uint64_t *out, unsigned nbits, unsigned nbits
 extern "C" int mi_fill_synthetic_dev(mi_ctx *c, uint64_t *out, uint64_t count, uint64_t seed)
 {
     CTX_OK(c);
+    MI_OWN(c, out);
     MI_REQUIRE(out || count == 0, "null buffer");
     return launch_fill_synthetic(c, (u64 *)out, count, seed);
 }
@@ -887,6 +1012,7 @@ extern "C" int mi_fill_synthetic_2d_dev(mi_ctx *c, uint64_t *out, uint64_t out_p
                                         uint64_t global_cols, uint64_t col0, uint64_t seed)
 {
     CTX_OK(c);
+    MI_OWN(c, out);
     MI_REQUIRE(out || nrows * ncols == 0, "null buffer");
     MI_REQUIRE(out_pitch >= ncols && col0 + ncols <= global_cols, "bad column window");
     return launch_fill_synthetic_2d(c, (u64 *)out, out_pitch, nrows, ncols, global_cols, col0, seed);
@@ -896,6 +1022,8 @@ extern "C" int mi_copy_2d_dev(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, cons
                               uint64_t nrows, uint64_t ncols)
 {
     CTX_OK(c);
+    MI_OWN(c, dst);
+    MI_OWN(c, src);
     MI_REQUIRE((dst && src) || nrows * ncols == 0, "null buffer");
     MI_REQUIRE(dst_pitch >= ncols && src_pitch >= ncols, "pitch smaller than ncols");
     return launch_copy_2d(c, (u64 *)dst, dst_pitch, (const u64 *)src, src_pitch, nrows, ncols);
@@ -912,6 +1040,7 @@ extern "C" void *mi_dev_alloc(mi_ctx *c, uint64_t bytes)
         mi_set_error("hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
         return nullptr;
     }
+    mi_own_add(p, bytes ? bytes : 8, c->logical, "mi_dev_alloc");
     return p;
 }
 
@@ -919,15 +1048,153 @@ extern "C" int mi_dev_free(mi_ctx *c, void *p)
 {
     CTX_OK(c);
     if (p) {
+        MI_OWN(c, p);
         MI_HIP_CHECK(hipStreamSynchronize(c->stream));
         MI_HIP_CHECK(hipFree(p));
+        mi_own_del(p);
     }
+    return MI_OK;
+}
+
+
+// ------------------------------------------------------------------ sparse device memory (HIP virtual-memory management)
+// A row-sharded proof (host/starks.hpp) addresses FULL-HEIGHT sections on every device -- the evaluator's programs, the code-object cache
+// and the openings keep the one-device image's offsets -- but a device only ever touches its own rows of them: 20 GB of the 157 GB an
+// extended part spans at zkEVM size.  mi_vmm_reserve takes the ADDRESS RANGE, mi_vmm_back puts physical memory under the parts that are
+// used, in 64 MiB pieces (tools/vmm_probe.hip: this stack maps under a terabyte of addresses).  Nothing outside a backed part may be
+// touched: such an access faults like any wild pointer.
+namespace {
+// Pieces of ONE size at multiples of it.  The driver of this stack (ROCm 7.2) refuses hipMemSetAccess on a second mapping of a
+// reservation when the two mappings differ in size and lie far apart (tools/vmm_probe3.hip, profiles/r05_vmm_probe3.txt: 74 MiB at
+// 2 MiB, then 4 MiB at 400 GiB -> "invalid argument"; equal sizes at any distance are taken), so every piece is VMM_PIECE long.
+constexpr uint64_t VMM_PIECE = 64ull << 20;
+struct VmmRange { int device = 0; uint64_t bytes = 0, backed = 0; std::map<uint64_t, hipMemGenericAllocationHandle_t> pieces; }; // by piece index
+std::mutex g_vmm_mu;
+std::map<uintptr_t, VmmRange> g_vmm;
+}
+extern "C" int mi_vmm_reserve(mi_ctx *c, uint64_t bytes, void **base)
+{
+    CTX_OK(c);
+    MI_REQUIRE(base && bytes, "null argument");
+    *base = nullptr;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    size_t gran = 0;
+    MI_HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    MI_REQUIRE(gran && VMM_PIECE % gran == 0, "the driver's mapping granularity does not divide 64 MiB");
+    const uint64_t size = (bytes + VMM_PIECE - 1) / VMM_PIECE * VMM_PIECE;
+    void *p = nullptr;
+    MI_HIP_CHECK(hipMemAddressReserve(&p, size, VMM_PIECE, nullptr, 0));
+    {
+        std::lock_guard<std::mutex> lock(g_vmm_mu);
+        VmmRange &R = g_vmm[(uintptr_t)p];
+        R.device = c->device; R.bytes = size;
+    }
+    mi_own_add(p, size, c->logical, "mi_vmm_reserve");
+    *base = p;
+    return MI_OK;
+}
+// physical memory under [offset, offset + bytes) of the range (widened to 64 MiB boundaries); what is backed already stays as it is.
+// Fresh pieces are NOT zeroed.
+extern "C" int mi_vmm_back(mi_ctx *c, void *base, uint64_t offset, uint64_t bytes)
+{
+    CTX_OK(c);
+    if (!bytes) return MI_OK;
+    std::lock_guard<std::mutex> lock(g_vmm_mu);
+    auto it = g_vmm.find((uintptr_t)base);
+    MI_REQUIRE(it != g_vmm.end(), "not a range of mi_vmm_reserve");
+    VmmRange &R = it->second;
+    MI_REQUIRE(R.device == c->device, "the range belongs to another device");
+    MI_REQUIRE(offset + bytes <= R.bytes && offset + bytes >= offset, "beyond the reserved range");
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = R.device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (uint64_t i = offset / VMM_PIECE; i <= (offset + bytes - 1) / VMM_PIECE; i++) {
+        if (R.pieces.count(i)) continue;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, VMM_PIECE, &prop, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            mi_set_error("mi_vmm_back: cannot create a 64 MiB piece of device memory (%s); %.1f GB backed in this range, %.1f of %.1f GB free on device %d",
+                         hipGetErrorString(e), R.backed / 1e9, fr / 1e9, tot / 1e9, R.device);
+            return MI_ERR_NOMEM;
+        }
+        char *at = (char *)base + i * VMM_PIECE;
+        e = hipMemMap(at, VMM_PIECE, 0, h, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemRelease(h);
+            mi_set_error("mi_vmm_back: hipMemMap of the piece at offset %.2f GB failed: %s", i * VMM_PIECE / 1e9, hipGetErrorString(e));
+            return MI_ERR_HIP;
+        }
+        e = hipMemSetAccess(at, VMM_PIECE, &acc, 1);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemUnmap(at, VMM_PIECE);
+            (void)hipMemRelease(h);
+            mi_set_error("mi_vmm_back: hipMemSetAccess of the piece at offset %.2f GB failed: %s", i * VMM_PIECE / 1e9, hipGetErrorString(e));
+            return MI_ERR_HIP;
+        }
+        R.pieces[i] = h;
+        R.backed += VMM_PIECE;
+    }
+    return MI_OK;
+}
+// one more device may read and write the backed parts of the range directly (a peer's kernels write a shard's row image); parts backed
+// LATER are not covered: call it again after mi_vmm_back
+extern "C" int mi_vmm_allow_peer(mi_ctx *c, void *base, int peer_device)
+{
+    CTX_OK(c);
+    std::lock_guard<std::mutex> lock(g_vmm_mu);
+    auto it = g_vmm.find((uintptr_t)base);
+    MI_REQUIRE(it != g_vmm.end(), "not a range of mi_vmm_reserve");
+    if (peer_device == it->second.device) return MI_OK;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = peer_device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (auto &pc : it->second.pieces) MI_HIP_CHECK(hipMemSetAccess((char *)base + pc.first * VMM_PIECE, VMM_PIECE, &acc, 1));
+    return MI_OK;
+}
+extern "C" int mi_vmm_backed_bytes(mi_ctx *c, void *base, uint64_t *bytes)
+{
+    CTX_OK(c);
+    std::lock_guard<std::mutex> lock(g_vmm_mu);
+    auto it = g_vmm.find((uintptr_t)base);
+    MI_REQUIRE(it != g_vmm.end() && bytes, "not a range of mi_vmm_reserve");
+    *bytes = it->second.backed;
+    return MI_OK;
+}
+extern "C" int mi_vmm_free(mi_ctx *c, void *base)
+{
+    CTX_OK(c);
+    if (!base) return MI_OK;
+    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lock(g_vmm_mu);
+    auto it = g_vmm.find((uintptr_t)base);
+    MI_REQUIRE(it != g_vmm.end(), "not a range of mi_vmm_reserve");
+    for (auto &pc : it->second.pieces) {
+        (void)hipMemUnmap((char *)base + pc.first * VMM_PIECE, VMM_PIECE);
+        (void)hipMemRelease(pc.second);
+    }
+    (void)hipMemAddressFree(base, it->second.bytes);
+    g_vmm.erase(it);
+    mi_own_del(base);
     return MI_OK;
 }
 
 extern "C" int mi_copy_h2d(mi_ctx *c, void *dst, const void *src, uint64_t bytes)
 {
     CTX_OK(c);
+    MI_OWN(c, dst);
     MI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
     return MI_OK;
@@ -937,6 +1204,7 @@ extern "C" int mi_copy_h2d(mi_ctx *c, void *dst, const void *src, uint64_t bytes
 extern "C" int mi_dev_zero(mi_ctx *c, void *p, uint64_t bytes)
 {
     CTX_OK(c);
+    MI_OWN(c, p);
     if (!bytes) return MI_OK;
     MI_REQUIRE(p, "null buffer");
     MI_HIP_CHECK(hipMemsetAsync(p, 0, bytes, c->stream));
@@ -947,6 +1215,7 @@ extern "C" int mi_dev_zero(mi_ctx *c, void *p, uint64_t bytes)
 extern "C" int mi_copy_h2d_2d(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src, uint64_t src_pitch, uint64_t width, uint64_t rows)
 {
     CTX_OK(c);
+    MI_OWN(c, dst);
     if (!width || !rows) return MI_OK;
     MI_REQUIRE(dst && src && dst_pitch >= width && src_pitch >= width, "bad 2-D copy");
     MI_HIP_CHECK(hipMemcpy2DAsync(dst, dst_pitch * 8, src, src_pitch * 8, width * 8, rows, hipMemcpyHostToDevice, c->stream));
@@ -957,6 +1226,7 @@ extern "C" int mi_copy_h2d_2d(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, cons
 extern "C" int mi_copy_d2h(mi_ctx *c, void *dst, const void *src, uint64_t bytes)
 {
     CTX_OK(c);
+    MI_OWN(c, src);
     MI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream));
     return MI_OK;

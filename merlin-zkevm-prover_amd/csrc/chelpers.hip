@@ -1198,6 +1198,21 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     MI_HIP_CHECK(hipSetDevice(c->device));
     MI_TRY(check_params(p, a, row0, nrows));
+    if (mi_check_on()) { // every table of the run belongs to the shard this context works for, and so does the program (its code object is loaded on ONE device)
+        // (checked where the run touches them: `pols` itself may be a VIRTUAL base -- a row shard's mirror holds the extended sections only,
+        // host/starks.hpp rowBase -- and the full-height tables are read at the run's rows)
+        for (const HostSection &S : p->sections)
+            if (S.role == 0 && a->pols) MI_TRY(mi_own_check(c->logical, (const u64 *)a->pols + S.offset + (p->stores_pols ? 0 : row0 * S.ncols), "mi_chelpers_run_dev (a section of params.pols)"));
+        for (const void *q : {(const void *)a->const_pols, (const void *)(a->x ? a->x + row0 * a->x_stride : nullptr), (const void *)(a->xdiv ? a->xdiv + 3 * row0 : nullptr),
+                              (const void *)(a->xdivw ? a->xdivw + 3 * row0 : nullptr), (const void *)(a->q ? a->q + 3 * row0 : nullptr), (const void *)(a->f ? a->f + 3 * row0 : nullptr)})
+            MI_TRY(mi_own_check(c->logical, q, "mi_chelpers_run_dev"));
+        if (p->run_logical >= 0 && p->run_logical != c->logical) {
+            mi_set_error("MI_MULTI_CHECK: mi_chelpers_run_dev: the program was first run for logical shard %d and is now run for shard %d (a program is loaded on one device)", p->run_logical, c->logical);
+            fprintf(stderr, "mi_stark: %s\n", mi_last_error());
+            return MI_ERR_INVALID;
+        }
+        const_cast<mi_chelpers_prog *>(p)->run_logical = c->logical;
+    }
     if (p->native) return chp::native_run(c, p, a, row0, nrows);
     MI_REQUIRE(!p->stores_pols, "the base-domain steps run through the compiled kernels: call mi_chelpers_build_native first");
     MI_REQUIRE(p->dev, "program was compiled without a context");
@@ -1228,16 +1243,16 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     const uint64_t grid = std::min<uint64_t>(n_groups, per_cu * (uint64_t)c->cu_count);
     const uint64_t wg_stride = p->staged_cols * chp::RS + (uint64_t)p->cold_words * 64 + 64;
     const uint64_t scratch_bytes = grid * wg_stride * 8 + 4096;
-    if (c->chelpers_stage_bytes < scratch_bytes) {
-        if (c->chelpers_stage) MI_HIP_CHECK(hipFree(c->chelpers_stage));
-        c->chelpers_stage = nullptr;
-        c->chelpers_stage_bytes = 0;
-        hipError_t e = hipMalloc((void **)&c->chelpers_stage, scratch_bytes);
+    if (c->pool->chelpers_stage_bytes < scratch_bytes) {
+        if (c->pool->chelpers_stage) MI_HIP_CHECK(hipFree(c->pool->chelpers_stage));
+        c->pool->chelpers_stage = nullptr;
+        c->pool->chelpers_stage_bytes = 0;
+        hipError_t e = hipMalloc((void **)&c->pool->chelpers_stage, scratch_bytes);
         if (e != hipSuccess) {
             mi_set_error("cannot allocate %llu bytes of operand staging: %s", (unsigned long long)scratch_bytes, hipGetErrorString(e));
             return MI_ERR_NOMEM;
         }
-        c->chelpers_stage_bytes = scratch_bytes;
+        c->pool->chelpers_stage_bytes = scratch_bytes;
     }
     chp::GArgs A = {};
     A.n_sections = (uint32_t)p->sections.size();
@@ -1262,7 +1277,7 @@ extern "C" int mi_chelpers_run_dev(mi_ctx *c, const mi_chelpers_prog *p, const m
     A.lds_bytes = (uint32_t)lds;
     A.consts = c->chelpers_scratch;
     A.q = (u64 *)(p->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
-    A.scratch = c->chelpers_stage;
+    A.scratch = c->pool->chelpers_stage;
     if (!p->eval_patches.empty()) { // this proof's evaluations into the immediates that stand for them
         std::vector<chp::GInstr> patched(p->gpu);
         for (const mi_chelpers_prog::Patch &pt : p->eval_patches) patched[pt.instr].a_imm = gl::canon(a->evals[(uint64_t)pt.eval * 3 + pt.word]);

@@ -185,6 +185,7 @@ struct HostTmp {
 // [tile of 64 rows][column][row in tile] (mi_chelpers_set_tiled_section): the generated kernels read it in place, nothing is copied
 struct HostSection { uint64_t offset, ncols, nrows; uint32_t col0; int role; bool tiled = false; };
 struct mi_chelpers_prog {
+    int run_logical = -1;          // MI_MULTI_CHECK: the logical shard the program first ran for (common.h)
     std::vector<chp::DInstr> host; // the translated program, operands in place (host debug executor)
     std::vector<chp::GInstr> gpu;  // the same program over staged columns (kernel)
     chp::GInstr *dev = nullptr;

@@ -1306,17 +1306,18 @@ int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_
     const NativeProg *N = P->native;
     MI_REQUIRE(N, "native code was not built");
     uint64_t batch = c->chelpers_batch_rows;
-    if (batch == 0) { // about 8 GiB of tile-major copy
-        batch = (8ull << 30) / ((uint64_t)N->sc * 8);
+    if (batch == 0) { // about 8 GiB of tile-major copy (MI_CHELPERS_BATCH_GIB: another size -- a one-GPU rehearsal of eight shards at full size has 2)
+        static const double gib = [] { const char *e = getenv("MI_CHELPERS_BATCH_GIB"); const double v = e ? atof(e) : 8.0; return v >= 0.01 && v <= 64 ? v : 8.0; }();
+        batch = (uint64_t)(gib * (double)(1ull << 30)) / ((uint64_t)N->sc * 8);
         batch = std::max<uint64_t>(64, batch & ~(uint64_t)63);
     }
     batch = std::min(batch, (nrows + 63) & ~(uint64_t)63);
     const uint64_t max_tiles = batch / 64;
     MI_REQUIRE(max_tiles + 1 < (1ull << 31), "batch too large");
-    MI_TRY(grow(&c->chelpers_tiled, &c->chelpers_tiled_bytes, (max_tiles + 1) * N->sc * 512, "the tile-major operand copy"));
-    MI_TRY(grow(&c->chelpers_spill, &c->chelpers_spill_bytes, max_tiles * N->nw * 512, "the chunk-boundary spill"));
-    MI_TRY(grow(&c->chelpers_cst, &c->chelpers_cst_bytes, (uint64_t)N->cst_words * 8 + 64, "the constraint program's constants"));
-    if (N->n_lin_sums) MI_TRY(grow(&c->chelpers_lin, &c->chelpers_lin_bytes, max_tiles * N->n_lin_sums * 3 * 512, "the linear sums"));
+    MI_TRY(grow(&c->pool->chelpers_tiled, &c->pool->chelpers_tiled_bytes, (max_tiles + 1) * N->sc * 512, "the tile-major operand copy"));
+    MI_TRY(grow(&c->pool->chelpers_spill, &c->pool->chelpers_spill_bytes, max_tiles * N->nw * 512, "the chunk-boundary spill"));
+    MI_TRY(grow(&c->pool->chelpers_cst, &c->pool->chelpers_cst_bytes, (uint64_t)N->cst_words * 8 + 64, "the constraint program's constants"));
+    if (N->n_lin_sums) MI_TRY(grow(&c->pool->chelpers_lin, &c->pool->chelpers_lin_bytes, max_tiles * N->n_lin_sums * 3 * 512, "the linear sums"));
     if (batch_out) *batch_out = batch;
     return MI_OK;
 }
@@ -1355,9 +1356,9 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     std::vector<u64> cst;
     fill_constants(P, N, a, cst);
     const uint64_t cst_words = N->cst_words;
-    MI_TRY(grow(&c->chelpers_cst, &c->chelpers_cst_bytes, cst_words * 8 + 64, "the constraint program's constants"));
+    MI_TRY(grow(&c->pool->chelpers_cst, &c->pool->chelpers_cst_bytes, cst_words * 8 + 64, "the constraint program's constants"));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // an earlier run may still be reading the table
-    MI_HIP_CHECK(hipMemcpyAsync(c->chelpers_cst, cst.data(), cst_words * 8, hipMemcpyHostToDevice, c->stream));
+    MI_HIP_CHECK(hipMemcpyAsync(c->pool->chelpers_cst, cst.data(), cst_words * 8, hipMemcpyHostToDevice, c->stream));
     if (!N->lin_dev.empty()) { // the linear kernel's terms with this proof's coefficients
         std::vector<LinTermW> tw(N->lin_dev.size());
         for (size_t i = 0; i < tw.size(); i++) {
@@ -1394,25 +1395,25 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             if (S.tiled) { xsec = ptr; continue; } // read in place
             if (!N->sec_slab_mask[si]) continue;
             hipLaunchKernelGGL(k_chp_transpose, dim3((unsigned)(tiles + 1), (unsigned)((S.ncols + 63) / 64)), dim3(256), 0, c->stream, ptr, pitch,
-                               (uint32_t)S.ncols, S.nrows - 1, c->chelpers_tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
+                               (uint32_t)S.ncols, S.nrows - 1, c->pool->chelpers_tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
             MI_HIP_CHECK(hipGetLastError());
         }
         if (N->n_lin_sums) {
             const dim3 g((unsigned)tiles), bl(64);
             const uint32_t ns = (uint32_t)N->lin_slabs.size();
             switch (N->n_lin_sums) {
-            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 1u); break;
-            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 2u); break;
-            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 3u); break;
-            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->chelpers_lin, b0, 4u); break;
+            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 1u); break;
+            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 2u); break;
+            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 3u); break;
+            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 4u); break;
             }
             MI_HIP_CHECK(hipGetLastError());
         }
         for (Chunk &C : N->chunks) {
-            const u64 *tiled = c->chelpers_tiled, *cstp = c->chelpers_cst;
-            u64 *spill = c->chelpers_spill, *outp = out;
+            const u64 *tiled = c->pool->chelpers_tiled, *cstp = c->pool->chelpers_cst;
+            u64 *spill = c->pool->chelpers_spill, *outp = out;
             uint64_t row_base = b0, rend = row_end;
-            const u64 *linp = c->chelpers_lin;
+            const u64 *linp = c->pool->chelpers_lin;
             const u64 *polsp = (const u64 *)a->pols, *cpolsp = (const u64 *)a->const_pols;
             void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &xsec, &polsp, &cpolsp};
             MI_HIP_CHECK(hipModuleLaunchKernel(C.fn, (unsigned)tiles, 1, 1, 64, 1, 1, 0, c->stream, args, nullptr));

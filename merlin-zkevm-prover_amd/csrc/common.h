@@ -70,8 +70,31 @@ struct NttPlan {
     PowTable lde_scale; // shift^k / n
 };
 
+// Grow-only device buffers the entry points size per call.  A context owns one set; the contexts of shards that share a physical device
+// (csrc/multi.hip, "device groups": a one-GPU box rehearsing eight shards at full size) point at their group leader's set instead --
+// they also share the leader's streams, so the users of a buffer are ordered -- and eight shards do not hold eight 8 GiB operand copies.
+struct CtxPool {
+    // device scratch of the entry points that need a few hundred MB per call (plookup tables, evaluation partials): kept
+    // for the life of the context -- memory that goes back to the driver, also through the stream-ordered pool, is wiped in the
+    // background and slows down whatever runs next (DESIGN.md, "released and fresh device memory")
+    char *scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    u64 *chelpers_stage = nullptr;   // constraint evaluators: per-workgroup transposed operand staging
+    uint64_t chelpers_stage_bytes = 0;
+    // native-code constraint evaluators (chelpers_native.hip): constants table, tile-major operand copy of one batch of rows, chunk spill
+    u64 *chelpers_cst = nullptr, *chelpers_tiled = nullptr, *chelpers_spill = nullptr, *chelpers_lin = nullptr;
+    uint64_t chelpers_cst_bytes = 0, chelpers_tiled_bytes = 0, chelpers_spill_bytes = 0, chelpers_lin_bytes = 0;
+};
+
 struct mi_ctx {
     int device = 0;
+    // The LOGICAL shard this context works for (csrc/multi.hip sets it: shard g's context; 0 for every other context, the home of a
+    // proof's image included).  Several shards may sit on one physical device; with MI_MULTI_CHECK=1 every device pointer an entry point
+    // is handed must belong to the context's logical shard (mi_own_check), so that a one-GPU rehearsal catches what only a real multi-GPU
+    // node would otherwise show: a buffer, a program or an event of one shard used on behalf of another.
+    int logical = 0;
+    CtxPool own_pool;
+    CtxPool *pool = &own_pool;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int poseidon_variant = 2; // 2 = full rounds on 32-bit halves (v_mad_u64_u32) + grouped optimised partial rounds; 0 / 1 = naive rounds
@@ -88,11 +111,6 @@ struct mi_ctx {
     u64 *pinned = nullptr; // 4 KiB of page-locked host memory: the few words an entry point hands back (a hash, a flag) are copied
                            // through it -- pageable async copies go through the runtime's staging pool, whose housekeeping after a
                            // few dozen of them stalled a later launch by ~40 ms (seen in an earlier benchmark's FRI phase)
-    // grow-only device scratch of the entry points that need a few hundred MB per call (plookup tables, evaluation partials): kept
-    // for the life of the context -- memory that goes back to the driver, also through the stream-ordered pool, is wiped in the
-    // background and slows down whatever runs next (DESIGN.md, "released and fresh device memory")
-    char *scratch = nullptr;
-    uint64_t scratch_bytes = 0;
     std::map<uint32_t, NttPlan> plans;
     std::vector<void *> owned; // tables to free
     static constexpr int N_TIMERS = 64;
@@ -116,11 +134,6 @@ struct mi_ctx {
     u64 *pack_stage[3] = {};
     uint64_t pack_stage_bytes = 0; // of each
     hipEvent_t ev_pack_sent[3] = {};
-    u64 *chelpers_stage = nullptr;   // constraint evaluators: per-workgroup transposed operand staging
-    uint64_t chelpers_stage_bytes = 0;
-    // native-code constraint evaluators (chelpers_native.hip): constants table, tile-major operand copy of one batch of rows, chunk spill
-    u64 *chelpers_cst = nullptr, *chelpers_tiled = nullptr, *chelpers_spill = nullptr, *chelpers_lin = nullptr;
-    uint64_t chelpers_cst_bytes = 0, chelpers_tiled_bytes = 0, chelpers_spill_bytes = 0, chelpers_lin_bytes = 0;
     uint64_t chelpers_batch_rows = 0; // rows per batch (0: sized for about 8 GiB of operand copy)
     uint64_t chelpers_min_words = 0; // benchmarking: LDS words per row to allocate at least (occupancy of a bigger program)
     // Entry points serialise on the context (scratch, plans, workspace and timers are shared state) and make
@@ -130,6 +143,20 @@ struct mi_ctx {
 };
 
 int mi_ensure_workspace(mi_ctx *ctx, uint64_t bytes);
+
+// ---- MI_MULTI_CHECK=1: which logical shard owns which device address range (capi.hip).  Every allocation the library makes for a shard
+// (mi_dev_alloc, mi_vmm_reserve, the pools and buffers of csrc/multi.hip) is entered; an entry point then refuses a pointer that belongs
+// to ANOTHER shard than the one its context works for.  Addresses nobody entered (a caller's own allocations: torch tensors in the tests)
+// pass and are counted.  Off (the default): one relaxed load per entry point.
+bool mi_check_on();
+void mi_own_add(const void *p, uint64_t bytes, int shard, const char *what);
+void mi_own_del(const void *p);
+void mi_own_set_leaders(const uint32_t *lead, uint32_t n); // device groups: a group's shards share buffers (the check compares leaders)
+int mi_own_check(int shard, const void *p, const char *what); // MI_OK, or MI_ERR_INVALID with the two shards and the range's name in mi_last_error
+#define MI_OWN(c, p)                                                                   \
+    do {                                                                               \
+        if (mi_check_on()) MI_TRY(mi_own_check((c)->logical, (const void *)(p), __func__)); \
+    } while (0)
 int mi_scratch(mi_ctx *ctx, uint64_t bytes, void **p); // *p = ctx->scratch, at least `bytes` long; stream-ordered use only
 int mi_get_plan(mi_ctx *ctx, uint32_t log_n, NttPlan **plan);
 int mi_make_pow_table(mi_ctx *ctx, PowTable *t, uint64_t count_log, u64 s0, u64 g);

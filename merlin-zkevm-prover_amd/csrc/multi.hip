@@ -15,6 +15,18 @@
 // then each shard builds the subtree over its rows, the G subtree roots meet on shard 0 and the top log2 G levels are hashed there:
 // the same root, node for node, as the single-device tree.  Openings: the row's values from the owning shard's column windows, its
 // lower siblings from that shard's subtree, the top log2 G from the roots' tree.
+//
+// Round 5.  (1) TRANSIENT commits (mi_multi_set_transient: what a row-sharded Starks::genProof asks for): every shard names a row image,
+// nobody will open values from the tree, so a tile's rows are written ONCE -- by a kernel of the extending shard straight into each
+// owner's row image, where the leaf sponge then absorbs them at the image's pitch -- instead of twice (contiguous windows + image);
+// the extended tiles live in a ring of two, the windows are gone: 21.5 GB of buffers per device at zkEVM size instead of 36.5, half the
+// bytes on the links.  (2) DEVICE GROUPS (mi_multi_create2(..., group_same_device)): shards that share a physical device share that
+// device's streams, staging, tile ring, NTT workspace and per-context pools -- ordered by the one stream -- so that eight logical shards
+// at the full 2^23 rows fit one GPU.  Off (the default), every shard is its own group, as on a real node.  (3) Cross-device 2-D copies
+// (row images, the image, the base section, device sources) are KERNELS of the device that issues them (k_rows_2d), not
+// hipMemcpy2DAsync(hipMemcpyDefault): 256-byte rows at a 5 320-byte pitch across xGMI behave the same on every runtime, and a
+// one-GPU box runs the very code an eight-GPU node runs.  (4) MI_MULTI_CHECK=1: every buffer, stream and event belongs to a logical
+// shard; an operation issued for shard g that touches another shard's is refused (common.h mi_own_check), peer operands are declared.
 #include "common.h"
 #include <algorithm>
 #include <chrono>
@@ -50,13 +62,35 @@ struct Plan { // merlin-zkevm-prover_amd/shard.py ShardPlan, word for word in me
 
 struct Stats { double lde_ms = 0, absorb_ms = 0, wait_ms = 0, upload_ms = 0; std::vector<uint64_t> bytes_to; };
 
+// rows x w words from src (row pitch spitch) to dst (row pitch dpitch): the 2-D copies of a commit as a kernel of the issuing device.
+// One element per lane and step: a row segment of 32 columns is one 256-byte run on both sides, whatever the pitches' alignment
+// (a 665-column section starts its rows on 8-byte boundaries only).
+__global__ __launch_bounds__(256) void k_rows_2d(u64 *__restrict__ dst, uint64_t dpitch, const u64 *__restrict__ src, uint64_t spitch, uint32_t w, uint64_t rows)
+{
+    const uint64_t total = rows * w, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+        const uint64_t r = e / w;
+        const uint32_t c = (uint32_t)(e - r * w);
+        dst[r * dpitch + c] = src[r * spitch + c];
+    }
+}
+
 } // namespace
 
 struct mi_multi {
     uint32_t G = 0;
     std::vector<int> dev;
     std::vector<mi_ctx *> ctx;
+    // device groups: lead[g] = the first shard of g's group (g itself unless mi_multi_create2 grouped the shards of one physical device).
+    // A group has ONE set of streams (cs[g] == cs[lead[g]] ...), one staging ring, one tile ring, one NTT workspace; its contexts share
+    // the leader's pools (CtxPool).  Everything a group does is ordered by its streams.
+    std::vector<uint32_t> lead;
+    bool grouped = false;
     std::vector<hipStream_t> cs, xs, us, us2; // compute, exchange, upload (us2: the lower rows of a strided upload -- a second DMA engine)
+    std::vector<hipStream_t> own_streams;     // what mi_multi_destroy destroys (a grouped shard's entries above are its leader's)
+    bool transient_next = false;              // mi_multi_set_transient: the NEXT commit keeps no rows (row images for every shard)
+    // MI_MULTI_CHECK: which group a stream or an event was created for; an event is recorded on a stream of ITS group only
+    std::map<void *, uint32_t> tag;
     std::vector<hipEvent_t> ev_us2;           // per shard: us2's half of the current tile is up
     int upload_mode = -1;                     // -1 auto (page-locked source -> strided DMA, pageable -> host-packed), 0 packed, 1 strided
     int last_upload = -1;                     // what the last commit did: -1 device source, 0 host-packed staging, 1 strided DMA from the page-locked source
@@ -110,6 +144,8 @@ struct mi_multi_tree {
     bool keep_rows = true;                      // ext / recv still hold the rows (openings read them)
     std::vector<char> rows_lent;                // per shard: ext / recv / stage live in a lent region (not freed here)
     uint64_t e_ext = 0, e_recv = 0, e_stage = 0, e_nodes = 0; // elements of the buffers (for the pool)
+    std::vector<u64 *> gbuf;                    // transient commits: per group leader, [tile ring | staging | NTT workspace] while the commit runs
+    uint64_t e_gbuf = 0;
 };
 
 #define MM_DEV(m, g) MI_HIP_CHECK(hipSetDevice((m)->dev[g]))
@@ -117,7 +153,52 @@ struct mi_multi_tree {
 extern "C" void mi_multi_destroy(mi_multi *m);
 static int copy_dd(const mi_multi *m, void *dst, int gd, const void *src, int gs, uint64_t bytes, hipStream_t s);
 
+// ---- MI_MULTI_CHECK helpers: events and streams carry the group they were created for
+static int mm_own(const mi_multi *m, uint32_t shard, const void *p, const char *what)
+{
+    (void)m;
+    return mi_check_on() ? mi_own_check((int)shard, p, what) : MI_OK;
+}
+#define MM_OWN(m, g, p, what) MI_TRY(mm_own(m, g, p, what))
+static int mm_new_event(mi_multi *m, uint32_t g, hipEvent_t *e, unsigned flags)
+{
+    MI_HIP_CHECK(hipEventCreateWithFlags(e, flags));
+    if (mi_check_on()) m->tag[(void *)*e] = m->lead[g];
+    return MI_OK;
+}
+static void mm_del_event(mi_multi *m, hipEvent_t e)
+{
+    if (!e) return;
+    if (mi_check_on()) m->tag.erase((void *)e);
+    (void)hipEventDestroy(e);
+}
+// hipEventRecord, refused when the event was created for another group than the stream's (on a real node: for another device)
+static int mm_record(mi_multi *m, hipEvent_t e, hipStream_t s)
+{
+    if (mi_check_on()) {
+        auto a = m->tag.find((void *)e), b = m->tag.find((void *)s);
+        if (a != m->tag.end() && b != m->tag.end() && a->second != b->second) {
+            mi_set_error("MI_MULTI_CHECK: an event of shard group %u is recorded on a stream of group %u (on a real multi-GPU node: an event of another device)", a->second, b->second);
+            fprintf(stderr, "mi_stark: %s\n", mi_last_error());
+            return MI_ERR_INVALID;
+        }
+    }
+    MI_HIP_CHECK(hipEventRecord(e, s));
+    return MI_OK;
+}
+#define MM_RECORD(m, e, s) MI_TRY(mm_record(m, e, s))
+
+extern "C" int mi_multi_create2(mi_multi **out, const int *devices, int n_shards, int group_same_device);
 extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
+{
+    const char *e = getenv("MI_MULTI_GROUP_SAME_DEVICE");
+    return mi_multi_create2(out, devices, n_shards, e && e[0] == '1');
+}
+
+// group_same_device != 0: shards that name the same physical device form one GROUP (see the header of this file): one set of streams
+// and buffers for all of them.  What a one-GPU box needs to rehearse many shards at full size; on a node with one shard per device it
+// changes nothing.
+extern "C" int mi_multi_create2(mi_multi **out, const int *devices, int n_shards, int group_same_device)
 {
     MI_REQUIRE(out && devices && n_shards >= 1 && is_pow2((uint64_t)n_shards), "the number of shards must be a power of two");
     MI_REQUIRE(n_shards <= MI_MAX_SLABS, "at most 16 shards (one leaf-hash launch absorbs one column window per shard)");
@@ -139,24 +220,45 @@ extern "C" int mi_multi_create(mi_multi **out, const int *devices, int n_shards)
     m->lent.assign(n_shards, nullptr);
     m->lent_elems.assign(n_shards, 0);
     m->pool.resize(n_shards);
+    m->grouped = group_same_device != 0;
+    m->lead.resize(n_shards);
+    for (int g = 0; g < n_shards; g++) {
+        m->lead[g] = (uint32_t)g;
+        for (int h = 0; h < g && m->grouped; h++)
+            if (devices[h] == devices[g]) { m->lead[g] = (uint32_t)h; break; }
+    }
+    mi_own_set_leaders(m->lead.data(), (uint32_t)n_shards);
     for (int g = 0; g < n_shards; g++) {
         mi_ctx *c = nullptr;
         int st = mi_ctx_create(&c, devices[g]);
         if (st != MI_OK) { mi_multi_destroy(m); return st; }
+        c->logical = g;
         m->ctx.push_back(c);
+        const uint32_t L = m->lead[g];
+        if (L != (uint32_t)g) { // a grouped shard: its leader's streams and pools
+            c->pool = &m->ctx[L]->own_pool;
+            m->cs.push_back(m->cs[L]); m->xs.push_back(m->xs[L]); m->us.push_back(m->us[L]); m->us2.push_back(m->us2[L]);
+            m->ev_us2.push_back(nullptr);
+            for (int i = 0; i < mi_multi::HS; i++) m->hstage_sent[i].push_back(nullptr);
+            mi_ctx_set_stream(c, m->cs[L]);
+            continue;
+        }
         hipStream_t s[4];
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++) {
             if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) { mi_set_error("mi_multi_create: cannot create a stream"); mi_multi_destroy(m); return MI_ERR_HIP; }
+            m->own_streams.push_back(s[i]);
+            if (mi_check_on()) m->tag[(void *)s[i]] = (uint32_t)g;
+        }
         m->cs.push_back(s[0]); m->xs.push_back(s[1]); m->us.push_back(s[2]); m->us2.push_back(s[3]);
         {
             hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { mi_set_error("mi_multi_create: cannot create an event"); mi_multi_destroy(m); return MI_ERR_HIP; }
+            if (mm_new_event(m, (uint32_t)g, &e, hipEventDisableTiming) != MI_OK) { mi_set_error("mi_multi_create: cannot create an event"); mi_multi_destroy(m); return MI_ERR_HIP; }
             m->ev_us2.push_back(e);
         }
         mi_ctx_set_stream(c, s[0]);
         for (int i = 0; i < mi_multi::HS; i++) {
             hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { mi_set_error("mi_multi_create: cannot create an event"); mi_multi_destroy(m); return MI_ERR_HIP; }
+            if (mm_new_event(m, (uint32_t)g, &e, hipEventDisableTiming) != MI_OK) { mi_set_error("mi_multi_create: cannot create an event"); mi_multi_destroy(m); return MI_ERR_HIP; }
             m->hstage_sent[i].push_back(e);
         }
     }
@@ -216,12 +318,14 @@ extern "C" void mi_multi_destroy(mi_multi *m)
         (void)hipSetDevice(m->dev[g]);
         if (g < m->cs.size()) { (void)hipStreamSynchronize(m->cs[g]); (void)hipStreamSynchronize(m->xs[g]); (void)hipStreamSynchronize(m->us[g]); }
         if (g < m->us2.size()) (void)hipStreamSynchronize(m->us2[g]);
-        if (g < m->pool.size()) for (auto &c : m->pool[g]) (void)hipFree(c.p);
-        if (m->ctx[g]) { mi_ctx_set_stream(m->ctx[g], nullptr); mi_ctx_destroy(m->ctx[g]); }
-        if (g < m->cs.size()) { (void)hipStreamDestroy(m->cs[g]); (void)hipStreamDestroy(m->xs[g]); (void)hipStreamDestroy(m->us[g]); }
-        if (g < m->us2.size()) (void)hipStreamDestroy(m->us2[g]);
+    }
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        (void)hipSetDevice(m->dev[g]);
+        if (g < m->pool.size()) for (auto &c : m->pool[g]) { mi_own_del(c.p); (void)hipFree(c.p); }
+        if (m->ctx[g]) { m->ctx[g]->pool = &m->ctx[g]->own_pool; mi_ctx_set_stream(m->ctx[g], nullptr); mi_ctx_destroy(m->ctx[g]); }
         if (g < m->ev_us2.size() && m->ev_us2[g]) (void)hipEventDestroy(m->ev_us2[g]);
     }
+    for (hipStream_t s : m->own_streams) (void)hipStreamDestroy(s); // (a stream is destroyed on any current device)
     for (int i = 0; i < mi_multi::HS; i++) {
         if (m->hstage[i]) (void)hipHostFree(m->hstage[i]);
         for (hipEvent_t e : m->hstage_sent[i]) if (e) (void)hipEventDestroy(e);
@@ -230,6 +334,8 @@ extern "C" void mi_multi_destroy(mi_multi *m)
 }
 
 extern "C" int mi_multi_shards(const mi_multi *m) { return m ? (int)m->G : 0; }
+// the first shard of `shard`'s device group (the shard itself unless mi_multi_create2 grouped the shards of one physical device)
+extern "C" int mi_multi_lead(const mi_multi *m, int shard) { return (m && shard >= 0 && (uint32_t)shard < m->G) ? (int)m->lead[shard] : -1; }
 // The peer-access matrix recorded by mi_multi_create: out[a * G + b] for shard a's device reaching shard b's memory -- 2 same device,
 // 1 enabled, 0 no direct access, -1 enabling failed.  Returns the number of pairs that are neither 1 nor 2; warning (optional) receives
 // the sentence mi_multi_create printed about them ("" when every pair is direct).
@@ -304,6 +410,8 @@ extern "C" int mi_multi_set_device(mi_multi *m, int shard)
 extern "C" int mi_multi_copy(mi_multi *m, void *dst, int dst_shard, const void *src, int src_shard, uint64_t bytes)
 {
     MI_REQUIRE(m && dst && src && dst_shard >= 0 && (uint32_t)dst_shard < m->G && src_shard >= 0 && (uint32_t)src_shard < m->G, "bad argument");
+    MM_OWN(m, (uint32_t)dst_shard, dst, "mi_multi_copy (dst: memory of dst_shard)");
+    MM_OWN(m, (uint32_t)src_shard, src, "mi_multi_copy (src: memory of src_shard)");
     MM_DEV(m, src_shard);
     return copy_dd(m, dst, dst_shard, src, src_shard, bytes, m->cs[src_shard]);
 }
@@ -328,8 +436,12 @@ extern "C" void mi_multi_tree_free(mi_multi_tree *t)
         if (!lent && g < t->recv.size()) back(t->recv[g], t->e_recv);
         if (g < t->nodes.size()) back(t->nodes[g], t->e_nodes);
         if (!lent && g < t->stage.size()) back(t->stage[g], t->e_stage);
+        if (g < t->gbuf.size() && t->gbuf[g]) { // a transient commit that did not finish: its group's contexts still work in the buffer
+            for (uint32_t h = 0; h < m->G; h++) if (m->lead[h] == g) (void)mi_ctx_lend_workspace(m->ctx[h], nullptr, 0);
+            if (!lent) back(t->gbuf[g], t->e_gbuf);
+        }
     }
-    if (t->roots) { (void)hipSetDevice(m->dev[0]); (void)hipFree(t->roots); }
+    if (t->roots) { (void)hipSetDevice(m->dev[0]); mi_own_del(t->roots); (void)hipFree(t->roots); }
     delete t;
 }
 
@@ -361,6 +473,138 @@ static int copy_dd(const mi_multi *m, void *dst, int gd, const void *src, int gs
     return MI_OK;
 }
 
+// rows x w words, 2-D, issued by shard g on stream s: a kernel of g's device when g's device reaches both sides directly (always, inside
+// one device; across devices when peer access is on: the recorded matrix), the runtime's 2-D copy -- staged through the host -- otherwise
+static int rows_2d(const mi_multi *m, uint32_t g, int dst_dev, int src_dev, u64 *dst, uint64_t dpitch, const u64 *src, uint64_t spitch, uint64_t w, uint64_t rows, hipStream_t s)
+{
+    if (!w || !rows) return MI_OK;
+    auto direct = [&](int d) {
+        if (d == m->dev[g]) return true;
+        for (uint32_t q = 0; q < m->G; q++)
+            if (m->dev[q] == d) return m->peer[(size_t)g * m->G + q] == 1;
+        return false; // (a device no shard sits on: nobody asked the driver)
+    };
+    if (direct(dst_dev) && direct(src_dev)) {
+        const uint64_t total = rows * w;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(k_rows_2d, dim3(blocks), dim3(256), 0, s, dst, dpitch, src, spitch, (uint32_t)w, rows);
+        MI_HIP_CHECK(hipGetLastError());
+    } else {
+        MI_HIP_CHECK(hipMemcpy2DAsync(dst, dpitch * 8, src, spitch * 8, w * 8, rows, hipMemcpyDefault, s));
+    }
+    return MI_OK;
+}
+
+// The NEXT commit is TRANSIENT: nobody will open row values from its tree (mi_multi_group_proofs with_values, mi_multi_gather_rows) and
+// every shard has a row image (mi_multi_set_row_images with G non-null pointers): the tiles' rows go straight into the images and are
+// absorbed there; the tree keeps the subtrees only.  One-shot, like mi_multi_lend.  Without row images for every shard the commit refuses.
+extern "C" int mi_multi_set_transient(mi_multi *m, int on)
+{
+    MI_REQUIRE(m, "null argument");
+    m->transient_next = on != 0;
+    return MI_OK;
+}
+// elements of device memory a transient commit of this shape takes per device GROUP (tile ring + staging + NTT workspace): what
+// a caller that lends a region to a group's leader must offer (mi_multi_lend) for the commit to allocate nothing
+extern "C" uint64_t mi_multi_transient_need(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards)
+{
+    Plan p;
+    if (!shards || !is_pow2(shards)) return 0;
+    p.init(n, n_ext, ncols, shards);
+    const uint64_t maxw = *std::max_element(p.round_w.begin(), p.round_w.end());
+    const uint64_t al = 31;
+    return ((2 * n_ext * maxw + al) & ~al) + ((2 * n * maxw + al) & ~al) + std::max<uint64_t>((2 * n + n_ext) * maxw + 4096, 1ull << 17) + 64;
+}
+
+namespace {
+// what both forms of the commit share
+struct CommitEnv {
+    mi_multi *m; mi_multi_tree *t;
+    const uint64_t *src; uint64_t src_pitch; int src_device; uint32_t src_owner; // src_owner: the shard the device source belongs to
+    uint64_t n, n_ext, ncols;
+    bool from_host, strided;
+    int hs_next = 0;
+    std::vector<hipEvent_t> tm; // timing events, destroyed at the end
+    struct Timed { uint32_t g; int kind; hipEvent_t a, b; }; // kind 0 lde, 1 absorb, 2 wait
+    std::vector<Timed> timed;
+    ~CommitEnv() { for (hipEvent_t x : tm) if (x) (void)hipEventDestroy(x); }
+    int stamp(hipStream_t s, hipEvent_t *e)
+    {
+        MI_HIP_CHECK(hipEventCreate(e));
+        tm.push_back(*e);
+        MI_HIP_CHECK(hipEventRecord(*e, s));
+        return MI_OK;
+    }
+};
+
+// the base-domain columns [c0, c0 + w) of the section onto shard g's device, into `st` ([n x w] at pitch w): enqueued on g's upload
+// stream(s) behind `consumed` and `based` (the staging buffer's last readers), `up` is recorded when the tile is there
+int upload_tile(CommitEnv &E, uint32_t g, uint64_t w, uint64_t c0, u64 *st, hipEvent_t consumed, hipEvent_t based, hipEvent_t up)
+{
+    mi_multi *m = E.m;
+    const uint64_t n = E.n;
+    const uint32_t L = m->lead[g];
+    MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], consumed, 0));
+    MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], based, 0));
+    if (E.from_host && E.strided) {
+        // the tile's columns straight out of the caller's page-locked trace: rows of 8 w bytes at the trace's pitch, upper and lower
+        // rows on two streams (two DMA engines of THIS device; profiles/r02_pcie_chunk_sweep.json: 39.5 GB/s per link at 32 columns)
+        const uint64_t half = n / 2;
+        MI_HIP_CHECK(hipStreamWaitEvent(m->us2[g], consumed, 0));
+        MI_HIP_CHECK(hipStreamWaitEvent(m->us2[g], based, 0));
+        MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, E.src + c0, E.src_pitch * 8, w * 8, n - half, hipMemcpyHostToDevice, m->us[g]));
+        if (half) MI_HIP_CHECK(hipMemcpy2DAsync(st + (n - half) * w, w * 8, E.src + (n - half) * E.src_pitch + c0, E.src_pitch * 8, w * 8, half, hipMemcpyHostToDevice, m->us2[g]));
+        MM_RECORD(m, m->ev_us2[L], m->us2[g]);
+        MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], m->ev_us2[L], 0));
+    } else if (E.from_host) {
+        const int hs = E.hs_next++ % mi_multi::HS;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (m->hstage_user[hs] >= 0) MI_HIP_CHECK(hipEventSynchronize(m->hstage_sent[hs][m->hstage_user[hs]])); // the copy that last read this slot is done
+        u64 *hbuf = m->hstage[hs];
+        const uint64_t *src = E.src;
+        const uint64_t src_pitch = E.src_pitch;
+        const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)m->pack_threads, (n * w * 8) >> 22));
+        const uint64_t rows_per = (n + T - 1) / T;
+        std::vector<std::thread> th;
+        for (int ti = 0; ti < T; ti++) {
+            const uint64_t r0 = (uint64_t)ti * rows_per, r1 = std::min(n, r0 + rows_per);
+            if (r0 >= r1) break;
+            auto work = [=]() {
+                const uint64_t *s_ = src + r0 * src_pitch + c0;
+                u64 *d_ = hbuf + r0 * w;
+                if (w % 8 == 0) { // 64-byte groups: unaligned loads, streaming stores (the staging is read next by the DMA engine, not by this core)
+                    for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w)
+                        for (uint64_t j = 0; j < w; j += 8) {
+                            const __m128i v0 = _mm_loadu_si128((const __m128i *)(s_ + j)), v1 = _mm_loadu_si128((const __m128i *)(s_ + j + 2));
+                            const __m128i v2 = _mm_loadu_si128((const __m128i *)(s_ + j + 4)), v3 = _mm_loadu_si128((const __m128i *)(s_ + j + 6));
+                            _mm_stream_si128((__m128i *)(d_ + j), v0); _mm_stream_si128((__m128i *)(d_ + j + 2), v1);
+                            _mm_stream_si128((__m128i *)(d_ + j + 4), v2); _mm_stream_si128((__m128i *)(d_ + j + 6), v3);
+                        }
+                    _mm_sfence();
+                } else {
+                    for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w) memcpy(d_, s_, w * 8);
+                }
+            };
+            if (T == 1) work(); else th.emplace_back(work);
+        }
+        for (auto &x : th) x.join();
+        m->stats[g].upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        MI_HIP_CHECK(hipMemcpyAsync(st, hbuf, n * w * 8, hipMemcpyHostToDevice, m->us[g]));
+        MM_RECORD(m, m->hstage_sent[hs][L], m->us[g]);
+        m->hstage_user[hs] = (int)L;
+    } else {
+        // a device source (stages 2-4: a section of the proof's image): read by a kernel of THIS shard's device, across xGMI when the
+        // section lives on another one -- a declared peer operand
+        MM_OWN(m, E.src_owner, E.src + c0, "mi_multi_commit (the device source: memory of the shard that holds the section)");
+        MI_TRY(rows_2d(m, g, m->dev[g], E.src_device, st, w, (const u64 *)E.src + c0, E.src_pitch, w, n, m->us[g]));
+    }
+    MM_RECORD(m, up, m->us[g]);
+    return MI_OK;
+}
+} // namespace
+
+static int commit_transient(CommitEnv &E, uint64_t *base, uint64_t base_pitch, uint32_t base_owner);
+
 // Stage commit.  src: the n x ncols row-major base-domain section at row pitch src_pitch (elements) -- in HOST memory (src_device < 0;
 // pageable is fine, host threads read it) or on device `src_device` (the image of a proof: stages 2-4).  image / base (optional, on
 // device image_device): receive the whole extension (n_ext x ncols at image_pitch) / the section itself (n x ncols at base_pitch) in
@@ -369,15 +613,25 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
                                uint64_t ncols, uint64_t *image, uint64_t image_pitch, uint64_t *base, uint64_t base_pitch, int image_device, uint64_t root[4])
 {
     MI_REQUIRE(m, "null argument");
-    // mi_multi_lend and mi_multi_set_row_images arm ONE commit: they are disarmed however this call ends, also by a refused argument
-    // (a later commit, possibly of another stage, must not carve its buffers out of a region its caller considers live again)
-    struct RowImgGuard { mi_multi *m; ~RowImgGuard() { m->row_img.clear(); m->row_img_pitch = m->row_img_halo = 0; } } rowimgguard{m};
-    struct LendGuard { mi_multi *m; ~LendGuard() { for (uint32_t g = 0; g < m->G; g++) if (m->lent[g]) { (void)hipSetDevice(m->dev[g]); (void)mi_ctx_lend_workspace(m->ctx[g], nullptr, 0); m->lent[g] = nullptr; m->lent_elems[g] = 0; } } } lendguard{m};
+    // mi_multi_lend, mi_multi_set_row_images and mi_multi_set_transient arm ONE commit: they are disarmed however this call ends, also by
+    // a refused argument (a later commit, possibly of another stage, must not carve its buffers out of a region its caller considers
+    // live again)
+    struct RowImgGuard { mi_multi *m; ~RowImgGuard() { m->row_img.clear(); m->row_img_pitch = m->row_img_halo = 0; m->transient_next = false; } } rowimgguard{m};
+    struct LendGuard { mi_multi *m; ~LendGuard() { for (uint32_t g = 0; g < m->G; g++) if (m->lent[g]) { (void)hipSetDevice(m->dev[g]); for (uint32_t h = 0; h < m->G; h++) if (m->lead[h] == m->lead[g]) (void)mi_ctx_lend_workspace(m->ctx[h], nullptr, 0); m->lent[g] = nullptr; m->lent_elems[g] = 0; } } } lendguard{m};
     MI_REQUIRE(out && src && root, "null argument");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n && ncols > 4, "sizes: powers of two, more than 4 columns (linear_hash copies shorter rows)");
     MI_REQUIRE(n_ext % m->G == 0 && n_ext / m->G >= 2, "too few rows for this many shards");
     const auto t_begin = std::chrono::steady_clock::now();
     const uint32_t G = m->G;
+    int image_owner = -1; // the shard image / base belong to: the first one on image_device
+    for (uint32_t g = 0; g < G && image_owner < 0; g++) if (m->dev[g] == image_device) image_owner = (int)g;
+    MI_REQUIRE(!(image || base) || image_owner >= 0, "image_device is not the device of any shard");
+    int src_owner = 0;
+    if (src_device >= 0) {
+        src_owner = -1;
+        for (uint32_t g = 0; g < G && src_owner < 0; g++) if (m->dev[g] == src_device) src_owner = (int)g;
+        MI_REQUIRE(src_owner >= 0, "src_device is not the device of any shard");
+    }
     mi_multi_tree *t = new mi_multi_tree();
     struct Guard { mi_multi_tree *t; ~Guard() { if (t) mi_multi_tree_free(t); } } guard{t};
     t->m = m;
@@ -386,48 +640,23 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
     const size_t R = p.rounds();
     const uint64_t maxw = *std::max_element(p.round_w.begin(), p.round_w.end());
     constexpr int NS = 2; // device staging buffers per shard
-    t->ext.assign(G, nullptr); t->recv.assign(G, nullptr); t->nodes.assign(G, nullptr); t->stage.assign(G, nullptr);
+    t->ext.assign(G, nullptr); t->recv.assign(G, nullptr); t->nodes.assign(G, nullptr); t->stage.assign(G, nullptr); t->gbuf.assign(G, nullptr);
     t->rows_lent.assign(G, 0);
     MI_REQUIRE(m->row_img.empty() || (m->row_img_pitch >= ncols && m->row_img_halo <= n_ext / m->G), "row images: pitch smaller than ncols or halo larger than a shard");
+    if (mi_check_on())
+        for (uint32_t q = 0; q < G && !m->row_img.empty(); q++)
+            if (m->row_img[q]) MM_OWN(m, q, m->row_img[q] + (uint64_t)q * p.rows_per_rank * m->row_img_pitch, "mi_multi_set_row_images (imgs[q] is memory of shard q)");
+    const bool transient = m->transient_next;
+    if (transient) {
+        MI_REQUIRE(!m->row_img.empty() && !image, "a transient commit writes row images only (mi_multi_set_row_images for every shard, no whole-extension image)");
+        for (uint32_t q = 0; q < G; q++) MI_REQUIRE(m->row_img[q], "a transient commit needs a row image for EVERY shard");
+    }
+    CommitEnv E{m, t, src, src_pitch, src_device, (uint32_t)src_owner, n, n_ext, ncols, src_device < 0, false};
     for (uint32_t g = 0; g < G; g++) {
-        MM_DEV(m, g);
-        auto alloc = [&](u64 **q, uint64_t elems) -> int {
-            if ((*q = m->take(g, std::max<uint64_t>(elems, 1)))) return MI_OK;
-            hipError_t e = hipMalloc((void **)q, std::max<uint64_t>(elems, 1) * 8);
-            if (e != hipSuccess && !m->pool[g].empty()) { // make room: give the cached buffers back and try once more
-                (void)hipGetLastError();
-                for (auto &c : m->pool[g]) (void)hipFree(c.p);
-                m->pool[g].clear();
-                e = hipMalloc((void **)q, std::max<uint64_t>(elems, 1) * 8);
-            }
-            if (e != hipSuccess) { mi_set_error("mi_multi_commit: shard %u cannot allocate %.2f GB: %s", g, elems * 8 / 1e9, hipGetErrorString(e)); return MI_ERR_NOMEM; }
-            return MI_OK;
-        };
-        const uint64_t e_ext = (n_ext * p.per_rank + 31) & ~31ull, e_recv = G > 1 ? (p.rows_per_rank * G * p.per_rank + 31) & ~31ull : 0, e_stage = (NS * n * maxw + 31) & ~31ull;
-        t->e_ext = std::max<uint64_t>(n_ext * p.per_rank, 1); t->e_recv = std::max<uint64_t>(p.rows_per_rank * G * p.per_rank, 1); t->e_stage = std::max<uint64_t>(NS * n * maxw, 1);
-        t->e_nodes = std::max<uint64_t>((2 * p.rows_per_rank - 1) * 4, 1);
-        const uint64_t e_ws = (2 * n + n_ext) * maxw + 4096; // the tile's transforms (launch_lde into a compact window: INTT intermediate + one n_ext ping-pong buffer [+ coefficients when the middle pass is not fused])
-        if (m->lent[g] && m->lent_elems[g] >= e_ext + e_recv + e_stage + e_ws) { // the row buffers, the staging and the transforms' workspace out of the lent region
-            u64 *q = m->lent[g];
-            t->ext[g] = q; q += e_ext;
-            if (G > 1) { t->recv[g] = q; q += e_recv; }
-            t->stage[g] = q; q += e_stage;
-            MI_TRY(mi_ctx_lend_workspace(m->ctx[g], q, (m->lent_elems[g] - (uint64_t)(q - m->lent[g])) * 8));
-            t->rows_lent[g] = 1;
-        } else {
-            MI_TRY(alloc(&t->ext[g], n_ext * p.per_rank));
-            if (G > 1) MI_TRY(alloc(&t->recv[g], p.rows_per_rank * G * p.per_rank));
-            MI_TRY(alloc(&t->stage[g], NS * n * maxw));
-        }
-        MI_TRY(alloc(&t->nodes[g], (2 * p.rows_per_rank - 1) * 4));
         m->stats[g] = Stats();
         m->stats[g].bytes_to.assign(G, 0);
     }
-    MM_DEV(m, 0);
-    MI_HIP_CHECK(hipMalloc((void **)&t->roots, (2 * G - 1) * 4 * 8));
-    const bool from_host = src_device < 0;
-    bool strided = false; // host source read by the devices' DMA engines in place
-    if (from_host) {
+    if (E.from_host) {
         hipPointerAttribute_t at;
         const uint64_t last = (n - 1) * src_pitch + ncols - 1;
         bool locked = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
@@ -441,10 +670,10 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
         // where the packed form's contiguous copies are the faster (1.07 s against 1.40 s per zkEVM step: profiles/r04_sp4_upload_ab.json)
         bool two_devices = false;
         for (uint32_t g = 1; g < G; g++) two_devices = two_devices || m->dev[g] != m->dev[0];
-        strided = mode == 1 || (mode == -1 && locked && two_devices);
+        E.strided = mode == 1 || (mode == -1 && locked && two_devices);
     }
-    m->last_upload = from_host ? (strided ? 1 : 0) : -1;
-    if (from_host && !strided) {
+    m->last_upload = E.from_host ? (E.strided ? 1 : 0) : -1;
+    if (E.from_host && !E.strided) {
         const uint64_t need = n * maxw * 8;
         if (m->hstage_bytes < need) {
             for (int i = 0; i < mi_multi::HS; i++) {
@@ -457,47 +686,98 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
             m->hstage_bytes = need;
         }
     }
+    auto alloc = [&](uint32_t g, u64 **q, uint64_t elems, const char *what) -> int {
+        elems = std::max<uint64_t>(elems, 1);
+        if ((*q = m->take(g, elems))) return MI_OK;
+        hipError_t e = hipMalloc((void **)q, elems * 8);
+        if (e != hipSuccess && !m->pool[g].empty()) { // make room: give the cached buffers back and try once more
+            (void)hipGetLastError();
+            for (auto &c : m->pool[g]) { mi_own_del(c.p); (void)hipFree(c.p); }
+            m->pool[g].clear();
+            e = hipMalloc((void **)q, elems * 8);
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); mi_set_error("mi_multi_commit: shard %u cannot allocate %.2f GB (%s): %s", g, elems * 8 / 1e9, what, hipGetErrorString(e)); return MI_ERR_NOMEM; }
+        mi_own_add(*q, elems * 8, (int)g, what);
+        return MI_OK;
+    };
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        t->e_nodes = std::max<uint64_t>((2 * p.rows_per_rank - 1) * 4, 1);
+        MI_TRY(alloc(g, &t->nodes[g], (2 * p.rows_per_rank - 1) * 4, "subtree nodes"));
+    }
+    MM_DEV(m, 0);
+    MI_HIP_CHECK(hipMalloc((void **)&t->roots, (2 * G - 1) * 4 * 8));
+    mi_own_add(t->roots, (2 * G - 1) * 4 * 8, 0, "roots of the subtrees");
+
+    if (transient) {
+        // ---- buffers per GROUP: [tile ring | staging ring | NTT workspace], lent to the leader or from its pool
+        const uint64_t e_ring = (2 * n_ext * maxw + 31) & ~31ull, e_stage = (NS * n * maxw + 31) & ~31ull;
+        const uint64_t e_ws = std::max<uint64_t>((2 * n + n_ext) * maxw + 4096, 1ull << 17); // (a lent workspace is at least 1 MiB)
+        t->e_gbuf = e_ring + e_stage + e_ws;
+        t->keep_rows = false;
+        for (uint32_t L = 0; L < G; L++) {
+            if (m->lead[L] != L) continue;
+            MM_DEV(m, L);
+            if (m->lent[L] && m->lent_elems[L] >= t->e_gbuf) { t->gbuf[L] = m->lent[L]; t->rows_lent[L] = 1; MM_OWN(m, L, m->lent[L], "mi_multi_lend (a region of the leader shard's device)"); }
+            else MI_TRY(alloc(L, &t->gbuf[L], t->e_gbuf, "tile ring, staging and NTT workspace of a transient commit"));
+            for (uint32_t h = 0; h < G; h++)
+                if (m->lead[h] == L) MI_TRY(mi_ctx_lend_workspace(m->ctx[h], t->gbuf[L] + e_ring + e_stage, e_ws * 8));
+        }
+        MI_TRY(commit_transient(E, base, base_pitch, (uint32_t)std::max(image_owner, 0)));
+    } else {
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        const uint64_t e_ext = (n_ext * p.per_rank + 31) & ~31ull, e_recv = G > 1 ? (p.rows_per_rank * G * p.per_rank + 31) & ~31ull : 0, e_stage = (NS * n * maxw + 31) & ~31ull;
+        t->e_ext = std::max<uint64_t>(n_ext * p.per_rank, 1); t->e_recv = std::max<uint64_t>(p.rows_per_rank * G * p.per_rank, 1); t->e_stage = std::max<uint64_t>(NS * n * maxw, 1);
+        const uint64_t e_ws = (2 * n + n_ext) * maxw + 4096; // the tile's transforms (launch_lde into a compact window: INTT intermediate + one n_ext ping-pong buffer [+ coefficients when the middle pass is not fused])
+        if (m->lent[g] && m->lent_elems[g] >= e_ext + e_recv + e_stage + e_ws) { // the row buffers, the staging and the transforms' workspace out of the lent region
+            u64 *q = m->lent[g];
+            MM_OWN(m, g, q, "mi_multi_lend (a region of that shard's device)");
+            t->ext[g] = q; q += e_ext;
+            if (G > 1) { t->recv[g] = q; q += e_recv; }
+            t->stage[g] = q; q += e_stage;
+            MI_TRY(mi_ctx_lend_workspace(m->ctx[g], q, (m->lent_elems[g] - (uint64_t)(q - m->lent[g])) * 8));
+            t->rows_lent[g] = 1;
+        } else {
+            if (m->lent[g])
+                fprintf(stderr, "mi_stark: mi_multi_commit: the region lent to shard %u (%.1f GB) is smaller than the %.1f GB its row buffers, staging and workspace take at %u shards: allocating them instead\n",
+                        g, m->lent_elems[g] * 8 / 1e9, (e_ext + e_recv + e_stage + e_ws) * 8 / 1e9, G);
+            MI_TRY(alloc(g, &t->ext[g], n_ext * p.per_rank, "extended column tiles"));
+            if (G > 1) MI_TRY(alloc(g, &t->recv[g], p.rows_per_rank * G * p.per_rank, "row windows"));
+            MI_TRY(alloc(g, &t->stage[g], NS * n * maxw, "tile staging"));
+        }
+    }
     // events: per shard and round
     std::vector<std::vector<hipEvent_t>> ev_lde(G), ev_sent(G);
-    std::vector<hipEvent_t> ev_up(G * NS), ev_consumed(G * NS), ev_based(G * NS), tm; // tm: timing events, destroyed at the end
-    struct EvGuard { std::vector<std::vector<hipEvent_t>> *a, *b; std::vector<hipEvent_t> *c, *d, *e, *f;
-                     ~EvGuard() { for (auto *vv : {a, b}) for (auto &v : *vv) for (hipEvent_t x : v) if (x) (void)hipEventDestroy(x);
-                                  for (auto *v : {c, d, e, f}) for (hipEvent_t x : *v) if (x) (void)hipEventDestroy(x); } } evguard{&ev_lde, &ev_sent, &ev_up, &ev_consumed, &ev_based, &tm};
+    std::vector<hipEvent_t> ev_up(G * NS), ev_consumed(G * NS), ev_based(G * NS);
+    struct EvGuard { mi_multi *m; std::vector<std::vector<hipEvent_t>> *a, *b; std::vector<hipEvent_t> *c, *d, *e;
+                     ~EvGuard() { for (auto *vv : {a, b}) for (auto &v : *vv) for (hipEvent_t x : v) mm_del_event(m, x);
+                                  for (auto *v : {c, d, e}) for (hipEvent_t x : *v) mm_del_event(m, x); } } evguard{m, &ev_lde, &ev_sent, &ev_up, &ev_consumed, &ev_based};
     for (uint32_t g = 0; g < G; g++) {
         MM_DEV(m, g);
         ev_lde[g].assign(R, nullptr); ev_sent[g].assign(R, nullptr);
         for (size_t k = 0; k < R; k++) {
-            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_lde[g][k], hipEventDisableTiming));
-            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_sent[g][k], hipEventDisableTiming));
+            MI_TRY(mm_new_event(m, g, &ev_lde[g][k], hipEventDisableTiming));
+            MI_TRY(mm_new_event(m, g, &ev_sent[g][k], hipEventDisableTiming));
         }
         for (int s = 0; s < NS; s++) {
-            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_up[g * NS + s], hipEventDisableTiming));
-            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_consumed[g * NS + s], hipEventDisableTiming));
-            MI_HIP_CHECK(hipEventCreateWithFlags(&ev_based[g * NS + s], hipEventDisableTiming));
-            MI_HIP_CHECK(hipEventRecord(ev_consumed[g * NS + s], m->cs[g]));
-            MI_HIP_CHECK(hipEventRecord(ev_based[g * NS + s], m->xs[g]));
+            MI_TRY(mm_new_event(m, g, &ev_up[g * NS + s], hipEventDisableTiming));
+            MI_TRY(mm_new_event(m, g, &ev_consumed[g * NS + s], hipEventDisableTiming));
+            MI_TRY(mm_new_event(m, g, &ev_based[g * NS + s], hipEventDisableTiming));
+            MM_RECORD(m, ev_consumed[g * NS + s], m->cs[g]);
+            MM_RECORD(m, ev_based[g * NS + s], m->xs[g]);
         }
     }
-    struct Timed { uint32_t g; int kind; hipEvent_t a, b; }; // kind 0 lde, 1 absorb, 2 wait
-    std::vector<Timed> timed;
-    auto stamp = [&](uint32_t g, hipStream_t s, hipEvent_t *e) -> int {
-        MI_HIP_CHECK(hipEventCreate(e));
-        tm.push_back(*e);
-        MI_HIP_CHECK(hipEventRecord(*e, s));
-        (void)g;
-        return MI_OK;
-    };
-    int hs_next = 0;
     std::vector<int> slot_of(G, 0);
     auto absorb_round = [&](size_t k) -> int {
         for (uint32_t q = 0; q < G; q++) {
             MM_DEV(m, q);
             hipEvent_t w0, w1, a0, a1;
-            MI_TRY(stamp(q, m->cs[q], &w0));
+            MI_TRY(E.stamp(m->cs[q], &w0));
             for (uint32_t g = 0; g < G; g++)
                 if (g != q && p.width(k, g)) MI_HIP_CHECK(hipStreamWaitEvent(m->cs[q], ev_sent[g][k], 0));
-            MI_TRY(stamp(q, m->cs[q], &w1));
-            timed.push_back({q, 2, w0, w1});
+            MI_TRY(E.stamp(m->cs[q], &w1));
+            E.timed.push_back({q, 2, w0, w1});
             const u64 *bases[MI_MAX_SLABS];
             uint64_t pitches[MI_MAX_SLABS], widths[MI_MAX_SLABS];
             uint32_t nw = 0;
@@ -506,14 +786,16 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
                 if (!w) continue;
                 MI_REQUIRE(nw < MI_MAX_SLABS, "more shards than one absorb launch takes windows");
                 bases[nw] = g == q ? t->ext[q] + p.ext_base(k) + (uint64_t)q * p.rows_per_rank * w : t->recv[q] + p.recv_off(k, g);
+                MM_OWN(m, q, bases[nw], "mi_multi_commit (absorb: a column window of this shard's rows)");
                 pitches[nw] = w; widths[nw] = w;
                 nw++;
             }
             if (!nw) continue;
-            MI_TRY(stamp(q, m->cs[q], &a0));
+            MM_OWN(m, q, t->nodes[q], "mi_multi_commit (absorb: this shard's leaf digests)");
+            MI_TRY(E.stamp(m->cs[q], &a0));
             MI_TRY(launch_linear_hash_absorb(m->ctx[q], t->nodes[q], nw, bases, pitches, widths, p.rows_per_rank, k == 0, k + 1 == R));
-            MI_TRY(stamp(q, m->cs[q], &a1));
-            timed.push_back({q, 1, a0, a1});
+            MI_TRY(E.stamp(m->cs[q], &a1));
+            E.timed.push_back({q, 1, a0, a1});
         }
         return MI_OK;
     };
@@ -524,105 +806,64 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
             MM_DEV(m, g);
             const int slot = slot_of[g]++ % NS;
             u64 *st = t->stage[g] + (uint64_t)slot * n * maxw;
+            MM_OWN(m, g, st, "mi_multi_commit (this shard's tile staging)");
             // ---- the tile's base-domain columns onto shard g's device
-            MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], ev_consumed[g * NS + slot], 0));
-            MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], ev_based[g * NS + slot], 0));
-            if (from_host && strided) {
-                // the tile's columns straight out of the caller's page-locked trace: rows of 8 w bytes at the trace's pitch, upper and lower
-                // rows on two streams (two DMA engines of THIS device; profiles/r02_pcie_chunk_sweep.json: 39.5 GB/s per link at 32 columns)
-                const uint64_t half = n / 2;
-                MI_HIP_CHECK(hipStreamWaitEvent(m->us2[g], ev_consumed[g * NS + slot], 0));
-                MI_HIP_CHECK(hipStreamWaitEvent(m->us2[g], ev_based[g * NS + slot], 0));
-                MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, src + c0, src_pitch * 8, w * 8, n - half, hipMemcpyHostToDevice, m->us[g]));
-                if (half) MI_HIP_CHECK(hipMemcpy2DAsync(st + (n - half) * w, w * 8, src + (n - half) * src_pitch + c0, src_pitch * 8, w * 8, half, hipMemcpyHostToDevice, m->us2[g]));
-                MI_HIP_CHECK(hipEventRecord(m->ev_us2[g], m->us2[g]));
-                MI_HIP_CHECK(hipStreamWaitEvent(m->us[g], m->ev_us2[g], 0));
-            } else if (from_host) {
-                const int hs = hs_next++ % mi_multi::HS;
-                const auto t0 = std::chrono::steady_clock::now();
-                if (m->hstage_user[hs] >= 0) MI_HIP_CHECK(hipEventSynchronize(m->hstage_sent[hs][m->hstage_user[hs]])); // the copy that last read this slot is done
-                u64 *hbuf = m->hstage[hs];
-                const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)m->pack_threads, (n * w * 8) >> 22));
-                const uint64_t rows_per = (n + T - 1) / T;
-                std::vector<std::thread> th;
-                for (int ti = 0; ti < T; ti++) {
-                    const uint64_t r0 = (uint64_t)ti * rows_per, r1 = std::min(n, r0 + rows_per);
-                    if (r0 >= r1) break;
-                    auto work = [=]() {
-                        const uint64_t *s_ = src + r0 * src_pitch + c0;
-                        u64 *d_ = hbuf + r0 * w;
-                        if (w % 8 == 0) { // 64-byte groups: unaligned loads, streaming stores (the staging is read next by the DMA engine, not by this core)
-                            for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w)
-                                for (uint64_t j = 0; j < w; j += 8) {
-                                    const __m128i v0 = _mm_loadu_si128((const __m128i *)(s_ + j)), v1 = _mm_loadu_si128((const __m128i *)(s_ + j + 2));
-                                    const __m128i v2 = _mm_loadu_si128((const __m128i *)(s_ + j + 4)), v3 = _mm_loadu_si128((const __m128i *)(s_ + j + 6));
-                                    _mm_stream_si128((__m128i *)(d_ + j), v0); _mm_stream_si128((__m128i *)(d_ + j + 2), v1);
-                                    _mm_stream_si128((__m128i *)(d_ + j + 4), v2); _mm_stream_si128((__m128i *)(d_ + j + 6), v3);
-                                }
-                            _mm_sfence();
-                        } else {
-                            for (uint64_t r = r0; r < r1; r++, s_ += src_pitch, d_ += w) memcpy(d_, s_, w * 8);
-                        }
-                    };
-                    if (T == 1) work(); else th.emplace_back(work);
-                }
-                for (auto &x : th) x.join();
-                m->stats[g].upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                MI_HIP_CHECK(hipMemcpyAsync(st, hbuf, n * w * 8, hipMemcpyHostToDevice, m->us[g]));
-                MI_HIP_CHECK(hipEventRecord(m->hstage_sent[hs][g], m->us[g]));
-                m->hstage_user[hs] = (int)g;
-            } else {
-                MI_HIP_CHECK(hipMemcpy2DAsync(st, w * 8, src + c0, src_pitch * 8, w * 8, n, hipMemcpyDefault, m->us[g]));
-            }
-            MI_HIP_CHECK(hipEventRecord(ev_up[g * NS + slot], m->us[g]));
+            MI_TRY(upload_tile(E, g, w, c0, st, ev_consumed[g * NS + slot], ev_based[g * NS + slot], ev_up[g * NS + slot]));
             // ---- LDE of the tile
             MI_HIP_CHECK(hipStreamWaitEvent(m->cs[g], ev_up[g * NS + slot], 0));
             hipEvent_t l0, l1;
-            MI_TRY(stamp(g, m->cs[g], &l0));
+            MI_TRY(E.stamp(m->cs[g], &l0));
+            MM_OWN(m, g, t->ext[g] + p.ext_base(k), "mi_multi_commit (this shard's extended tiles)");
             MI_TRY(launch_lde(m->ctx[g], t->ext[g] + p.ext_base(k), w, st, w, n_ext, n, w));
-            MI_TRY(stamp(g, m->cs[g], &l1));
-            timed.push_back({g, 0, l0, l1});
-            MI_HIP_CHECK(hipEventRecord(ev_consumed[g * NS + slot], m->cs[g]));
-            MI_HIP_CHECK(hipEventRecord(ev_lde[g][k], m->cs[g]));
+            MI_TRY(E.stamp(m->cs[g], &l1));
+            E.timed.push_back({g, 0, l0, l1});
+            MM_RECORD(m, ev_consumed[g * NS + slot], m->cs[g]);
+            MM_RECORD(m, ev_lde[g][k], m->cs[g]);
             // ---- exchange stream: the section itself and the whole extended tile into the row-major image (if asked), my tile's rows to their owners
             if (base) {
                 MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_up[g * NS + slot], 0));
-                MI_HIP_CHECK(hipMemcpy2DAsync(base + c0, base_pitch * 8, st, w * 8, w * 8, n, hipMemcpyDefault, m->xs[g]));
+                MM_OWN(m, (uint32_t)image_owner, base + c0, "mi_multi_commit (base: memory of the shard on image_device)");
+                MI_TRY(rows_2d(m, g, image_device, m->dev[g], (u64 *)base + c0, base_pitch, st, w, w, n, m->xs[g]));
             }
-            MI_HIP_CHECK(hipEventRecord(ev_based[g * NS + slot], m->xs[g]));
+            MM_RECORD(m, ev_based[g * NS + slot], m->xs[g]);
             MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_lde[g][k], 0));
             for (uint32_t q = 0; q < G; q++) {
                 if (q == g) continue;
                 const uint64_t cnt = p.rows_per_rank * w;
+                MM_OWN(m, q, t->recv[q] + p.recv_off(k, g), "mi_multi_commit (exchange: the receiving shard's row windows)");
                 MI_TRY(copy_dd(m, t->recv[q] + p.recv_off(k, g), (int)q, t->ext[g] + p.ext_base(k) + (uint64_t)q * cnt, (int)g, cnt * 8, m->xs[g]));
                 m->stats[g].bytes_to[q] += cnt * 8;
             }
-            if (image) MI_HIP_CHECK(hipMemcpy2DAsync(image + c0, image_pitch * 8, t->ext[g] + p.ext_base(k), w * 8, w * 8, n_ext, hipMemcpyDefault, m->xs[g]));
+            if (image) {
+                MM_OWN(m, (uint32_t)image_owner, image + c0, "mi_multi_commit (image: memory of the shard on image_device)");
+                MI_TRY(rows_2d(m, g, image_device, m->dev[g], (u64 *)image + c0, image_pitch, t->ext[g] + p.ext_base(k), w, w, n_ext, m->xs[g]));
+            }
             for (uint32_t q = 0; q < G && !m->row_img.empty(); q++) { // shard q's own rows (+ halo) of the tile, row-major, into its full-height section
                 u64 *ri = m->row_img[q];
                 if (!ri) continue;
                 const u64 *tile = t->ext[g] + p.ext_base(k);
                 const uint64_t r0 = (uint64_t)q * p.rows_per_rank, r1 = (r0 + p.rows_per_rank) % n_ext, pt = m->row_img_pitch;
-                MI_HIP_CHECK(hipMemcpy2DAsync(ri + r0 * pt + c0, pt * 8, tile + r0 * w, w * 8, w * 8, p.rows_per_rank, hipMemcpyDefault, m->xs[g]));
-                if (m->row_img_halo) MI_HIP_CHECK(hipMemcpy2DAsync(ri + r1 * pt + c0, pt * 8, tile + r1 * w, w * 8, w * 8, m->row_img_halo, hipMemcpyDefault, m->xs[g]));
+                MI_TRY(rows_2d(m, g, m->dev[q], m->dev[g], ri + r0 * pt + c0, pt, tile + r0 * w, w, w, p.rows_per_rank, m->xs[g]));
+                if (m->row_img_halo) MI_TRY(rows_2d(m, g, m->dev[q], m->dev[g], ri + r1 * pt + c0, pt, tile + r1 * w, w, w, m->row_img_halo, m->xs[g]));
                 m->stats[g].bytes_to[q] += q == g ? 0 : (p.rows_per_rank + m->row_img_halo) * w * 8;
             }
-            MI_HIP_CHECK(hipEventRecord(ev_sent[g][k], m->xs[g]));
+            MM_RECORD(m, ev_sent[g][k], m->xs[g]);
         }
         if (k > 0) MI_TRY(absorb_round(k - 1));
     }
     MI_TRY(absorb_round(R - 1));
+    } // (the windowed form)
     // ---- subtrees, then the G roots meet on shard 0
     std::vector<hipEvent_t> ev_root(G, nullptr);
+    struct RootEvGuard { mi_multi *m; std::vector<hipEvent_t> *v; ~RootEvGuard() { for (hipEvent_t x : *v) mm_del_event(m, x); } } rootguard{m, &ev_root};
     for (uint32_t g = 0; g < G; g++) {
         MM_DEV(m, g);
         MI_TRY(launch_merkle_levels(m->ctx[g], t->nodes[g], p.rows_per_rank));
-        MI_HIP_CHECK(hipEventCreateWithFlags(&ev_root[g], hipEventDisableTiming));
-        tm.push_back(ev_root[g]);
-        MI_HIP_CHECK(hipEventRecord(ev_root[g], m->cs[g]));
+        MI_TRY(mm_new_event(m, g, &ev_root[g], hipEventDisableTiming));
+        MM_RECORD(m, ev_root[g], m->cs[g]);
         MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_root[g], 0));
         MI_TRY(copy_dd(m, t->roots + 4 * g, 0, t->nodes[g] + (2 * p.rows_per_rank - 2) * 4, (int)g, 32, m->xs[g]));
-        MI_HIP_CHECK(hipEventRecord(ev_root[g], m->xs[g]));
+        MM_RECORD(m, ev_root[g], m->xs[g]);
     }
     MM_DEV(m, 0);
     for (uint32_t g = 0; g < G; g++) MI_HIP_CHECK(hipStreamWaitEvent(m->cs[0], ev_root[g], 0));
@@ -634,15 +875,149 @@ extern "C" int mi_multi_commit(mi_multi *m, mi_multi_tree **out, const uint64_t 
         MI_HIP_CHECK(hipStreamSynchronize(m->us[g])); MI_HIP_CHECK(hipStreamSynchronize(m->us2[g])); MI_HIP_CHECK(hipStreamSynchronize(m->xs[g])); MI_HIP_CHECK(hipStreamSynchronize(m->cs[g]));
     }
     for (int i = 0; i < 4; i++) root[i] = t->roots_host[(2 * G - 2) * 4 + i];
-    for (const Timed &x : timed) {
+    for (const CommitEnv::Timed &x : E.timed) {
         float ms = 0;
         (void)hipSetDevice(m->dev[x.g]);
         if (hipEventElapsedTime(&ms, x.a, x.b) != hipSuccess) { (void)hipGetLastError(); continue; }
         (x.kind == 0 ? m->stats[x.g].lde_ms : x.kind == 1 ? m->stats[x.g].absorb_ms : m->stats[x.g].wait_ms) += ms;
     }
+    if (transient) { // the group buffers served the commit only: back to their pool (a lent region is its owner's again when this returns)
+        for (uint32_t L = 0; L < G; L++) {
+            if (m->lead[L] != L || !t->gbuf[L]) continue;
+            MM_DEV(m, L);
+            for (uint32_t h = 0; h < G; h++) if (m->lead[h] == L) MI_TRY(mi_ctx_lend_workspace(m->ctx[h], nullptr, 0));
+            if (!t->rows_lent[L]) m->pool[L].push_back({t->gbuf[L], t->e_gbuf});
+            t->gbuf[L] = nullptr;
+        }
+    }
+    MM_DEV(m, 0);
     m->last_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     guard.t = nullptr;
     *out = t;
+    return MI_OK;
+}
+
+// The transient form (see the header of this file).  Per round and shard g of group L, on the group's streams:
+//     upload stream    the tile's base-domain columns into the group's staging ring
+//     compute stream   LDE into a slot of the group's TILE RING (two slots: the slot's previous tile has left for the row images)
+//     exchange stream  the section itself into `base` (optional); for EVERY shard q -- g included -- a kernel writes the tile's rows
+//                      [q R, (q + 1) R) and the halo after them (wrapping at n_ext) into q's row image at the tile's columns: one
+//                      write per element, 256-byte runs, across xGMI for q on another device
+// then shard q absorbs the round's columns of its rows WHERE THEY LANDED: windows of its row image, at the image's pitch.
+static int commit_transient(CommitEnv &E, uint64_t *base, uint64_t base_pitch, uint32_t base_owner)
+{
+    mi_multi *m = E.m;
+    mi_multi_tree *t = E.t;
+    const Plan &p = t->p;
+    const uint32_t G = m->G;
+    const uint64_t n = E.n, n_ext = E.n_ext;
+    const size_t R = p.rounds();
+    const uint64_t maxw = *std::max_element(p.round_w.begin(), p.round_w.end());
+    constexpr int NS = 2, NE = 2;
+    const uint64_t e_ring = (2 * n_ext * maxw + 31) & ~31ull;
+    const uint64_t pt = m->row_img_pitch, halo = m->row_img_halo, Rr = p.rows_per_rank;
+    // events per GROUP (staging slots, ring slots) and per shard and round (tile sent)
+    std::vector<hipEvent_t> ev_up(G * NS, nullptr), ev_consumed(G * NS, nullptr), ev_based(G * NS, nullptr), ev_free(G * NE, nullptr), ev_lde(G, nullptr);
+    std::vector<std::vector<hipEvent_t>> ev_sent(G);
+    struct EvGuard { mi_multi *m; std::vector<std::vector<hipEvent_t>> *a; std::vector<hipEvent_t> *v[5];
+                     ~EvGuard() { for (auto &x : *a) for (hipEvent_t e : x) mm_del_event(m, e); for (auto *w : v) for (hipEvent_t e : *w) mm_del_event(m, e); } }
+        evguard{m, &ev_sent, {&ev_up, &ev_consumed, &ev_based, &ev_free, &ev_lde}};
+    for (uint32_t g = 0; g < G; g++) {
+        MM_DEV(m, g);
+        ev_sent[g].assign(R, nullptr);
+        for (size_t k = 0; k < R; k++) MI_TRY(mm_new_event(m, g, &ev_sent[g][k], hipEventDisableTiming));
+        if (m->lead[g] != g) continue;
+        MI_TRY(mm_new_event(m, g, &ev_lde[g], hipEventDisableTiming));
+        for (int s = 0; s < NS; s++) {
+            MI_TRY(mm_new_event(m, g, &ev_up[g * NS + s], hipEventDisableTiming));
+            MI_TRY(mm_new_event(m, g, &ev_consumed[g * NS + s], hipEventDisableTiming));
+            MI_TRY(mm_new_event(m, g, &ev_based[g * NS + s], hipEventDisableTiming));
+            MM_RECORD(m, ev_consumed[g * NS + s], m->cs[g]);
+            MM_RECORD(m, ev_based[g * NS + s], m->xs[g]);
+        }
+        for (int s = 0; s < NE; s++) {
+            MI_TRY(mm_new_event(m, g, &ev_free[g * NE + s], hipEventDisableTiming));
+            MM_RECORD(m, ev_free[g * NE + s], m->xs[g]);
+        }
+    }
+    std::vector<int> slot_of(G, 0), ring_of(G, 0);
+    auto absorb_round = [&](size_t k) -> int {
+        for (uint32_t q = 0; q < G; q++) {
+            MM_DEV(m, q);
+            hipEvent_t w0, w1, a0, a1;
+            MI_TRY(E.stamp(m->cs[q], &w0));
+            for (uint32_t g = 0; g < G; g++)
+                if (p.width(k, g)) MI_HIP_CHECK(hipStreamWaitEvent(m->cs[q], ev_sent[g][k], 0)); // (g == q too: my own rows went through the exchange stream)
+            MI_TRY(E.stamp(m->cs[q], &w1));
+            E.timed.push_back({q, 2, w0, w1});
+            const u64 *bases[MI_MAX_SLABS];
+            uint64_t pitches[MI_MAX_SLABS], widths[MI_MAX_SLABS];
+            uint32_t nw = 0;
+            for (uint32_t g = 0; g < G; g++) {
+                const uint64_t w = p.width(k, g);
+                if (!w) continue;
+                MI_REQUIRE(nw < MI_MAX_SLABS, "more shards than one absorb launch takes windows");
+                bases[nw] = m->row_img[q] + (uint64_t)q * Rr * pt + p.c0(k, g);
+                MM_OWN(m, q, bases[nw], "mi_multi_commit (absorb: this shard's row image)");
+                pitches[nw] = pt; widths[nw] = w;
+                nw++;
+            }
+            if (!nw) continue;
+            MM_OWN(m, q, t->nodes[q], "mi_multi_commit (absorb: this shard's leaf digests)");
+            MI_TRY(E.stamp(m->cs[q], &a0));
+            MI_TRY(launch_linear_hash_absorb(m->ctx[q], t->nodes[q], nw, bases, pitches, widths, Rr, k == 0, k + 1 == R));
+            MI_TRY(E.stamp(m->cs[q], &a1));
+            E.timed.push_back({q, 1, a0, a1});
+        }
+        return MI_OK;
+    };
+    for (size_t k = 0; k < R; k++) {
+        for (uint32_t g = 0; g < G; g++) {
+            const uint64_t w = p.width(k, g), c0 = p.c0(k, g);
+            if (!w) continue;
+            MM_DEV(m, g);
+            const uint32_t L = m->lead[g];
+            const int slot = slot_of[L]++ % NS, rs = ring_of[L]++ % NE;
+            u64 *st = t->gbuf[L] + e_ring + (uint64_t)slot * n * maxw;
+            u64 *tile = t->gbuf[L] + (uint64_t)rs * n_ext * maxw;
+            MM_OWN(m, L, st, "mi_multi_commit (the group's tile staging)");
+            MM_OWN(m, L, tile, "mi_multi_commit (the group's tile ring)");
+            MI_TRY(upload_tile(E, g, w, c0, st, ev_consumed[L * NS + slot], ev_based[L * NS + slot], ev_up[L * NS + slot]));
+            // ---- LDE of the tile into the ring slot, once the slot's previous tile has left
+            MI_HIP_CHECK(hipStreamWaitEvent(m->cs[g], ev_up[L * NS + slot], 0));
+            MI_HIP_CHECK(hipStreamWaitEvent(m->cs[g], ev_free[L * NE + rs], 0));
+            hipEvent_t l0, l1;
+            MI_TRY(E.stamp(m->cs[g], &l0));
+            MI_TRY(launch_lde(m->ctx[g], tile, w, st, w, n_ext, n, w));
+            MI_TRY(E.stamp(m->cs[g], &l1));
+            E.timed.push_back({g, 0, l0, l1});
+            MM_RECORD(m, ev_consumed[L * NS + slot], m->cs[g]);
+            MM_RECORD(m, ev_lde[L], m->cs[g]);
+            // ---- exchange stream
+            if (base) {
+                MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_up[L * NS + slot], 0));
+                MM_OWN(m, base_owner, base + c0, "mi_multi_commit (base: memory of the shard on image_device)");
+                MI_TRY(rows_2d(m, g, m->dev[base_owner], m->dev[g], (u64 *)base + c0, base_pitch, st, w, w, n, m->xs[g]));
+            }
+            MM_RECORD(m, ev_based[L * NS + slot], m->xs[g]);
+            MI_HIP_CHECK(hipStreamWaitEvent(m->xs[g], ev_lde[L], 0));
+            for (uint32_t q = 0; q < G; q++) { // a declared peer operand: q's row image, written by g's device
+                u64 *ri = m->row_img[q];
+                const uint64_t r0 = (uint64_t)q * Rr, r1 = (r0 + Rr) % n_ext;
+                MM_OWN(m, q, ri + r0 * pt + c0, "mi_multi_commit (a shard's row image)");
+                if (r1 != 0 || !halo) MI_TRY(rows_2d(m, g, m->dev[q], m->dev[g], ri + r0 * pt + c0, pt, tile + r0 * w, w, w, Rr + (r1 ? halo : 0), m->xs[g])); // rows and halo in one piece
+                else { // the last shard: its halo is the extension's first rows
+                    MI_TRY(rows_2d(m, g, m->dev[q], m->dev[g], ri + r0 * pt + c0, pt, tile + r0 * w, w, w, Rr, m->xs[g]));
+                    MI_TRY(rows_2d(m, g, m->dev[q], m->dev[g], ri + c0, pt, tile, w, w, halo, m->xs[g]));
+                }
+                m->stats[g].bytes_to[q] += m->dev[q] == m->dev[g] ? 0 : (Rr + halo) * w * 8;
+            }
+            MM_RECORD(m, ev_sent[g][k], m->xs[g]);
+            MM_RECORD(m, ev_free[L * NE + rs], m->xs[g]);
+        }
+        if (k > 0) MI_TRY(absorb_round(k - 1));
+    }
+    MI_TRY(absorb_round(R - 1));
     return MI_OK;
 }
 

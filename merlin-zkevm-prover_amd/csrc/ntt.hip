@@ -43,8 +43,16 @@
 #define NTT_MULW(x, t) ((x) ^ (t))
 #define NTT_CANON(x) (x)
 #else
+#ifdef MI_NTT_AB_NOMULW   // (class diagnosis builds: ntt_math.h)
+#define NTT_MULW(x, t) ((x) ^ (t))
+#else
 #define NTT_MULW(x, t) gl::mul_w((x), (t))
+#endif
+#ifdef MI_NTT_AB_NOCANON
+#define NTT_CANON(x) (x)
+#else
 #define NTT_CANON(x) gl::canon(x)
+#endif
 #endif
 
 struct NttPass {

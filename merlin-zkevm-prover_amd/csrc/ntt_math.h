@@ -12,6 +12,21 @@
 #ifndef MI_DFT_CANON
 #define MI_DFT_CANON(x) gl::canon(x)
 #endif
+// Diagnosis builds (tools/pmc_ntt_classes.sh, `make ab-ntt-classes`): ONE class of the butterflies' arithmetic compiled out -- results are
+// wrong, the data flow stays -- so that the difference in SQ_INSTS_VALU against the shipped build is that class's instruction count:
+//   MI_NTT_AB_NOCANON   no canonical form (the butterflies' v operand, the stores)        MI_NTT_AB_NOADDSUB  u + v, u - v become u ^ v
+//   MI_NTT_AB_NOPOW2    the shift twiddles 2^e become 1                                   MI_NTT_AB_NOMULW    twiddle multiplies become xor
+#ifdef MI_NTT_AB_NOCANON
+#undef MI_DFT_CANON
+#define MI_DFT_CANON(x) (x)
+#endif
+#ifdef MI_NTT_AB_NOADDSUB
+#define MI_DFT_ADD(u, v) ((u) ^ (v))
+#define MI_DFT_SUB(u, v) ((u) ^ (v) ^ 1)
+#else
+#define MI_DFT_ADD(u, v) gl::add_wc((u), (v))
+#define MI_DFT_SUB(u, v) gl::sub_wc((u), (v))
+#endif
 
 namespace nttm {
 
@@ -29,6 +44,9 @@ template <int E>
 MI_HD u64 mul_pow2(u64 x)
 {
     static_assert(E >= 0 && E < 192, "exponent out of range");
+#ifdef MI_NTT_AB_NOPOW2
+    return x;
+#endif
     if constexpr (E == 0) {
         return x;
     } else if constexpr (E >= 96) {
@@ -71,8 +89,8 @@ MI_HD void dft_reg(u64 (&x)[1 << Q])
                 constexpr int e0 = 3 * j * (64 / len);              // w_len^j = w_64^(j * 64/len) = 2^e0
                 constexpr int e = INV ? (192 - e0) % 192 : e0;
                 const u64 u = x[s + j], v = MI_DFT_CANON(x[s + j + half]);
-                x[s + j] = gl::add_wc(u, v);
-                x[s + j + half] = mul_pow2<e>(gl::sub_wc(u, v));
+                x[s + j] = MI_DFT_ADD(u, v);
+                x[s + j + half] = mul_pow2<e>(MI_DFT_SUB(u, v));
             });
         });
     });

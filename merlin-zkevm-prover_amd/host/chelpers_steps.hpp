@@ -53,6 +53,7 @@ struct StarkMirror
     };
     std::vector<RowShard> rowShards;
     mi_multi *multi = nullptr;
+    bool syncHomeFirst = false; // a row shard reads THIS device's tables (it is grouped with shard 0): what this context queued comes first
 };
 // one proof in flight per process (prover.cpp:187-260): the image of the running genProof
 inline StarkMirror *&currentMirror()
@@ -178,6 +179,7 @@ inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const 
     }
     if (isRowShardedStep(m, step)) {
         // the other devices first (their launches return at once), this device's rows beside them, then everybody's q rows are home
+        if (m->syncHomeFirst) check(mi_ctx_sync(ctx()), "Steps (row shards: this device's tables are ready)");
         for (const StarkMirror::RowShard &S : m->rowShards) {
             mi_chelpers_prog *&sp = (*S.progs)[{step, (const void *)ops}];
             if (!sp) {

@@ -137,7 +137,14 @@ public:
             mi::check(mi_multi_group_proofs(multiTree, (uint64_t *)proofs, idx, nq, 0), "MerkleTreeGL::getGroupProofs (sharded tree)");
             std::vector<uint64_t> sib((uint64_t *)proofs, (uint64_t *)proofs + nq * stride);
             uint64_t *d_out = mi::devAlloc(nq * stride, "MerkleTreeGL::getGroupProofs (alloc)");
-            mi::check(mi_merkle_group_proofs_dev(c, d_out, nullptr, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs (rows of a sharded tree)");
+            // rows another device holds are NOT read here: with row shards this device's image has memory under its own rows only (a sparse
+            // address range, host/starks.hpp mi::Arena): row 0 stands in for them in this launch, their values come from their holder below
+            std::vector<uint64_t> local(idx, idx + nq);
+            for (uint64_t q = 0; q < nq && !shardSources.empty(); q++) {
+                const uint64_t g = idx[q] / rowsPerShard;
+                if (g != 0 && g < shardSources.size() && shardSources[g]) local[q] = 0;
+            }
+            mi::check(mi_merkle_group_proofs_dev(c, d_out, nullptr, d_source, width, height, width, local.data(), nq), "MerkleTreeGL::getGroupProofs (rows of a sharded tree)");
             mi::check(mi_copy_d2h(c, proofs, d_out, nq * stride * 8), "MerkleTreeGL::getGroupProofs (d2h)");
             mi::devFree(d_out);
             for (uint64_t q = 0; q < nq; q++) std::memcpy((uint64_t *)proofs + q * stride + width, &sib[q * stride + width], (stride - width) * 8);

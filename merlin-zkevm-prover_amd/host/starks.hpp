@@ -75,15 +75,32 @@ struct StarkFiles
 namespace mi {
 // The process's HBM arena: grown (never shrunk) to the largest plan asked for, so that consecutive proofs -- zkEVM, c12a,
 // recursive1, ... share pAddress in the reference and share this here -- allocate nothing.
+//
+// Two forms.  DENSE (one device): one allocation of the whole plan.  SPARSE (several devices, MI_STARK_DEVICES; MI_STARK_SPARSE_IMAGE=0
+// switches it off): an ADDRESS RANGE (mi_vmm_reserve) under which a proof backs what it touches (back(): idempotent, additive).  A
+// row-sharded proof keeps only ITS rows of the three wide extended sections on this device -- 20 of their 157 GB at zkEVM size and eight
+// devices --, the rest of the range stays addresses; a proof that needs the whole image backs the whole image.
 struct Arena
 {
     uint64_t *base = nullptr;
     uint64_t elems = 0;
-    uint64_t *reserve(uint64_t want)
+    bool sparse = false;
+    uint64_t *reserve(uint64_t want, bool wantSparse = false)
     {
         if (want <= elems) return base;
         mi_ctx *c = ctx();
-        if (base) mi_dev_free(c, base);
+        if (base) { if (sparse) check(mi_vmm_free(c, base), "Starks (HBM arena: free)"); else mi_dev_free(c, base); }
+        base = nullptr;
+        sparse = wantSparse;
+        if (sparse) {
+            // addresses are free: room for any later, larger Starks of this process without moving (1 TiB of addresses: tools/vmm_probe.hip)
+            const uint64_t range = std::max<uint64_t>(want * 8, 1ULL << 40);
+            void *p = nullptr;
+            check(mi_vmm_reserve(c, range, &p), "Starks (HBM arena: address range)");
+            base = (uint64_t *)p;
+            elems = range / 8;
+            return base;
+        }
         base = (uint64_t *)mi_dev_alloc(c, want * 8);
         if (!base) {
             uint64_t fr = 0, tot = 0;
@@ -94,16 +111,31 @@ struct Arena
         elems = want;
         return base;
     }
+    // physical memory under elements [off, off + n) (sparse form; the dense form has it all)
+    void back(uint64_t off, uint64_t n)
+    {
+        if (!sparse || !n) return;
+        if (mi_vmm_back(ctx(), base, off * 8, n * 8) != MI_OK) {
+            std::fprintf(stderr, "mi_stark: the proof's HBM plan does not fit the device: %s\n", mi_last_error());
+            fail("Starks (HBM arena: back)");
+        }
+    }
+    uint64_t backedBytes()
+    {
+        uint64_t b = elems * 8;
+        if (sparse) check(mi_vmm_backed_bytes(ctx(), base, &b), "Starks (HBM arena)");
+        return b;
+    }
 };
 inline Arena &arena()
 {
     static Arena a;
     return a;
 }
-// The same on the OTHER devices of a row-sharded proof (shard g >= 1): the full-height mirror of the image's extended part.  One per
-// process and device, shared by every Starks of the prover (zkEVM, c12a, recursive1, recursive2 live side by side: prover.cpp:128-132) --
-// a proof fills it anew, one proof is in flight -- and sized for the largest of them; what belongs to a proving key (its constants and
-// their extension) stays with its Starks.
+// The same on the OTHER devices of a row-sharded proof (shard g >= 1): the full-height mirror of the image's extended part -- an address
+// range of which the shard's own rows (and the halo after them) are backed.  One per process and device, shared by every Starks of the
+// prover (zkEVM, c12a, recursive1, recursive2 live side by side: prover.cpp:128-132) -- a proof fills it anew, one proof is in flight --;
+// what belongs to a proving key (its constants and their extension) stays with its Starks.
 struct ShardArena
 {
     uint64_t *base = nullptr;
@@ -113,15 +145,24 @@ struct ShardArena
         if (want <= elems) return base;
         check(mi_multi_set_device(mm, g), "Starks (row-shard mirror: device)");
         mi_ctx *c = mi_multi_ctx(mm, g);
-        if (base) mi_dev_free(c, base);
-        base = (uint64_t *)mi_dev_alloc(c, want * 8);
-        if (!base) {
-            std::fprintf(stderr, "mi_stark: the row-shard mirror on shard %d needs %.1f GB of that device's memory\n", g, want * 8 / 1e9);
-            fail("Starks (row-shard mirror)");
-        }
-        elems = want;
+        if (base) check(mi_vmm_free(c, base), "Starks (row-shard mirror: free)");
+        const uint64_t range = std::max<uint64_t>(want * 8, 1ULL << 39);
+        void *p = nullptr;
+        check(mi_vmm_reserve(c, range, &p), "Starks (row-shard mirror: address range)");
+        base = (uint64_t *)p;
+        elems = range / 8;
         check(mi_multi_set_device(mm, 0), "Starks (row-shard mirror: device)");
         return base;
+    }
+    void back(mi_multi *mm, int g, uint64_t off, uint64_t n)
+    {
+        if (!n) return;
+        check(mi_multi_set_device(mm, g), "Starks (row-shard mirror: device)");
+        if (mi_vmm_back(mi_multi_ctx(mm, g), base, off * 8, n * 8) != MI_OK) {
+            std::fprintf(stderr, "mi_stark: the row-shard mirror of shard %d does not fit its device: %s\n", g, mi_last_error());
+            fail("Starks (row-shard mirror: back)");
+        }
+        check(mi_multi_set_device(mm, 0), "Starks (row-shard mirror: device)");
     }
 };
 inline ShardArena &shardArena(int g)
@@ -227,7 +268,9 @@ public:
                 (void)mi_multi_set_device(mm, (int)g);
                 mi_ctx *cg = mi_multi_ctx(mm, (int)g);
                 for (auto &p : rowMem[g].progs) if (p.second) mi_chelpers_free(cg, p.second);
-                for (uint64_t *q : {rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv, rowMem[g].lev}) if (q) mi_dev_free(cg, q); // (the mirror is the process's)
+                if (rowMem[g].ownsTables)
+                    for (uint64_t *q : {rowMem[g].constN, rowMem[g].const2ns, rowMem[g].x2ns, rowMem[g].xdiv, rowMem[g].lev}) if (q) mi_dev_free(cg, q); // (the mirror is the process's)
+                if (rowMem[g].evalsPart) mi_dev_free(cg, rowMem[g].evalsPart);
             }
             (void)mi_multi_set_device(mm, 0);
         }
@@ -287,8 +330,9 @@ public:
         if (ownRowsOnly && rowMem.size() > 1)
             for (int t = 1; t <= 2; t++) // xDivXSubXi / xDivXSubWXi: every device filled the rows it evaluates
                 if (offset >= lateOffsets[t] && offset < lateOffsets[t] + 3 * NExtended) {
-                    const uint64_t g = (offset - lateOffsets[t]) / 3 / (NExtended / rowMem.size());
-                    if (g == 0) break;
+                    uint64_t g = (offset - lateOffsets[t]) / 3 / (NExtended / rowMem.size());
+                    if (g == 0 || rowMem[g].aliasFrom == 0) break; // (a shard grouped with this device fills this device's table)
+                    if (rowMem[g].aliasFrom > 0) g = (uint64_t)rowMem[g].aliasFrom;
                     mi_multi *mm = mi::multi();
                     mi::check(mi_multi_set_device(mm, (int)g), "Starks::peekImage (device)");
                     mi::check(mi_copy_d2h(mi_multi_ctx(mm, (int)g), out, rowMem[g].xdiv + (t - 1) * 3 * NExtended + (offset - lateOffsets[t]), n * 8), "Starks::peekImage (x / (x - xi) on a peer)");
@@ -298,8 +342,8 @@ public:
         if (constRowsOnly && offset >= lateOffsets[0] && offset < lateOffsets[0] + starkInfo.nConstants * NExtended &&
             (offset - lateOffsets[0]) / starkInfo.nConstants >= NExtended / rowMem.size()) { // a row of the extended constants this device did not fetch
             mi_multi *mm = mi::multi();
-            mi::check(mi_multi_set_device(mm, 1), "Starks::peekImage (device)");
-            mi::check(mi_copy_d2h(mi_multi_ctx(mm, 1), out, rowMem[1].const2ns + (offset - lateOffsets[0]), n * 8), "Starks::peekImage (constants on a peer)");
+            mi::check(mi_multi_set_device(mm, constRowsFrom), "Starks::peekImage (device)");
+            mi::check(mi_copy_d2h(mi_multi_ctx(mm, constRowsFrom), out, rowMem[constRowsFrom].const2ns + (offset - lateOffsets[0]), n * 8), "Starks::peekImage (constants on a peer)");
             mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
             return;
         }
@@ -308,18 +352,27 @@ public:
     uint64_t lateOffsets[3] = {0, 0, 0};
 
 private:
-    bool ownsConstants = false, witnessLocked = false;
+    bool ownsConstants = false, witnessLocked = false, sparseImage = false;
     // Row-sharded step42ns (several devices): what shard g >= 1 keeps on ITS device from proof to proof -- a full-height mirror of the
     // image's extended part [cm1_2ns, end) of which the stage commits fill its own rows and the halo after them (157 GB of address range
     // at zkEVM size on a device that holds little else; 20 GB of it ever written), the constant polynomials and room for their extension
     // and x_2ns --, and its compiled programs.
     struct RowShardMem
     {
-        uint64_t *ext = nullptr, *constN = nullptr, *const2ns = nullptr, *x2ns = nullptr, *xdiv = nullptr, *lev = nullptr; // xdiv: xDivXSubXi | xDivXSubWXi; lev: LEv | LpEv | partial evals
+        uint64_t *ext = nullptr, *constN = nullptr, *const2ns = nullptr, *x2ns = nullptr, *xdiv = nullptr, *lev = nullptr; // xdiv: xDivXSubXi | xDivXSubWXi; lev: LEv | LpEv
+        uint64_t *evalsPart = nullptr; // this shard's share of the evaluations (3 nEvals words)
+        // Tables of the proving key.  A shard that leads its device group (or is alone on its device) OWNS them on its device; a shard
+        // grouped with another (mi_multi_create2: logical shards of one physical device) reads its LEADER's -- and a shard grouped with
+        // shard 0 reads what THIS device's proof holds (d_constN, the per-proof const_2ns / x_2ns / x-division tables / LEv): aliasFrom
+        // is that leader, 0 meaning this device's image.  One physical device then holds one copy, which is what lets eight logical
+        // shards rehearse the zkEVM's size on one GPU.
+        bool ownsTables = false;
+        int aliasFrom = -1;
         std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
         bool tablesReady = false; // const2ns and x2ns are computed (once per Starks: they belong to the proving key)
     };
     std::vector<RowShardMem> rowMem; // by shard; [0] unused (shard 0 is this device and its image)
+    int constRowsFrom = 1;      // ... the shard whose resident copy a check reads the other rows from
     bool constRowsOnly = false; // (per proof) the extended constants on this device: only its rows (+ halo), fetched from a peer's resident copy
     bool rowSharded = false, ownRowsOnly = false; // ownRowsOnly (per proof): this device's image holds only ITS rows (+ halo) of cm1..3_2ns
     uint64_t *rowBase(int g) const { return rowMem[g].ext - starkInfo.mapOffsets.section[cm1_2ns]; } // virtual: + an extended section's offset = that device's copy
@@ -340,7 +393,11 @@ private:
         }
         // the proof's HBM now, not inside the first genProof: like the reference, which allocates pAddress when the prover starts
         // (prover.cpp:99-120).  273 GB of fresh device memory take the driver 5.7 s; a later, larger Starks grows the arena once more.
-        mi::arena().reserve(starkInfo.mapTotalN + 4 * treeElems + scratchElems);
+        {
+            const char *sp = std::getenv("MI_STARK_SPARSE_IMAGE");
+            sparseImage = mi::multi() != nullptr && !(sp && sp[0] == '0');
+        }
+        mi::arena().reserve(starkInfo.mapTotalN + 4 * treeElems + scratchElems, sparseImage);
         // Several devices (MI_STARK_DEVICES): the witness section of pAddress is page-locked ONCE, here -- like pAddress itself it lives as
         // long as the prover (prover.cpp:99-120) --, so that every device's DMA engines read their column tiles of stage 1 straight out of
         // it over their own PCIe link (csrc/multi.hip "strided"); pageable, the tiles are packed by host threads first, and eight links
@@ -353,7 +410,7 @@ private:
             TimerStopAndLog(STARK_PAGE_LOCK_WITNESS);
         }
         // Row-sharded step42ns: on by default when MI_STARK_DEVICES names DISTINCT devices (MI_STARK_ROW_SHARDED=0 / 1 overrides: logical
-        // shards on one device rehearse it at sizes where G mirrors fit beside the image)
+        // shards on one device rehearse it -- at the zkEVM's full size too, when they form a device group: MI_MULTI_GROUP_SAME_DEVICE=1)
         if (mi_multi *mm = mi::multi()) {
             const int G = mi_multi_shards(mm);
             bool distinct = true;
@@ -372,14 +429,19 @@ private:
                     RowShardMem &R = rowMem[g];
                     R.ext = mi::shardArena(g).reserve(mm, g, extElems); // (re-read at every proof: a later, larger Starks may move it)
                     mi::check(mi_multi_set_device(mm, g), "Starks::Starks (row shards: device)");
+                    R.evalsPart = (uint64_t *)mi_dev_alloc(cg, (3 * starkInfo.evMap.size() + 16) * 8);
+                    if (!R.evalsPart) mi::fail("Starks::Starks (row shards: device memory)");
+                    const int L = mi_multi_lead(mm, g);
+                    if (L != g) { R.aliasFrom = L; continue; } // its leader's tables (resolved per proof: the leader may be this device's image)
+                    R.ownsTables = true;
                     R.x2ns = (uint64_t *)mi_dev_alloc(cg, NExtended * 8);
                     R.xdiv = (uint64_t *)mi_dev_alloc(cg, 6 * NExtended * 8);
-                    R.lev = (uint64_t *)mi_dev_alloc(cg, (6 * N + 3 * starkInfo.evMap.size() + 16) * 8);
+                    R.lev = (uint64_t *)mi_dev_alloc(cg, (6 * N + 16) * 8);
                     if (starkInfo.nConstants) {
                         R.constN = (uint64_t *)mi_dev_alloc(cg, starkInfo.nConstants * N * 8);
                         R.const2ns = (uint64_t *)mi_dev_alloc(cg, starkInfo.nConstants * NExtended * 8);
                     }
-                    if (!R.ext || !R.x2ns || !R.xdiv || !R.lev || (starkInfo.nConstants && (!R.constN || !R.const2ns))) mi::fail("Starks::Starks (row shards: device memory)");
+                    if (!R.x2ns || !R.xdiv || !R.lev || (starkInfo.nConstants && (!R.constN || !R.const2ns))) mi::fail("Starks::Starks (row shards: device memory)");
                     if (starkInfo.nConstants)
                         mi::check(mi_copy_h2d(cg, R.constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (row shards: constant polynomials h2d)");
                 }
@@ -538,11 +600,56 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
 
     // ---- the HBM plan: image | trees | late scratch
     const uint64_t imageElems = starkInfo.mapTotalN;
-    uint64_t *d_mem = mi::arena().reserve(imageElems + 4 * treeElems + scratchElems);
+    uint64_t *d_mem = mi::arena().reserve(imageElems + 4 * treeElems + scratchElems, sparseImage);
     uint64_t *d_nodes[4];
     for (int t = 0; t < 4; t++) d_nodes[t] = d_mem + imageElems + t * treeElems;
     uint64_t *d_late = d_mem + imageElems + 4 * treeElems;
     auto sec = [&](eSection s) { return d_mem + off(s); };
+    mi_multi *mm = mi::multi();
+    auto sharded = [&](uint64_t ncols) { return mm && ncols > 4 && NExtended / (uint64_t)mi_multi_shards(mm) >= 64; };
+    // Row shards active (several devices, the table steps): NOBODY on this device reads another shard's rows of the extension any more --
+    // step42ns, step52ns and evmap take this device's rows, the openings fetch a row's values from the device that holds it -- so the
+    // commits no longer send the whole extension here (seven links into one device: 137 GB per zkEVM-size proof, the sharded commit's
+    // longest transfer): this device, like the others, receives its own rows and the halo -- and, the image being an address range
+    // (mi::Arena, sparse), holds physical memory under those rows only.
+    ownRowsOnly = rowSharded && parserSteps;
+    {
+        const uint64_t G = rowMem.size(), R = G ? NExtended / G : 0, halo = 1ULL << extendBits;
+        const eSection wide[3] = {cm1_2ns, cm2_2ns, cm3_2ns};
+        mi::Arena &A = mi::arena();
+        if (A.sparse) {
+            const uint64_t before = A.backedBytes();
+            if (ownRowsOnly) {
+                A.back(0, off(cm1_2ns));                                                    // the base-domain part (from stage 4: the late plan)
+                for (eSection e : wide) A.back(off(e), (sharded(cols(e)) ? R + halo : NExtended) * cols(e)); // this device's rows (+ halo); a narrow section is committed here, whole
+                A.back(off(cm4_2ns), imageElems - off(cm4_2ns));                            // the quotient's chunks, q, f: built and folded here
+                A.back(imageElems, 4 * treeElems + scratchElems);
+            } else A.back(0, imageElems + 4 * treeElems + scratchElems);
+            if (A.backedBytes() != before) // the other devices' kernels write this device's rows of a tile straight into the image
+                for (int g = 1; g < mi_multi_shards(mm); g++) mi::check(mi_vmm_allow_peer(c, A.base, mi_ctx_device(mi_multi_ctx(mm, g))), "Starks::genProof (image: peer access)");
+        }
+        // the other shards' mirrors: their rows (+ halo, wrapping) of the extended sections, their rows of q and f
+        for (uint64_t g = 1; g < G; g++) {
+            mi::ShardArena &S = mi::shardArena((int)g);
+            rowMem[g].ext = S.reserve(mm, (int)g, imageElems - off(cm1_2ns));
+            mi_ctx *cg = mi_multi_ctx(mm, (int)g);
+            uint64_t before = 0, after = 0;
+            mi::check(mi_multi_set_device(mm, (int)g), "Starks::genProof (row shards: device)");
+            mi::check(mi_vmm_backed_bytes(cg, S.base, &before), "Starks::genProof (row-shard mirror)");
+            const uint64_t r0 = g * R, o0 = off(cm1_2ns);
+            for (eSection e : {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns}) {
+                const uint64_t w = cols(e), first = std::min(R + halo, NExtended - r0);
+                S.back(mm, (int)g, off(e) - o0 + r0 * w, first * w);
+                if (first < R + halo) S.back(mm, (int)g, off(e) - o0, (R + halo - first) * w); // the last shard's halo: the extension's first rows
+            }
+            for (eSection e : {q_2ns, f_2ns}) S.back(mm, (int)g, off(e) - o0 + r0 * cols(e), R * cols(e));
+            mi::check(mi_multi_set_device(mm, (int)g), "Starks::genProof (row shards: device)");
+            mi::check(mi_vmm_backed_bytes(cg, S.base, &after), "Starks::genProof (row-shard mirror)");
+            if (after != before)
+                for (int h = 0; h < mi_multi_shards(mm); h++) mi::check(mi_vmm_allow_peer(cg, S.base, mi_ctx_device(mi_multi_ctx(mm, h))), "Starks::genProof (row-shard mirror: peer access)");
+        }
+        if (G) mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
+    }
     auto lend = [&](uint64_t *p, uint64_t elems) { // LDE / NTT scratch out of a region that is not live
         const uint64_t atLeast = 16 * 2 * (N + NExtended);
         mi::check(mi_ctx_lend_workspace(c, elems >= atLeast ? p : nullptr, elems * 8), "Starks::genProof (lend workspace)");
@@ -569,8 +676,6 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     // tiles (stage 1: uploaded over ITS OWN PCIe link) and hashes the leaves and the subtree of its rows -- while the row-major extension
     // still lands in this device's image, where the constraint evaluation reads it.  The shard on this device works in the same dead
     // regions the single-device path lends as scratch.
-    mi_multi *mm = mi::multi();
-    auto sharded = [&](uint64_t ncols) { return mm && ncols > 4 && NExtended / (uint64_t)mi_multi_shards(mm) >= 64; };
     // The witness TILE-MAJOR in the image ([64 rows][column][row in tile], mi_lde_merkle_host_keep_tiled): the three base-domain steps read
     // nearly every column of cm1_n (the zkEVM's: 497 / 647 / 553 of 665), and from a row-major section each of them first makes a tile-major
     // copy of it (a read and a write of 44.6 GB); kept tile-major -- written that way behind the upload, where the row-major copy was written
@@ -610,25 +715,43 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStart(STARK_STEP_1_LDE_AND_MERKLETREE);
     mi_multi_tree *mtree[4] = {};
     const int dev0 = mi_ctx_device(c);
-    // Row shards active (several devices, the table steps): NOBODY on this device reads another shard's rows of the extension any more --
-    // step42ns, step52ns and evmap take this device's rows, the openings fetch a row's values from the device that holds it -- so the
-    // commits no longer send the whole extension here (seven links into one device: 137 GB per zkEVM-size proof, the sharded commit's
-    // longest transfer): this device, like the others, receives its own rows and the halo.
-    ownRowsOnly = rowSharded && parserSteps;
-    for (size_t g = 1; g < rowMem.size(); g++) rowMem[g].ext = mi::shardArena((int)g).reserve(mm, (int)g, starkInfo.mapTotalN - off(cm1_2ns));
-    auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, uint64_t *scratch, uint64_t scratchElems, Goldilocks::Element *root) {
+    // Scratch of a stage's transforms and of shard 0's commit buffers: a region of the image that is not live.  With the whole image
+    // backed, the reference's choices (starks.cpp:52 lends p_cm2_2ns; :102-104 reuses cm3_2ns); with only this device's rows of the
+    // extended sections backed (ownRowsOnly), stages 1 and 2 borrow COMPUTED BASE-DOMAIN sections that nothing has written yet --
+    // cm2_n .. tmpExp_n before step2prev, cm3_n | cm4_n before step3prev -- and zero them again afterwards (they start every proof as
+    // zeros, see above).  Stage 3: cm1_n | cm2_n, whose last reader has run, in both forms.
+    struct Scratch { uint64_t *p; uint64_t elems; bool rezero; };
+    auto stageScratch = [&](int stage) -> Scratch {
+        if (stage == 3) return {sec(cm1_n), off(cm3_n) - off(cm1_n), false};
+        if (!ownRowsOnly) return stage == 1 ? Scratch{sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns), false} : Scratch{sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns), false};
+        return stage == 1 ? Scratch{sec(cm2_n), off(cm1_2ns) - off(cm2_n), true} : Scratch{sec(cm3_n), off(tmpExp_n) - off(cm3_n), true};
+    };
+    auto doneWith = [&](const Scratch &S) {
+        if (!S.rezero || !S.elems) return;
+        lend(nullptr, 0);
+        mi::check(mi_dev_zero(c, S.p, S.elems * 8), "Starks::genProof (zero the borrowed base-domain sections)");
+    };
+    auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, const Scratch &scr, Goldilocks::Element *root) {
         mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
-        mi::check(mi_multi_lend(mm, 0, scratch, scratchElems * 8), "Starks::genProof (sharded commit: lend)");
+        mi::check(mi_multi_lend(mm, 0, scr.p, scr.elems * 8), "Starks::genProof (sharded commit: lend)");
         if (rowSharded) { // every other shard keeps its own rows of this extension (+ the rows its shifted reads reach) on its device, for step42ns
             std::vector<uint64_t *> imgs(rowMem.size(), nullptr);
             for (size_t g = 1; g < rowMem.size(); g++) imgs[g] = rowBase((int)g) + (image - d_mem);
-            if (ownRowsOnly) { imgs[0] = image; image = nullptr; }
+            if (ownRowsOnly) {
+                // ... and so does this device: nobody opens values from the tree (the openings read the images), every shard has a row
+                // image: a TRANSIENT commit -- a tile's rows are written once, by a kernel of the shard that extended it, straight into
+                // their owner's image and absorbed there (csrc/multi.hip)
+                imgs[0] = image;
+                image = nullptr;
+                mi::check(mi_multi_set_transient(mm, 1), "Starks::genProof (sharded commit: transient)");
+            }
             mi::check(mi_multi_set_row_images(mm, imgs.data(), ncols, 1ULL << extendBits), "Starks::genProof (sharded commit: row images)");
         }
         mi::check(mi_multi_commit(mm, &mtree[t], src, ncols, srcDevice, N, NExtended, ncols, image, ncols, base, ncols, dev0, (uint64_t *)root),
                   "Starks::genProof (sharded extendPol + merkelize)");
         mi::check(mi_multi_tree_release_rows(mtree[t]), "Starks::genProof (sharded commit: release)"); // the openings read the rows from the image
-        lend(scratch, scratchElems); // ... and the region serves this context's transforms until the next stage, as on the one-device path
+        if (scr.rezero) doneWith(scr);
+        else lend(scr.p, scr.elems); // ... and the region serves this context's transforms until the next stage, as on the one-device path
     };
     // a section whose commit is NOT sharded (at most 4 columns: linear_hash copies such rows) still has to reach the row shards: their rows
     // (+ halo, wrapping) out of this image, contiguous because whole rows of a section are
@@ -645,9 +768,10 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     };
     if (sharded(cols(cm1_n))) {
-        commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns), root0.address());
+        commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), stageScratch(1), root0.address());
     } else {
-        lend(sec(cm2_2ns), off(cm4_2ns) - off(cm2_2ns));
+        const Scratch scr = stageScratch(1);
+        lend(scr.p, scr.elems);
         if (m.tiledWitness)
             mi::check(mi_lde_merkle_host_keep_tiled(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
                                                     cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
@@ -656,6 +780,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
                                               cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
         mi::check(mi_copy_d2h(c, root0.address(), d_nodes[0] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 1)");
         mirrorRows(cm1_2ns);
+        doneWith(scr);
     }
     transcript.put(root0.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_1_LDE_AND_MERKLETREE);
@@ -685,13 +810,15 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStopAndLog(STARK_STEP_2_CALCULATEH1H2);
     TimerStart(STARK_STEP_2_LDE_AND_MERKLETREE);
     if (sharded(cols(cm2_n))) {
-        commitSharded(1, sec(cm2_n), dev0, cols(cm2_n), sec(cm2_2ns), nullptr, sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns), root1.address());
+        commitSharded(1, sec(cm2_n), dev0, cols(cm2_n), sec(cm2_2ns), nullptr, stageScratch(2), root1.address());
     } else {
-        lend(sec(cm3_2ns), off(cm4_2ns) - off(cm3_2ns));
+        const Scratch scr = stageScratch(2);
+        lend(scr.p, scr.elems);
         mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
         mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
         mi::check(mi_copy_d2h(c, root1.address(), d_nodes[1] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 2)");
         mirrorRows(cm2_2ns);
+        doneWith(scr);
     }
     transcript.put(root1.address(), HASH_SIZE);
     TimerStopAndLog(STARK_STEP_2_LDE_AND_MERKLETREE);
@@ -738,7 +865,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS_2);
     TimerStart(STARK_STEP_3_LDE_AND_MERKLETREE);
     if (sharded(cols(cm3_n))) { // (scratch: cm1_n | cm2_n, their last reader has run)
-        commitSharded(2, sec(cm3_n), dev0, cols(cm3_n), sec(cm3_2ns), nullptr, sec(cm1_n), off(cm3_n) - off(cm1_n), root2.address());
+        commitSharded(2, sec(cm3_n), dev0, cols(cm3_n), sec(cm3_2ns), nullptr, stageScratch(3), root2.address());
     } else {
         lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run
         mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
@@ -779,36 +906,55 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     uint64_t *rest = scratchElems ? d_late + lateUsed : d_mem + poolUsed;
     const uint64_t restElems = scratchElems ? scratchElems - lateUsed : poolElems - poolUsed;
     lend(rest, restElems);
+    // the tables a shard reads: its own, its group leader's, or -- grouped with shard 0 -- this device's (RowShardMem::aliasFrom)
+    struct ShardTables { uint64_t *constN, *const2ns, *x2ns, *xdiv, *xdivw, *lev; };
+    auto tablesOf = [&](size_t g) -> ShardTables {
+        const RowShardMem &R = rowMem[g];
+        if (R.aliasFrom < 0) return {R.constN, R.const2ns, R.x2ns, R.xdiv, R.xdiv + 3 * NExtended, R.lev};
+        if (R.aliasFrom == 0) return {d_constN, m.d_const2ns, m.d_x2ns, m.d_xdiv, m.d_xdivw, lev};
+        const RowShardMem &L = rowMem[R.aliasFrom];
+        return {L.constN, L.const2ns, L.x2ns, L.xdiv, L.xdiv + 3 * NExtended, L.lev};
+    };
+    bool followsHome = false; // a shard reads THIS device's tables: they are computed here in full, and before that shard runs
+    std::vector<size_t> tableOwners;
+    for (size_t g = 1; g < rowMem.size(); g++) {
+        followsHome = followsHome || rowMem[g].aliasFrom == 0;
+        if (rowMem[g].ownsTables) tableOwners.push_back(g);
+    }
     if (rowSharded && parserSteps) { // the other devices extend the constants and build x_2ns for themselves, beside this one (launches return at once)
         const uint64_t R = NExtended / rowMem.size();
         for (size_t g = 1; g < rowMem.size(); g++) {
             mi::check(mi_multi_set_device(mm, (int)g), "Starks::genProof (row shards: device)");
             mi_ctx *cg = mi_multi_ctx(mm, (int)g);
-            if (!rowMem[g].tablesReady) { // constants of the proving key: extended ONCE and kept (a device that holds 20 GB of a proof has the room)
+            if (rowMem[g].ownsTables && !rowMem[g].tablesReady) { // constants of the proving key: extended ONCE and kept (a device that holds 20 GB of a proof has the room)
                 if (nConst) mi::check(mi_lde_dev(cg, rowMem[g].const2ns, nConst, rowMem[g].constN, nConst, NExtended, N, nConst), "Starks::genProof (row shards: constant polynomials, extended)");
                 mi::check(mi_geom_seq_dev(cg, rowMem[g].x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))), "Starks::genProof (row shards: x_2ns)");
                 rowMem[g].tablesReady = true;
             }
+            const ShardTables T = tablesOf(g);
             mi::StarkMirror::RowShard S;
-            S.shard = (int)g; S.d_mem = rowBase((int)g); S.d_const2ns = rowMem[g].const2ns; S.d_x2ns = rowMem[g].x2ns; S.d_xdiv = rowMem[g].xdiv; S.d_xdivw = rowMem[g].xdiv + 3 * NExtended; S.row0 = g * R; S.rows = R; S.progs = &rowMem[g].progs;
+            S.shard = (int)g; S.d_mem = rowBase((int)g); S.d_const2ns = T.const2ns; S.d_x2ns = T.x2ns; S.d_xdiv = T.xdiv; S.d_xdivw = T.xdivw; S.row0 = g * R; S.rows = R; S.progs = &rowMem[g].progs;
             m.rowShards.push_back(S);
         }
         m.multi = mm;
+        m.syncHomeFirst = followsHome;
         mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     }
     constRowsOnly = false;
-    if (nConst && ownRowsOnly && !m.rowShards.empty()) {
+    if (nConst && ownRowsOnly && !m.rowShards.empty() && !followsHome && !tableOwners.empty()) {
         // this device's image is planned to the last byte and cannot keep the extended constants from proof to proof; the other devices
         // can and do, and of all it would compute here (68 ms at zkEVM size) this device reads only its own rows and the halo: they come
         // across from the others' resident copies, a slice from each (seven links at once: 3.6 GB)
-        const uint64_t need = NExtended / rowMem.size() + (1ULL << extendBits), G1 = rowMem.size() - 1, per = (need + G1 - 1) / G1;
-        for (size_t g = 1; g < rowMem.size(); g++) {
-            const uint64_t r0 = (g - 1) * per, r1 = std::min(need, r0 + per);
+        const uint64_t need = NExtended / rowMem.size() + (1ULL << extendBits), G1 = tableOwners.size(), per = (need + G1 - 1) / G1;
+        for (size_t i = 0; i < G1; i++) {
+            const size_t g = tableOwners[i];
+            const uint64_t r0 = i * per, r1 = std::min(need, r0 + per);
             if (r0 < r1) mi::check(mi_multi_copy(mm, m.d_const2ns + r0 * nConst, 0, rowMem[g].const2ns + r0 * nConst, (int)g, (r1 - r0) * nConst * 8), "Starks::genProof (constant polynomials: this device's rows from a peer)");
         }
-        for (size_t g = 1; g < rowMem.size(); g++) mi::check(mi_multi_sync(mm, (int)g), "Starks::genProof (constant polynomials: rows arrived)");
+        for (size_t g : tableOwners) mi::check(mi_multi_sync(mm, (int)g), "Starks::genProof (constant polynomials: rows arrived)");
         mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
         constRowsOnly = true;
+        constRowsFrom = (int)tableOwners[0];
     } else if (nConst) mi::check(mi_lde_dev(c, m.d_const2ns, nConst, d_constN, nConst, NExtended, N, nConst), "Starks::genProof (constant polynomials, extended)");
     mi::check(mi_geom_seq_dev(c, m.d_x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))),
               "Starks::genProof (x_2ns)"); // starks.hpp:155-160
@@ -885,10 +1031,12 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
             mi::check(mi_ctx_sync(c), "Starks::genProof (evmap shards: LEv / LpEv ready)");
             std::vector<std::vector<Goldilocks::Element>> share(G, std::vector<Goldilocks::Element>(nEvals * 3));
             for (const mi::StarkMirror::RowShard &S : m.rowShards) {
-                uint64_t *lg = rowMem[S.shard].lev, *lpg = lg + 3 * N;
+                if (rowMem[S.shard].aliasFrom == 0) continue; // reads this device's LEv / LpEv in place
+                uint64_t *lg = tablesOf(S.shard).lev, *lpg = lg + 3 * N;
+                const int owner = rowMem[S.shard].aliasFrom > 0 ? rowMem[S.shard].aliasFrom : S.shard; // (its leader's buffer: one per device)
                 const uint64_t k0 = S.shard * nk;
-                mi::check(mi_multi_copy(mm, lg + 3 * k0, S.shard, lev + 3 * k0, 0, nk * 3 * 8), "Starks::genProof (evmap shards: LEv slice)");
-                mi::check(mi_multi_copy(mm, lpg + 3 * k0, S.shard, lpev + 3 * k0, 0, nk * 3 * 8), "Starks::genProof (evmap shards: LpEv slice)");
+                mi::check(mi_multi_copy(mm, lg + 3 * k0, owner, lev + 3 * k0, 0, nk * 3 * 8), "Starks::genProof (evmap shards: LEv slice)");
+                mi::check(mi_multi_copy(mm, lpg + 3 * k0, owner, lpev + 3 * k0, 0, nk * 3 * 8), "Starks::genProof (evmap shards: LpEv slice)");
             }
             mi::check(mi_multi_sync(mm, 0), "Starks::genProof (evmap shards: slices sent)");
             for (const mi::StarkMirror::RowShard &S : m.rowShards) {
@@ -897,7 +1045,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
                     const EvMap &ev = starkInfo.evMap[i];
                     pg[i] = ev.type == EvMap::eType::_const ? S.d_const2ns + ev.id : S.d_mem + (ptr[i] - d_mem);
                 }
-                uint64_t *lg = rowMem[S.shard].lev, *lpg = lg + 3 * N, *eg = lg + 6 * N;
+                uint64_t *lg = tablesOf(S.shard).lev, *lpg = lg + 3 * N, *eg = rowMem[S.shard].evalsPart;
                 mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (evmap shards: device)");
                 mi::check(mi_evmap_range_dev(mi_multi_ctx(mm, S.shard), eg, nEvals, N, (unsigned)extendBits, pg.data(), dim.data(), stride.data(), prime.data(), lg, lpg, S.shard * nk, nk),
                           "Starks::genProof (evmap shards)");
@@ -907,7 +1055,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
             mi::check(mi_copy_d2h(c, share[0].data(), d_evals, nEvals * 3 * 8), "Starks::genProof (evals d2h)");
             for (const mi::StarkMirror::RowShard &S : m.rowShards) {
                 mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (evmap shards: device)");
-                mi::check(mi_copy_d2h(mi_multi_ctx(mm, S.shard), share[S.shard].data(), rowMem[S.shard].lev + 6 * N, nEvals * 3 * 8), "Starks::genProof (evmap shards: share d2h)");
+                mi::check(mi_copy_d2h(mi_multi_ctx(mm, S.shard), share[S.shard].data(), rowMem[S.shard].evalsPart, nEvals * 3 * 8), "Starks::genProof (evmap shards: share d2h)");
             }
             mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (evmap shards: device)");
             for (uint64_t i = 0; i < nEvals; i++)

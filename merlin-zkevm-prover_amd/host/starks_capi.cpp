@@ -149,6 +149,13 @@ uint64_t mis_phase_times(char *buf, uint64_t cap)
     return s.size() + 1;
 }
 uint64_t mis_min_free_bytes(void) { return mi::phaseTimer().minFree; }
+// bytes of device memory under the process's image arena (the whole plan when dense; what the proofs so far backed when it is an
+// address range: several devices, host/starks.hpp mi::Arena) and whether it is sparse
+uint64_t mis_image_backed_bytes(int *sparse)
+{
+    if (sparse) *sparse = mi::arena().sparse ? 1 : 0;
+    return mi::arena().base ? mi::arena().backedBytes() : 0;
+}
 // MI_STARK_DEVICES: the shards and what the driver said about direct access between their devices (mi_multi_peer_access); returns the
 // number of shards, 0 when the proof runs on one device
 int mis_peer_access(int *matrix, char *warning, uint64_t warning_cap, int *indirect_pairs)

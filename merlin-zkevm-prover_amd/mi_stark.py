@@ -57,7 +57,7 @@ EXPORTS = [
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
     "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_get_host_pack_threads",
-    "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_destroy", "mi_multi_shards", "mi_multi_peer_access", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
+    "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_create2", "mi_multi_lead", "mi_multi_set_transient", "mi_multi_transient_need", "mi_multi_check_stats", "mi_multi_own", "mi_vmm_reserve", "mi_vmm_back", "mi_vmm_allow_peer", "mi_vmm_backed_bytes", "mi_vmm_free", "mi_multi_destroy", "mi_multi_shards", "mi_multi_peer_access", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
     "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_compile_micro", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
 ]
@@ -230,6 +230,32 @@ class Context:
 
     def host_unregister(self, ptr):
         _check(lib().mi_host_unregister(self.h, ctypes.c_void_p(ptr)))
+
+    # ---- sparse device memory (mi_vmm_*): an address range, physical memory under the parts that are used
+    def vmm_reserve(self, nbytes):
+        base = ctypes.c_void_p()
+        _check(lib().mi_vmm_reserve(self.h, u64(nbytes), ctypes.byref(base)))
+        return int(base.value)
+
+    def vmm_back(self, base, offset, nbytes):
+        _check(lib().mi_vmm_back(self.h, ctypes.c_void_p(base), u64(offset), u64(nbytes)))
+
+    def vmm_backed_bytes(self, base):
+        out = ctypes.c_uint64()
+        _check(lib().mi_vmm_backed_bytes(self.h, ctypes.c_void_p(base), ctypes.byref(out)))
+        return int(out.value)
+
+    def vmm_free(self, base):
+        _check(lib().mi_vmm_free(self.h, ctypes.c_void_p(base)))
+
+    def copy_h2d(self, dst_ptr, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        _check(lib().mi_copy_h2d(self.h, ctypes.c_void_p(dst_ptr), _hp(host.reshape(-1)), u64(host.size * 8)))
+
+    def copy_d2h(self, src_ptr, count):
+        out = np.empty(count, dtype=np.uint64)
+        _check(lib().mi_copy_d2h(self.h, _hp(out), ctypes.c_void_p(src_ptr), u64(count * 8)))
+        return out
 
     # ---- host-pointer (drop-in) variants
     def ntt_host(self, src, n, ncols, inverse=False):
@@ -612,11 +638,25 @@ class Multi:
     """One process, several devices (csrc/multi.hip): the stage commit sharded over `devices` (a device may be named more than once:
     logical shards on one GPU)."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, group_same_device=False):
         devs = (ctypes.c_int * len(devices))(*devices)
         self.h = ctypes.c_void_p()
         self.devices = list(devices)
-        _check(lib().mi_multi_create(ctypes.byref(self.h), devs, ctypes.c_int(len(devices))))
+        _check(lib().mi_multi_create2(ctypes.byref(self.h), devs, ctypes.c_int(len(devices)), ctypes.c_int(int(group_same_device))))
+
+    def set_transient(self, on=True):
+        """the next commit keeps no rows: a row image for every shard (set_row_images), tiles written once into the images and absorbed there"""
+        _check(lib().mi_multi_set_transient(self.h, ctypes.c_int(int(on))))
+
+    @staticmethod
+    def transient_need(n, n_ext, ncols, shards):
+        """elements of device memory a transient commit takes per device group (what to lend its leader)"""
+        lib().mi_multi_transient_need.restype = ctypes.c_uint64
+        return int(lib().mi_multi_transient_need(u64(n), u64(n_ext), u64(ncols), ctypes.c_uint32(shards)))
+
+    def ctx_handle(self, shard):
+        lib().mi_multi_ctx.restype = ctypes.c_void_p
+        return ctypes.c_void_p(lib().mi_multi_ctx(self.h, ctypes.c_int(shard)))
 
     def commit(self, src_ptr, n, n_ext, ncols, src_device=-1, src_pitch=None, image_ptr=None, image_pitch=None, base_ptr=None, base_pitch=None, image_device=0):
         """src_ptr: address of the n x ncols row-major section (host memory when src_device < 0, else on that device) -> MultiTree"""
@@ -669,6 +709,13 @@ class Multi:
         if self.h:
             lib().mi_multi_destroy(self.h)
             self.h = ctypes.c_void_p()
+
+
+def multi_check_stats():
+    """MI_MULTI_CHECK=1: {enabled, checks, unknown (pointers nobody entered: they pass), violations}"""
+    out = (ctypes.c_uint64 * 4)()
+    _check(lib().mi_multi_check_stats(out))
+    return {"enabled": bool(out[0]), "checks": int(out[1]), "unknown": int(out[2]), "violations": int(out[3])}
 
 
 # ---- host debug hooks (same inline math as the kernels, run on the CPU; tests only)

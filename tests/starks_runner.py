@@ -34,6 +34,7 @@ def const_tree_image(const_n, n_const, nbits, nbits_ext, fast=False):
 
 _LIB = None
 _N_LIBS = 0
+LAST_CHECK = None   # MI_MULTI_CHECK statistics of the last child: {enabled, checks, unknown, violations}
 
 
 def starks_lib():
@@ -91,6 +92,10 @@ def gen_proof_on_device(si, progs, const_n, const_tree, witness, publics, workdi
     r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
     if r.returncode != 0:
         raise RuntimeError("Starks::genProof child failed (rc %d):\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-4000:]))
+    global LAST_CHECK
+    LAST_CHECK = json.load(open(os.path.join(workdir, "multi_check.json")))
+    if LAST_CHECK["enabled"] and LAST_CHECK["violations"]:
+        raise RuntimeError("MI_MULTI_CHECK: %s" % LAST_CHECK)
     return [open(os.path.join(workdir, "zkin.%d.%d.json" % (i, b))).read() for i, b in enumerate(batches)]
 
 
@@ -119,6 +124,9 @@ def _child(workdir, batches, steps_so):
     for i, b in enumerate(batches):
         L.mis_gen_proof(h, vp(publics.ctypes.data), ctypes.c_uint64(b), b"", b"")
         open(os.path.join(workdir, "zkin.%d.%d.json" % (i, b)), "w").write(L.mis_zkin(h).decode())
+    out = (ctypes.c_uint64 * 4)()
+    ctypes.CDLL(os.path.join(ROOT, "merlin-zkevm-prover_amd", "libmi_stark.so")).mi_multi_check_stats(out)
+    json.dump({"enabled": bool(out[0]), "checks": int(out[1]), "unknown": int(out[2]), "violations": int(out[3])}, open(os.path.join(workdir, "multi_check.json"), "w"))
     L.mis_destroy(h)
 
 

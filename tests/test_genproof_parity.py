@@ -169,22 +169,29 @@ def test_starks_genproof_with_sharded_commits_equals_the_oracle_prover(name, dev
     got4, again = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 4), env=dict(os.environ, MI_STARK_DEVICES=devices))
     assert got4 == want, first_difference(got4, want)
     assert again == want, first_difference(again, want)                 # (the second proof takes its shard buffers from the pool)
+    assert not sr.LAST_CHECK["enabled"] or (sr.LAST_CHECK["checks"] > 100 and sr.LAST_CHECK["violations"] == 0), sr.LAST_CHECK   # logical-shard discipline held
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,devices", [("zkevm_small", "0,0"), ("zkevm_14", "0,0,0,0"), ("recursive_12", "0,0,0,0"), ("zkevm_full_12", "0,0,0,0,0,0,0,0")])
-def test_starks_genproof_with_row_sharded_step42ns_equals_the_oracle_prover(name, devices, tmp_path):
+@pytest.mark.parametrize("name,devices,grouped", [("zkevm_small", "0,0", False), ("zkevm_14", "0,0,0,0", False), ("recursive_12", "0,0,0,0", False), ("zkevm_full_12", "0,0,0,0,0,0,0,0", False),
+                                                  ("zkevm_14", "0,0,0,0", True), ("recursive_12", "0,0,0,0", True), ("zkevm_full_12", "0,0,0,0,0,0,0,0", True)])
+def test_starks_genproof_with_row_sharded_step42ns_equals_the_oracle_prover(name, devices, grouped, tmp_path):
     """MI_STARK_ROW_SHARDED (the default when MI_STARK_DEVICES names distinct devices; forced here on logical shards of device 0): every
     shard but the first evaluates step42ns and step52ns over ITS rows of the extended domain -- from a full-height mirror on its device
     of which the stage commits wrote only those rows and the halo its shifted reads reach (blow-up 2: two rows; recursive_12: eight, and
     the last shard's wrap to row 0), its own extension of the constants, its own x_2ns and x / (x - xi) tables, through its own compiled
-    programs -- and sends its q and f rows home; the evaluation map is summed per device over its rows and the shares added.  Still the oracle prover's bytes, twice (the second proof reuses the shards' memory and programs)."""
+    programs -- and sends its q and f rows home; the evaluation map is summed per device over its rows and the shares added.  Still the oracle prover's bytes, twice (the second proof reuses the shards' memory and programs).
+    Round 5: every device's image -- this one's too -- is an ADDRESS RANGE with memory under its own rows only (mi_vmm_*), the commits are
+    TRANSIENT (rows written once, into the images), and with `grouped` the shards of the one physical device form a device group: one set
+    of streams and buffers, the proving key's tables held once (what lets eight shards rehearse the zkEVM's full size on one GPU).
+    Ungrouped, MI_MULTI_CHECK holds every buffer, program and event to its logical shard."""
     inputs, want = shaped_case(name)
     log = str(tmp_path / "row_shards.log")
     got4, again = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 4),
-                                         env=dict(os.environ, MI_STARK_DEVICES=devices, MI_STARK_ROW_SHARDED="1", MI_STARK_ROW_SHARD_LOG=log))
+                                         env=dict(os.environ, MI_STARK_DEVICES=devices, MI_STARK_ROW_SHARDED="1", MI_STARK_ROW_SHARD_LOG=log, MI_MULTI_GROUP_SAME_DEVICE="1" if grouped else "0"))
     assert got4 == want, first_difference(got4, want)
     assert again == want, first_difference(again, want)
+    assert not sr.LAST_CHECK["enabled"] or (sr.LAST_CHECK["checks"] > 100 and sr.LAST_CHECK["violations"] == 0), sr.LAST_CHECK
     G = len(devices.split(","))
     n_ext = 1 << inputs[0]["starkStruct"]["nBitsExt"]
     lines = open(log).read().split("\n")[:-1]
@@ -214,17 +221,30 @@ def test_fast_oracle_prover_is_the_oracle_prover():
 
 
 @pytest.mark.gpu
-def test_starks_genproof_equals_the_oracle_prover_at_2p16_rows_full_zkevm_shape(tmp_path):
+def test_starks_genproof_equals_the_oracle_prover_at_2p18_rows_full_zkevm_shape(tmp_path):
     """Every count of the zkEVM (665 / 128 / 371 / 265 columns, 218 constants, 1 768 evaluations, 21 lookups, 30 grand products, 128 queries,
-    the five programs at their real sizes) at 2^16 rows -> 2^17: the largest shape the oracle prover finishes inside a test (about a
-    minute of CPU), byte for byte."""
-    log_n = int(os.environ.get("MI_PARITY_LOG_N", "16"))          # a one-off at a larger size: profiles/r04_genproof_parity_large.txt
+    the five programs at their real sizes) at 2^18 rows -> 2^19 (round 5: was 2^16; the oracle prover takes about 105 s of the box's 16 threads), byte for byte.  MI_PARITY_LOG_N
+    runs it at another size -- 2^22 once per round, recorded under profiles/ -- and MI_PARITY_DEVICES / MI_PARITY_ROW_SHARDED /
+    MI_PARITY_GROUPED prove it with sharded commits, row shards and device groups as well."""
+    log_n = int(os.environ.get("MI_PARITY_LOG_N", "18"))          # a one-off at a larger size: profiles/r04_genproof_parity_large.txt
     t0 = time.time()
     inputs = shaped_inputs(["--log-n", str(log_n)], fast=True)
     t1 = time.time()
-    want, _ = og.gen_proof(*inputs, fast=True)
+    # MI_PARITY_ORACLE_FILE: the oracle prover's text is kept there (the inputs are seeded: the same on every run), so that further device
+    # configurations at a large size -- sharded commits, row shards -- are compared without spending the oracle's minutes again
+    keep = os.environ.get("MI_PARITY_ORACLE_FILE", "")
+    if keep and os.path.exists(keep):
+        want = open(keep).read()
+    else:
+        want, _ = og.gen_proof(*inputs, fast=True)
+        if keep:
+            open(keep, "w").write(want)
     t2 = time.time()
-    got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,))
+    env = dict(os.environ)
+    if os.environ.get("MI_PARITY_DEVICES"):
+        env.update(MI_STARK_DEVICES=os.environ["MI_PARITY_DEVICES"], MI_STARK_ROW_SHARDED=os.environ.get("MI_PARITY_ROW_SHARDED", "1"),
+                   MI_MULTI_GROUP_SAME_DEVICE=os.environ.get("MI_PARITY_GROUPED", "1"))
+    got4, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,), env=env)
     print("full zkEVM shape at 2^%d rows: inputs %.0f s, oracle prover %.0f s, Starks::genProof (child process, incl. compiling) %.0f s, zkin.json %d bytes, equal: %s"
           % (log_n, t1 - t0, t2 - t1, time.time() - t2, len(want), got4 == want))
     assert got4 == want, first_difference(got4, want)

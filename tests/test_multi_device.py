@@ -283,3 +283,197 @@ def test_a_lent_region_serves_the_shard_and_is_returned(big_enough):
     assert [int(v) for v in t2.root] == want_root and bool((ctx.to_host(region[:1024]) == 1).all())
     t.free(); t2.free(); m.close(); ctx.close()
     assert free_before > 0
+
+
+# ------------------------------------------------------------------ round 5: transient commits, device groups, sparse memory, MI_MULTI_CHECK
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,ncols,G,halo,pitch_extra,grouped,lend", [(10, 37, 2, 2, 0, False, False), (12, 128, 4, 8, 5, True, True), (11, 665, 8, 2, 0, True, False),
+                                                                       (9, 9, 4, 128, 0, False, True), (14, 371, 8, 2, 0, False, False), (12, 665, 16, 2, 3, True, True),
+                                                                       (10, 5, 8, 2, 0, True, False)])   # fewer columns than shards
+def test_transient_commit_writes_every_row_once_and_gives_the_single_device_tree(log_n, ncols, G, halo, pitch_extra, grouped, lend):
+    """mi_multi_set_transient (what a row-sharded Starks::genProof asks for): a row image for EVERY shard, tiles written once by a kernel
+    of the extending shard into their owners' images (own rows + halo, wrapping), absorbed there at the image's pitch; the tree keeps
+    subtrees only.  Root, every leaf digest and the siblings equal the single-device tree; every image holds its shard's rows and halo
+    and nothing else; the base-domain section is kept; with and without device groups (shards of one physical device sharing streams,
+    tile ring and workspace) and with the group's buffers lent by the caller."""
+    n, n_ext, pitch = 1 << log_n, 2 << log_n, ncols + pitch_extra
+    trace = glo.splitmix64(0x5EED0900 + log_n, n * ncols).reshape(n, ncols)
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    want = ctx.to_host(ext).reshape(n_ext, ncols)
+    want_nodes = ctx.to_host(nodes)
+    m = mi_stark.Multi([0] * G, group_same_device=grouped)
+    SENT = 0x5A5A5A5A5A5A5A5A
+    imgs = [ctx.zeros(n_ext * pitch).fill_(SENT) for _ in range(G)]
+    base = ctx.zeros(n * ncols)
+    need = mi_stark.Multi.transient_need(n, n_ext, ncols, G)
+    region = ctx.zeros(need + 64) if lend else None
+    ctx.sync()
+    for rep in range(2):                                                # (the second commit takes its buffers from the pool)
+        m.set_row_images([t_.data_ptr() for t_ in imgs], pitch, halo)
+        m.set_transient()
+        if lend:
+            region[:] = 0x7777
+            ctx.sync()
+            m.lend(0, region.data_ptr(), region.numel() * 8)
+        t = m.commit(trace.ctypes.data, n, n_ext, ncols, base_ptr=base.data_ptr())
+        assert [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+        R = n_ext // G
+        for g in range(G):
+            assert np.array_equal(t.leaf_digests(g).reshape(-1), want_nodes[4 * g * R:4 * (g + 1) * R]), g
+            got = ctx.to_host(imgs[g]).reshape(n_ext, pitch)
+            rows = np.zeros(n_ext, dtype=bool)
+            rows[g * R:(g + 1) * R] = True
+            rows[[(r % n_ext) for r in range((g + 1) * R, (g + 1) * R + halo)]] = True
+            assert np.array_equal(got[rows][:, :ncols], want[rows]), g
+            assert (got[~rows] == SENT).all() and (got[:, ncols:] == SENT).all(), g
+        assert np.array_equal(ctx.to_host(base), trace.reshape(-1))
+        if lend:
+            assert bool((ctx.to_host(region[:1024]) != 0x7777).any())    # the group's buffers came out of the lent region
+        idx = np.array(sorted({0, n_ext - 1, R, R - 1, n_ext // 2}), dtype=np.uint64)
+        sib = t.group_proofs(idx, with_values=False)
+        ref = ctx.empty(idx.size * (ncols + 4 * (log_n + 1)))
+        ctx.merkle_group_proofs(ref, nodes, ext, n_ext, ncols, idx)
+        assert np.array_equal(sib[:, ncols:], ctx.to_host(ref).reshape(idx.size, -1)[:, ncols:])
+        with pytest.raises(mi_stark.MiStarkError, match="released"):
+            t.group_proofs(idx)                                          # no row values in a transient tree: the caller opens them from its images
+        st = m.last_stats()
+        assert sum(sum(s["bytes_sent_to_shard"]) for s in st["per_shard"]) == 0   # (one physical device: nothing crosses a link)
+        t.free()
+    # one-shot: the next commit is an ordinary one
+    t = m.commit(trace.ctypes.data, n, n_ext, ncols)
+    assert [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]] and t.group_proofs(np.array([1], dtype=np.uint64)).shape[0] == 1
+    t.free()
+    # a transient commit without an image for every shard is refused
+    m.set_row_images([imgs[0].data_ptr()] + [0] * (G - 1), pitch, halo)
+    m.set_transient()
+    if G > 1:
+        with pytest.raises(mi_stark.MiStarkError, match="EVERY shard"):
+            m.commit(trace.ctypes.data, n, n_ext, ncols)
+    m.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_sparse_device_memory_backs_only_what_is_asked_for():
+    """mi_vmm_*: an address range far larger than the device, physical memory under two parts of it (idempotent, additive, in 64 MiB
+    pieces: equal sizes are what this driver's hipMemSetAccess takes at any distance, tools/vmm_probe3.hip), kernels and copies through
+    the mapping, the device's free memory as the account."""
+    import torch
+    ctx = mi_stark.Context(0)
+    free0 = torch.cuda.mem_get_info()[0]
+    rng = 600 << 30                                                      # 600 GiB of addresses on a 288 GiB device
+    base = ctx.vmm_reserve(rng)
+    assert ctx.vmm_backed_bytes(base) == 0 and torch.cuda.mem_get_info()[0] > free0 - (64 << 20)
+    a_off, b_off = (3 << 20) + 4096, (400 << 30) + 123 * 8                # unaligned on purpose
+    a_len, b_len = 70 << 20, (2 << 20) + 8
+    ctx.vmm_back(base, a_off, a_len)
+    ctx.vmm_back(base, b_off, b_len)
+    backed = ctx.vmm_backed_bytes(base)
+    P = 64 << 20
+    assert backed % P == 0 and a_len + b_len <= backed <= 3 * P + P            # a: two or three pieces, b: one
+    ctx.vmm_back(base, a_off + 4096, a_len // 2)                          # inside what is backed: nothing new
+    assert ctx.vmm_backed_bytes(base) == backed
+    ctx.vmm_back(base, a_off + a_len - 4096, 70 << 20)                    # overlaps the end of what is backed: only the new pieces
+    assert backed < ctx.vmm_backed_bytes(base) <= backed + 2 * P
+    backed = ctx.vmm_backed_bytes(base)
+    data = glo.splitmix64(0xABCD, 1 << 16)
+    for off in (a_off, a_off + a_len - (1 << 19), b_off):
+        ctx.copy_h2d(base + off, data)
+        assert np.array_equal(ctx.copy_d2h(base + off, data.size), data)
+    # a kernel through the mapping: a transform whose input and output live in the sparse range
+    n, ncols = 1 << 12, 3
+    src = glo.splitmix64(0x77, n * ncols)
+    ctx.copy_h2d(base + a_off, src)
+    L = mi_stark.lib()
+    import ctypes
+    mi_stark._check(L.mi_ntt_dev(ctx.h, ctypes.c_void_p(base + a_off + (1 << 20)), ctypes.c_uint64(ncols), ctypes.c_void_p(base + a_off), ctypes.c_uint64(ncols),
+                                 ctypes.c_uint64(n), ctypes.c_uint64(ncols), ctypes.c_int(0)))
+    ctx.sync()
+    assert np.array_equal(ctx.copy_d2h(base + a_off + (1 << 20), n * ncols).reshape(n, ncols), glo.ntt(src.reshape(n, ncols), n, ncols))
+    ctx.vmm_back(base, 123 << 30, 1)                                      # scattered single pieces, in any order
+    ctx.vmm_back(base, 7 << 30, 1)
+    ctx.vmm_back(base, 599 << 30, 1 << 20)
+    assert ctx.vmm_backed_bytes(base) == backed + 3 * P
+    backed += 3 * P
+    assert free0 - torch.cuda.mem_get_info()[0] < backed + (512 << 20)    # (plus the context's own tables)
+    with pytest.raises(mi_stark.MiStarkError, match="beyond the reserved range"):
+        ctx.vmm_back(base, rng - 4096, 1 << 20)
+    ctx.vmm_free(base)
+    ctx.close()
+
+
+def _run_py(code, env):
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n" % (os.path.join(root, "tests"), os.path.join(root, "merlin-zkevm-prover_amd"))
+    return subprocess.run([sys.executable, "-c", pre + code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+
+
+@pytest.mark.gpu
+def test_multi_check_refuses_what_only_a_real_multi_gpu_node_would_show():
+    """MI_MULTI_CHECK=1: on one GPU every logical shard is device 0 and every pointer is valid everywhere -- the check is what makes a
+    wrong-shard operand fail HERE.  A buffer allocated for shard 1 handed to an entry point working for shard 0, mi_multi_copy with the
+    wrong owner, a row image that is another shard's memory: refused, with the two shards named; a correct sharded commit with row
+    images: many checks, no violation.  (The whole GPU suite runs with the check on: tests/conftest.py.)"""
+    code = r'''
+import ctypes, numpy as np, glo, mi_stark
+L = mi_stark.lib()
+ctx = mi_stark.Context(0)
+m = mi_stark.Multi([0, 0, 0, 0])
+L.mi_dev_alloc.restype = ctypes.c_void_p
+c = [m.ctx_handle(g) for g in range(4)]
+n = 1 << 10
+a1 = L.mi_dev_alloc(c[1], ctypes.c_uint64(n * 8 * 4))          # memory of shard 1
+a2 = L.mi_dev_alloc(c[2], ctypes.c_uint64(n * 8 * 4))          # memory of shard 2
+u = ctypes.c_uint64
+ok = L.mi_geom_seq_dev(c[1], ctypes.c_void_p(a1), u(n), u(1), u(7))                 # shard 1 on its own memory
+bad = L.mi_geom_seq_dev(c[2], ctypes.c_void_p(a1), u(n), u(1), u(7))                # shard 2 on shard 1's memory
+msg = L.mi_last_error().decode()
+assert ok == 0 and bad != 0 and "logical shard 1" in msg and "shard 2" in msg, (ok, bad, msg)
+assert L.mi_multi_copy(m.h, ctypes.c_void_p(a2), 2, ctypes.c_void_p(a1), 1, u(64)) == 0        # declared: dst of 2, src of 1
+assert L.mi_multi_copy(m.h, ctypes.c_void_p(a2), 1, ctypes.c_void_p(a1), 1, u(64)) != 0        # dst is NOT shard 1's
+assert L.mi_multi_copy(m.h, ctypes.c_void_p(a2), 2, ctypes.c_void_p(a1 + 8), 3, u(64)) != 0    # src is NOT shard 3's
+# row images: imgs[q] must be shard q's memory
+log_n, ncols = 10, 37
+nn, ne = 1 << log_n, 2 << log_n
+trace = glo.splitmix64(5, nn * ncols)
+imgs = [L.mi_dev_alloc(c[g], u(ne * ncols * 8)) for g in range(4)]
+m.set_row_images(imgs, ncols, 2); m.set_transient()
+t = m.commit(trace.ctypes.data, nn, ne, ncols)
+good_root = [int(v) for v in t.root]
+t.free()
+swapped = [imgs[0], imgs[2], imgs[1], imgs[3]]
+m.set_row_images(swapped, ncols, 2); m.set_transient()
+try:
+    m.commit(trace.ctypes.data, nn, ne, ncols)
+    raise SystemExit("a row image in another shard's memory was accepted")
+except mi_stark.MiStarkError as e:
+    assert "MI_MULTI_CHECK" in str(e), str(e)
+st = mi_stark.multi_check_stats()
+assert st["enabled"] and st["checks"] > 50 and st["violations"] == 4, st
+print("OK", st, good_root)
+'''
+    r = _run_py(code, {"MI_MULTI_CHECK": "1"})
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    # with the check off the very same wrong-shard call goes through (every pointer IS valid on the one device) -- which is the point of the check
+    off = r'''
+import ctypes, mi_stark
+L = mi_stark.lib()
+ctx = mi_stark.Context(0)
+m = mi_stark.Multi([0, 0])
+L.mi_dev_alloc.restype = ctypes.c_void_p
+a1 = L.mi_dev_alloc(m.ctx_handle(1), ctypes.c_uint64(8192))
+u = ctypes.c_uint64
+assert L.mi_geom_seq_dev(m.ctx_handle(0), ctypes.c_void_p(a1), u(1024), u(1), u(7)) == 0
+assert not mi_stark.multi_check_stats()["enabled"]
+print("OK")
+'''
+    r = _run_py(off, {"MI_MULTI_CHECK": "0"})
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_the_suite_runs_with_the_multi_check_on():
+    st = mi_stark.multi_check_stats()
+    assert st["enabled"], "tests/conftest.py sets MI_MULTI_CHECK=1 for the GPU suite"
+    assert st["violations"] == 0, st

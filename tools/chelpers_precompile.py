@@ -29,7 +29,10 @@ STARKS_CONFIGS = [
     ["--log-n", "12", "--ext-bits", "3", "--qdeg", "7", "--widths", "18", "0", "39", "--tmpexp", "14", "--n-const", "52", "--n-evals", "118",
      "--n-queries", "43", "--n-lookups", "0", "0", "--n-products", "1", "--fri-steps", "15", "11", "7", "4", "--field-ops", "0", "201", "1761", "3483", "463"],
     ["--log-n", "12"],                                      # the zkEVM's full widths, counts and program sizes at 2^12 rows
-    ["--log-n", "16"],                                      # ... and at 2^16 (tests/test_genproof_parity.py's largest)
+    ["--log-n", "16"],                                      # ... and at 2^16, 2^18 (tests/test_genproof_parity.py's largest in the suite)
+    ["--log-n", "18"],
+    ["--log-n", "21"],                                      # ... and the once-per-round runs at 2^21 / 2^22 (MI_PARITY_LOG_N)
+    ["--log-n", "22"],
 ]
 
 
