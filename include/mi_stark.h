@@ -215,6 +215,7 @@ int mi_multi_set_row_images(mi_multi *m, uint64_t *const *imgs, uint64_t pitch, 
  * group's leader (mi_multi_lend) or from its pool.  What a row-sharded Starks::genProof asks for (host/starks.hpp). */
 int mi_multi_set_transient(mi_multi *m, int on);
 uint64_t mi_multi_transient_need(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards);
+uint64_t mi_multi_windowed_need(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards); /* elements one shard of an ordinary commit takes (tiles, row windows, staging, workspace) */
 /* MI_MULTI_CHECK=1 (environment, read once): logical-shard discipline.  Every device range the library allocates for a shard
  * (mi_dev_alloc and mi_vmm_reserve through that shard's context, the buffers of csrc/multi.hip) is entered with its shard; an entry
  * point then refuses (MI_ERR_INVALID, the reason on stderr) a device pointer that belongs to ANOTHER shard than the one its context

@@ -516,6 +516,18 @@ extern "C" uint64_t mi_multi_transient_need(uint64_t n, uint64_t n_ext, uint64_t
     return ((2 * n_ext * maxw + al) & ~al) + ((2 * n * maxw + al) & ~al) + std::max<uint64_t>((2 * n + n_ext) * maxw + 4096, 1ull << 17) + 64;
 }
 
+// elements of device memory the WINDOWED (non-transient) commit takes on one shard: extended tiles, row windows, staging, NTT workspace --
+// what a region lent to that shard must offer (host/starks.hpp checks it before it shards a stage: 103 GB at 2^23 x 665 and two shards)
+extern "C" uint64_t mi_multi_windowed_need(uint64_t n, uint64_t n_ext, uint64_t ncols, uint32_t shards)
+{
+    Plan p;
+    if (!shards || !is_pow2(shards)) return 0;
+    p.init(n, n_ext, ncols, shards);
+    const uint64_t maxw = *std::max_element(p.round_w.begin(), p.round_w.end());
+    const uint64_t e_ext = (n_ext * p.per_rank + 31) & ~31ull, e_recv = shards > 1 ? (p.rows_per_rank * shards * p.per_rank + 31) & ~31ull : 0, e_stage = (2 * n * maxw + 31) & ~31ull;
+    return e_ext + e_recv + e_stage + (2 * n + n_ext) * maxw + 4096;
+}
+
 namespace {
 // what both forms of the commit share
 struct CommitEnv {

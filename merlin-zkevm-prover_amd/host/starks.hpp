@@ -731,6 +731,27 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         lend(nullptr, 0);
         mi::check(mi_dev_zero(c, S.p, S.elems * 8), "Starks::genProof (zero the borrowed base-domain sections)");
     };
+    // A stage is committed over the shards unless this device could not hold its share: the whole image is planned to the last byte, and
+    // shard 0's buffers of an ordinary (windowed) commit must fit the region the stage lends -- at two devices 103 GB of tiles and row
+    // windows against the 67 GB of cm2_2ns | cm3_2ns.  Then the stage runs on this device alone, and says so once.  (A
+    // row-sharded proof commits transiently: 21.5 GB whatever the number of devices, and its image is sparse.)
+    auto shardedStage = [&](int stage, uint64_t ncols) {
+        if (!sharded(ncols)) return false;
+        if (ownRowsOnly) return true;
+        const uint64_t need = mi_multi_windowed_need(N, NExtended, ncols, (uint32_t)mi_multi_shards(mm));
+        if (stageScratch(stage).elems >= need) return true;
+        uint64_t fr = 0, tot = 0;
+        mi::check(mi_dev_mem_info(c, &fr, &tot), "Starks::genProof (device memory)");
+        if (fr >= need * 8 + (2ULL << 30)) return true; // (the shard allocates them instead: a small STARK, or a device with room)
+        static bool told[4] = {};
+        if (!told[stage]) {
+            told[stage] = true;
+            zklog.warning("Starks: stage " + std::to_string(stage) + " is committed on one device: shard 0 of " + std::to_string(mi_multi_shards(mm)) + " needs " +
+                          std::to_string(need * 8 / 1000000000) + " GB of buffers beside the image, the region the stage lends has " +
+                          std::to_string(stageScratch(stage).elems * 8 / 1000000000) + " GB (more devices need less; MI_STARK_ROW_SHARDED=1 commits transiently)");
+        }
+        return false;
+    };
     auto commitSharded = [&](int t, const uint64_t *src, int srcDevice, uint64_t ncols, uint64_t *image, uint64_t *base, const Scratch &scr, Goldilocks::Element *root) {
         mi::check(mi_ctx_sync(c), "Starks::genProof (sharded commit: sync)"); // the section and the scratch's last readers ran on this context's stream
         mi::check(mi_multi_lend(mm, 0, scr.p, scr.elems * 8), "Starks::genProof (sharded commit: lend)");
@@ -767,7 +788,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         mi::check(mi_multi_sync(mm, 0), "Starks::genProof (row shards: sync)");
         mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     };
-    if (sharded(cols(cm1_n))) {
+    if (shardedStage(1, cols(cm1_n))) {
         commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), stageScratch(1), root0.address());
     } else {
         const Scratch scr = stageScratch(1);
@@ -809,7 +830,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     numCommited += starkInfo.puCtx.size() * 2;
     TimerStopAndLog(STARK_STEP_2_CALCULATEH1H2);
     TimerStart(STARK_STEP_2_LDE_AND_MERKLETREE);
-    if (sharded(cols(cm2_n))) {
+    if (shardedStage(2, cols(cm2_n))) {
         commitSharded(1, sec(cm2_n), dev0, cols(cm2_n), sec(cm2_2ns), nullptr, stageScratch(2), root1.address());
     } else {
         const Scratch scr = stageScratch(2);
@@ -864,7 +885,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     else perRowStep(m, params, 2);
     TimerStopAndLog(STARK_STEP_3_CALCULATE_EXPS_2);
     TimerStart(STARK_STEP_3_LDE_AND_MERKLETREE);
-    if (sharded(cols(cm3_n))) { // (scratch: cm1_n | cm2_n, their last reader has run)
+    if (shardedStage(3, cols(cm3_n))) { // (scratch: cm1_n | cm2_n, their last reader has run)
         commitSharded(2, sec(cm3_n), dev0, cols(cm3_n), sec(cm3_2ns), nullptr, stageScratch(3), root2.address());
     } else {
         lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run

@@ -416,9 +416,9 @@ def test_multi_check_refuses_what_only_a_real_multi_gpu_node_would_show():
     wrong owner, a row image that is another shard's memory: refused, with the two shards named; a correct sharded commit with row
     images: many checks, no violation.  (The whole GPU suite runs with the check on: tests/conftest.py.)"""
     code = r'''
-import ctypes, numpy as np, glo, mi_stark
+import ctypes, numpy as np, torch, glo, mi_stark
+ctx = mi_stark.Context(0)            # (torch's HIP runtime first: the library binds to the one that is loaded)
 L = mi_stark.lib()
-ctx = mi_stark.Context(0)
 m = mi_stark.Multi([0, 0, 0, 0])
 L.mi_dev_alloc.restype = ctypes.c_void_p
 c = [m.ctx_handle(g) for g in range(4)]
@@ -450,16 +450,16 @@ try:
 except mi_stark.MiStarkError as e:
     assert "MI_MULTI_CHECK" in str(e), str(e)
 st = mi_stark.multi_check_stats()
-assert st["enabled"] and st["checks"] > 50 and st["violations"] == 4, st
+assert st["enabled"] and st["checks"] > 30 and st["violations"] == 4, st
 print("OK", st, good_root)
 '''
     r = _run_py(code, {"MI_MULTI_CHECK": "1"})
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     # with the check off the very same wrong-shard call goes through (every pointer IS valid on the one device) -- which is the point of the check
     off = r'''
-import ctypes, mi_stark
-L = mi_stark.lib()
+import ctypes, torch, mi_stark
 ctx = mi_stark.Context(0)
+L = mi_stark.lib()
 m = mi_stark.Multi([0, 0])
 L.mi_dev_alloc.restype = ctypes.c_void_p
 a1 = L.mi_dev_alloc(m.ctx_handle(1), ctypes.c_uint64(8192))
