@@ -445,7 +445,8 @@ def run(args):
            "hbm": {"total_gb": total_hbm / 1e9, "free_before_gb": free0 / 1e9, "plan_gb": plan / 1e9, "peak_hbm_gb": (total_hbm - min_free) / 1e9,
                    "fits_one_gpu": bool(total_hbm - min_free < total_hbm)},
            "setup_s": {"inputs": t_inputs, "starks_ctor_incl_const_upload": t_create, "per_row_steps_library_build": t_steps_lib},
-           "checks": checks, "dtype": "u64", "data": "synthetic"}
+           "checks": checks, "zkin_sha256": digests[0] if digests else None,   # the proof's text: a run on one device and a sharded one must agree on it
+           "dtype": "u64", "data": "synthetic"}
     # several devices (MI_STARK_DEVICES): what the driver answered about direct access between them -- a pair without it stages its
     # exchange through the host, and a reader of this line should not have to guess that from the times
     mat = (ctypes.c_int * 256)()
