@@ -259,6 +259,11 @@ def proof_kernel_rooflines(stats_csv, proofs_in_profile, zk):
     return out
 
 
+def shape_is_zkevm_default(workload):
+    """the committed kernel profile is of bench_starks.py's default (zkEVM-shaped, 2^23 rows) proof: rooflines only for that workload"""
+    return workload.startswith("2^23 rows, sections [665, 128, 371]")
+
+
 def genproof_leg(shape):
     """BASELINE's 'batch-proof wall time' and north_star's NTT + Merkle + FRI under the SAME command the driver times: after this process has
     released its HBM, a child runs bench_starks.py -- Starks::genProof of the product class (host/starks.hpp) over the synthetic zkEVM-shaped
@@ -291,12 +296,28 @@ def genproof_leg(shape):
         out["batch"] = {sh: {"genproof_ms": o["genproof_ms"], "workload": o["workload"], "peak_hbm_gb": o["peak_hbm_gb"], "checks": o["checks"],
                              "fri_ms": o["phase_ms"].get("STARK_STEP_FRI")} for sh, o in j["starks"].items()}
         out["batch_note"] = "the three Starks::genProof calls of genBatchProof (zkEVM, c12a, recursive1 shapes) in one process sharing the HBM arena; c12a's starkStruct is assumed (DESIGN.md)"
-    stats = os.path.join(ROOT, "profiles", "r04_starks_genproof_kernel_stats.csv")
-    if os.path.exists(stats):
+    # per-kernel rooflines of the proof: from the NEWEST committed rocprofv3 summary of the same command (a profiler cannot run inside this
+    # process); stamped with the file and its round so that a reader sees how old the kernel times are -- the proof's own wall time above is live
+    import glob
+    import re as _re
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_starks_genproof_kernel_stats.csv")))
+    if cands and shape_is_zkevm_default(zk["workload"]):
+        stats = cands[-1]
         out["kernel_rooflines"] = proof_kernel_rooflines(stats, 2, {"n": 1 << 23, "n_ext": 1 << 24, "n_evals": 1768,
                                                                     "widths": {"cm1": 665, "cm2": 128, "cm3": 371, "cm4": 6, "tmpexp": 265, "const": 218}})
-        out["kernel_rooflines_source"] = ("profiles/r04_starks_genproof_kernel_stats.csv: rocprofv3 --kernel-trace --stats -- python3 bench_starks.py --proofs 2 --check-rows 0 "
-                                          "(same command as this leg's zkEVM proof, two proofs; per-proof averages)")
+        rnd = _re.search(r"r(\d\d)_", os.path.basename(stats)).group(1)
+        out["kernel_rooflines_source"] = {"file": "profiles/" + os.path.basename(stats), "recorded_in_round": int(rnd),
+                                          "command": "rocprofv3 --kernel-trace --stats -- python3 bench_starks.py --proofs 2 --check-rows 0 (tools/prof_starks.sh): the same command as this leg's zkEVM proof, two proofs, per-proof averages",
+                                          "note": "kernel TIMES are the profile's, not this run's (compare ms above with the profile's own proof time); algorithmic bytes follow the shape"}
+        cbw = os.path.join(ROOT, "profiles", "r%s_copybuffer_where.json" % rnd)
+        if os.path.exists(cbw):
+            cb = json.load(open(cbw))
+            out["copybuffer_launches"] = {"what": "`__amd_rocclr_copyBuffer`, second line of that profile (%d launches, %.0f ms over the run): the runtime's staging copies of bench_starks.py's INPUT GENERATION "
+                                                  "(the synthetic witness is made on the device and copied to pageable host memory; the constants' upload in the Starks constructor) -- %d launches / %.0f ms fall before the "
+                                                  "first proof, %.1f ms inside the proofs.  Stage 1's upload is page-locked staging moved by the SDMA engines (tools/h2d_probe.hip: 57 GB/s, no kernel), not on the CUs."
+                                                  % (cb["copyBuffer_launches"], cb["copyBuffer_ms_total"], cb["before_the_first_proof"]["launches"], cb["before_the_first_proof"]["ms"],
+                                                     sum(x["ms"] for x in cb["inside_proofs"])),
+                                          "source": "profiles/" + os.path.basename(cbw) + " (tools/copybuffer_where.py over the kernel trace)"}
     return out
 
 
@@ -713,8 +734,8 @@ def main():
                     devs = os.environ.get("MI_BENCH_LEG_DEVICES") or ",".join(str(d_) for d_ in range(world))   # (the override: a one-GPU box rehearsing the plumbing)
                     if len(devs.split(",")) > 1:
                         env = dict(os.environ, MI_STARK_DEVICES=devs)
-                        if len(set(devs.split(","))) == 1:
-                            env["MI_STARK_ROW_SHARDED"] = "1"
+                        if len(set(devs.split(","))) == 1:   # logical shards of one GPU: a device group, so that the full size fits (host/starks.hpp)
+                            env.update(MI_STARK_ROW_SHARDED="1", MI_MULTI_GROUP_SAME_DEVICE="1", MI_CHELPERS_BATCH_GIB="2")
                         cmd = [sys.executable, os.path.join(ROOT, "bench_starks.py"), "--log-n", str(args.log_n), "--proofs", "2", "--check-rows", "8"]
                         t_c0 = time.perf_counter()
                         legs["genproof_timeout_s"] = lim = left()
@@ -787,6 +808,9 @@ def main():
             out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this command, gfx950 x2 read correction: tools/pmc_leaf.sh)" % pmc_name
             out["valu"] = valu_roofline(perms, leaf_ms, pmc)
+            nb = os.path.join(ROOT, "profiles", "r05_ntt_valu_breakdown.json")
+            if os.path.exists(nb):   # where the NTT passes' VALU instructions go, class by class (tools/pmc_ntt_classes.sh: builds with one class compiled out)
+                out["valu"]["ntt_breakdown"] = json.load(open(nb))
         if world == 1 and not args.no_cpu_baseline:
             th = host_keep.numpy().view(np.uint64).reshape(n, ncols) if host_keep is not None else None
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, ncols, th)

@@ -90,7 +90,14 @@ MI_HD void dft_reg(u64 (&x)[1 << Q])
                 constexpr int e = INV ? (192 - e0) % 192 : e0;
                 const u64 u = x[s + j], v = MI_DFT_CANON(x[s + j + half]);
                 x[s + j] = MI_DFT_ADD(u, v);
-                x[s + j + half] = mul_pow2<e>(MI_DFT_SUB(u, v));
+                if constexpr (e >= 96) {
+                    // (u - v) * 2^e with 2^96 = -1: (v - u) * 2^(e - 96).  Every nontrivial twiddle of the INVERSE transform is of this kind
+                    // (e = 192 - e0); taking the difference the other way round costs the canonical form of u (one compare on the common
+                    // path) instead of a negation of the difference (canonical form + a 64-bit subtraction): profiles/r05_ntt_valu_breakdown.txt
+                    x[s + j + half] = mul_pow2<e - 96>(MI_DFT_SUB(v, MI_DFT_CANON(u)));
+                } else {
+                    x[s + j + half] = mul_pow2<e>(MI_DFT_SUB(u, v));
+                }
             });
         });
     });

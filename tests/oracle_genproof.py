@@ -131,11 +131,17 @@ def gen_proof(si, progs, const_n, const_tree, witness, publics, fast=False):
     challenges[C(3)] = tr.get_field()
     base_step("step3prev")
     k = 0
+    zjobs = []
     for ctx in (si["puCtx"], si["peCtx"], si["ciCtx"]):         # :455-536: lookups, permutations, connections, z = cm_n[numCommited + running index]
         for x in ctx:
             num, den, z = st.exp_pol(x["numId"]), st.exp_pol(x["denId"]), st.pol(si["cm_n"][num_commited + k])
-            glo.calculate_z(mem, z[0], z[1], num[0], num[1], den[0], den[1], N)   # (whether the product closes is polinomial.hpp:606's zkassert: a
-            k += 1                                                                # release build goes on, and so do the synthetic shapes)
+            zjobs.append((z[0], z[1], num[0], num[1], den[0], den[1]))  # (whether the product closes is polinomial.hpp:606's zkassert: a
+            k += 1                                                      # release build goes on, and so do the synthetic shapes)
+    # the products are independent of one another (each reads its own numerator and denominator and writes its own z column): a few at a
+    # time on host threads -- the foreign call releases the interpreter lock -- which changes no value and shortens the large parity runs
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        list(pool.map(lambda a: glo.calculate_z(mem, a[0], a[1], a[2], a[3], a[4], a[5], N), zjobs))
     base_step("step3")
     nodes[2] = commit("cm3_n", "cm3_2ns")
     root2 = nodes[2][-4:].copy()

@@ -236,9 +236,23 @@ def test_starks_genproof_equals_the_oracle_prover_at_2p18_rows_full_zkevm_shape(
     if keep and os.path.exists(keep):
         want = open(keep).read()
     else:
-        want, _ = og.gen_proof(*inputs, fast=True)
+        import threading
+        stop = threading.Event()
+
+        def heartbeat():                      # a large run is minutes of silent CPU work: a runner that watches the output must see it is alive
+            while not stop.wait(60):
+                print("... oracle prover at work, %.0f s" % (time.time() - t1), flush=True)
+        hb = threading.Thread(target=heartbeat, daemon=True)
+        hb.start()
+        try:
+            want, _ = og.gen_proof(*inputs, fast=True)
+        finally:
+            stop.set()
         if keep:
             open(keep, "w").write(want)
+        if keep and os.environ.get("MI_PARITY_ORACLE_ONLY") == "1":   # a size whose oracle proof and device proof do not fit one time slot
+            print("oracle prover at 2^%d rows: inputs %.0f s, proof %.0f s, %d bytes -> %s" % (log_n, t1 - t0, time.time() - t1, len(want), keep), flush=True)
+            pytest.skip("the oracle prover's proof is saved; run again without MI_PARITY_ORACLE_ONLY to compare")
     t2 = time.time()
     env = dict(os.environ)
     if os.environ.get("MI_PARITY_DEVICES"):
