@@ -733,7 +733,31 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k % NS][s], c->copy_stream[0]));
         return MI_OK;
     };
+    // A PAGE-LOCKED trace (hipHostMalloc / mi_host_register) lets some chunks skip the host's packers: the packed form moves at the rate 16
+    // threads gather rows (51 GB/s measured end to end against the link's 57.3), so every MI_UPLOAD_STRIDED_EVERY-th chunk (default 4: the
+    // first two never, the kernels wait for them) is read IN PLACE by the DMA engines as a strided 2-D copy on the second copy stream while
+    // the packers work on the next one: the link carries both, the packers 3/4 of the bytes.  0 switches it off; a pageable trace takes
+    // the packed form throughout (the DMA engines cannot read it).
+    bool src_locked = false;
+    int strided_every = 4;
+    if (packed) {
+        if (const char *e = getenv("MI_UPLOAD_STRIDED_EVERY")) strided_every = atoi(e);
+        if (strided_every > 0) {
+            hipPointerAttribute_t a0, a1;
+            src_locked = hipPointerGetAttributes(&a0, trace_host) == hipSuccess && a0.type == hipMemoryTypeHost &&
+                         hipPointerGetAttributes(&a1, trace_host + (n * ncols - 1)) == hipSuccess && a1.type == hipMemoryTypeHost;
+            (void)hipGetLastError(); // (a pageable pointer is "invalid value" to the query, not an error of this call)
+        }
+    }
+    auto strided_chunk = [&](uint64_t k) { return packed && src_locked && k >= 2 && strided_every > 0 && (k % (uint64_t)strided_every) == (uint64_t)strided_every - 1; };
     auto upload = [&](uint64_t k) -> int { // the chunk's upper and lower rows on two copy streams (two DMA engines)
+        if (strided_chunk(k)) {
+            const uint64_t cw = cws[k];
+            MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[1], c->ev_consumed[k % NS], 0)); // the LDE that read this device buffer is done
+            MI_HIP_CHECK(hipMemcpy2DAsync(st[k % NS], cw * 8, trace_host + c0s[k], ncols * 8, cw * 8, n, hipMemcpyHostToDevice, c->copy_stream[1]));
+            for (int s2 = 0; s2 < 2; s2++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k % NS][s2], c->copy_stream[1]));
+            return MI_OK;
+        }
         if (packed) return upload_packed(k);
         const uint64_t cw = cws[k], half = n / 2 ? n / 2 : n;
         for (int s = 0; s < 2; s++) {
@@ -769,7 +793,7 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
         if (k + 1 < n_chunks) MI_TRY(upload(k + 1));
     }
     // the strided form reads trace_host from the copy engines: nothing of it may still be queued when the caller gets its trace back
-    if (!packed)
+    if (!packed || src_locked)
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamSynchronize(c->copy_stream[s]));
     return launch_merkle_levels(c, (u64 *)nodes, n_ext);
 }

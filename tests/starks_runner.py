@@ -89,6 +89,10 @@ def gen_proof_on_device(si, progs, const_n, const_tree, witness, publics, workdi
         proc.kill()
         so, se = proc.communicate()
         raise RuntimeError("Starks::genProof child made no progress for %.0f s; stacks:\n%s\nstderr tail:\n%s" % (limit, bt, se[-1500:]))
+    try:   # (tens of GB at the large parity sizes: a second run in the same temporary directory tree must find the disk free)
+        os.remove(os.path.join(workdir, "parity.inputs.npz"))
+    except OSError:
+        pass
     r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
     if r.returncode != 0:
         raise RuntimeError("Starks::genProof child failed (rc %d):\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-4000:]))
