@@ -733,13 +733,15 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k % NS][s], c->copy_stream[0]));
         return MI_OK;
     };
-    // A PAGE-LOCKED trace (hipHostMalloc / mi_host_register) lets some chunks skip the host's packers: the packed form moves at the rate 16
-    // threads gather rows (51 GB/s measured end to end against the link's 57.3), so every MI_UPLOAD_STRIDED_EVERY-th chunk (default 4: the
-    // first two never, the kernels wait for them) is read IN PLACE by the DMA engines as a strided 2-D copy on the second copy stream while
-    // the packers work on the next one: the link carries both, the packers 3/4 of the bytes.  0 switches it off; a pageable trace takes
-    // the packed form throughout (the DMA engines cannot read it).
+    // A PAGE-LOCKED trace (hipHostMalloc / mi_host_register) could let some chunks skip the host's packers -- the packed form moves at the
+    // rate 16 threads gather rows (51-53 GB/s end to end against the link's 57.3) --: with MI_UPLOAD_STRIDED_EVERY = k > 0 every k-th chunk
+    // (never the first two: the kernels wait for them) is read IN PLACE by the DMA engines as a strided 2-D copy on the second copy stream
+    // while the packers work on the next one.  MEASURED SLOWER and therefore OFF by default (profiles/r05_upload_mix_ab.txt, full size,
+    // page-locked trace: all packed 868-873 ms per step; k = 4: 969-981; k = 3: 1 008; k = 2: 1 068): a 32-column strided read crosses the
+    // link at 38 GB/s (256-byte requests) and takes from the packed copies beside it more than the packers gain.  The knob stays for wider
+    // chunks on another host.  A pageable trace takes the packed form throughout (the DMA engines cannot read it).
     bool src_locked = false;
-    int strided_every = 4;
+    int strided_every = 0;
     if (packed) {
         if (const char *e = getenv("MI_UPLOAD_STRIDED_EVERY")) strided_every = atoi(e);
         if (strided_every > 0) {
