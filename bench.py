@@ -706,10 +706,10 @@ def main():
             except Exception as e:
                 single_process = {"error": "before the child: " + repr(e)}
             if rank == 0 and single_process is None:
-                # Both legs together get MI_BENCH_LEG_BUDGET_S (default 150 s) of wall time, each child what is left of it, killed as a process
+                # Both legs together get MI_BENCH_LEG_BUDGET_S (default 240 s; the commit at most 40 % of it) of wall time, each child what is left of it, killed as a process
                 # group at its limit and never waited for beyond that (run_child): the contract line below is printed inside the driver's
                 # limit whatever these never-yet-run-on-hardware paths do on first contact.
-                leg_budget = float(os.environ.get("MI_BENCH_LEG_BUDGET_S", "150"))
+                leg_budget = float(os.environ.get("MI_BENCH_LEG_BUDGET_S", "240"))
                 t_legs0 = time.perf_counter()
                 left = lambda: leg_budget - (time.perf_counter() - t_legs0)
                 legs = {"budget_s": leg_budget}
@@ -717,7 +717,7 @@ def main():
                     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", "2", "--warmup", "1", "--pcie-steps", "0",
                            "--log-n", str(args.log_n), "--cols", str(ncols)]
                     t_c0 = time.perf_counter()
-                    legs["commit_timeout_s"] = lim = min(left(), 0.55 * leg_budget)
+                    legs["commit_timeout_s"] = lim = min(left(), 0.4 * leg_budget)
                     rc, so, se, note = run_child(cmd, lim)
                     if rc != 0:
                         single_process = {"error": "child: %s" % (note or "exited %s" % rc), "stderr_tail": se[-800:]}
@@ -736,6 +736,11 @@ def main():
                         env = dict(os.environ, MI_STARK_DEVICES=devs)
                         if len(set(devs.split(","))) == 1:   # logical shards of one GPU: a device group, so that the full size fits (host/starks.hpp)
                             env.update(MI_STARK_ROW_SHARDED="1", MI_MULTI_GROUP_SAME_DEVICE="1", MI_CHELPERS_BATCH_GIB="2")
+                        else:
+                            # real devices, first contact: the images as plain allocations (hipMalloc + hipDeviceEnablePeerAccess: the path every
+                            # runtime has walked) rather than address ranges with per-piece peer access (hipMemSetAccess for another device has
+                            # only ever run on one GPU here); 288 GB a device holds the dense form.  MI_BENCH_LEG_SPARSE=1 asks for the sparse one.
+                            env.setdefault("MI_STARK_SPARSE_IMAGE", "1" if os.environ.get("MI_BENCH_LEG_SPARSE") == "1" else "0")
                         cmd = [sys.executable, os.path.join(ROOT, "bench_starks.py"), "--log-n", str(args.log_n), "--proofs", "2", "--check-rows", "8"]
                         t_c0 = time.perf_counter()
                         legs["genproof_timeout_s"] = lim = left()

@@ -140,23 +140,34 @@ struct ShardArena
 {
     uint64_t *base = nullptr;
     uint64_t elems = 0;
-    uint64_t *reserve(mi_multi *mm, int g, uint64_t want)
+    bool sparse = true;
+    uint64_t *reserve(mi_multi *mm, int g, uint64_t want, bool wantSparse = true)
     {
         if (want <= elems) return base;
         check(mi_multi_set_device(mm, g), "Starks (row-shard mirror: device)");
         mi_ctx *c = mi_multi_ctx(mm, g);
-        if (base) check(mi_vmm_free(c, base), "Starks (row-shard mirror: free)");
-        const uint64_t range = std::max<uint64_t>(want * 8, 1ULL << 39);
-        void *p = nullptr;
-        check(mi_vmm_reserve(c, range, &p), "Starks (row-shard mirror: address range)");
-        base = (uint64_t *)p;
-        elems = range / 8;
+        if (base) { if (sparse) check(mi_vmm_free(c, base), "Starks (row-shard mirror: free)"); else mi_dev_free(c, base); }
+        sparse = wantSparse;
+        if (sparse) {
+            const uint64_t range = std::max<uint64_t>(want * 8, 1ULL << 39);
+            void *p = nullptr;
+            check(mi_vmm_reserve(c, range, &p), "Starks (row-shard mirror: address range)");
+            base = (uint64_t *)p;
+            elems = range / 8;
+        } else { // MI_STARK_SPARSE_IMAGE=0: one allocation of the whole extended part (157 GB at zkEVM size on a device that holds little else)
+            base = (uint64_t *)mi_dev_alloc(c, want * 8);
+            if (!base) {
+                std::fprintf(stderr, "mi_stark: the row-shard mirror on shard %d needs %.1f GB of that device's memory\n", g, want * 8 / 1e9);
+                fail("Starks (row-shard mirror)");
+            }
+            elems = want;
+        }
         check(mi_multi_set_device(mm, 0), "Starks (row-shard mirror: device)");
         return base;
     }
     void back(mi_multi *mm, int g, uint64_t off, uint64_t n)
     {
-        if (!n) return;
+        if (!n || !sparse) return;
         check(mi_multi_set_device(mm, g), "Starks (row-shard mirror: device)");
         if (mi_vmm_back(mi_multi_ctx(mm, g), base, off * 8, n * 8) != MI_OK) {
             std::fprintf(stderr, "mi_stark: the row-shard mirror of shard %d does not fit its device: %s\n", g, mi_last_error());
@@ -427,7 +438,7 @@ private:
                     mi::check(mi_multi_set_device(mm, g), "Starks::Starks (row shards: device)");
                     mi_ctx *cg = mi_multi_ctx(mm, g);
                     RowShardMem &R = rowMem[g];
-                    R.ext = mi::shardArena(g).reserve(mm, g, extElems); // (re-read at every proof: a later, larger Starks may move it)
+                    R.ext = mi::shardArena(g).reserve(mm, g, extElems, sparseImage); // (re-read at every proof: a later, larger Starks may move it)
                     mi::check(mi_multi_set_device(mm, g), "Starks::Starks (row shards: device)");
                     R.evalsPart = (uint64_t *)mi_dev_alloc(cg, (3 * starkInfo.evMap.size() + 16) * 8);
                     if (!R.evalsPart) mi::fail("Starks::Starks (row shards: device memory)");
@@ -631,7 +642,8 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         // the other shards' mirrors: their rows (+ halo, wrapping) of the extended sections, their rows of q and f
         for (uint64_t g = 1; g < G; g++) {
             mi::ShardArena &S = mi::shardArena((int)g);
-            rowMem[g].ext = S.reserve(mm, (int)g, imageElems - off(cm1_2ns));
+            rowMem[g].ext = S.reserve(mm, (int)g, imageElems - off(cm1_2ns), sparseImage);
+            if (!S.sparse) continue; // one allocation: everything is there
             mi_ctx *cg = mi_multi_ctx(mm, (int)g);
             uint64_t before = 0, after = 0;
             mi::check(mi_multi_set_device(mm, (int)g), "Starks::genProof (row shards: device)");

@@ -200,6 +200,20 @@ def test_starks_genproof_with_row_sharded_step42ns_equals_the_oracle_prover(name
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,devices", [("zkevm_small", "0,0"), ("recursive_12", "0,0,0,0")])
+def test_row_sharded_proof_with_dense_images_equals_the_oracle_prover(name, devices, tmp_path):
+    """MI_STARK_SPARSE_IMAGE=0: the image and the row-shard mirrors as plain allocations instead of address ranges (what bench.py's
+    single-process leg asks for on real devices at first contact: hipMalloc + hipDeviceEnablePeerAccess); the commits are transient all
+    the same and borrow base-domain sections as scratch.  Still the oracle prover's bytes."""
+    inputs, want = shaped_case(name)
+    got4, again = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4, 4),
+                                         env=dict(os.environ, MI_STARK_DEVICES=devices, MI_STARK_ROW_SHARDED="1", MI_STARK_SPARSE_IMAGE="0"))
+    assert got4 == want, first_difference(got4, want)
+    assert again == want, first_difference(again, want)
+    assert not sr.LAST_CHECK["enabled"] or (sr.LAST_CHECK["checks"] > 100 and sr.LAST_CHECK["violations"] == 0), sr.LAST_CHECK
+
+
+@pytest.mark.gpu
 def test_row_sharded_and_per_row_proofs_alternate_on_one_starks(tmp_path):
     """One Starks, several devices configured, proofs of both kinds in turn: the table steps (row shards active: this device's image holds
     only ITS rows of the extension, the others are opened from the devices that hold them) and recorded per-row steps (everything on this
