@@ -624,6 +624,7 @@ def main():
                                              log=lambda m: print(m, file=sys.stderr, flush=True))
 
     verify = None
+    ext_windows = None
     if world == 1 and not args.no_verify:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from verify_full import verify_lde_merkle
@@ -696,6 +697,7 @@ def main():
         if cpu_group is not None:
             try:
                 trace = root = None
+                ext_windows = None   # (a one-rank rehearsal verified the result above: its window list holds the extension)
                 bufs.clear()
                 gc.collect()
                 torch.cuda.empty_cache()
@@ -711,8 +713,14 @@ def main():
                 # limit whatever these never-yet-run-on-hardware paths do on first contact.
                 leg_budget = float(os.environ.get("MI_BENCH_LEG_BUDGET_S", "240"))
                 t_legs0 = time.perf_counter()
+                free_b, total_b = torch.cuda.mem_get_info()
+                while free_b < 0.97 * total_b and time.perf_counter() - t_legs0 < 20:   # released memory is handed back (and wiped) asynchronously
+                    time.sleep(0.5)
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    free_b, total_b = torch.cuda.mem_get_info()
                 left = lambda: leg_budget - (time.perf_counter() - t_legs0)
-                legs = {"budget_s": leg_budget}
+                legs = {"budget_s": leg_budget, "hbm_free_before_gb": free_b / 1e9}
                 try:
                     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", "2", "--warmup", "1", "--pcie-steps", "0",
                            "--log-n", str(args.log_n), "--cols", str(ncols)]
