@@ -477,3 +477,40 @@ def test_the_suite_runs_with_the_multi_check_on():
     st = mi_stark.multi_check_stats()
     assert st["enabled"], "tests/conftest.py sets MI_MULTI_CHECK=1 for the GPU suite"
     assert st["violations"] == 0, st
+
+
+def test_commit_buffer_needs_follow_the_plan():
+    """What a caller must lend (no GPU needed): a transient commit takes a tile ring of two, two staging buffers and the NTT workspace per
+    device GROUP -- 21.5 GB at 2^23 x 665 whatever the number of shards --, a windowed one the shard's tiles and row windows as well
+    (36.5 GB at eight shards, 103 GB at two: ADVICE r04's shortfall against the 67 GB stage 1 lends)."""
+    import ctypes
+    L = mi_stark.lib()
+    L.mi_multi_transient_need.restype = ctypes.c_uint64
+    L.mi_multi_windowed_need.restype = ctypes.c_uint64
+    u = ctypes.c_uint64
+    n, ne = 1 << 23, 1 << 24
+    t8 = L.mi_multi_transient_need(u(n), u(ne), u(665), ctypes.c_uint32(8)) * 8
+    t2 = L.mi_multi_transient_need(u(n), u(ne), u(665), ctypes.c_uint32(2)) * 8
+    assert t8 == t2 and 21.4e9 < t8 < 21.6e9
+    w8 = L.mi_multi_windowed_need(u(n), u(ne), u(665), ctypes.c_uint32(8)) * 8
+    w2 = L.mi_multi_windowed_need(u(n), u(ne), u(665), ctypes.c_uint32(2)) * 8
+    assert 36.4e9 < w8 < 36.7e9 and 102e9 < w2 < 104e9 and w2 > 67e9
+    small = L.mi_multi_transient_need(u(1 << 10), u(1 << 11), u(37), ctypes.c_uint32(2))
+    assert small >= (1 << 17)                                           # (a lent NTT workspace is at least 1 MiB)
+    assert L.mi_multi_transient_need(u(n), u(ne), u(665), ctypes.c_uint32(3)) == 0      # not a power of two
+
+
+def test_mi_stark_devices_is_parsed_strictly(tmp_path):
+    """MI_STARK_DEVICES (host/mi_runtime.hpp): digits and commas only -- atoi would read "a,b" as devices 0,0."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "p.cpp"
+    src.write_text('#include "mi_runtime.hpp"\n#include <cstdio>\nint main() { int d[64]; int n = mi::parseDevices(d, 64); std::printf("%d:", n); for (int i = 0; i < n; i++) std::printf(" %d", d[i]); std::printf("\\n"); return 0; }\n')
+    exe = tmp_path / "p"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(root, "merlin-zkevm-prover_amd", "host"), str(src), "-o", str(exe),
+                           "-L", os.path.join(root, "merlin-zkevm-prover_amd"), "-lmi_stark", "-Wl,-rpath," + os.path.join(root, "merlin-zkevm-prover_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    run = lambda v: subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, MI_STARK_DEVICES=v))
+    assert run("0,1,2,3").stdout.strip() == "4: 0 1 2 3" and run("7").stdout.strip() == "1: 7" and run("").stdout.strip() == "0:"
+    for bad in ("a,b", "0,,1", "0,1,", "0;1", "-1,0", "0 ,1"):
+        r = run(bad)
+        assert r.returncode != 0 and "MI_STARK_DEVICES" in r.stderr, (bad, r.returncode, r.stdout, r.stderr)
