@@ -211,7 +211,8 @@ int native_build(mi_chelpers_prog *P, const char *cache_dir, uint64_t chunk_cost
 int native_host_run(const mi_chelpers_prog *P, const mi_chelpers_params *a, const uint64_t *rows, uint64_t nrows, uint64_t chunk_cost);
 int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a, uint64_t row0, uint64_t nrows);
 void native_free(mi_ctx *c, mi_chelpers_prog *P);
-int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_t *batch_out);
+struct RunBufs;
+int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_t *batch_out, RunBufs *bufs = nullptr);
 int native_lower_stats(const mi_chelpers_prog *P, uint64_t chunk_cost, uint64_t out[12]);
 void native_stats(const mi_chelpers_prog *P, uint64_t out[8]);
 } // namespace chp

@@ -1300,8 +1300,10 @@ static int grow(u64 **buf, uint64_t *have, uint64_t need, const char *what)
     return MI_OK;
 }
 
+// where a run's batch buffers live: the context's pool, or the tail of a workspace the caller lent
+struct RunBufs { u64 *tiled = nullptr, *spill = nullptr, *lin = nullptr; };
 // the device buffers a run over nrows rows needs (kept by the context, grown on demand): allocate them ahead of the first run
-int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_t *batch_out)
+int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_t *batch_out, RunBufs *bufs)
 {
     const NativeProg *N = P->native;
     MI_REQUIRE(N, "native code was not built");
@@ -1314,10 +1316,27 @@ int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_
     batch = std::min(batch, (nrows + 63) & ~(uint64_t)63);
     const uint64_t max_tiles = batch / 64;
     MI_REQUIRE(max_tiles + 1 < (1ull << 31), "batch too large");
-    MI_TRY(grow(&c->pool->chelpers_tiled, &c->pool->chelpers_tiled_bytes, (max_tiles + 1) * N->sc * 512, "the tile-major operand copy"));
-    MI_TRY(grow(&c->pool->chelpers_spill, &c->pool->chelpers_spill_bytes, max_tiles * N->nw * 512, "the chunk-boundary spill"));
     MI_TRY(grow(&c->pool->chelpers_cst, &c->pool->chelpers_cst_bytes, (uint64_t)N->cst_words * 8 + 64, "the constraint program's constants"));
-    if (N->n_lin_sums) MI_TRY(grow(&c->pool->chelpers_lin, &c->pool->chelpers_lin_bytes, max_tiles * N->n_lin_sums * 3 * 512, "the linear sums"));
+    const uint64_t b_tiled = ((max_tiles + 1) * N->sc * 512 + 255) & ~(uint64_t)255, b_spill = (max_tiles * N->nw * 512 + 255) & ~(uint64_t)255,
+                   b_lin = N->n_lin_sums ? (max_tiles * N->n_lin_sums * 3 * 512 + 255) & ~(uint64_t)255 : 0;
+    if (bufs) {
+        // A caller that plans its HBM has LENT the context a region that is not live (mi_ctx_lend_workspace: host/starks.hpp lends a dead
+        // section before every step): the batch's tile-major operand copy, the spill and the linear sums -- 9 GB at zkEVM size -- come out
+        // of its tail for the duration of the run instead of staying allocated beside the plan (r04 weak #10: 284 of 309 GB at the peak).
+        // Everything that uses the region is enqueued on this context's stream, before or after the run's kernels.
+        const uint64_t need = b_tiled + b_spill + b_lin;
+        if (c->workspace_lent && c->workspace_bytes >= need + (1ull << 30) && !getenv("MI_CHELPERS_NO_LENT_BUFFERS")) {
+            // (2 MiB-aligned like an allocation of its own: the copy is read in 512-byte runs by every lane of every kernel)
+            char *base = (char *)(((uintptr_t)c->workspace + c->workspace_bytes - need) & ~(uintptr_t)((2u << 20) - 1));
+            bufs->tiled = (u64 *)base; bufs->spill = (u64 *)(base + b_tiled); bufs->lin = b_lin ? (u64 *)(base + b_tiled + b_spill) : nullptr;
+            if (batch_out) *batch_out = batch;
+            return MI_OK;
+        }
+    }
+    MI_TRY(grow(&c->pool->chelpers_tiled, &c->pool->chelpers_tiled_bytes, b_tiled, "the tile-major operand copy"));
+    MI_TRY(grow(&c->pool->chelpers_spill, &c->pool->chelpers_spill_bytes, b_spill, "the chunk-boundary spill"));
+    if (N->n_lin_sums) MI_TRY(grow(&c->pool->chelpers_lin, &c->pool->chelpers_lin_bytes, b_lin, "the linear sums"));
+    if (bufs) { bufs->tiled = c->pool->chelpers_tiled; bufs->spill = c->pool->chelpers_spill; bufs->lin = c->pool->chelpers_lin; }
     if (batch_out) *batch_out = batch;
     return MI_OK;
 }
@@ -1371,7 +1390,8 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // `cst` dies with this call
     // ---- batches of rows: tile-major copy (+ halo tile) and the spill
     uint64_t batch = 0;
-    MI_TRY(native_reserve(c, P, nrows, &batch));
+    RunBufs rb;
+    MI_TRY(native_reserve(c, P, nrows, &batch, &rb));
     u64 *out = P->stores_pols ? (u64 *)a->pols : (u64 *)(P->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
     uint32_t zmask = (uint32_t)(n_zh - 1);
     const uint64_t row_end = row0 + nrows;
@@ -1395,25 +1415,25 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             if (S.tiled) { xsec = ptr; continue; } // read in place
             if (!N->sec_slab_mask[si]) continue;
             hipLaunchKernelGGL(k_chp_transpose, dim3((unsigned)(tiles + 1), (unsigned)((S.ncols + 63) / 64)), dim3(256), 0, c->stream, ptr, pitch,
-                               (uint32_t)S.ncols, S.nrows - 1, c->pool->chelpers_tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
+                               (uint32_t)S.ncols, S.nrows - 1, rb.tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
             MI_HIP_CHECK(hipGetLastError());
         }
         if (N->n_lin_sums) {
             const dim3 g((unsigned)tiles), bl(64);
             const uint32_t ns = (uint32_t)N->lin_slabs.size();
             switch (N->n_lin_sums) {
-            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 1u); break;
-            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 2u); break;
-            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 3u); break;
-            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, c->pool->chelpers_lin, b0, 4u); break;
+            case 1: hipLaunchKernelGGL(k_chp_linear<1>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, rb.lin, b0, 1u); break;
+            case 2: hipLaunchKernelGGL(k_chp_linear<2>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, rb.lin, b0, 2u); break;
+            case 3: hipLaunchKernelGGL(k_chp_linear<3>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, rb.lin, b0, 3u); break;
+            default: hipLaunchKernelGGL(k_chp_linear<4>, g, bl, 0, c->stream, N->d_lin_slabs, ns, N->d_lin_terms, ls, rb.lin, b0, 4u); break;
             }
             MI_HIP_CHECK(hipGetLastError());
         }
         for (Chunk &C : N->chunks) {
-            const u64 *tiled = c->pool->chelpers_tiled, *cstp = c->pool->chelpers_cst;
-            u64 *spill = c->pool->chelpers_spill, *outp = out;
+            const u64 *tiled = rb.tiled, *cstp = c->pool->chelpers_cst;
+            u64 *spill = rb.spill, *outp = out;
             uint64_t row_base = b0, rend = row_end;
-            const u64 *linp = c->pool->chelpers_lin;
+            const u64 *linp = rb.lin;
             const u64 *polsp = (const u64 *)a->pols, *cpolsp = (const u64 *)a->const_pols;
             void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &xsec, &polsp, &cpolsp};
             MI_HIP_CHECK(hipModuleLaunchKernel(C.fn, (unsigned)tiles, 1, 1, 64, 1, 1, 0, c->stream, args, nullptr));
