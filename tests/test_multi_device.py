@@ -514,3 +514,43 @@ def test_mi_stark_devices_is_parsed_strictly(tmp_path):
     for bad in ("a,b", "0,,1", "0,1,", "0;1", "-1,0", "0 ,1"):
         r = run(bad)
         assert r.returncode != 0 and "MI_STARK_DEVICES" in r.stderr, (bad, r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_transient_commit_from_a_device_section_at_a_wider_pitch():
+    """Stages 2-3 of a row-sharded proof: the section is on a device (the image) at a row pitch wider than itself, the row images have the
+    section's own pitch inside a wider mirror, the buffers are lent; root, digests, images and halo as from one device."""
+    log_n, ncols, pitch, G, halo = 12, 128, 200, 4, 2
+    n, n_ext = 1 << log_n, 2 << log_n
+    wide = glo.splitmix64(0x5EED0B00, n * pitch).reshape(n, pitch)
+    trace = np.ascontiguousarray(wide[:, 40:40 + ncols])
+    ctx = mi_stark.Context(0)
+    ext, nodes = single_device(ctx, trace, n, n_ext, ncols)
+    want = ctx.to_host(ext).reshape(n_ext, ncols)
+    want_nodes = ctx.to_host(nodes)
+    d_wide = ctx.to_device(wide)
+    SENT = 0x3C3C3C3C3C3C3C3C
+    imgs = [ctx.zeros(n_ext * pitch).fill_(SENT) for _ in range(G)]
+    region = ctx.zeros(mi_stark.Multi.transient_need(n, n_ext, ncols, G) + 64)
+    ctx.sync()
+    for grouped in (False, True):
+        m = mi_stark.Multi([0] * G, group_same_device=grouped)
+        for x in imgs:
+            x.fill_(SENT)
+        ctx.sync()
+        m.set_row_images([t_.data_ptr() + 8 * 40 for t_ in imgs], pitch, halo)
+        m.set_transient()
+        m.lend(0, region.data_ptr(), region.numel() * 8)
+        t = m.commit(d_wide.data_ptr() + 8 * 40, n, n_ext, ncols, src_device=0, src_pitch=pitch)
+        assert [int(v) for v in t.root] == [int(v) for v in want_nodes[-4:]]
+        R = n_ext // G
+        for g in range(G):
+            assert np.array_equal(t.leaf_digests(g).reshape(-1), want_nodes[4 * g * R:4 * (g + 1) * R]), g
+            got = ctx.to_host(imgs[g]).reshape(n_ext, pitch)
+            rows = np.zeros(n_ext, dtype=bool)
+            rows[g * R:(g + 1) * R] = True
+            rows[[(r % n_ext) for r in range((g + 1) * R, (g + 1) * R + halo)]] = True
+            assert np.array_equal(got[rows][:, 40:40 + ncols], want[rows]), g
+            assert (got[~rows] == SENT).all() and (got[:, :40] == SENT).all() and (got[:, 40 + ncols:] == SENT).all(), g
+        t.free(); m.close()
+    ctx.close()
