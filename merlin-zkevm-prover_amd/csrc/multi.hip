@@ -104,8 +104,8 @@ struct mi_multi {
     double last_wall_ms = 0;
     // what hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess answered per ordered pair of shards (row a, column b: a's device reaching
     // b's memory): 2 same device, 1 peer access enabled, 0 the devices cannot reach each other directly, -1 enabling it failed.  A pair
-    // that is not 1 or 2 moves its exchange through host memory (the runtime stages the copies) or, for the kernels that write a peer's
-    // row image, cannot run at all: `warnings` says so in words, mi_multi_create prints it, the commit refuses kernels across such a pair.
+    // that is not 1 or 2 moves its exchange through host memory (the runtime stages the copies; the kernels that write a peer's row image
+    // are replaced by the runtime's 2-D copy across such a pair: rows_2d): `warnings` says so in words, mi_multi_create prints it.
     std::vector<int> peer;
     std::string warnings;
     // mi_multi_lend: a caller that plans a device's HBM (host/starks.hpp: the proof's image fills the device that also is shard 0) hands the
