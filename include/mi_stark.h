@@ -516,6 +516,10 @@ int mi_dbg_host_chelpers_run(const mi_chelpers_prog *prog, const mi_chelpers_par
 /* Verification hook: out[r] = (accumulate ? out[r] : 0) + sum_c coef[c] * src[r*pitch + c] mod p for r < nrows (device
  * pointers; coef: ncols canonical values; accumulate lets a matrix stored as several column windows be summed).  The LDE is linear, so the full-size checks compare the oracle's extension of this one column
  * of the trace with the same combination of the extended trace: a checksum over every column at every row. */
+/* EXPERIMENT (round 5): the transform of ncols contiguous COLUMNS (column-major: column c at src + c n) with the passes after the first
+ * as radix-256 passes over tiles of 32 consecutive rows of one column, a workgroup walking over the columns (csrc/ntt.hip k_ntt_pass_cm);
+ * n = 2^16 or 2^24; *ms_cm = the time of those passes.  tools/ntt_colmajor_probe.py; not used by the product's transforms. */
+int mi_dbg_ntt_colmajor_dev(mi_ctx *ctx, uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t ncols, int inverse, float *ms_cm);
 int mi_dbg_lincomb_cols_dev(mi_ctx *ctx, uint64_t *out, const uint64_t *src, uint64_t pitch, uint64_t nrows,
                             uint64_t ncols, const uint64_t *coef, int accumulate);
 

@@ -900,6 +900,152 @@ int launch_ntt(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64
     return MI_OK;
 }
 
+// ------------------------------------------------------------------ EXPERIMENT (round 5, r04 next #4b): a radix-256 pass over COLUMN-MAJOR data
+// x(row, col) = base[col * cpitch + row].  The tile is 256 strided groups x 32 CONSECUTIVE ROWS of one column (what a tile-major LDE needs:
+// the last pass then writes 64-row tiles in 256-byte runs).  A workgroup keeps ITS 32 rows and walks over all the columns (the twiddle
+// table of its rows is built once), and moves 16 bytes per lane by pairing adjacent rows.  tools/ntt_colmajor_probe.py measures it against the row-major pass of the same data; it is not
+// part of the product's transforms.  Only passes with log_K >= 5 (not the first: there consecutive rows of a tile are 256 outputs apart).
+struct NttPassCM {
+    const u64 *src;
+    u64 *dst;
+    uint64_t src_cpitch, dst_cpitch;
+    uint32_t ncols, log_n, log_K, apply_scale, unit_tw, weak_out;
+    uint64_t n_tiles;
+    const u64 *tw_lo, *tw_hi;
+    uint32_t tw_lo_bits;
+    const u64 *sc_lo, *sc_hi;
+    uint32_t sc_lo_bits;
+    const u64 *w256;
+};
+
+template <bool INV>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass_cm(const NttPassCM a) // (two workgroups per CU, like the row-major pass: at most 128 VGPRs)
+{
+    constexpr int LOG_R = 8, LOG_B = 5, B = 32, R = 256, RA = 16, RB = 16;
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    u64 *tile = smem;         // [R][B]
+    u64 *w256 = tile + R * B; // [256]
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n = 1ull << a.log_n, K = 1ull << a.log_K, mK = n >> LOG_R;
+    uint64_t lt = blockIdx.x;
+    if ((a.n_tiles & 7) == 0) lt = (lt & 7) * (a.n_tiles >> 3) + (lt >> 3);
+    const uint64_t beta0 = lt << LOG_B;
+    if (tid < 256) w256[tid] = a.w256[tid];
+    // this thread's step-B item: row beta = beta0 + b, outputs k1 = kap + 16 kb.  With K >= 32 the 32 rows of a tile share i' = beta >> log_K,
+    // so the inter-pass twiddle w_n^(i' k1 K) depends on k1 alone (and the inverse transform's scale 1 / n on nothing): ONE table of 256 per
+    // workgroup, in LDS, for all of its columns -- the row-major pass builds the same table once per tile
+    u64 *tw = w256 + 256; // [R]
+    const uint32_t b = tid & (B - 1), kap = tid >> LOG_B;
+    if (!a.unit_tw && tid < (uint32_t)R) {
+        const uint64_t ip = beta0 >> a.log_K;
+        uint64_t ex = (ip * tid) << a.log_K;
+        if (INV) ex = (n - ex) & (n - 1);
+        u64 v = 1;
+        if (ex) v = gl::mul(a.tw_hi[ex >> a.tw_lo_bits], a.tw_lo[ex & ((1ull << a.tw_lo_bits) - 1)]);
+        if (a.apply_scale) v = gl::mul(v, gl::mul(a.sc_hi[0], a.sc_lo[0])); // (a constant scale: 1 / n)
+        tw[tid] = v;
+    }
+    // load item: row pair bp, bp + 1 of strided group i1 = tid / 16 + 32 k
+    const uint32_t bp = (tid & 15) * 2, i1_0 = tid >> 4;
+    const bool odd = b & 1;
+    const uint64_t qstride = (uint64_t)RA << a.log_K; // rows between the outputs kb, kb + 1
+    const uint64_t beta_e = beta0 + (b & ~1u); // the EVEN row of my pair (K >= 32: both rows of a pair have the same i')
+    const uint64_t orow_e = ((((beta_e >> a.log_K) << LOG_R) + kap) << a.log_K) + (beta_e & (K - 1)); // its first output row (kb = 0)
+    for (uint32_t c = 0; c < a.ncols; c++) {
+        const u64 *p = a.src + (uint64_t)c * a.src_cpitch + beta0 + bp + (uint64_t)i1_0 * mK;
+        ulonglong2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const U64x2 w = *reinterpret_cast<const U64x2 *>(p + (uint64_t)k * 32 * mK);
+            v[k] = make_ulonglong2(w.x, w.y);
+        }
+        if (c) __syncthreads(); // the previous column's step B has read the tile
+#pragma unroll
+        for (int k = 0; k < 8; k++) *reinterpret_cast<ulonglong2 *>(&tile[(i1_0 + 32 * k) * B + bp]) = v[k];
+        __syncthreads();
+        tile_step_a<LOG_R, INV, LOG_B>(tile, w256, tid);
+        __syncthreads();
+        u64 x[RB];
+        tile_step_b<LOG_R, INV, LOG_B>(tile, kap, b, x);
+        if (a.unit_tw) {
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) x[kb] = NTT_CANON(x[kb]);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) x[kb] = NTT_MULW(x[kb], tw[kap + RA * kb]);
+            if (!a.weak_out) {
+#pragma unroll
+                for (int kb = 0; kb < RB; kb++) x[kb] = NTT_CANON(x[kb]);
+            }
+        }
+        // adjacent rows are adjacent addresses: the paired 16-byte stores of the row-major kernel, with "column pair" read as "row pair"
+        store_pairs<RB>(a.dst + (uint64_t)c * a.dst_cpitch + orow_e, qstride, x, odd, true, false);
+    }
+}
+
+// Probe entry (tools/ntt_colmajor_probe.py): the length-n transform of ncols contiguous columns (column c at src + c * n, dst + c * n;
+// n = 2^24 or 2^16: radix-256 passes only), the first pass by the product's single-column kernel column by column, the others by
+// k_ntt_pass_cm over all columns at once; *ms_cm = the time of those passes (HIP events).  Results equal mi_ntt_dev's per column.
+extern "C" int mi_dbg_ntt_colmajor_dev(mi_ctx *ctx, uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t ncols, int inverse, float *ms_cm)
+{
+    if (!ctx) return MI_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    MI_HIP_CHECK(hipSetDevice(ctx->device));
+    MI_REQUIRE(dst && src && ncols >= 1 && (n == (1ull << 24) || n == (1ull << 16)), "n = 2^16 or 2^24, at least one column");
+    const uint32_t L = ilog2_u64(n), P = L / 8;
+    NttPlan *plan;
+    MI_TRY(mi_get_plan(ctx, L, &plan));
+    const PowTable *scale = inverse ? &plan->inv_scale : nullptr;
+    MI_TRY(mi_ensure_workspace(ctx, 2 * n * ncols * 8));
+    u64 *W0 = ctx->workspace, *W1 = ctx->workspace + n * ncols;
+    // pass 0, column by column, through the product's kernel (the single-column form: the same tile, twiddles per element)
+    for (uint64_t c = 0; c < ncols; c++) {
+        std::vector<Buf> bufs;
+        bufs.push_back({const_cast<u64 *>((const u64 *)src) + c * n, 1});
+        bufs.push_back({W0 + c * n, 1});
+        for (uint32_t i = 2; i <= P; i++) bufs.push_back({nullptr, 1});
+        MI_TRY(run_passes(ctx, plan, bufs, 1, inverse != 0, n, scale, 0, 1));
+    }
+    hipEvent_t e0, e1;
+    MI_HIP_CHECK(hipEventCreate(&e0));
+    MI_HIP_CHECK(hipEventCreate(&e1));
+    MI_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    const size_t lds = ((size_t)256 * 32 + 256 + 256) * 8;
+    auto kf = k_ntt_pass_cm<false>;
+    auto ki = k_ntt_pass_cm<true>;
+    MI_HIP_CHECK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void *)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const u64 *cur = W0;
+    for (uint32_t ps = 1; ps < P; ps++) {
+        NttPassCM a = {};
+        a.src = cur;
+        a.dst = ps == P - 1 ? (u64 *)dst : (cur == W0 ? W1 : W0);
+        a.src_cpitch = a.dst_cpitch = n;
+        a.ncols = (uint32_t)ncols;
+        a.log_n = L;
+        a.log_K = 8 * ps;
+        a.tw_lo = plan->tw.lo; a.tw_hi = plan->tw.hi; a.tw_lo_bits = plan->tw.lo_bits;
+        a.apply_scale = (ps == P - 1 && scale) ? 1 : 0;
+        a.unit_tw = (ps == P - 1 && !scale) ? 1 : 0;
+        a.weak_out = ps == P - 1 ? 0 : 1;
+        if (a.apply_scale) { a.sc_lo = scale->lo; a.sc_hi = scale->hi; a.sc_lo_bits = scale->lo_bits; }
+        a.n_tiles = (n >> 8) >> 5;
+        a.w256 = ctx->w256;
+        if (inverse) hipLaunchKernelGGL(ki, dim3((unsigned)a.n_tiles), dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(kf, dim3((unsigned)a.n_tiles), dim3(512), lds, ctx->stream, a);
+        MI_HIP_CHECK(hipGetLastError());
+        cur = a.dst;
+    }
+    MI_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    MI_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    MI_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_cm) *ms_cm = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MI_OK;
+}
+
 int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_t in_pitch, uint64_t n_ext, uint64_t n,
                uint64_t ncols)
 {

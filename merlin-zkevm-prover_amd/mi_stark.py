@@ -64,7 +64,7 @@ EXPORTS = [
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_2d", "mi_dev_zero",
     "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
-    "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev",
+    "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev", "mi_dbg_ntt_colmajor_dev",
     "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_get_host_pack_threads",
     "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_create2", "mi_multi_lead", "mi_multi_set_transient", "mi_multi_transient_need", "mi_multi_windowed_need", "mi_multi_check_stats", "mi_multi_own", "mi_vmm_reserve", "mi_vmm_back", "mi_vmm_allow_peer", "mi_vmm_backed_bytes", "mi_vmm_free", "mi_multi_destroy", "mi_multi_shards", "mi_multi_peer_access", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
     "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",

@@ -48,6 +48,30 @@ def main():
             res[name + "_ms"] = e0.elapsed_time(e1) / a.reps
         res["ratio"] = res["column_major_C_single_columns_ms"] / res["row_major_C_columns_ms"]
         out["inverse" if inv else "forward"] = res
+    # ---- the experimental column-major pass (csrc/ntt.hip k_ntt_pass_cm: 32 consecutive rows of one column per tile row, the workgroup walks
+    # over the columns with its twiddles in registers, 16-byte accesses along the rows): passes 2.. of the same transform over all C columns at
+    # once, checked against the single-column transforms above, timed against the row-major passes (2 of the 3 passes of the row-major time)
+    import ctypes
+    import numpy as np
+    L = mi_stark.lib()
+    if a.log_n in (16, 24):
+        ref = ctx.empty(n * C)
+        for inv in (False, True):
+            for c in range(C):
+                ctx.ntt(ref, src, n, 1, inverse=inv, dst_off=c * n, src_off=c * n)
+            ms = ctypes.c_float(0)
+            best = None
+            for _ in range(a.reps):
+                mi_stark._check(L.mi_dbg_ntt_colmajor_dev(ctx.h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), ctypes.c_uint64(n), ctypes.c_uint64(C),
+                                                          ctypes.c_int(int(inv)), ctypes.byref(ms)))
+                best = ms.value if best is None else min(best, ms.value)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(dst, ref))
+            key = "inverse" if inv else "forward"
+            passes = a.log_n // 8
+            out[key]["column_major_passes_after_the_first_with_shared_twiddles_ms"] = best
+            out[key]["row_major_same_passes_ms_estimate"] = out[key]["row_major_C_columns_ms"] * (passes - 1) / passes
+            out[key]["experimental_kernel_equals_the_product_transform"] = same
     print(json.dumps(out, indent=1))
     ctx.close()
 
