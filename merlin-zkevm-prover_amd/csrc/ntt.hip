@@ -983,6 +983,70 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// EXPERIMENT, continued: the FIRST radix-256 pass, ROW-major in (the caller's trace: 32 adjacent columns of one row per tile row, 16-byte
+// loads as in k_ntt_pass) -> COLUMN-major out.  In the first pass (K = 1) the 256 outputs of a column are CONSECUTIVE rows beta * 256 + k1,
+// but a thread holds 16 of them 16 apart for ONE column: the tile goes back through LDS as [column][k1] (pitch 257) and leaves as 2 KB
+// runs, 16 bytes per lane, lanes along the rows.
+template <bool INV>
+__global__ __launch_bounds__(512) void k_ntt_first_rm2cm(const NttPassCM a, uint64_t src_pitch)
+{
+    constexpr int LOG_R = 8, LOG_B = 5, B = 32, R = 256, RA = 16, RB = 16, TP = R + 1;
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    u64 *tile = smem;           // [R][B], then [B][TP]
+    u64 *w256 = tile + B * TP;  // [256]
+    u64 *tw = w256 + 256;       // [R]
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n = 1ull << a.log_n, mK = n >> LOG_R;
+    const uint32_t n_col_tiles = (a.ncols + B - 1) / B;
+    uint64_t lt = blockIdx.x;
+    if ((a.n_tiles & 7) == 0) lt = (lt & 7) * (a.n_tiles >> 3) + (lt >> 3);
+    const uint64_t beta = lt / n_col_tiles; // = i' (K = 1)
+    const uint32_t c0 = (uint32_t)(lt % n_col_tiles) * B;
+    if (tid < 256) {
+        w256[tid] = a.w256[tid];
+        uint64_t ex = beta * tid; // < n
+        if (INV) ex = (n - ex) & (n - 1);
+        tw[tid] = ex ? gl::mul(a.tw_hi[ex >> a.tw_lo_bits], a.tw_lo[ex & ((1ull << a.tw_lo_bits) - 1)]) : 1;
+    }
+    // load: lanes along column pairs, 32 rows per sweep (k_ntt_pass, WIDE)
+    const uint32_t bp = (tid & 15) * 2, i1_0 = tid >> 4;
+    const uint32_t col = c0 + bp;
+    const u64 *p = a.src + (beta + (uint64_t)i1_0 * mK) * src_pitch + col;
+    ulonglong2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        v[k] = make_ulonglong2(0, 0);
+        const u64 *pr = p + (uint64_t)k * 32 * mK * src_pitch;
+        if (col + 1 < a.ncols) { const U64x2 w = *reinterpret_cast<const U64x2 *>(pr); v[k] = make_ulonglong2(w.x, w.y); }
+        else if (col < a.ncols) v[k].x = pr[0];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) *reinterpret_cast<ulonglong2 *>(&tile[(i1_0 + 32 * k) * B + bp]) = v[k];
+    __syncthreads();
+    tile_step_a<LOG_R, INV, LOG_B>(tile, w256, tid);
+    __syncthreads();
+    const uint32_t b = tid & (B - 1), kap = tid >> LOG_B;
+    u64 x[RB];
+    tile_step_b<LOG_R, INV, LOG_B>(tile, kap, b, x);
+#pragma unroll
+    for (int kb = 0; kb < RB; kb++) x[kb] = NTT_MULW(x[kb], tw[kap + RA * kb]);
+    __syncthreads(); // every thread has read its step-B inputs: the tile is rewritten as [column][k1]
+#pragma unroll
+    for (int kb = 0; kb < RB; kb++) tile[b * TP + kap + RA * kb] = x[kb];
+    __syncthreads();
+    // store: 32 columns x 128 row pairs; lanes along the row pairs of one column (2 KB runs)
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const uint32_t idx = it * 512 + tid, cc = idx >> 7, pr2 = (idx & 127) * 2;
+        if (c0 + cc < a.ncols) {
+            U64x2 w;
+            w.x = tile[cc * TP + pr2];
+            w.y = tile[cc * TP + pr2 + 1];
+            *reinterpret_cast<U64x2 *>(a.dst + (uint64_t)(c0 + cc) * a.dst_cpitch + beta * R + pr2) = w;
+        }
+    }
+}
+
 // Probe entry (tools/ntt_colmajor_probe.py): the length-n transform of ncols contiguous columns (column c at src + c * n, dst + c * n;
 // n = 2^24 or 2^16: radix-256 passes only), the first pass by the product's single-column kernel column by column, the others by
 // k_ntt_pass_cm over all columns at once; *ms_cm = the time of those passes (HIP events).  Results equal mi_ntt_dev's per column.
@@ -992,6 +1056,10 @@ extern "C" int mi_dbg_ntt_colmajor_dev(mi_ctx *ctx, uint64_t *dst, const uint64_
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     MI_HIP_CHECK(hipSetDevice(ctx->device));
     MI_REQUIRE(dst && src && ncols >= 1 && (n == (1ull << 24) || n == (1ull << 16)), "n = 2^16 or 2^24, at least one column");
+    // inverse & 2: the SOURCE is row-major (n x ncols at pitch ncols) and the first pass is the experimental row-major -> column-major
+    // kernel as well (timed with the others): the whole transform in the transposed form; the result stays column-major
+    const bool rm_src = (inverse & 2) != 0;
+    inverse &= 1;
     const uint32_t L = ilog2_u64(n), P = L / 8;
     NttPlan *plan;
     MI_TRY(mi_get_plan(ctx, L, &plan));
@@ -999,7 +1067,7 @@ extern "C" int mi_dbg_ntt_colmajor_dev(mi_ctx *ctx, uint64_t *dst, const uint64_
     MI_TRY(mi_ensure_workspace(ctx, 2 * n * ncols * 8));
     u64 *W0 = ctx->workspace, *W1 = ctx->workspace + n * ncols;
     // pass 0, column by column, through the product's kernel (the single-column form: the same tile, twiddles per element)
-    for (uint64_t c = 0; c < ncols; c++) {
+    for (uint64_t c = 0; c < ncols && !rm_src; c++) {
         std::vector<Buf> bufs;
         bufs.push_back({const_cast<u64 *>((const u64 *)src) + c * n, 1});
         bufs.push_back({W0 + c * n, 1});
@@ -1015,6 +1083,22 @@ extern "C" int mi_dbg_ntt_colmajor_dev(mi_ctx *ctx, uint64_t *dst, const uint64_
     auto ki = k_ntt_pass_cm<true>;
     MI_HIP_CHECK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MI_HIP_CHECK(hipFuncSetAttribute((const void *)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (rm_src) {
+        NttPassCM a = {};
+        a.src = (const u64 *)src; a.dst = W0; a.dst_cpitch = n; a.ncols = (uint32_t)ncols; a.log_n = L;
+        a.tw_lo = plan->tw.lo; a.tw_hi = plan->tw.hi; a.tw_lo_bits = plan->tw.lo_bits;
+        a.n_tiles = (n >> 8) * ((ncols + 31) / 32);
+        MI_REQUIRE(a.n_tiles < (1ull << 22), "NTT grid too large");
+        a.w256 = ctx->w256;
+        const size_t lds1 = ((size_t)32 * 257 + 256 + 256) * 8;
+        auto k1f = k_ntt_first_rm2cm<false>;
+        auto k1i = k_ntt_first_rm2cm<true>;
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *)k1f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *)k1i, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        if (inverse) hipLaunchKernelGGL(k1i, dim3((unsigned)a.n_tiles), dim3(512), lds1, ctx->stream, a, ncols);
+        else hipLaunchKernelGGL(k1f, dim3((unsigned)a.n_tiles), dim3(512), lds1, ctx->stream, a, ncols);
+        MI_HIP_CHECK(hipGetLastError());
+    }
     const u64 *cur = W0;
     for (uint32_t ps = 1; ps < P; ps++) {
         NttPassCM a = {};

@@ -72,6 +72,19 @@ def main():
             out[key]["column_major_passes_after_the_first_with_shared_twiddles_ms"] = best
             out[key]["row_major_same_passes_ms_estimate"] = out[key]["row_major_C_columns_ms"] * (passes - 1) / passes
             out[key]["experimental_kernel_equals_the_product_transform"] = same
+            # ... and the WHOLE transform in the transposed form: row-major source -> first pass (row-major in, column-major out through an LDS
+            # transpose: k_ntt_first_rm2cm) -> the column-major passes; result column-major, compared with the row-major transform transposed
+            ctx.ntt(ref, src, n, C, inverse=inv)
+            want_cm = ref.view(n, C).t().contiguous().view(-1)
+            best = None
+            for _ in range(a.reps):
+                mi_stark._check(L.mi_dbg_ntt_colmajor_dev(ctx.h, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), ctypes.c_uint64(n), ctypes.c_uint64(C),
+                                                          ctypes.c_int(int(inv) | 2), ctypes.byref(ms)))
+                best = ms.value if best is None else min(best, ms.value)
+            torch.cuda.synchronize()
+            out[key]["whole_transform_row_major_in_column_major_out_ms"] = best
+            out[key]["whole_transform_equals_the_row_major_transform_transposed"] = bool(torch.equal(dst, want_cm))
+            del want_cm
     print(json.dumps(out, indent=1))
     ctx.close()
 
