@@ -222,7 +222,7 @@ def proof_kernel_rooflines(stats_csv, proofs_in_profile, zk):
     N, NE = zk["n"], zk["n_ext"]
     w = zk["widths"]                                        # cm1, cm2, cm3, cm4_2ns, tmpExp, constants
     fam = {"leaf_hashing": ("k_linear_hash_rows_lines",), "ntt_passes": ("k_ntt_pass", "k_lde_mid"), "constraint_kernels": ("chelpers_chunk",),
-           "operand_transpose": ("k_chp_transpose",), "linear_kernel": ("k_chp_linear",), "evmap": ("k_evmap_partial", "k_evmap_reduce")}
+           "operand_transpose": ("k_chp_transpose",), "linear_kernel": ("k_chp_linear",), "evmap": ("k_evmap_partial", "k_evmap_partial_tiled", "k_evmap_reduce")}
     ns = {k: 0.0 for k in fam}
     calls = {k: 0 for k in fam}
     for row in csv.DictReader(open(stats_csv)):

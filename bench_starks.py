@@ -232,6 +232,12 @@ def tiled_witness(si, n, w1):
     return all(si["varPolMap"][int(si["exp2pol"][str(e)])]["section"] != "cm1_n" for e in ids)
 
 
+def tiled_ext(ne, w):
+    """host/starks.hpp's rule for keeping a wide extended section (cm1_2ns .. cm3_2ns) tile-major in the image: one device, device steps,
+    at least one tile of rows, more than 4 columns.  step42ns / step52ns are compiled for that layout."""
+    return os.environ.get("MI_STARK_TILED_EXT", "1")[:1] != "0" and ne >= 64 and w > 4 and not os.environ.get("MI_STARK_DEVICES", "")
+
+
 def compiled_programs(args, shard=None):
     """The five programs through mi_chelpers_compile + the native build with the in-tree code-object cache (no GPU needed): what
     Starks does on first use, done ahead so that the GPU box finds every kernel in the cache."""
@@ -244,6 +250,10 @@ def compiled_programs(args, shard=None):
         p = mi_stark.ChelpersProgram(None, ops, ar, sections=secs[name], n_const=args.n_const, nrows_ext=n if base else ne, step=STEP_ID[name])
         if base and tiled_witness(si, n, cols["cm1_n"]):
             p.set_tiled_section(off["cm1_n"])
+        if not base:
+            for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns"):
+                if tiled_ext(ne, cols[k]):
+                    p.set_tiled_section(off[k])
         if shard is not None:
             p.precompile_shard(*shard)
         else:

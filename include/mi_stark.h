@@ -129,6 +129,9 @@ static inline uint64_t mi_merkle_proof_levels(uint64_t nrows)
 int mi_merkle_group_proofs_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src,
                                uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx,
                                uint64_t nqueries);
+/* The same over a TILE-MAJOR source ([height / 64][ncols_total][64], mi_lde_merkle_dev_tiled): the first `width` columns of row idx[q]. */
+int mi_merkle_group_proofs_tiled_dev(mi_ctx *ctx, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src_tiled,
+                                     uint64_t ncols_total, uint64_t height, uint64_t width, const uint64_t *idx, uint64_t nqueries);
 
 /* mi_lde_merkle_host, how a column chunk crosses PCIe: `threads` host threads pack it out of the row-major host trace into
  * page-locked staging (streaming stores), which then moves as one contiguous copy at the full rate -- a strided 2-D copy of a
@@ -155,6 +158,17 @@ int mi_lde_merkle_host_keep(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_
  * the compiled base-domain steps read in place.  Costs what the row-major copy costs and hides behind the upload like it. */
 int mi_lde_merkle_host_keep_tiled(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base_tiled,
                                   const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
+/* The extension TILE-MAJOR (ext_tiled: n_ext x ncols, n_ext a multiple of 64, ncols > 4); base (may be NULL) receives the trace itself,
+ * row-major at base_pitch, or tile-major too with base_pitch = 0 (n a multiple of 64 then).  The extension of a
+ * column chunk goes into a compact buffer (out of the lent workspace's tail) and the leaf kernel, absorbing the chunk's words, writes
+ * them into the section -- a lane owns one of 64 consecutive rows, so a word of every lane is a 512-byte run of a tile -- where the
+ * row-major form (extendPol's: starks.cpp:52) would have been written.  What Starks::genProof's constraint kernels, its linear
+ * combination, evmap and openings read in place (host/starks.hpp); the tree is the same tree. */
+int mi_lde_merkle_host_tiled(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext_tiled, uint64_t *base, uint64_t base_pitch,
+                             const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols);
+/* The same for a section that is in HBM already (src: n x ncols at row pitch src_pitch, row-major): starks.cpp:133-138,214-219. */
+int mi_lde_merkle_dev_tiled(mi_ctx *ctx, uint64_t *nodes, uint64_t *ext_tiled, const uint64_t *src, uint64_t src_pitch, uint64_t n,
+                            uint64_t n_ext, uint64_t ncols);
 int mi_host_register(mi_ctx *ctx, void *p, uint64_t bytes);   /* hipHostRegister (portable: every device may read it): page-lock a host range for DMA */
 int mi_host_unregister(mi_ctx *ctx, void *p);
 
@@ -263,6 +277,12 @@ int mi_q_split_dev(mi_ctx *ctx, uint64_t *qq2, const uint64_t *qq1, uint64_t n, 
 int mi_evmap_dev(mi_ctx *ctx, uint64_t *evals /* device, n_evals*3 */, uint64_t n_evals, uint64_t n,
                  unsigned ext_bits, const uint64_t *const *pol_ptr, const uint32_t *pol_dim,
                  const uint64_t *pol_stride, const uint8_t *prime, const uint64_t *lev, const uint64_t *lpev);
+/* The same with some polynomials in TILE-MAJOR sections: tile_cols[i] != 0 is the width of polynomial i's section ([n_ext / 64]
+ * [tile_cols[i]][64]) and pol_ptr[i] its element of row 0 (section + 64 * column); pol_stride[i] is ignored for it.  Such polynomials
+ * are summed by a kernel whose lanes take rows (a column's rows are the contiguous ones there); the evaluations are the same. */
+int mi_evmap_tiled_dev(mi_ctx *ctx, uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const uint64_t *const *pol_ptr,
+                       const uint32_t *pol_dim, const uint64_t *pol_stride, const uint8_t *prime, const uint64_t *tile_cols,
+                       const uint64_t *lev, const uint64_t *lpev);
 /* the same sums over rows [row0, row0 + nrows) of the base domain only (lev / lpev still indexed by the absolute row): a row shard's
  * share -- the shares of a partition of [0, n) add up (in F_p^3) to mi_evmap_dev's evaluations */
 int mi_evmap_range_dev(mi_ctx *ctx, uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const uint64_t *const *pol_ptr,
@@ -410,13 +430,18 @@ int mi_chelpers_build_native(mi_chelpers_prog *prog, const char *cache_dir, uint
  * row-major: the generated kernels read it in place, a lane per row and 512 contiguous bytes per operand and wave, and the per-batch
  * tile-major copy of that section (k_chp_transpose: a read and a write of the whole section per step) is not made.  For a section every
  * base-domain step reads but nothing writes or reads by stride: the witness cm1_n (host/starks.hpp; starks.cpp:66-210 read it three
- * times).  Call after mi_chelpers_compile and before mi_chelpers_build_native / _precompile_shard / _lower_stats; one section per
- * program, named by its offset; the program then runs through the compiled kernels only, over rows from a multiple of 64. */
+ * times), and the extended sections cm1_2ns .. cm3_2ns as mi_lde_merkle_*_tiled leave them.  Call after mi_chelpers_compile and before
+ * mi_chelpers_build_native / _precompile_shard / _lower_stats, once per tile-major section, named by its offset; the program then runs
+ * through the compiled kernels only, over rows from a multiple of 64. */
 int mi_chelpers_set_tiled_section(mi_chelpers_prog *prog, uint64_t section_offset);
 /* dst (tile-major as above, nrows x ncols_total) <- src (row-major, src_pitch words per row, ncols columns), placed at column col0 of
  * the tiles; nrows a multiple of 64; values canonicalised. */
 int mi_tile_major_dev(mi_ctx *ctx, uint64_t *dst, uint64_t ncols_total, uint64_t col0, const uint64_t *src, uint64_t src_pitch,
                       uint64_t nrows, uint64_t ncols);
+/* the way back, for checks: dst (row-major, dst_pitch words per row) <- rows [row0, row0 + nrows) x columns [col0, col0 + ncols) of the
+ * tile-major section src_tiled (nrows_total x ncols_total) */
+int mi_untile_dev(mi_ctx *ctx, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src_tiled, uint64_t ncols_total, uint64_t nrows_total,
+                  uint64_t col0, uint64_t row0, uint64_t nrows, uint64_t ncols);
 /* What the native backend makes of the program, without compiling anything: out = kernels, instructions evaluated as
  * Horner-chain accumulator steps, chain pieces, estimated VALU instructions per row, chain coefficients (+- C^e), per-piece
  * constants, folded (polynomial - evaluation) leaves, temporary words moved through the spill per row, polynomial elements

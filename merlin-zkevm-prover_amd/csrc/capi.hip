@@ -543,8 +543,21 @@ extern "C" int mi_merkle_build(mi_ctx *c, uint64_t *nodes, const uint64_t *src, 
     return MI_OK;
 }
 
+static int group_proofs_impl(mi_ctx *c, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src, uint64_t pitch, uint64_t height, uint64_t width,
+                             const uint64_t *idx, uint64_t nq, bool tiled);
 extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src,
                                           uint64_t pitch, uint64_t height, uint64_t width, const uint64_t *idx, uint64_t nq)
+{
+    return group_proofs_impl(c, proofs, nodes, src, pitch, height, width, idx, nq, false);
+}
+extern "C" int mi_merkle_group_proofs_tiled_dev(mi_ctx *c, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src_tiled,
+                                                uint64_t ncols_total, uint64_t height, uint64_t width, const uint64_t *idx, uint64_t nq)
+{
+    if (c && width > ncols_total) { mi_set_error("mi_merkle_group_proofs_tiled_dev: more values asked for than the section has columns"); return MI_ERR_INVALID; }
+    return group_proofs_impl(c, proofs, nodes, src_tiled, ncols_total, height, width, idx, nq, true);
+}
+static int group_proofs_impl(mi_ctx *c, uint64_t *proofs, const uint64_t *nodes, const uint64_t *src, uint64_t pitch, uint64_t height, uint64_t width,
+                             const uint64_t *idx, uint64_t nq, bool tiled)
 {
     CTX_OK(c);
     MI_OWN(c, proofs);
@@ -557,7 +570,7 @@ extern "C" int mi_merkle_group_proofs_dev(mi_ctx *c, uint64_t *proofs, const uin
     u64 *di = c->small; // the indices: the context's 4 KiB words (512 queries) or its scratch, no allocation per call
     if (nq * 8 > 4096) MI_TRY(mi_scratch(c, nq * 8, (void **)&di));
     MI_HIP_CHECK(hipMemcpyAsync(di, idx, nq * 8, hipMemcpyHostToDevice, c->stream));
-    MI_TRY(launch_group_proofs(c, (u64 *)proofs, (const u64 *)nodes, (const u64 *)src, pitch, height, width, (const u64 *)di, nq));
+    MI_TRY(launch_group_proofs(c, (u64 *)proofs, (const u64 *)nodes, (const u64 *)src, pitch, height, width, (const u64 *)di, nq, tiled));
     MI_HIP_CHECK(hipStreamSynchronize(c->stream)); // idx is the caller's pageable memory: it may go once this returns
     return MI_OK;
 }
@@ -585,12 +598,14 @@ extern "C" int mi_get_host_pack_threads(mi_ctx *c)
     return effective_pack_threads(c);
 }
 
-// base_pitch == 0: the base-domain section is kept tile-major (mi_lde_merkle_host_keep_tiled)
+// base_pitch == 0: the base-domain section is kept tile-major (mi_lde_merkle_host_keep_tiled); ext_tiled: so is the extension -- a
+// chunk is extended into a compact buffer and the leaf kernel, absorbing it, writes its words into the section (launch_linear_hash_absorb_emit)
 static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint64_t ext_pitch, uint64_t *base, uint64_t base_pitch,
-                                const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+                                const uint64_t *trace_host, uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols, bool ext_tiled = false)
 {
     if (n == 0 || ncols == 0) return MI_OK;
     MI_REQUIRE(nodes && ext && trace_host, "null buffer");
+    MI_REQUIRE(!ext_tiled || (n_ext % 64 == 0 && ncols > 4 && ext_pitch == ncols), "a tile-major extension has a multiple of 64 rows, more than 4 columns and no pitch of its own");
     MI_REQUIRE(!base || base_pitch == 0 || base_pitch >= ncols, "pitch smaller than ncols");
     MI_REQUIRE(!base || base_pitch != 0 || n % 64 == 0, "a tile-major section has a multiple of 64 rows");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
@@ -651,7 +666,8 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
     // compact staging buffers [n x chunk]
     constexpr int NS = mi_ctx::N_STAGE;
     const uint64_t max_cw = *std::max_element(cws.begin(), cws.end()); // widest chunk of the schedule
-    const uint64_t stage_bytes = NS * n * max_cw * 8;
+    const uint64_t z_pitch = (max_cw + 15) & ~15ull, z_bytes = ext_tiled ? n_ext * z_pitch * 8 + 256 : 0; // the compact extension of one chunk
+    const uint64_t stage_bytes = NS * n * max_cw * 8 + z_bytes;
     // With a lent workspace (a caller that plans its HBM: host/starks.hpp) the staging comes out of the lent buffer's tail and nothing
     // is allocated; the transforms of this call see the rest.  Later work on the stream is ordered behind this call's kernels, which
     // wait for the last upload, so the tail is free again when the call's work is done.
@@ -680,6 +696,7 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
         stage_base = c->stage;
     }
     u64 *const st[NS] = {stage_base, stage_base + n * max_cw, stage_base + 2 * n * max_cw};
+    u64 *const zbuf = ext_tiled ? (u64 *)(((uintptr_t)(stage_base + NS * n * max_cw) + 127) & ~(uintptr_t)127) : nullptr;
     // the copy streams must not overtake work already queued on the compute stream that still reads the staging buffers
     for (int i = 0; i < NS; i++) MI_HIP_CHECK(hipEventRecord(c->ev_consumed[i], c->stream));
     if (packed) {
@@ -773,6 +790,7 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
         return MI_OK;
     };
     auto absorb = [&](uint64_t k) -> int {
+        if (ext_tiled) return launch_linear_hash_absorb_emit(c, (u64 *)nodes, zbuf, z_pitch, cws[k], n_ext, k == 0, k + 1 == n_chunks, (u64 *)ext, ncols, c0s[k]);
         if (ncols <= 4) // linear_hash copies rows of at most 4 elements instead of hashing them: one chunk, plain leaf kernel
             return launch_linear_hash_rows(c, (u64 *)nodes, (const u64 *)ext, ext_pitch, ncols, n_ext);
         const u64 *base = (const u64 *)ext + c0s[k];
@@ -785,7 +803,8 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
     MI_TRY(upload(0));
     for (uint64_t k = 0; k < n_chunks; k++) {
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_uploaded[k % NS][s], 0));
-        MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k % NS], cws[k], n_ext, n, cws[k]));
+        if (ext_tiled) MI_TRY(launch_lde(c, zbuf, z_pitch, st[k % NS], cws[k], n_ext, n, cws[k]));
+        else MI_TRY(launch_lde(c, (u64 *)ext + c0s[k], ext_pitch, st[k % NS], cws[k], n_ext, n, cws[k]));
         if (base && base_pitch) MI_TRY(launch_copy_2d(c, (u64 *)base + c0s[k], base_pitch, st[k % NS], cws[k], n, cws[k])); // the base-domain section stays too
         else if (base) MI_TRY(launch_tile_major(c, (u64 *)base, ncols, c0s[k], st[k % NS], cws[k], n, cws[k]));
         MI_HIP_CHECK(hipEventRecord(c->ev_consumed[k % NS], c->stream));
@@ -831,6 +850,63 @@ extern "C" int mi_lde_merkle_host_keep_tiled(mi_ctx *c, uint64_t *nodes, uint64_
     return lde_merkle_host_impl(c, nodes, ext, ext_pitch, base_tiled, 0, trace_host, n, n_ext, ncols, chunk_cols);
 }
 
+extern "C" int mi_lde_merkle_host_tiled(mi_ctx *c, uint64_t *nodes, uint64_t *ext_tiled, uint64_t *base, uint64_t base_pitch, const uint64_t *trace_host,
+                                        uint64_t n, uint64_t n_ext, uint64_t ncols, uint64_t chunk_cols)
+{
+    CTX_OK(c);
+    MI_OWN(c, nodes);
+    MI_OWN(c, ext_tiled);
+    MI_OWN(c, base);
+    return lde_merkle_host_impl(c, nodes, ext_tiled, ncols, base, base_pitch, trace_host, n, n_ext, ncols, chunk_cols, true);
+}
+
+// Device source: the section is extended in column chunks into a compact buffer (out of the tail of the workspace the caller lent, or
+// the context's staging allocation) and absorbed from there by the emitting leaf kernel.
+extern "C" int mi_lde_merkle_dev_tiled(mi_ctx *c, uint64_t *nodes, uint64_t *ext_tiled, const uint64_t *src, uint64_t src_pitch, uint64_t n, uint64_t n_ext,
+                                       uint64_t ncols)
+{
+    CTX_OK(c);
+    MI_OWN(c, nodes);
+    MI_OWN(c, ext_tiled);
+    MI_OWN(c, src);
+    if (n == 0 || ncols == 0) return MI_OK;
+    MI_REQUIRE(nodes && ext_tiled && src, "null buffer");
+    MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
+    MI_REQUIRE(n_ext % 64 == 0 && ncols > 4 && src_pitch >= ncols, "a tile-major extension has a multiple of 64 rows and more than 4 columns");
+    const uint64_t cw_max = std::min<uint64_t>(ncols, 96), z_pitch = (cw_max + 15) & ~15ull, z_bytes = n_ext * z_pitch * 8 + 256;
+    struct WorkspaceCarve {
+        mi_ctx *c; uint64_t saved = 0;
+        ~WorkspaceCarve() { if (saved) c->workspace_bytes = c->workspace_limit = saved; }
+    } carve{c};
+    u64 *zraw = nullptr;
+    if (c->workspace_lent && c->workspace_bytes >= z_bytes + cw_max * (n + n_ext) * 8 + (1ull << 20)) {
+        carve.saved = c->workspace_bytes;
+        c->workspace_bytes = c->workspace_limit = (carve.saved - z_bytes) & ~(uint64_t)255;
+        zraw = c->workspace + c->workspace_bytes / 8;
+    } else {
+        if (c->stage_bytes < z_bytes) {
+            MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->stage) MI_HIP_CHECK(hipFree(c->stage));
+            c->stage = nullptr;
+            c->stage_bytes = 0;
+            hipError_t e = hipMalloc((void **)&c->stage, z_bytes);
+            if (e != hipSuccess) {
+                mi_set_error("cannot allocate %llu bytes for a chunk's compact extension: %s", (unsigned long long)z_bytes, hipGetErrorString(e));
+                return MI_ERR_NOMEM;
+            }
+            c->stage_bytes = z_bytes;
+        }
+        zraw = c->stage;
+    }
+    u64 *const zbuf = (u64 *)(((uintptr_t)zraw + 127) & ~(uintptr_t)127);
+    for (uint64_t c0 = 0; c0 < ncols; c0 += cw_max) {
+        const uint64_t cw = std::min(cw_max, ncols - c0);
+        MI_TRY(launch_lde(c, zbuf, z_pitch, (const u64 *)src + c0, src_pitch, n_ext, n, cw));
+        MI_TRY(launch_linear_hash_absorb_emit(c, (u64 *)nodes, zbuf, z_pitch, cw, n_ext, c0 == 0, c0 + cw == ncols, (u64 *)ext_tiled, ncols, c0));
+    }
+    return launch_merkle_levels(c, (u64 *)nodes, n_ext);
+}
+
 extern "C" int mi_tile_major_dev(mi_ctx *c, uint64_t *dst, uint64_t ncols_total, uint64_t col0, const uint64_t *src, uint64_t src_pitch,
                                  uint64_t nrows, uint64_t ncols)
 {
@@ -842,6 +918,18 @@ extern "C" int mi_tile_major_dev(mi_ctx *c, uint64_t *dst, uint64_t ncols_total,
     MI_REQUIRE(nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
     MI_REQUIRE(src_pitch >= ncols && col0 + ncols <= ncols_total, "columns outside the section");
     return launch_tile_major(c, (u64 *)dst, ncols_total, col0, (const u64 *)src, src_pitch, nrows, ncols);
+}
+
+extern "C" int mi_untile_dev(mi_ctx *c, uint64_t *dst, uint64_t dst_pitch, const uint64_t *src_tiled, uint64_t ncols_total, uint64_t nrows_total, uint64_t col0,
+                             uint64_t row0, uint64_t nrows, uint64_t ncols)
+{
+    CTX_OK(c);
+    MI_OWN(c, dst);
+    MI_OWN(c, src_tiled);
+    if (nrows == 0 || ncols == 0) return MI_OK;
+    MI_REQUIRE(dst && src_tiled, "null buffer");
+    MI_REQUIRE(nrows_total % 64 == 0 && row0 + nrows <= nrows_total && col0 + ncols <= ncols_total && dst_pitch >= ncols, "rows or columns outside the section");
+    return launch_untile(c, (u64 *)dst, dst_pitch, (const u64 *)src_tiled, ncols_total, col0, row0, nrows, ncols);
 }
 
 extern "C" int mi_set_host_pack_threads(mi_ctx *c, int threads)
@@ -924,6 +1012,21 @@ extern "C" int mi_evmap_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, uint64
     for (uint64_t i = 0; i < n_evals; i++) MI_OWN(c, pol_ptr[i]);
     return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
                         prime, (const u64 *)lev, (const u64 *)lpev, 0, n);
+}
+
+// The same with some of the polynomials in TILE-MAJOR sections ([n_ext / 64][width][64], mi_lde_merkle_dev_tiled): tile_cols[i] != 0 is the
+// width of polynomial i's section and pol_ptr[i] its element of row 0 (section + 64 * column); pol_stride[i] is ignored for it.
+extern "C" int mi_evmap_tiled_dev(mi_ctx *c, uint64_t *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits,
+                                  const uint64_t *const *pol_ptr, const uint32_t *pol_dim, const uint64_t *pol_stride,
+                                  const uint8_t *prime, const uint64_t *tile_cols, const uint64_t *lev, const uint64_t *lpev)
+{
+    CTX_OK(c);
+    if (n_evals == 0) return MI_OK;
+    MI_REQUIRE(evals && pol_ptr && pol_dim && pol_stride && prime && tile_cols && lev && lpev, "null buffer");
+    MI_OWN(c, evals); MI_OWN(c, lev); MI_OWN(c, lpev);
+    for (uint64_t i = 0; i < n_evals; i++) MI_OWN(c, pol_ptr[i]);
+    return launch_evmap(c, (u64 *)evals, n_evals, n, ext_bits, (const u64 *const *)pol_ptr, pol_dim, (const u64 *)pol_stride,
+                        prime, (const u64 *)lev, (const u64 *)lpev, 0, n, tile_cols);
 }
 
 // the partial sums over rows [row0, row0 + nrows) of the base domain (a row shard's share; the shares add up to mi_evmap_dev's result)

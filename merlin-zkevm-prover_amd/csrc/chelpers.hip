@@ -1092,14 +1092,14 @@ extern "C" int mi_chelpers_build_native(mi_chelpers_prog *p, const char *cache_d
     return chp::native_build(p, cache_dir, chunk_cost, 0, 1);
 }
 
-// A section the caller keeps tile-major in HBM (include/mi_stark.h): the generated kernels read it in place.
+// A section the caller keeps tile-major in HBM (include/mi_stark.h): the generated kernels read it in place.  Any number of a program's
+// sections may be.
 extern "C" int mi_chelpers_set_tiled_section(mi_chelpers_prog *p, uint64_t section_offset)
 {
     if (!p) return MI_ERR_INVALID;
     MI_REQUIRE(!p->native, "mi_chelpers_set_tiled_section comes before mi_chelpers_build_native");
     HostSection *hit = nullptr;
     for (HostSection &S : p->sections) {
-        MI_REQUIRE(!S.tiled || (S.role == 0 && S.offset == section_offset), "one tile-major section per program");
         if (S.role == 0 && S.offset == section_offset) hit = &S;
     }
     MI_REQUIRE(hit, "no declared section starts at this offset");

@@ -93,7 +93,7 @@ static constexpr uint32_t LIN_MIN_TERMS = 256; // below this a pass over the sec
 struct LinTermH { uint32_t staged_col, coef, sum; };
 struct LinTerm { uint32_t lds_off, coef; };    // byte offset of the column inside a staged row; index of the coefficient (LinTermW carries its value)
 struct LinSlabD { uint32_t section, col0, ncols, t0[LIN_MAX_SUMS + 1]; };
-struct LinSections { const u64 *ptr[MAX_SECTIONS]; uint64_t pitch[MAX_SECTIONS], row_mask[MAX_SECTIONS]; };
+struct LinSections { const u64 *ptr[MAX_SECTIONS]; uint64_t pitch[MAX_SECTIONS], row_mask[MAX_SECTIONS]; uint32_t tiled[MAX_SECTIONS]; }; // tiled: [rows / 64][pitch columns][64]
 
 struct Chunk {
     size_t i0 = 0, i1 = 0;          // instructions [i0, i1) of mi_chelpers_prog::host
@@ -284,7 +284,7 @@ static int lower(const mi_chelpers_prog *P, NativeProg *N, uint64_t chunk_cost, 
             uint32_t col, sh;
             int dim;
             const HostSection *S = resolve_pol(P, lk, m.folded >= 0 ? H[m.folded].a : (m.yside == 0 ? H[i].b : H[i].a), col, dim, sh);
-            return S && !S->tiled; // (the linear kernel fetches along the rows of a row-major section)
+            return S != nullptr; // (row-major or tile-major: the linear kernel fetches either)
         };
         for (size_t i = 0; i < n; i++) cand += is_lin(i);
         uint32_t lin_min = LIN_MIN_TERMS;
@@ -569,7 +569,8 @@ struct Gen {
         recent[expr] = {name, cur_group};
         return group_loads[expr] = name;
     }
-    std::set<uint32_t> shifts, xshifts; // row shifts read from the tile-major copy / from the section kept tile-major (0 included)
+    std::set<uint32_t> shifts; // row shifts read from the tile-major copy
+    std::set<std::pair<uint32_t, uint32_t>> xshifts; // (section kept tile-major, row shift) pairs read in place (shift 0 included)
     bool uses_zh = false;
     // Stores into params.pols at the row itself (the base-domain steps): a lane owns a row, so a store is 64 eight-byte writes a pitch
     // apart -- one 64-byte sector touched per word (measured: 19 of step3's 95 ms, 11 of step3prev's 47).  The words a kernel stores are
@@ -649,12 +650,12 @@ struct Gen {
             return MI_ERR_INVALID;
         }
         const bool three = pdim == 3;
-        if (S->tiled) xshifts.insert(sh); // read in place: X<shift>, columns counted from the section's first
+        if (S->tiled) xshifts.insert({(uint32_t)(S - P->sections.data()), sh}); // read in place: X<section>_<shift>, columns counted from the section's first
         else if (sh) shifts.insert(sh);   // (a T<shift> no load names is dropped by the compiler)
         v.dim = three ? 3 : 1;
         for (int j = 0; j < v.dim; j++) {
             const uint32_t sc = col - S->col0 + j; // column of the section
-            if (S->tiled) snprintf(buf, sizeof buf, "X%u[%llu]", sh, (unsigned long long)sc * 64);
+            if (S->tiled) snprintf(buf, sizeof buf, "X%u_%u[%llu]", (uint32_t)(S - P->sections.data()), sh, (unsigned long long)sc * 64);
             else if ((N->sec_inplace_mask[S - P->sections.data()] >> (sc / 64)) & 1) // in place, row-major (role 0: the polynomial area, 1: the constants)
                 snprintf(buf, sizeof buf, "%s[%lluULL + ((row + %uu) & %lluULL) * %lluULL]", S->role == 0 ? "pols" : "cpols",
                          (unsigned long long)((S->role == 0 ? S->offset : 0) + sc), sh, (unsigned long long)(S->nrows - 1),
@@ -929,7 +930,7 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
     char line[1024];
     snprintf(line, sizeof line,
              "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(%u, %u))) void chelpers_chunk(const u64 *__restrict__ tiled, u64 *__restrict__ spill, "
-             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin, const u64 *__restrict__ xsec, const u64 *__restrict__ pols, const u64 *__restrict__ cpols)\n{\n"
+             "const u64 *__restrict__ cst, u64 *__restrict__ out, u64 row_base, u64 row_end, u32 zmask, const u64 *__restrict__ lin, const u64 *__restrict__ pols, const u64 *__restrict__ cpols)\n{\n"
              "  const u32 lane = threadIdx.x;\n  const u64 tile = blockIdx.x;\n  const u64 row = row_base + tile * 64 + lane;\n"
              "  const u64 *__restrict__ T0 = tiled + tile * %lluULL + lane;\n  u64 *__restrict__ S = spill + tile * %lluULL + lane;\n",
              waves, waves, (unsigned long long)N->sc * 64, (unsigned long long)N->nw * 64);
@@ -945,14 +946,14 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
                  (unsigned long long)N->sc * 64, s);
         src += line;
     }
-    for (const HostSection &S : P->sections) {
-        if (!S.tiled) continue;
-        // the section kept tile-major: tile = row / 64 of the whole section (row_base is a multiple of 64), rows wrap at its end
-        for (uint32_t s : g.xshifts) {
-            snprintf(line, sizeof line, "  const u64 *__restrict__ X%u = xsec + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + ((lane + %uu) & 63u);\n", s, s,
-                     (unsigned long long)(S.nrows / 64 - 1), (unsigned long long)S.ncols * 64, s);
-            src += line;
-        }
+    for (const auto &xs : g.xshifts) {
+        // a section kept tile-major (a part of the polynomial area): tile = row / 64 of the whole section (row_base is a multiple of 64),
+        // rows wrap at its end
+        const HostSection &S = P->sections[xs.first];
+        const uint32_t s = xs.second;
+        snprintf(line, sizeof line, "  const u64 *__restrict__ X%u_%u = pols + %lluULL + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + ((lane + %uu) & 63u);\n",
+                 xs.first, s, (unsigned long long)S.offset, s, (unsigned long long)(S.nrows / 64 - 1), (unsigned long long)S.ncols * 64, s);
+        src += line;
     }
     if (g.uses_zh) {
         snprintf(line, sizeof line, "  const u64 zh = cst[%u + (u32)(row & zmask)];\n", N->zh_off);
@@ -1189,6 +1190,23 @@ int launch_tile_major(mi_ctx *ctx, u64 *dst, uint64_t ncols_total, uint64_t col0
     return MI_OK;
 }
 
+// rows [row0, row0 + nrows) x columns [col0, col0 + ncols) of a tile-major section -> row-major (checks and tests: nothing in a proof reads it)
+__global__ __launch_bounds__(256) void k_untile(u64 *__restrict__ dst, uint64_t dst_pitch, const u64 *__restrict__ src, uint64_t ncols_total, uint64_t col0,
+                                                 uint64_t row0, uint64_t nrows, uint64_t ncols)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < nrows * ncols; e += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = e / ncols, cc = e % ncols, row = row0 + r;
+        dst[r * dst_pitch + cc] = src[((row >> 6) * ncols_total + col0 + cc) * 64 + (row & 63)];
+    }
+}
+int launch_untile(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t ncols_total, uint64_t col0, uint64_t row0, uint64_t nrows, uint64_t ncols)
+{
+    if (!nrows || !ncols) return MI_OK;
+    hipLaunchKernelGGL(k_untile, dim3(mi_grid_256(nrows * ncols)), dim3(256), 0, ctx->stream, dst, dst_pitch, src, ncols_total, col0, row0, nrows, ncols);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
 namespace chp {
 
 // sums of polynomial elements times constants, straight from the row-major sections (see "linear terms" above).  One wave per
@@ -1216,17 +1234,25 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
         for (int j = 0; j < 3; j++) chpa::acc_set(acc[s2][j], 0);
     if (threadIdx.x < 16) cb[LIN_TMAX * 4 + threadIdx.x] = 0; // the slack stays zero (offset 0, coefficient 0)
     u64 stage[LIN_COLS]; // 64 x LIN_COLS elements / 64 lanes
+    uint32_t stage_tiled = 0; // the staged slab came out of a tile-major section: stage[i] is column i of the lane's row
     uint4 cstage[LIN_TMAX * 32 / 1024];
     auto issue = [&](uint32_t sl) {
         const uint32_t si = slabs[sl].section, c0 = slabs[sl].col0, nc = slabs[sl].ncols;
         const u64 *src = sec.ptr[si];
         const uint64_t pitch = sec.pitch[si], mask = sec.row_mask[si];
+        if (sec.tiled[si]) { // (wave-uniform) element i of the stage = column i of this lane's own row: 512-byte runs, nothing to turn
+            const u64 *t = src + ((((row_base >> 6) + tile) & (mask >> 6)) * pitch + c0) * 64 + lane;
 #pragma unroll
-        for (uint32_t i = 0; i < LIN_COLS; i++) {
-            const uint32_t e = i * 64 + lane, r = e / LIN_COLS, cc = e % LIN_COLS;
-            const uint64_t row = (row_base + tile * 64 + r) & mask;
-            stage[i] = src[row * pitch + c0 + (cc < nc ? cc : 0)]; // no term reads a column past the section's last: any valid address will do
+            for (uint32_t i = 0; i < LIN_COLS; i++) stage[i] = t[(uint64_t)(i < nc ? i : 0) * 64];
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < LIN_COLS; i++) {
+                const uint32_t e = i * 64 + lane, r = e / LIN_COLS, cc = e % LIN_COLS;
+                const uint64_t row = (row_base + tile * 64 + r) & mask;
+                stage[i] = src[row * pitch + c0 + (cc < nc ? cc : 0)]; // no term reads a column past the section's last: any valid address will do
+            }
         }
+        stage_tiled = sec.tiled[si];
         const uint32_t tb = slabs[sl].t0[0], n16 = (slabs[sl].t0[LIN_MAX_SUMS] - tb) * 2; // 16-byte pieces of this slab's terms
         const uint4 *tp = (const uint4 *)(terms + tb);
 #pragma unroll
@@ -1240,10 +1266,15 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
     for (uint32_t sl = 0; sl < n_slabs; sl++) {
         u64 *b = buf;
         uint4 *c4 = (uint4 *)cb;
+        if (stage_tiled) {
 #pragma unroll
-        for (uint32_t i = 0; i < LIN_COLS; i++) {
-            const uint32_t e = i * 64 + lane;
-            b[(e / LIN_COLS) * (LIN_COLS + 1) + e % LIN_COLS] = stage[i];
+            for (uint32_t i = 0; i < LIN_COLS; i++) b[lane * (LIN_COLS + 1) + i] = stage[i];
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < LIN_COLS; i++) {
+                const uint32_t e = i * 64 + lane;
+                b[(e / LIN_COLS) * (LIN_COLS + 1) + e % LIN_COLS] = stage[i];
+            }
         }
 #pragma unroll
         for (uint32_t k = 0; k < LIN_TMAX * 32 / 1024; k++) c4[k * 64 + lane] = cstage[k];
@@ -1395,7 +1426,6 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
     u64 *out = P->stores_pols ? (u64 *)a->pols : (u64 *)(P->step == MI_CHELPERS_STEP52NS ? a->f : a->q);
     uint32_t zmask = (uint32_t)(n_zh - 1);
     const uint64_t row_end = row0 + nrows;
-    const u64 *xsec = nullptr;
     for (const HostSection &S : P->sections)
         if (S.tiled) MI_REQUIRE(row0 % 64 == 0 && is_pow2(S.nrows) && S.nrows >= 64, "a program with a tile-major section runs over rows from a multiple of 64");
     for (uint64_t b0 = row0; b0 < row_end; b0 += batch) {
@@ -1411,8 +1441,8 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             else if (S.role == 3) { MI_REQUIRE(a->xdiv, "null xDivXSubXi"); ptr = (const u64 *)a->xdiv; pitch = 3; }
             else { MI_REQUIRE(a->xdivw, "null xDivXSubWXi"); ptr = (const u64 *)a->xdivw; pitch = 3; }
             MI_REQUIRE(is_pow2(S.nrows), "section row counts must be powers of two");
-            ls.ptr[si] = ptr; ls.pitch[si] = pitch; ls.row_mask[si] = S.nrows - 1;
-            if (S.tiled) { xsec = ptr; continue; } // read in place
+            ls.ptr[si] = ptr; ls.pitch[si] = pitch; ls.row_mask[si] = S.nrows - 1; ls.tiled[si] = S.tiled ? 1 : 0;
+            if (S.tiled) continue; // read in place
             if (!N->sec_slab_mask[si]) continue;
             hipLaunchKernelGGL(k_chp_transpose, dim3((unsigned)(tiles + 1), (unsigned)((S.ncols + 63) / 64)), dim3(256), 0, c->stream, ptr, pitch,
                                (uint32_t)S.ncols, S.nrows - 1, rb.tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
@@ -1435,7 +1465,7 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             uint64_t row_base = b0, rend = row_end;
             const u64 *linp = rb.lin;
             const u64 *polsp = (const u64 *)a->pols, *cpolsp = (const u64 *)a->const_pols;
-            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &xsec, &polsp, &cpolsp};
+            void *args[] = {&tiled, &spill, &cstp, &outp, &row_base, &rend, &zmask, &linp, &polsp, &cpolsp};
             MI_HIP_CHECK(hipModuleLaunchKernel(C.fn, (unsigned)tiles, 1, 1, 64, 1, 1, 0, c->stream, args, nullptr));
         }
     }

@@ -55,6 +55,11 @@ struct LeafSlabs {
     uint32_t width[MI_MAX_SLABS];
     uint32_t nslabs;
     uint32_t carry_in; // 1: the sponge capacity starts from digests[row] (earlier columns were absorbed by an earlier launch)
+    // EMIT form (launch_linear_hash_absorb_emit): the one window is a compact chunk whose rows start on 128-byte lines, a lane owns one
+    // of 64 CONSECUTIVE rows, and every word it absorbs is also written to columns [emit_col0, emit_col0 + width) of the tile-major
+    // section emit = [nrows / 64][emit_cols][64]
+    u64 *emit;
+    uint32_t emit_cols, emit_col0;
 };
 
 // Two-level power table: g^e = hi[e >> lo_bits] * lo[e & mask]   (lo[j] = s0 * g^j, hi[j] = g^(j << lo_bits))
@@ -175,10 +180,14 @@ int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n);
 int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows);
 int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const u64 *const *bases, const uint64_t *pitches,
                               const uint64_t *widths, uint64_t nrows, bool first, bool final);
+// the same over ONE compact window (pitch a multiple of 16 elements, base on a 128-byte line, nrows a multiple of 64), leaving the absorbed
+// columns tile-major in dst = [nrows / 64][dst_cols][64] at columns [col0, col0 + width) as well
+int launch_linear_hash_absorb_emit(mi_ctx *ctx, u64 *digests, const u64 *base, uint64_t pitch, uint64_t width, uint64_t nrows, bool first, bool final,
+                                   u64 *dst, uint64_t dst_cols, uint64_t col0);
 int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves);
 int launch_merkle_zero_width(mi_ctx *ctx, u64 *nodes, uint64_t nleaves); // the tree over rows of width 0: one value per level
 int launch_group_proofs(mi_ctx *ctx, u64 *proofs, const u64 *nodes, const u64 *src, uint64_t pitch, uint64_t height,
-                        uint64_t width, const u64 *idx_dev, uint64_t nq);
+                        uint64_t width, const u64 *idx_dev, uint64_t nq, bool tiled = false);
 int launch_ntt(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t n, uint64_t ncols,
                int inverse);
 int launch_lde(mi_ctx *ctx, u64 *out, uint64_t out_pitch, const u64 *in, uint64_t in_pitch, uint64_t n_ext, uint64_t n,
@@ -189,7 +198,8 @@ int launch_fri_fold(mi_ctx *ctx, u64 *out, const u64 *pol, unsigned prev_bits, u
 int launch_fri_transpose(mi_ctx *ctx, u64 *aux, const u64 *pol, uint64_t degree, unsigned tbits);
 int launch_q_split(mi_ctx *ctx, u64 *qq2, const u64 *qq1, uint64_t n, uint64_t n_ext, unsigned qdeg);
 int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n, unsigned ext_bits, const u64 *const *pol_ptr,
-                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev, uint64_t row0, uint64_t nrows);
+                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev, uint64_t row0, uint64_t nrows,
+                 const uint64_t *tile_cols = nullptr);
 int launch_batch_inverse3(mi_ctx *ctx, u64 *res, const u64 *src, uint64_t n);
 int launch_calculate_h1h2(mi_ctx *ctx, u64 *h1, uint64_t h1_stride, u64 *h2, uint64_t h2_stride, const u64 *f, uint64_t f_stride, const u64 *t,
                           uint64_t t_stride, unsigned dim, uint64_t n);
@@ -207,3 +217,4 @@ int launch_fill_synthetic_2d(mi_ctx *ctx, u64 *out, uint64_t out_pitch, uint64_t
 int launch_copy_2d(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols);
 // row-major [nrows x ncols] at src_pitch -> columns [col0, col0 + ncols) of the tile-major section dst = [nrows / 64][ncols_total][64], canonical
 int launch_tile_major(mi_ctx *ctx, u64 *dst, uint64_t ncols_total, uint64_t col0, const u64 *src, uint64_t src_pitch, uint64_t nrows, uint64_t ncols);
+int launch_untile(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t ncols_total, uint64_t col0, uint64_t row0, uint64_t nrows, uint64_t ncols);

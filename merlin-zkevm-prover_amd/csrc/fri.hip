@@ -173,7 +173,7 @@ struct EvDesc {
     uint32_t pad;
 };
 
-__global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial, const EvDesc *__restrict__ desc,
+__global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial, const EvDesc *__restrict__ desc, uint32_t n_act,
                                                        uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
                                                        const u64 *__restrict__ lev, const u64 *__restrict__ lpev, uint64_t row0)
 {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial
     const uint64_t k0 = row0 + (uint64_t)blockIdx.y * rows_per_slice; // rows [row0, n) of the base domain (row0 > 0: a row shard's partial sums)
     uint64_t k1 = k0 + rows_per_slice;
     if (k1 > n) k1 = n;
-    const bool active = i < n_evals;
+    const bool active = i < n_act; // (the first n_act descriptors: the row-major polynomials; `partial` has n_evals per slice)
     EvDesc d = {nullptr, 0, 1, 0, 0, 0};
     if (active) d = desc[i];
     const u64 *sl = sL[d.prime ? 1 : 0];
@@ -232,6 +232,65 @@ __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial
     o[0] = gl::canon(chpa::acc_reduce(r0)); o[1] = gl::canon(chpa::acc_reduce(r1)); o[2] = gl::canon(chpa::acc_reduce(r2));
 }
 
+// The same sums for polynomials that live in TILE-MAJOR sections ([tile of 64 rows][column][row in tile], Starks::genProof's extended
+// sections): there a column's rows are contiguous, so a lane takes ROWS (64 consecutive rows of the base domain = every 2^ext_bits-th
+// row of one or more tiles) and a wave takes CG evaluations, each lane summing its rows' products; the lanes' sums meet at the end.
+// LEv / LpEv of the slice are read by every group of evaluations: the groups of one slice are neighbours in the grid (x runs fastest),
+// so the slice's 48 bytes per row stay in the L2s while they are wanted.
+template <int CG>
+__global__ __launch_bounds__(64) void k_evmap_partial_tiled(u64 *__restrict__ partial, const EvDesc *__restrict__ desc, uint32_t i0, uint32_t n_t,
+                                                           uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
+                                                           const u64 *__restrict__ lev, const u64 *__restrict__ lpev, uint64_t row0)
+{
+    const uint32_t lane = threadIdx.x, g0 = i0 + blockIdx.x * CG;
+    const uint64_t k0 = row0 + (uint64_t)blockIdx.y * rows_per_slice;
+    uint64_t k1 = k0 + rows_per_slice;
+    if (k1 > n) k1 = n;
+    EvDesc d[CG];
+    bool on[CG];
+#pragma unroll
+    for (int j = 0; j < CG; j++) {
+        on[j] = g0 + j < i0 + n_t;
+        d[j] = desc[on[j] ? g0 + j : g0];
+    }
+    chpa::Acc a[CG][3];
+#pragma unroll
+    for (int j = 0; j < CG; j++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) chpa::acc_set(a[j][e], 0);
+    for (uint64_t kc = k0; kc < k1; kc += 64) {
+        const bool act = kc + lane < k1;
+        const uint64_t k = act ? kc + lane : k0, r = k << ext_bits;
+        u64 l[3], lp[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const u64 x = lev[k * 3 + e], y = lpev[k * 3 + e];
+            l[e] = act ? x : 0; lp[e] = act ? y : 0; // a lane past the slice's end adds zeros
+        }
+#pragma unroll
+        for (int j = 0; j < CG; j++) {
+            if (!on[j]) continue; // (wave-uniform)
+            const u64 *q = d[j].ptr + (r >> 6) * d[j].stride + (r & 63);
+            const u64 w0 = d[j].prime ? lp[0] : l[0], w1 = d[j].prime ? lp[1] : l[1], w2 = d[j].prime ? lp[2] : l[2];
+            if (d[j].dim == 1) {
+                const u64 v = q[0];
+                chpa::acc_mac(a[j][0], v, w0); chpa::acc_mac(a[j][1], v, w1); chpa::acc_mac(a[j][2], v, w2);
+            } else chpa::acc_mul33(a[j][0], a[j][1], a[j][2], q[0], q[64], q[128], w0, w1, w2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CG; j++) {
+        if (!on[j]) continue;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            u64 x = gl::canon(chpa::acc_reduce(a[j][e]));
+#pragma unroll
+            for (int o = 32; o; o >>= 1) x = gl::add(x, (u64)__shfl_xor((unsigned long long)x, o));
+            if (lane == 0) partial[((uint64_t)blockIdx.y * n_evals + g0 + j) * 3 + e] = x;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ partial,
                                                       const EvDesc *__restrict__ desc, uint32_t n_evals, uint32_t n_slices)
 {
@@ -247,19 +306,28 @@ __global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, c
 }
 
 int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, unsigned ext_bits, const u64 *const *pol_ptr,
-                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev, uint64_t row0, uint64_t nrows)
+                 const uint32_t *pol_dim, const u64 *pol_stride, const uint8_t *prime, const u64 *lev, const u64 *lpev, uint64_t row0, uint64_t nrows,
+                 const uint64_t *tile_cols)
 {
     if (n_evals == 0) return MI_OK;
     MI_REQUIRE(row0 + nrows <= n_total && nrows > 0, "rows outside the base domain");
     const uint64_t n = nrows; // the slices below cover [row0, row0 + nrows)
     MI_REQUIRE(n_evals < (1u << 24), "too many evaluations");
-    std::vector<EvDesc> d(n_evals);
+    // row-major polynomials first, then the ones in tile-major sections (tile_cols[i] = the section's width; pol_ptr[i] = its element of row 0)
+    std::vector<EvDesc> d, dt;
     for (uint64_t i = 0; i < n_evals; i++) {
         MI_REQUIRE(pol_dim[i] == 1 || pol_dim[i] == 3, "polynomial dim must be 1 or 3");
-        d[i] = EvDesc{pol_ptr[i], pol_stride[i], pol_dim[i], prime[i] ? 1u : 0u, (uint32_t)i, 0};
+        if (tile_cols && tile_cols[i]) {
+            MI_REQUIRE(((n_total << ext_bits) & 63) == 0 && tile_cols[i] < (1ull << 32), "a tile-major section has a multiple of 64 rows");
+            dt.push_back(EvDesc{pol_ptr[i], tile_cols[i] * 64, pol_dim[i], prime[i] ? 1u : 0u, (uint32_t)i, 0});
+        } else d.push_back(EvDesc{pol_ptr[i], pol_stride[i], pol_dim[i], prime[i] ? 1u : 0u, (uint32_t)i, 0});
     }
     // order by address like the reference does (starks.cpp:560-607) -- here it buys coalescing
-    std::sort(d.begin(), d.end(), [](const EvDesc &a, const EvDesc &b) { return a.ptr < b.ptr; });
+    auto by_ptr = [](const EvDesc &a, const EvDesc &b) { return a.ptr < b.ptr; };
+    std::sort(d.begin(), d.end(), by_ptr);
+    std::sort(dt.begin(), dt.end(), by_ptr);
+    const uint32_t n_rm = (uint32_t)d.size(), n_t = (uint32_t)dt.size();
+    d.insert(d.end(), dt.begin(), dt.end());
     const uint32_t n_slices = (uint32_t)std::min<uint64_t>(n, 1024);
     const uint64_t rows_per_slice = (n + n_slices - 1) / n_slices;
     const uint64_t desc_bytes = n_evals * sizeof(EvDesc), part_bytes = (uint64_t)n_slices * n_evals * 3 * 8;
@@ -270,8 +338,14 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, un
     MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // d is a stack-lifetime host buffer
     const unsigned gx = (unsigned)((n_evals + 255) / 256);
-    hipLaunchKernelGGL(k_evmap_partial, dim3(gx, n_slices), dim3(256), 0, ctx->stream, partial, ddesc, (uint32_t)n_evals, row0 + nrows,
-                       (uint32_t)ext_bits, rows_per_slice, lev, lpev, row0);
+    if (n_rm)
+        hipLaunchKernelGGL(k_evmap_partial, dim3((n_rm + 255) / 256, n_slices), dim3(256), 0, ctx->stream, partial, ddesc, n_rm, (uint32_t)n_evals, row0 + nrows,
+                           (uint32_t)ext_bits, rows_per_slice, lev, lpev, row0);
+    if (n_t) {
+        constexpr int CG = 4;
+        hipLaunchKernelGGL(k_evmap_partial_tiled<CG>, dim3((n_t + CG - 1) / CG, n_slices), dim3(64), 0, ctx->stream, partial, ddesc, n_rm, n_t, (uint32_t)n_evals,
+                           row0 + nrows, (uint32_t)ext_bits, rows_per_slice, lev, lpev, row0);
+    }
     hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, partial, ddesc, (uint32_t)n_evals, n_slices);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;

@@ -316,7 +316,13 @@ __device__ __forceinline__ void lines_landed() { asm volatile("s_waitcnt vmcnt(0
 // is one slab.  carry_in: the sponge capacity starts from digests[row] -- an earlier call absorbed the columns
 // before these -- instead of zero.  Only the last slab may have a width that is not a multiple of 8 (zero padding
 // exists at the end of a row only).
-template <int MDS>
+//
+// EMIT (launch_linear_hash_absorb_emit): the window is a compact chunk whose rows start on 128-byte lines, so the offset is zero for
+// every row and a wave may take 64 CONSECUTIVE rows -- one tile of a tile-major section [tile][column][64 rows], in which the words a
+// lane absorbs are 512-byte runs of the wave: each word is stored there as it is taken out of the ring (one store per word beside
+// the ~2 100 instructions a word's share of the permutation costs; HBM is idle under this kernel).  That is how Starks::genProof gets
+// its extended sections in the layout the constraint kernels read, without a transposing copy (host/starks.hpp).
+template <int MDS, bool EMIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_linear_hash_rows_lines(
     u64 *__restrict__ digests, const LeafSlabs sl, uint64_t nrows)
 {
@@ -324,11 +330,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * 4 + wave;
-    const uint64_t row = (gw >> 4) * 1024 + (uint64_t)lane * 16 + (gw & 15);
+    const uint64_t row = EMIT ? gw * 64 + lane : (gw >> 4) * 1024 + (uint64_t)lane * 16 + (gw & 15);
     const bool active = row < nrows;
     // idle lanes shadow a valid row (of the same residue class when there is one: then their line requests coincide
     // with an active lane's; every load of a shadow is bounds-checked like any other)
-    const uint64_t srow = active ? row : ((gw & 15) < nrows ? (gw & 15) : 0);
+    const uint64_t srow = active ? row : (EMIT ? lane : ((gw & 15) < nrows ? (gw & 15) : 0));
+    // EMIT: this wave's tile, this lane's row of it (nrows is a multiple of 64: a wave is active or idle as a whole)
+    u64 *const etile = EMIT ? sl.emit + (gw * sl.emit_cols + sl.emit_col0) * 64 + lane : nullptr;
     ulonglong2 *wave_ring = ring + wave * 64;
     const u64 *my = reinterpret_cast<const u64 *>(wave_ring + lane); // element in slot a: my[(a >> 1) * 512 + (a & 1)]
     u64 s[12];
@@ -366,6 +374,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 uint32_t a = p24 + i;
                 a = a >= LEAF_RING ? a - LEAF_RING : a;
                 s[i] = (pos + i < end) ? my[(a >> 1) * 512 + (a & 1)] : 0;
+            }
+            if (EMIT && active) {
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++)
+                    if (pos + i < end) etile[(uint64_t)(pos - o + i) * 64] = s[i];
             }
             p24 = p24 + 8 >= LEAF_RING ? p24 + 8 - LEAF_RING : p24 + 8;
             // fewer than 8 unconsumed elements left and the row goes on: request the next line during this permutation
@@ -425,12 +438,15 @@ __global__ __launch_bounds__(256) void k_merkle_top(u64 *level, uint64_t n)
 // one workgroup per query: row values then the sibling of every level (merkleTreeGL.cpp:12-35)
 __global__ __launch_bounds__(64) void k_group_proofs(u64 *__restrict__ proofs, const u64 *__restrict__ nodes,
                                                      const u64 *__restrict__ src, uint64_t pitch, uint64_t height,
-                                                     uint32_t width, uint32_t levels, const u64 *__restrict__ idx)
+                                                     uint32_t width, uint32_t levels, const u64 *__restrict__ idx, uint32_t tiled)
 {
     const uint64_t q = blockIdx.x;
     const uint64_t id = idx[q];
     u64 *out = proofs + q * ((uint64_t)width + 4ull * levels);
-    for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[id * pitch + i]);
+    if (tiled) // the source is a tile-major section [height / 64][pitch columns][64 rows]
+        for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[((id >> 6) * pitch + i) * 64 + (id & 63)]);
+    else
+        for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[id * pitch + i]);
     if (!nodes) return; // values only: the siblings come from elsewhere (a tree sharded over several devices, csrc/multi.hip)
     for (uint32_t e = threadIdx.x; e < levels * 4; e += 64) {
         const uint32_t l = e >> 2, k = e & 3;
@@ -474,10 +490,14 @@ int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count)
 
 static int launch_leaf_slabs(mi_ctx *ctx, u64 *digests, const LeafSlabs &sl, uint64_t nrows)
 {
-    const uint64_t waves = ((nrows + 1023) / 1024) * 16;
+    const uint64_t waves = sl.emit ? nrows / 64 : ((nrows + 1023) / 1024) * 16;
     const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (sl.emit)
+        return by_variant(ctx, [&](auto v) {
+            hipLaunchKernelGGL((k_linear_hash_rows_lines<decltype(v)::value, true>), dim3(grid), dim3(256), 0, ctx->stream, digests, sl, nrows);
+        });
     return by_variant(ctx, [&](auto v) {
-        hipLaunchKernelGGL((k_linear_hash_rows_lines<decltype(v)::value>), dim3(grid), dim3(256), 0, ctx->stream, digests, sl, nrows);
+        hipLaunchKernelGGL((k_linear_hash_rows_lines<decltype(v)::value, false>), dim3(grid), dim3(256), 0, ctx->stream, digests, sl, nrows);
     });
 }
 
@@ -531,6 +551,28 @@ int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const 
     return launch_leaf_slabs(ctx, digests, sl, nrows);
 }
 
+int launch_linear_hash_absorb_emit(mi_ctx *ctx, u64 *digests, const u64 *base, uint64_t pitch, uint64_t width, uint64_t nrows, bool first, bool final,
+                                   u64 *dst, uint64_t dst_cols, uint64_t col0)
+{
+    if (nrows == 0 || width == 0) return MI_OK;
+    MI_REQUIRE_1D_GRID(nrows + 1024);
+    MI_REQUIRE(dst && nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
+    MI_REQUIRE(width < (1ull << 30) && pitch >= width && pitch % 16 == 0 && ((uintptr_t)base & 127) == 0,
+               "the emitting leaf kernel reads a compact chunk whose rows start on 128-byte lines");
+    MI_REQUIRE(final || width % 8 == 0, "a window that is not the row's last must have a width that is a multiple of 8");
+    MI_REQUIRE(col0 + width <= dst_cols && dst_cols < (1ull << 32), "columns outside the tile-major section");
+    LeafSlabs sl = {};
+    sl.base[0] = base;
+    sl.pitch[0] = pitch;
+    sl.width[0] = (uint32_t)width;
+    sl.nslabs = 1;
+    sl.carry_in = first ? 0 : 1;
+    sl.emit = dst;
+    sl.emit_cols = (uint32_t)dst_cols;
+    sl.emit_col0 = (uint32_t)col0;
+    return launch_leaf_slabs(ctx, digests, sl, nrows);
+}
+
 int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)
 {
     MI_REQUIRE(is_pow2(nleaves), "number of leaves must be a power of two");
@@ -568,13 +610,14 @@ int launch_merkle_levels(mi_ctx *ctx, u64 *nodes, uint64_t nleaves)
 }
 
 int launch_group_proofs(mi_ctx *ctx, u64 *proofs, const u64 *nodes, const u64 *src, uint64_t pitch, uint64_t height,
-                        uint64_t width, const u64 *idx_dev, uint64_t nq)
+                        uint64_t width, const u64 *idx_dev, uint64_t nq, bool tiled)
 {
     if (nq == 0) return MI_OK;
     MI_REQUIRE(is_pow2(height), "tree height must be a power of two");
+    MI_REQUIRE(!tiled || height % 64 == 0, "a tile-major section has a multiple of 64 rows");
     const uint32_t levels = ilog2_u64(height);
     hipLaunchKernelGGL(k_group_proofs, dim3((unsigned)nq), dim3(64), 0, ctx->stream, proofs, nodes, src, pitch, height,
-                       (uint32_t)width, levels, idx_dev);
+                       (uint32_t)width, levels, idx_dev, tiled ? 1u : 0u);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

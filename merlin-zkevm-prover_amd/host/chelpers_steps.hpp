@@ -32,6 +32,8 @@ struct StarkMirror
     struct Sec { uint64_t offset, cols; };
     Sec cmN[4] = {}, cm2ns[4] = {}; // cm1_n cm2_n cm3_n tmpExp_n / cm1_2ns .. cm4_2ns
     bool tiledWitness = false;      // cm1_n lies tile-major in the image (host/starks.hpp): the base-domain steps read it in place
+    bool tiledExt[4] = {};          // cm1_2ns .. cm4_2ns lie tile-major in the image: step42ns / step52ns read them in place
+    bool anyTiledExt() const { return tiledExt[0] || tiledExt[1] || tiledExt[2] || tiledExt[3]; }
     uint64_t qOffset = 0, fOffset = 0;
     uint64_t *d_constN = nullptr, *d_const2ns = nullptr, nConst = 0;
     uint64_t *d_xn = nullptr, *d_x2ns = nullptr, *d_xdiv = nullptr, *d_xdivw = nullptr;
@@ -64,6 +66,8 @@ inline StarkMirror *&currentMirror()
 
 inline bool isBaseStep(int step) { return step == MI_CHELPERS_STEP2PREV || step == MI_CHELPERS_STEP3PREV || step == MI_CHELPERS_STEP3; }
 constexpr int MI_STEP_KEY_TRACED = 0x10000, MI_STEP_KEY_TILED = 0x20000; // flags in the first half of a program-cache key
+// a program is compiled for the layout of the sections it reads: one entry per layout (base-domain steps: the witness; the others: the extension)
+inline int stepLayoutKey(const StarkMirror *m, int step) { return (isBaseStep(step) ? m->tiledWitness : m->anyTiledExt()) ? MI_STEP_KEY_TILED : 0; }
 
 inline StarkMirror *mirrorOf(StepsParams &params)
 {
@@ -92,6 +96,9 @@ inline void buildStepProgram(const StarkMirror *m, int step, mi_chelpers_prog *p
 {
     if (isBaseStep(step) && m->tiledWitness && m->cmN[0].cols)
         check(mi_chelpers_set_tiled_section(prog, m->cmN[0].offset), "Steps (the witness section is tile-major)");
+    if (!isBaseStep(step))
+        for (unsigned s = 0; s < (step == MI_CHELPERS_STEP52NS ? 4u : 3u); s++)
+            if (m->tiledExt[s] && m->cm2ns[s].cols) check(mi_chelpers_set_tiled_section(prog, m->cm2ns[s].offset), "Steps (an extended section is tile-major)");
     const char *backend = std::getenv("MI_CHELPERS_BACKEND"); // "interpreter": the extended-domain steps through the SIMT interpreter (A/B)
     if (isBaseStep(step) || !backend || std::string(backend) != "interpreter")
         check(mi_chelpers_build_native(prog, m->cacheDir.empty() ? nullptr : m->cacheDir.c_str(), 0), "Steps (compile the program)");
@@ -168,8 +175,7 @@ inline void runRowShard(StarkMirror *m, int step, const StarkMirror::RowShard &S
 inline void runChelpersStep(int step, const uint64_t *ops, uint64_t nops, const uint64_t *args, uint64_t nargs, StepsParams &params, uint64_t nrows)
 {
     StarkMirror *m = mirrorOf(params);
-    // (a base-domain program is compiled for the layout of the witness section: one entry per layout)
-    mi_chelpers_prog *&prog = (*m->progs)[{step | (isBaseStep(step) && m->tiledWitness ? MI_STEP_KEY_TILED : 0), (const void *)ops}];
+    mi_chelpers_prog *&prog = (*m->progs)[{step | stepLayoutKey(m, step), (const void *)ops}];
     if (!prog) {
         const std::vector<mi_chelpers_section> secs = stepSections(m, step);
         const bool base = isBaseStep(step);

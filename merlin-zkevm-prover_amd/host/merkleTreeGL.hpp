@@ -19,7 +19,7 @@
 class MerkleTreeGL
 {
     uint64_t *d_source = nullptr, *d_nodes = nullptr; // HBM copies
-    bool d_source_borrowed = false, d_nodes_borrowed = false;
+    bool d_source_borrowed = false, d_nodes_borrowed = false, d_source_tiled = false;
     mi_multi_tree *multiTree = nullptr;               // set: the nodes are subtrees on several devices
     mi_multi *shardMulti = nullptr;                   // with shardSources: the rows of other shards are read on their devices
     std::vector<const uint64_t *> shardSources;
@@ -31,7 +31,7 @@ class MerkleTreeGL
         if (d_source && !d_source_borrowed) mi::devFree(d_source);
         if (d_nodes && !d_nodes_borrowed) mi::devFree(d_nodes);
         d_source = d_nodes = nullptr;
-        d_source_borrowed = d_nodes_borrowed = false;
+        d_source_borrowed = d_nodes_borrowed = d_source_tiled = false;
     }
 
 public:
@@ -75,11 +75,13 @@ public:
         d_source_borrowed = true;
     }
     // a tree that was built in HBM by someone else (StarksDevice): leaves and nodes borrowed, ready for getRoot / getGroupProofs
-    void setDeviceTree(uint64_t *dev_source, uint64_t *dev_nodes)
+    // tiled: the leaves' rows lie TILE-MAJOR ([height / 64][width][64], mi_lde_merkle_dev_tiled) -- the openings gather a row's values
+    void setDeviceTree(uint64_t *dev_source, uint64_t *dev_nodes, bool tiled = false)
     {
         releaseDevice();
         d_source = dev_source; d_nodes = dev_nodes;
         d_source_borrowed = d_nodes_borrowed = true;
+        d_source_tiled = tiled;
     }
     // a tree whose subtrees live on several devices (csrc/multi.hip) while the rows are read from a row-major image on this one: the view
     // owns the sharded tree from here on
@@ -162,7 +164,8 @@ public:
         if (d_nodes && d_source) {
             mi_ctx *c = mi::ctx();
             uint64_t *d_out = mi::devAlloc(nq * stride, "MerkleTreeGL::getGroupProofs (alloc)");
-            mi::check(mi_merkle_group_proofs_dev(c, d_out, d_nodes, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs");
+            if (d_source_tiled) mi::check(mi_merkle_group_proofs_tiled_dev(c, d_out, d_nodes, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs (tile-major rows)");
+            else mi::check(mi_merkle_group_proofs_dev(c, d_out, d_nodes, d_source, width, height, width, idx, nq), "MerkleTreeGL::getGroupProofs");
             mi::check(mi_copy_d2h(c, proofs, d_out, nq * stride * 8), "MerkleTreeGL::getGroupProofs (d2h)");
             mi::devFree(d_out);
             return;

@@ -358,9 +358,21 @@ public:
             mi::check(mi_multi_set_device(mm, 0), "Starks::peekImage (device)");
             return;
         }
+        const eSection ext[3] = {cm1_2ns, cm2_2ns, cm3_2ns};
+        for (int t = 0; t < 3; t++)
+            if (tiledExtLast[t] && offset >= off(ext[t]) && offset < off(ext[t]) + cols(ext[t]) * NExtended) { // a tile-major section: the row's words, gathered
+                const uint64_t w = cols(ext[t]), row = (offset - off(ext[t])) / w, col = (offset - off(ext[t])) % w;
+                if (col + n > w) mi::fail("Starks::peekImage (a peek into a tile-major section stays inside one row)");
+                uint64_t *tmp = mi::devAlloc(n, "Starks::peekImage (alloc)");
+                mi::check(mi_untile_dev(mi::ctx(), tmp, n, deviceImage() + off(ext[t]), w, NExtended, col, row, 1, n), "Starks::peekImage (tile-major section)");
+                mi::check(mi_copy_d2h(mi::ctx(), out, tmp, n * 8), "Starks::peekImage");
+                mi::devFree(tmp);
+                return;
+            }
         mi::check(mi_copy_d2h(mi::ctx(), out, deviceImage() + offset, n * 8), "Starks::peekImage");
     }
     uint64_t lateOffsets[3] = {0, 0, 0};
+    bool tiledExtLast[4] = {false, false, false, false}; // the last proof kept cm1_2ns .. cm3_2ns tile-major in the image (MI_STARK_TILED_EXT)
 
 private:
     bool ownsConstants = false, witnessLocked = false, sparseImage = false;
@@ -540,8 +552,8 @@ inline mi_chelpers_prog *Starks::tracedProgram(mi::StarkMirror &m, Steps *steps,
     static const int ids[5] = {MI_CHELPERS_STEP2PREV, MI_CHELPERS_STEP3PREV, MI_CHELPERS_STEP3, MI_CHELPERS_STEP42NS, MI_CHELPERS_STEP52NS};
     const int step = ids[which];
     const bool base = which <= 2;
-    const std::pair<int, const void *> key = {step | mi::MI_STEP_KEY_TRACED | (base && m.tiledWitness ? mi::MI_STEP_KEY_TILED : 0),
-                                              (const void *)&typeid(*steps)}; // per Steps class (one per proving key) and witness layout
+    const std::pair<int, const void *> key = {step | mi::MI_STEP_KEY_TRACED | mi::stepLayoutKey(&m, step),
+                                              (const void *)&typeid(*steps)}; // per Steps class (one per proving key) and layout of the sections
     if (emptySteps.count(key)) return nullptr;
     mi_chelpers_prog *&prog = progs[key];
     if (!prog) {
@@ -703,6 +715,18 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         for (auto &x : starkInfo.ciCtx) ok = ok && !inWitness(exp2pol(x.numId)) && !inWitness(exp2pol(x.denId));
         m.tiledWitness = ok;
     }
+    // The wide extended sections TILE-MAJOR as well (mi_lde_merkle_host_tiled / _dev_tiled: the leaf kernel writes them while it absorbs a
+    // chunk of the extension, where extendPol's row-major form would have been written): step42ns read nearly every column of them from a
+    // tile-major copy it made per batch of rows (87 ms of a 2.15 s zkEVM-size proof, 413 GB moved); now the generated kernels, the linear
+    // kernel of step52ns, evmap and the openings read the sections in place.  One device only (a sharded commit delivers row-major rows,
+    // csrc/multi.hip); cm4_2ns (the quotient's chunks: qDim * qDeg columns out of an NTT of their own) stays row-major.
+    // MI_STARK_TILED_EXT=0: row-major as before.
+    {
+        const char *e = std::getenv("MI_STARK_TILED_EXT");
+        const bool on = deviceSteps && !(e && e[0] == '0') && !mm && NExtended >= 64;
+        for (int i = 0; i < 3; i++) m.tiledExt[i] = on && cols(s2[i]) > 4;
+        for (int i = 0; i < 4; i++) tiledExtLast[i] = m.tiledExt[i];
+    }
     mi::currentMirror() = &m;
 
     transcript.put(&publicInputs[0], starkInfo.nPublics);
@@ -805,7 +829,10 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     } else {
         const Scratch scr = stageScratch(1);
         lend(scr.p, scr.elems);
-        if (m.tiledWitness)
+        if (m.tiledExt[0])
+            mi::check(mi_lde_merkle_host_tiled(c, d_nodes[0], sec(cm1_2ns), sec(cm1_n), m.tiledWitness ? 0 : cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
+                                               cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
+        else if (m.tiledWitness)
             mi::check(mi_lde_merkle_host_keep_tiled(c, d_nodes[0], sec(cm1_2ns), cols(cm1_n), sec(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
                                                     cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
         else
@@ -847,8 +874,12 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     } else {
         const Scratch scr = stageScratch(2);
         lend(scr.p, scr.elems);
-        mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
-        mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
+        if (m.tiledExt[1])
+            mi::check(mi_lde_merkle_dev_tiled(c, d_nodes[1], sec(cm2_2ns), sec(cm2_n), cols(cm2_n), N, NExtended, cols(cm2_n)), "Starks::genProof (stage 2: extendPol + merkelize)");
+        else {
+            mi::check(mi_lde_dev(c, sec(cm2_2ns), cols(cm2_n), sec(cm2_n), cols(cm2_n), NExtended, N, cols(cm2_n)), "Starks::genProof (stage 2: extendPol)");
+            mi::check(mi_merkle_build_dev(c, d_nodes[1], sec(cm2_2ns), cols(cm2_n), cols(cm2_n), NExtended), "Starks::genProof (stage 2: merkelize)");
+        }
         mi::check(mi_copy_d2h(c, root1.address(), d_nodes[1] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 2)");
         mirrorRows(cm2_2ns);
         doneWith(scr);
@@ -901,8 +932,12 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         commitSharded(2, sec(cm3_n), dev0, cols(cm3_n), sec(cm3_2ns), nullptr, stageScratch(3), root2.address());
     } else {
         lend(sec(cm1_n), off(cm3_n) - off(cm1_n)); // cm1_n | cm2_n: their last reader has run
-        mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
-        mi::check(mi_merkle_build_dev(c, d_nodes[2], sec(cm3_2ns), cols(cm3_n), cols(cm3_n), NExtended), "Starks::genProof (stage 3: merkelize)");
+        if (m.tiledExt[2])
+            mi::check(mi_lde_merkle_dev_tiled(c, d_nodes[2], sec(cm3_2ns), sec(cm3_n), cols(cm3_n), N, NExtended, cols(cm3_n)), "Starks::genProof (stage 3: extendPol + merkelize)");
+        else {
+            mi::check(mi_lde_dev(c, sec(cm3_2ns), cols(cm3_n), sec(cm3_n), cols(cm3_n), NExtended, N, cols(cm3_n)), "Starks::genProof (stage 3: extendPol)");
+            mi::check(mi_merkle_build_dev(c, d_nodes[2], sec(cm3_2ns), cols(cm3_n), cols(cm3_n), NExtended), "Starks::genProof (stage 3: merkelize)");
+        }
         mi::check(mi_copy_d2h(c, root2.address(), d_nodes[2] + treeElems - HASH_SIZE, HASH_SIZE * 8), "Starks::genProof (root 3)");
         mirrorRows(cm3_2ns);
     }
@@ -1044,17 +1079,26 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         std::vector<uint32_t> dim(nEvals);
         std::vector<uint64_t> stride(nEvals);
         std::vector<uint8_t> prime(nEvals);
+        std::vector<uint64_t> tileCols(nEvals, 0); // a polynomial of a tile-major section: the section's width (its pointer: row 0 = section + 64 * column)
         for (uint64_t i = 0; i < nEvals; i++) {
             const EvMap &ev = starkInfo.evMap[i];
             if (ev.type == EvMap::eType::_const) { ptr[i] = m.d_const2ns + ev.id; stride[i] = nConst; dim[i] = 1; }
             else {
                 const PolRef p = polRef(ev.type == EvMap::eType::cm ? starkInfo.cm_2ns[ev.id] : starkInfo.qs[ev.id]);
                 ptr[i] = d_mem + p.offset; stride[i] = p.stride; dim[i] = (uint32_t)p.dim;
+                for (int t = 0; t < 3; t++)
+                    if (m.tiledExt[t] && p.offset >= off(s2[t]) && p.offset < off(s2[t]) + cols(s2[t])) { // (polRef: offset = the element of row 0)
+                        ptr[i] = sec(s2[t]) + 64 * (p.offset - off(s2[t]));
+                        tileCols[i] = cols(s2[t]);
+                    }
             }
             prime[i] = ev.prime ? 1 : 0;
         }
         if (m.rowShards.empty()) {
-            mi::check(mi_evmap_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev), "Starks::genProof (evmap)");
+            if (m.anyTiledExt())
+                mi::check(mi_evmap_tiled_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), tileCols.data(), lev, lpev), "Starks::genProof (evmap)");
+            else
+                mi::check(mi_evmap_dev(c, d_evals, nEvals, N, (unsigned)extendBits, ptr.data(), dim.data(), stride.data(), prime.data(), lev, lpev), "Starks::genProof (evmap)");
             mi::check(mi_copy_d2h(c, evals.address(), d_evals, nEvals * 3 * 8), "Starks::genProof (evals d2h)");
         } else {
             // row shards: a device's rows of the extension hold every 2^extendBits-th row the sums run over, so each device sums ITS base-domain
@@ -1143,7 +1187,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
                     views[t].setShardSources(mm, srcs, NExtended / rowMem.size());
                 }
             }
-            else views[t].setDeviceTree(sec(s2[t]), d_nodes[t]);
+            else views[t].setDeviceTree(sec(s2[t]), d_nodes[t], m.tiledExt[t]);
         }
         // FRI's polynomials, step trees and opening buffers come out of the same remainder (the fold transforms in registers: no
         // NTT scratch is in use any more)

@@ -58,7 +58,7 @@ EXPORTS = [
     "mi_ntt_dev", "mi_lde_dev", "mi_ntt", "mi_lde",
     "mi_poseidon_hash_full_result", "mi_poseidon_hash", "mi_transcript_put", "mi_poseidon_linear_hash", "mi_poseidon_permute_dev",
     "mi_linear_hash_rows_dev", "mi_linear_hash_absorb_dev", "mi_merkle_build_dev", "mi_merkle_levels_dev", "mi_merkle_build",
-    "mi_merkle_group_proofs_dev",
+    "mi_merkle_group_proofs_dev", "mi_merkle_group_proofs_tiled_dev", "mi_lde_merkle_host_tiled", "mi_lde_merkle_dev_tiled", "mi_evmap_tiled_dev", "mi_untile_dev",
     "mi_fri_fold_dev", "mi_fri_fold_range_dev", "mi_fri_transpose_dev", "mi_q_split_dev", "mi_evmap_dev", "mi_evmap_range_dev", "mi_batch_inverse3_dev", "mi_calculate_h1h2_dev", "mi_calculate_z_dev", "mi_calculate_z_batch_dev",
     "mi_geom_seq_dev", "mi_geom_seq3_dev", "mi_x_div_x_sub_dev", "mi_zhinv",
     "mi_fill_synthetic_dev", "mi_fill_synthetic_2d_dev", "mi_copy_2d_dev", "mi_dev_alloc", "mi_dev_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_2d", "mi_dev_zero",
@@ -215,6 +215,28 @@ class Context:
         _check(lib().mi_lde_merkle_host_keep_tiled(self.h, _dp(nodes), _dp(ext), u64(ext_pitch or ncols), _dp(base_tiled),
                                                    ctypes.c_void_p(host_trace_ptr), u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
 
+    def lde_merkle_host_tiled(self, nodes, ext_tiled, base, host_trace_ptr, n, n_ext, ncols, base_pitch=0, chunk_cols=0):
+        """lde_merkle_host with the extension left TILE-MAJOR ([rows / 64][ncols][64]); base (or None): the trace itself, tile-major too
+        (base_pitch 0) or row-major at base_pitch."""
+        _check(lib().mi_lde_merkle_host_tiled(self.h, _dp(nodes), _dp(ext_tiled), _dp(base) if base is not None else None, u64(base_pitch),
+                                              ctypes.c_void_p(host_trace_ptr), u64(n), u64(n_ext), u64(ncols), u64(chunk_cols)))
+
+    def lde_merkle_dev_tiled(self, nodes, ext_tiled, src, n, n_ext, ncols, src_pitch=None, src_off=0):
+        """extendPol + merkelize of a device-resident row-major section, the extension left TILE-MAJOR."""
+        _check(lib().mi_lde_merkle_dev_tiled(self.h, _dp(nodes), _dp(ext_tiled), _dp(src, src_off), u64(src_pitch or ncols), u64(n), u64(n_ext), u64(ncols)))
+
+    def merkle_group_proofs_tiled(self, proofs, nodes, src_tiled, ncols_total, height, width, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        _check(lib().mi_merkle_group_proofs_tiled_dev(self.h, _dp(proofs), _dp(nodes), _dp(src_tiled), u64(ncols_total), u64(height), u64(width),
+                                                      _hp(idx), u64(idx.size)))
+
+    def untile(self, dst, src_tiled, ncols_total, nrows_total, col0=0, row0=0, nrows=None, ncols=None, dst_pitch=None):
+        """dst (row-major) <- rows [row0, row0 + nrows) x columns [col0, col0 + ncols) of a tile-major section."""
+        nrows = nrows_total - row0 if nrows is None else nrows
+        ncols = ncols_total - col0 if ncols is None else ncols
+        _check(lib().mi_untile_dev(self.h, _dp(dst), u64(dst_pitch or ncols), _dp(src_tiled), u64(ncols_total), u64(nrows_total), u64(col0), u64(row0),
+                                   u64(nrows), u64(ncols)))
+
     def tile_major(self, dst, ncols_total, col0, src, nrows, ncols, src_pitch=None):
         """dst (tile-major, nrows x ncols_total) <- src (row-major device tensor) at column col0 of the tiles, canonical."""
         _check(lib().mi_tile_major_dev(self.h, _dp(dst), u64(ncols_total), u64(col0), _dp(src), u64(src_pitch or ncols), u64(nrows), u64(ncols)))
@@ -325,9 +347,20 @@ class Context:
     def q_split(self, qq2, qq1, n, n_ext, qdeg):
         _check(lib().mi_q_split_dev(self.h, _dp(qq2), _dp(qq1), u64(n), u64(n_ext), ctypes.c_uint(qdeg)))
 
-    def evmap(self, evals, pols, prime, lev, lpev, n, ext_bits, row0=None, nrows=None):
-        """pols: list of (tensor, offset_elems, dim, stride); row0 / nrows: only the partial sums over those rows of the base domain"""
+    def evmap(self, evals, pols, prime, lev, lpev, n, ext_bits, row0=None, nrows=None, tile_cols=None):
+        """pols: list of (tensor, offset_elems, dim, stride); row0 / nrows: only the partial sums over those rows of the base domain;
+        tile_cols: per polynomial, the width of its TILE-MAJOR section (offset_elems = 64 * column then) or 0"""
         k = len(pols)
+        if tile_cols is not None:
+            tc = np.ascontiguousarray(tile_cols, dtype=np.uint64)
+            ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() + 8 * off for (t, off, _, _) in pols])
+            dims = np.array([d for (_, _, d, _) in pols], dtype=np.uint32)
+            strides = np.array([s for (_, _, _, s) in pols], dtype=np.uint64)
+            pr = np.ascontiguousarray(prime, dtype=np.uint8)
+            _check(lib().mi_evmap_tiled_dev(self.h, _dp(evals), u64(k), u64(n), ctypes.c_uint(ext_bits), ptrs,
+                                            dims.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _hp(strides),
+                                            pr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), _hp(tc), _dp(lev), _dp(lpev)))
+            return
         ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() + 8 * off for (t, off, _, _) in pols])
         dims = np.array([d for (_, _, d, _) in pols], dtype=np.uint32)
         strides = np.array([s for (_, _, _, s) in pols], dtype=np.uint64)

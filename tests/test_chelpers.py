@@ -576,8 +576,8 @@ def _tile_major(a, nrows, ncols):
 
 
 def test_tiled_section_is_declared_before_the_build_and_never_stored_into(tmp_path):
-    """mi_chelpers_set_tiled_section: an offset that names no section, a second section, a call after the build and a program that stores
-    into the section are refused; the kernels of a program with such a section compile; the host executors (row-major) refuse it."""
+    """mi_chelpers_set_tiled_section: an offset that names no section, a call after the build and a program that stores into the section
+    are refused; the kernels of a program with such a section compile; the host executors (row-major) refuse it."""
     import mi_stark
     nrows = 256
     ops, args, pols, cpols, chal, pub, x, sections = _base_case(5, nrows)
@@ -586,8 +586,6 @@ def test_tiled_section_is_declared_before_the_build_and_never_stored_into(tmp_pa
         prog.set_tiled_section(17)
     prog.set_tiled_section(0)
     prog.set_tiled_section(0)
-    with pytest.raises(mi_stark.MiStarkError, match="one tile-major section per program"):
-        prog.set_tiled_section(nrows * 40)
     with pytest.raises(mi_stark.MiStarkError, match="host executors read row-major"):
         prog.run_base_host(pols.copy(), cpols, 7, chal, pub, x, 2, np.arange(4))
     for shard in (0, 1):
@@ -647,6 +645,74 @@ def test_base_step_program_reads_a_tile_major_section_in_place(seed, tmp_path):
     assert np.array_equal(ctx.to_host(d_pols)[nrows * 40:], part[nrows * 40:])
     with pytest.raises(mi_stark.MiStarkError, match="rows from a multiple of 64"):
         prog.run_base(d_pols, d_c, 7, chal, pub, d_x, 2, 5, 64)
+    prog.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiled_secs", [(0,), (0, 1), (0, 1, 2)])
+def test_native_step42ns_reads_tile_major_sections_in_place(tmp_path, tiled_secs):
+    """The extended sections as Starks::genProof keeps them (mi_lde_merkle_dev_tiled): one, two or all of a step42ns program's sections
+    tile-major, the others row-major through the per-batch copy; shifted rows across tile borders and around the end; batches; a row range."""
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 13
+    ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv = _synthetic_case(33, nrows, passes=3)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step42ns(ops, args, pols, cpols, n_const, chal, pub, x, xs, zhinv, want, 0, nrows)
+    secs = _synthetic_sections(nrows)
+    img = pols.copy()
+    for i in tiled_secs:
+        off, w, _ = secs[i]
+        img[off:off + nrows * w] = _tile_major(pols[off:off + nrows * w], nrows, w)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=secs, n_const=n_const, nrows_ext=nrows)
+    for i in tiled_secs:
+        prog.set_tiled_section(secs[i][0])
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=7000)["kernels"] >= 3
+    d_pols, d_c, d_x = ctx.to_device(img), ctx.to_device(cpols), ctx.to_device(x)
+    for batch in (0, 1024, 64):
+        ctx.set_chelpers_batch_rows(batch)
+        q = ctx.to_device(np.full(nrows * 3 + 6, 0xABCD, dtype=np.uint64))
+        prog.run(d_pols, d_c, n_const, chal, pub, d_x, xs, zhinv, q, 0, nrows)
+        got = ctx.to_host(q)
+        assert np.array_equal(got[:nrows * 3], want) and np.all(got[nrows * 3:] == 0xABCD), batch
+    ctx.set_chelpers_batch_rows(512)
+    q2 = ctx.to_device(np.zeros(nrows * 3, dtype=np.uint64))
+    r0 = nrows - 1024
+    prog.run(d_pols, d_c, n_const, chal, pub, d_x, xs, zhinv, q2, r0, 1024)
+    got2 = ctx.to_host(q2)
+    assert np.array_equal(got2[3 * r0:], want[3 * r0:]) and not got2[:3 * r0].any()
+    prog.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lin_min,tiled_secs", [(None, (0, 1, 2)), (1, (0, 1, 2)), (1, (0, 2)), (1, (1,))])
+def test_native_step52ns_reads_tile_major_sections_in_place(tmp_path, lin_min, tiled_secs, monkeypatch):
+    """... and step52ns, whose polynomial terms the linear kernel sums: out of tile-major sections it takes a lane's own row, out of
+    row-major ones it turns a slab through LDS -- both in one program."""
+    import mi_stark
+    if lin_min is not None:
+        monkeypatch.setenv("MI_CHELPERS_LIN_MIN", str(lin_min))
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 13
+    ops, args, pols, cpols, n_const, chal, evals, xd, xdw = _case52(43, nrows)
+    want = np.zeros(nrows * 3, dtype=np.uint64)
+    glo.chelpers_step52ns(ops, args, pols, cpols, n_const, chal, evals, xd, xdw, want, 0, nrows)
+    secs = _synthetic_sections(nrows)
+    img = pols.copy()
+    for i in tiled_secs:
+        off, w, _ = secs[i]
+        img[off:off + nrows * w] = _tile_major(pols[off:off + nrows * w], nrows, w)
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=secs, n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
+    for i in tiled_secs:
+        prog.set_tiled_section(secs[i][0])
+    prog.build_native(cache_dir=str(tmp_path), chunk_cost=1500)
+    f = ctx.zeros(nrows * 3)
+    for batch in (2048, 0):
+        ctx.set_chelpers_batch_rows(batch)
+        prog.run52(ctx.to_device(img), ctx.to_device(cpols), n_const, chal, evals, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
+        assert np.array_equal(ctx.to_host(f), want), batch
     prog.close()
     ctx.close()
 

@@ -42,10 +42,11 @@ def precompile_starks(jobs, only):
         if only >= 0 and ci != only:
             continue
         t0 = time.time()
-        # both layouts of the witness section: tile-major (one device) and row-major (MI_STARK_DEVICES, MI_STARK_TILED_WITNESS=0, a STARK
-        # whose lookups read witness columns): the base-domain programs' kernels differ, the others are found in the cache the second time
-        for tiled in ("1", "0"):
-            env = dict(os.environ, MI_STARK_TILED_WITNESS=tiled)
+        # both layouts of the image: the witness and the wide extended sections tile-major (one device), and row-major (MI_STARK_DEVICES,
+        # MI_STARK_TILED_WITNESS=0 / MI_STARK_TILED_EXT=0, a STARK whose lookups read witness columns); for the default configuration the
+        # A/B form too (witness tile-major, extension row-major).  Kernels that do not differ are found in the cache the second time.
+        for tiled, tiled_ext in (("1", "1"), ("0", "0")) + ((("1", "0"),) if ci == 0 else ()):
+            env = dict(os.environ, MI_STARK_TILED_WITNESS=tiled, MI_STARK_TILED_EXT=tiled_ext)
             procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench_starks.py")] + argv + ["--precompile", str(s), str(jobs)], env=env) for s in range(jobs)]
             if any(p.wait() for p in procs):
                 raise SystemExit("a precompile shard of bench_starks.py failed")

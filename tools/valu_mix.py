@@ -33,7 +33,7 @@ TWO_CLK = ("v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "
 
 def main():
     variant = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    prefix = "_Z24k_linear_hash_rows_linesILi%dEE" % variant
+    prefix = "_Z24k_linear_hash_rows_linesILi%dELb0EE" % variant
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "pos.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-S",
