@@ -426,7 +426,9 @@ int mi_set_chelpers_min_words(mi_ctx *ctx, uint64_t words);
  * interpreter; results are the same field elements.  Requires shifts < 64 and power-of-two section row counts. */
 int mi_chelpers_build_native(mi_chelpers_prog *prog, const char *cache_dir, uint64_t chunk_cost);
 /* A section the caller keeps TILE-MAJOR in HBM -- [tile of 64 rows][column][row in tile], element (row, col) at
- * (row / 64 * ncols + col) * 64 + row % 64, canonical values (mi_tile_major_dev, mi_lde_merkle_host_keep_tiled write it) -- instead of
+ * (row / 64 * ncols + col) * 64 + rev6(row % 64), rev6 = the 6-bit reversal (the rows that are multiples of 2^e are then the first
+ * 64 >> e words of a column's run in a tile: what evmap reads of an extension), canonical values (mi_tile_major_dev,
+ * mi_lde_merkle_host_keep_tiled / _host_tiled / _dev_tiled write it) -- instead of
  * row-major: the generated kernels read it in place, a lane per row and 512 contiguous bytes per operand and wave, and the per-batch
  * tile-major copy of that section (k_chp_transpose: a read and a write of the whole section per step) is not made.  For a section every
  * base-domain step reads but nothing writes or reads by stride: the witness cm1_n (host/starks.hpp; starks.cpp:66-210 read it three

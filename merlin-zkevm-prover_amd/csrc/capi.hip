@@ -873,13 +873,21 @@ extern "C" int mi_lde_merkle_dev_tiled(mi_ctx *c, uint64_t *nodes, uint64_t *ext
     MI_REQUIRE(nodes && ext_tiled && src, "null buffer");
     MI_REQUIRE(is_pow2(n) && is_pow2(n_ext) && n_ext >= n, "sizes must be powers of two with n_ext >= n");
     MI_REQUIRE(n_ext % 64 == 0 && ncols > 4 && src_pitch >= ncols, "a tile-major extension has a multiple of 64 rows and more than 4 columns");
-    const uint64_t cw_max = std::min<uint64_t>(ncols, 96), z_pitch = (cw_max + 15) & ~15ull, z_bytes = n_ext * z_pitch * 8 + 256;
+    // chunk width: the leaf kernel likes long launches, the compact chunk and the transform's scratch have to fit the region the caller
+    // lent (MI_TILED_CHUNK_COLS: experiments; multiples of 32)
+    static const uint64_t chunk_cols = [] { const char *e = getenv("MI_TILED_CHUNK_COLS"); const long v = e ? atol(e) : 0; return v >= 32 && v <= 1024 ? (uint64_t)v & ~31ull : 128; }();
+    uint64_t cw_max = std::min<uint64_t>(ncols, chunk_cols);
+    auto z_need = [&](uint64_t cw) { return n_ext * ((cw + 15) & ~15ull) * 8 + 256; };
+    auto fits = [&](uint64_t cw) { return c->workspace_bytes >= z_need(cw) + cw * (n + n_ext) * 8 + (1ull << 20); };
+    if (c->workspace_lent)
+        while (cw_max > 32 && !fits(cw_max)) cw_max = (cw_max - 1) & ~31ull; // the widest chunk the lent region holds beside the transform's scratch
+    const uint64_t z_pitch = (cw_max + 15) & ~15ull, z_bytes = z_need(cw_max);
     struct WorkspaceCarve {
         mi_ctx *c; uint64_t saved = 0;
         ~WorkspaceCarve() { if (saved) c->workspace_bytes = c->workspace_limit = saved; }
     } carve{c};
     u64 *zraw = nullptr;
-    if (c->workspace_lent && c->workspace_bytes >= z_bytes + cw_max * (n + n_ext) * 8 + (1ull << 20)) {
+    if (c->workspace_lent && fits(cw_max)) {
         carve.saved = c->workspace_bytes;
         c->workspace_bytes = c->workspace_limit = (carve.saved - z_bytes) & ~(uint64_t)255;
         zraw = c->workspace + c->workspace_bytes / 8;

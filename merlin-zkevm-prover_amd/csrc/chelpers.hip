@@ -1105,6 +1105,14 @@ extern "C" int mi_chelpers_set_tiled_section(mi_chelpers_prog *p, uint64_t secti
     MI_REQUIRE(hit, "no declared section starts at this offset");
     MI_REQUIRE(hit->nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
     hit->tiled = true;
+    // the per-batch tile-major copy holds the other sections' columns only (a batch of rows is sized by them): renumber the staged
+    // columns, the sections read in place behind them (a column keeps a number of its own: the operand statistics go by it)
+    uint32_t c0 = 0;
+    for (HostSection &S : p->sections)
+        if (!S.tiled) { S.col0 = c0; c0 += (uint32_t)S.ncols; }
+    p->staged_cols = c0 ? c0 : 1;
+    for (HostSection &S : p->sections)
+        if (S.tiled) { S.col0 = c0; c0 += (uint32_t)S.ncols; }
     return MI_OK;
 }
 

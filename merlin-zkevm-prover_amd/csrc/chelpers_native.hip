@@ -951,7 +951,7 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
         // rows wrap at its end
         const HostSection &S = P->sections[xs.first];
         const uint32_t s = xs.second;
-        snprintf(line, sizeof line, "  const u64 *__restrict__ X%u_%u = pols + %lluULL + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + ((lane + %uu) & 63u);\n",
+        snprintf(line, sizeof line, "  const u64 *__restrict__ X%u_%u = pols + %lluULL + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + gl::tile_pos((lane + %uu) & 63u);\n",
                  xs.first, s, (unsigned long long)S.offset, s, (unsigned long long)(S.nrows / 64 - 1), (unsigned long long)S.ncols * 64, s);
         src += line;
     }
@@ -1154,7 +1154,7 @@ int native_host_run(const mi_chelpers_prog *P, const mi_chelpers_params *a, cons
 
 // [rows x ncols] row-major (pitch words per row, rows taken modulo nrows) -> tiles [tile][SC columns][64 rows], canonical
 __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ src, uint64_t pitch, uint32_t ncols, uint64_t row_mask,
-                                                        u64 *__restrict__ tiled, uint32_t sc, uint32_t col0, uint64_t row_base, uint32_t slab_mask)
+                                                        u64 *__restrict__ tiled, uint32_t sc, uint32_t col0, uint64_t row_base, uint32_t slab_mask, uint32_t swz)
 {
     if (!((slab_mask >> blockIdx.y) & 1)) return; // no generated kernel reads a column of this slab
     __shared__ u64 t[64][65];
@@ -1169,7 +1169,8 @@ __global__ __launch_bounds__(256) void k_chp_transpose(const u64 *__restrict__ s
         }
     }
     __syncthreads();
-    u64 *dst = tiled + (tile * sc + col0 + c0) * 64 + l;
+    // swz: a section that STAYS tile-major (mi_tile_major_dev) keeps a row at gl::tile_pos of its index; the per-batch copy keeps it at the index
+    u64 *dst = tiled + (tile * sc + col0 + c0) * 64 + (swz ? gl::tile_pos(l) : l);
 #pragma unroll 4
     for (uint32_t cc = q; cc < 64; cc += 4)
         if (c0 + cc < ncols) dst[(uint64_t)cc * 64] = t[l][cc];
@@ -1184,7 +1185,7 @@ int launch_tile_major(mi_ctx *ctx, u64 *dst, uint64_t ncols_total, uint64_t col0
     for (uint64_t c0 = 0; c0 < ncols; c0 += 2048) { // (one launch carries a 32-bit mask of 64-column slabs)
         const uint64_t w = std::min<uint64_t>(2048, ncols - c0);
         hipLaunchKernelGGL(chp::k_chp_transpose, dim3((unsigned)(nrows / 64), (unsigned)((w + 63) / 64)), dim3(256), 0, ctx->stream, src + c0, src_pitch, (uint32_t)w,
-                           ~0ull, dst, (uint32_t)ncols_total, (uint32_t)(col0 + c0), (uint64_t)0, 0xffffffffu);
+                           ~0ull, dst, (uint32_t)ncols_total, (uint32_t)(col0 + c0), (uint64_t)0, 0xffffffffu, 1u);
         MI_HIP_CHECK(hipGetLastError());
     }
     return MI_OK;
@@ -1196,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_untile(u64 *__restrict__ dst, uint64_t 
 {
     for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < nrows * ncols; e += (uint64_t)gridDim.x * 256) {
         const uint64_t r = e / ncols, cc = e % ncols, row = row0 + r;
-        dst[r * dst_pitch + cc] = src[((row >> 6) * ncols_total + col0 + cc) * 64 + (row & 63)];
+        dst[r * dst_pitch + cc] = src[((row >> 6) * ncols_total + col0 + cc) * 64 + gl::tile_pos((uint32_t)(row & 63))];
     }
 }
 int launch_untile(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t ncols_total, uint64_t col0, uint64_t row0, uint64_t nrows, uint64_t ncols)
@@ -1241,7 +1242,7 @@ __global__ __launch_bounds__(64) void k_chp_linear(const LinSlabD *__restrict__ 
         const u64 *src = sec.ptr[si];
         const uint64_t pitch = sec.pitch[si], mask = sec.row_mask[si];
         if (sec.tiled[si]) { // (wave-uniform) element i of the stage = column i of this lane's own row: 512-byte runs, nothing to turn
-            const u64 *t = src + ((((row_base >> 6) + tile) & (mask >> 6)) * pitch + c0) * 64 + lane;
+            const u64 *t = src + ((((row_base >> 6) + tile) & (mask >> 6)) * pitch + c0) * 64 + gl::tile_pos(lane);
 #pragma unroll
             for (uint32_t i = 0; i < LIN_COLS; i++) stage[i] = t[(uint64_t)(i < nc ? i : 0) * 64];
         } else {
@@ -1339,9 +1340,10 @@ int native_reserve(mi_ctx *c, const mi_chelpers_prog *P, uint64_t nrows, uint64_
     const NativeProg *N = P->native;
     MI_REQUIRE(N, "native code was not built");
     uint64_t batch = c->chelpers_batch_rows;
-    if (batch == 0) { // about 8 GiB of tile-major copy (MI_CHELPERS_BATCH_GIB: another size -- a one-GPU rehearsal of eight shards at full size has 2)
-        static const double gib = [] { const char *e = getenv("MI_CHELPERS_BATCH_GIB"); const double v = e ? atof(e) : 8.0; return v >= 0.01 && v <= 64 ? v : 8.0; }();
-        batch = (uint64_t)(gib * (double)(1ull << 30)) / ((uint64_t)N->sc * 8);
+    if (batch == 0) { // about 9 GiB of batch buffers: tile-major copy (zkEVM step42ns with row-major sections: 8 of them), spill, linear sums
+                      // (MI_CHELPERS_BATCH_GIB: another size -- a one-GPU rehearsal of eight shards at full size has 2)
+        static const double gib = [] { const char *e = getenv("MI_CHELPERS_BATCH_GIB"); const double v = e ? atof(e) : 9.0; return v >= 0.01 && v <= 64 ? v : 9.0; }();
+        batch = (uint64_t)(gib * (double)(1ull << 30)) / (((uint64_t)N->sc + N->nw + 3 * (uint64_t)N->n_lin_sums) * 8);
         batch = std::max<uint64_t>(64, batch & ~(uint64_t)63);
     }
     batch = std::min(batch, (nrows + 63) & ~(uint64_t)63);
@@ -1445,7 +1447,7 @@ int native_run(mi_ctx *c, const mi_chelpers_prog *P, const mi_chelpers_params *a
             if (S.tiled) continue; // read in place
             if (!N->sec_slab_mask[si]) continue;
             hipLaunchKernelGGL(k_chp_transpose, dim3((unsigned)(tiles + 1), (unsigned)((S.ncols + 63) / 64)), dim3(256), 0, c->stream, ptr, pitch,
-                               (uint32_t)S.ncols, S.nrows - 1, rb.tiled, N->sc, S.col0, b0, N->sec_slab_mask[si]);
+                               (uint32_t)S.ncols, S.nrows - 1, rb.tiled, N->sc, S.col0, b0, N->sec_slab_mask[si], 0u);
             MI_HIP_CHECK(hipGetLastError());
         }
         if (N->n_lin_sums) {

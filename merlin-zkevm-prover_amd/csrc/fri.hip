@@ -232,17 +232,24 @@ __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial
     o[0] = gl::canon(chpa::acc_reduce(r0)); o[1] = gl::canon(chpa::acc_reduce(r1)); o[2] = gl::canon(chpa::acc_reduce(r2));
 }
 
-// The same sums for polynomials that live in TILE-MAJOR sections ([tile of 64 rows][column][row in tile], Starks::genProof's extended
-// sections): there a column's rows are contiguous, so a lane takes ROWS (64 consecutive rows of the base domain = every 2^ext_bits-th
-// row of one or more tiles) and a wave takes CG evaluations, each lane summing its rows' products; the lanes' sums meet at the end.
+// The same sums for polynomials that live in TILE-MAJOR sections ([tile of 64 rows][column][gl::tile_pos(row in tile)], Starks::genProof's
+// extended sections): there a column's rows are contiguous and the rows evmap wants -- the multiples of 2^ext_bits -- are the first
+// 64 >> ext_bits words of a tile's run, so a lane takes ROWS (64 consecutive rows of the base domain = the heads of 2^ext_bits tiles'
+// runs, whole sectors) and a wave takes CG evaluations, each lane summing its rows' products; the lanes' sums meet at the end.
 // LEv / LpEv of the slice are read by every group of evaluations: the groups of one slice are neighbours in the grid (x runs fastest),
-// so the slice's 48 bytes per row stay in the L2s while they are wanted.
-template <int CG>
-__global__ __launch_bounds__(64) void k_evmap_partial_tiled(u64 *__restrict__ partial, const EvDesc *__restrict__ desc, uint32_t i0, uint32_t n_t,
-                                                           uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
-                                                           const u64 *__restrict__ lev, const u64 *__restrict__ lpev, uint64_t row0)
+// so the slice's 48 bytes per row stay in the L2s while they are wanted.  Slices start at multiples of 64 rows (launch_evmap).
+// D3: the group's polynomials are extension-valued (three adjacent columns); base-field ones otherwise -- launched separately so that
+// the many base-field ones do not carry three words per value in registers.
+template <int CG, int UR, bool D3>
+__global__ __launch_bounds__(256) void k_evmap_partial_tiled(u64 *__restrict__ partial, const EvDesc *__restrict__ desc, uint32_t i0, uint32_t n_t,
+                                                            uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
+                                                            const u64 *__restrict__ lev, const u64 *__restrict__ lpev, uint64_t row0)
 {
-    const uint32_t lane = threadIdx.x, g0 = i0 + blockIdx.x * CG;
+    // a step of the loop takes UR x 64 base rows: their LEv / LpEv words go through LDS once for the workgroup's four waves (4 x CG
+    // evaluations), and every lane has UR x CG polynomial loads in flight (the kernel is bound by latency, not by bytes)
+    constexpr uint32_t ROWS = UR * 64, VW = D3 ? 3 : 1;
+    __shared__ u64 sL[2][ROWS * 3];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g0 = i0 + (blockIdx.x * 4 + wave) * CG;
     const uint64_t k0 = row0 + (uint64_t)blockIdx.y * rows_per_slice;
     uint64_t k1 = k0 + rows_per_slice;
     if (k1 > n) k1 = n;
@@ -251,31 +258,51 @@ __global__ __launch_bounds__(64) void k_evmap_partial_tiled(u64 *__restrict__ pa
 #pragma unroll
     for (int j = 0; j < CG; j++) {
         on[j] = g0 + j < i0 + n_t;
-        d[j] = desc[on[j] ? g0 + j : g0];
+        d[j] = desc[on[j] ? g0 + j : i0];
     }
     chpa::Acc a[CG][3];
 #pragma unroll
     for (int j = 0; j < CG; j++)
 #pragma unroll
         for (int e = 0; e < 3; e++) chpa::acc_set(a[j][e], 0);
-    for (uint64_t kc = k0; kc < k1; kc += 64) {
-        const bool act = kc + lane < k1;
-        const uint64_t k = act ? kc + lane : k0, r = k << ext_bits;
-        u64 l[3], lp[3];
+    // lane -> (tile tj of the 2^ext_bits tiles that 64 base rows spread over, word q of the tile's run): that word is row tile_pos(q)
+    // of the tile (an involution), base row tile_pos(q) >> ext_bits of the tile's 64 >> ext_bits
+    const uint32_t per_log = 6 - ext_bits, q = lane & ((1u << per_log) - 1), tj = lane >> per_log;
+    const uint32_t kin = (tj << per_log) + (gl::tile_pos(q) >> ext_bits);
+    const uint32_t q_idle = gl::tile_pos((uint32_t)((k0 << ext_bits) & 63));
+    for (uint64_t kc = k0; kc < k1; kc += ROWS) { // trip count is uniform over the workgroup
+        // the polynomial values first: their latency runs beside the LDS round of the weights
+        u64 v[UR][CG][VW];
 #pragma unroll
-        for (int e = 0; e < 3; e++) {
-            const u64 x = lev[k * 3 + e], y = lpev[k * 3 + e];
-            l[e] = act ? x : 0; lp[e] = act ? y : 0; // a lane past the slice's end adds zeros
+        for (uint32_t u = 0; u < UR; u++) {
+            const uint64_t kb = kc + u * 64;
+            const bool act = kb + kin < k1;
+            const uint64_t toff = act ? (kb >> per_log) + tj : (k0 >> per_log); // the tile of the extension
+            const uint32_t qq = act ? q : q_idle;
+#pragma unroll
+            for (int j = 0; j < CG; j++) {
+                const u64 *p = d[j].ptr + toff * d[j].stride + qq;
+#pragma unroll
+                for (uint32_t e = 0; e < VW; e++) v[u][j][e] = p[64 * e];
+            }
         }
+        __syncthreads(); // the previous rows' readers are done
+        for (uint32_t e = threadIdx.x; e < 2 * ROWS * 3; e += 256) {
+            const uint32_t t = e >= ROWS * 3, j = e - t * ROWS * 3;
+            sL[t][j] = kc * 3 + j < k1 * 3 ? (t ? lpev : lev)[kc * 3 + j] : 0; // rows past the slice's end weigh zero
+        }
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < CG; j++) {
-            if (!on[j]) continue; // (wave-uniform)
-            const u64 *q = d[j].ptr + (r >> 6) * d[j].stride + (r & 63);
-            const u64 w0 = d[j].prime ? lp[0] : l[0], w1 = d[j].prime ? lp[1] : l[1], w2 = d[j].prime ? lp[2] : l[2];
-            if (d[j].dim == 1) {
-                const u64 v = q[0];
-                chpa::acc_mac(a[j][0], v, w0); chpa::acc_mac(a[j][1], v, w1); chpa::acc_mac(a[j][2], v, w2);
-            } else chpa::acc_mul33(a[j][0], a[j][1], a[j][2], q[0], q[64], q[128], w0, w1, w2);
+        for (uint32_t u = 0; u < UR; u++) {
+            const u64 *l = &sL[0][(u * 64 + kin) * 3], *lp = &sL[1][(u * 64 + kin) * 3];
+#pragma unroll
+            for (int j = 0; j < CG; j++) {
+                if (!on[j]) continue; // (wave-uniform)
+                const u64 *w = d[j].prime ? lp : l;
+                if (!D3) {
+                    chpa::acc_mac(a[j][0], v[u][j][0], w[0]); chpa::acc_mac(a[j][1], v[u][j][0], w[1]); chpa::acc_mac(a[j][2], v[u][j][0], w[2]);
+                } else chpa::acc_mul33(a[j][0], a[j][1], a[j][2], v[u][j][0], v[u][j][VW - 1 ? 1 : 0], v[u][j][VW - 1], w[0], w[1], w[2]);
+            }
         }
     }
 #pragma unroll
@@ -291,14 +318,18 @@ __global__ __launch_bounds__(64) void k_evmap_partial_tiled(u64 *__restrict__ pa
     }
 }
 
-__global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ partial,
-                                                      const EvDesc *__restrict__ desc, uint32_t n_evals, uint32_t n_slices)
+// evaluations [0, n_rm): the row-major kernel's s_rm slices; the others: the tile-major kernels' s_t slices
+__global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ p_rm, uint32_t s_rm, uint32_t n_rm,
+                                                      const u64 *__restrict__ p_t, uint32_t s_t, uint32_t n_t, const EvDesc *__restrict__ desc, uint32_t n_evals)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_evals) return;
+    const bool rm = i < n_rm;
+    const u64 *partial = rm ? p_rm + (uint64_t)i * 3 : p_t + (uint64_t)(i - n_rm) * 3;
+    const uint32_t n_slices = rm ? s_rm : s_t, pitch = rm ? n_rm : n_t;
     E3 acc = {{0, 0, 0}};
     for (uint32_t s = 0; s < n_slices; s++) {
-        const u64 *p = partial + ((uint64_t)s * n_evals + i) * 3;
+        const u64 *p = partial + (uint64_t)s * pitch * 3;
         acc = gl::e3_add(acc, E3{{p[0], p[1], p[2]}});
     }
     u64 *o = evals + (uint64_t)desc[i].out_index * 3;
@@ -325,28 +356,49 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, un
     // order by address like the reference does (starks.cpp:560-607) -- here it buys coalescing
     auto by_ptr = [](const EvDesc &a, const EvDesc &b) { return a.ptr < b.ptr; };
     std::sort(d.begin(), d.end(), by_ptr);
-    std::sort(dt.begin(), dt.end(), by_ptr);
+    std::stable_sort(dt.begin(), dt.end(), [](const EvDesc &a, const EvDesc &b) { return a.dim != b.dim ? a.dim < b.dim : a.ptr < b.ptr; }); // base-field ones first
     const uint32_t n_rm = (uint32_t)d.size(), n_t = (uint32_t)dt.size();
+    uint32_t n_t1 = 0;
+    for (const EvDesc &e : dt) n_t1 += e.dim == 1;
     d.insert(d.end(), dt.begin(), dt.end());
-    const uint32_t n_slices = (uint32_t)std::min<uint64_t>(n, 1024);
-    const uint64_t rows_per_slice = (n + n_slices - 1) / n_slices;
-    const uint64_t desc_bytes = n_evals * sizeof(EvDesc), part_bytes = (uint64_t)n_slices * n_evals * 3 * 8;
+    // slices of rows: the row-major kernel's workgroups take 256 evaluations each, so a STARK whose committed polynomials are tile-major
+    // leaves it a few hundred (the constants, the quotient's chunks) and one workgroup per slice -- more, shorter slices then, or its
+    // waves walk their rows one latency after the other (13 ms for the zkEVM's 230 at 1024 slices); the tile-major kernels' steps take
+    // 128 base rows from a multiple of 64.  The two families keep their partial sums apart.
+    uint32_t s_rm = (uint32_t)std::min<uint64_t>(n, 1024), s_t = 0;
+    uint64_t rps_rm = (n + s_rm - 1) / s_rm, rps_t = 0;
+    if (n_t) {
+        MI_REQUIRE(row0 == 0 && ext_bits <= 6, "tile-major polynomials are summed over the whole domain");
+        rps_t = ((n + 1023) / 1024 + 127) & ~127ull;
+        s_t = (uint32_t)((n + rps_t - 1) / rps_t);
+        if (n_rm && n_rm <= 1024 && n >= (1ull << 16)) {
+            rps_rm = std::max<uint64_t>(256, n / (8192 / ((n_rm + 255) / 256)));
+            s_rm = (uint32_t)((n + rps_rm - 1) / rps_rm);
+        }
+    }
+    const uint64_t desc_bytes = (n_evals * sizeof(EvDesc) + 63) & ~63ull, part_rm = (uint64_t)s_rm * n_rm * 3 * 8, part_t = (uint64_t)s_t * n_t * 3 * 8; // [slice][evaluation of the family]
     char *scratch = nullptr;
-    MI_TRY(mi_scratch(ctx, desc_bytes + part_bytes + 64, (void **)&scratch));
+    MI_TRY(mi_scratch(ctx, desc_bytes + part_rm + part_t + 64, (void **)&scratch));
     EvDesc *ddesc = (EvDesc *)scratch;
-    u64 *partial = (u64 *)(scratch + ((desc_bytes + 63) & ~63ull));
-    MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    u64 *p_rm = (u64 *)(scratch + desc_bytes), *p_t = (u64 *)(scratch + desc_bytes + part_rm);
+    u64 *p_t0 = p_t - 3 * (uint64_t)n_rm; // the tile-major kernels index by descriptor: descriptor n_rm is the family's first
+    MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), n_evals * sizeof(EvDesc), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // d is a stack-lifetime host buffer
     const unsigned gx = (unsigned)((n_evals + 255) / 256);
     if (n_rm)
-        hipLaunchKernelGGL(k_evmap_partial, dim3((n_rm + 255) / 256, n_slices), dim3(256), 0, ctx->stream, partial, ddesc, n_rm, (uint32_t)n_evals, row0 + nrows,
-                           (uint32_t)ext_bits, rows_per_slice, lev, lpev, row0);
-    if (n_t) {
-        constexpr int CG = 4;
-        hipLaunchKernelGGL(k_evmap_partial_tiled<CG>, dim3((n_t + CG - 1) / CG, n_slices), dim3(64), 0, ctx->stream, partial, ddesc, n_rm, n_t, (uint32_t)n_evals,
-                           row0 + nrows, (uint32_t)ext_bits, rows_per_slice, lev, lpev, row0);
+        hipLaunchKernelGGL(k_evmap_partial, dim3((n_rm + 255) / 256, s_rm), dim3(256), 0, ctx->stream, p_rm, ddesc, n_rm, n_rm, row0 + nrows,
+                           (uint32_t)ext_bits, rps_rm, lev, lpev, row0);
+    if (n_t1) { // (UR = 2: 164 VGPRs, three waves per SIMD, 23.0 ms at zkEVM size; UR = 4: 180 VGPRs, two waves, 27.2 ms)
+        constexpr int CG = 4, UR = 2;
+        hipLaunchKernelGGL((k_evmap_partial_tiled<CG, UR, false>), dim3((n_t1 + 4 * CG - 1) / (4 * CG), s_t), dim3(256), 0, ctx->stream, p_t0, ddesc, n_rm, n_t1,
+                           n_t, row0 + nrows, (uint32_t)ext_bits, rps_t, lev, lpev, row0);
     }
-    hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, partial, ddesc, (uint32_t)n_evals, n_slices);
+    if (n_t > n_t1) {
+        constexpr int CG = 2, UR = 2;
+        hipLaunchKernelGGL((k_evmap_partial_tiled<CG, UR, true>), dim3((n_t - n_t1 + 4 * CG - 1) / (4 * CG), s_t), dim3(256), 0, ctx->stream, p_t0, ddesc,
+                           n_rm + n_t1, n_t - n_t1, n_t, row0 + nrows, (uint32_t)ext_bits, rps_t, lev, lpev, row0);
+    }
+    hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, p_rm, s_rm, n_rm, p_t, s_t, n_t, ddesc, (uint32_t)n_evals);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

@@ -30,6 +30,12 @@ static constexpr u64 GL_EPS = 0xFFFFFFFFULL; // 2^64 mod p = 2^32 - 1
 
 namespace gl {
 
+// Where a row sits inside its tile of 64 in a TILE-MAJOR section ([tile][column][64 rows], include/mi_stark.h): at the bit-reversal of
+// its index.  The words of a column are one 512-byte run of a tile either way; bit-reversed, the rows that are multiples of 2^e -- the
+// rows evmap reads of an extension with blow-up 2^e (starks.cpp:555-668) -- are the FIRST 64 >> e words of the run, whatever e is, and
+// not every 2^e-th word of it (half of every 64-byte sector fetched for nothing at blow-up 2, 7/8 at blow-up 8).
+MI_HD u32 tile_pos(u32 row_in_tile) { return __builtin_bitreverse32(row_in_tile) >> 26; }
+
 // true in at least one lane of the wave?  A correction that is needed with probability ~2^-32 per value (x >= p,
 // lo < hh after a multiply) is put behind a wave-uniform branch: the common path pays one compare instead of a
 // compare, two selects and a 64-bit add.  Host build: plain condition.

@@ -319,7 +319,7 @@ __device__ __forceinline__ void lines_landed() { asm volatile("s_waitcnt vmcnt(0
 //
 // EMIT (launch_linear_hash_absorb_emit): the window is a compact chunk whose rows start on 128-byte lines, so the offset is zero for
 // every row and a wave may take 64 CONSECUTIVE rows -- one tile of a tile-major section [tile][column][64 rows], in which the words a
-// lane absorbs are 512-byte runs of the wave: each word is stored there as it is taken out of the ring (one store per word beside
+// lane absorbs are 512-byte runs of the wave (a row at gl::tile_pos of its index): each word is stored there as it is taken out of the ring (one store per word beside
 // the ~2 100 instructions a word's share of the permutation costs; HBM is idle under this kernel).  That is how Starks::genProof gets
 // its extended sections in the layout the constraint kernels read, without a transposing copy (host/starks.hpp).
 template <int MDS, bool EMIT>
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // with an active lane's; every load of a shadow is bounds-checked like any other)
     const uint64_t srow = active ? row : (EMIT ? lane : ((gw & 15) < nrows ? (gw & 15) : 0));
     // EMIT: this wave's tile, this lane's row of it (nrows is a multiple of 64: a wave is active or idle as a whole)
-    u64 *const etile = EMIT ? sl.emit + (gw * sl.emit_cols + sl.emit_col0) * 64 + lane : nullptr;
+    u64 *const etile = EMIT ? sl.emit + (gw * sl.emit_cols + sl.emit_col0) * 64 + gl::tile_pos(lane) : nullptr;
     ulonglong2 *wave_ring = ring + wave * 64;
     const u64 *my = reinterpret_cast<const u64 *>(wave_ring + lane); // element in slot a: my[(a >> 1) * 512 + (a & 1)]
     u64 s[12];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void k_group_proofs(u64 *__restrict__ proofs, c
     const uint64_t id = idx[q];
     u64 *out = proofs + q * ((uint64_t)width + 4ull * levels);
     if (tiled) // the source is a tile-major section [height / 64][pitch columns][64 rows]
-        for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[((id >> 6) * pitch + i) * 64 + (id & 63)]);
+        for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[((id >> 6) * pitch + i) * 64 + gl::tile_pos((uint32_t)(id & 63))]);
     else
         for (uint32_t i = threadIdx.x; i < width; i += 64) out[i] = gl::canon(src[id * pitch + i]);
     if (!nodes) return; // values only: the siblings come from elsewhere (a tree sharded over several devices, csrc/multi.hip)

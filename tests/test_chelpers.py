@@ -570,9 +570,13 @@ def test_base_step_program_on_gpu_matches_oracle(seed, inplace_max, tmp_path, mo
     ctx.close()
 
 
+REV6 = np.array([int(format(i, "06b")[::-1], 2) for i in range(64)])
+
+
 def _tile_major(a, nrows, ncols):
-    """[nrows x ncols] row-major -> [nrows / 64][ncols][64], canonical (include/mi_stark.h: mi_chelpers_set_tiled_section)."""
-    return (np.asarray(a, dtype=np.uint64).reshape(nrows // 64, 64, ncols) % np.uint64(glo.P)).transpose(0, 2, 1).reshape(-1).copy()
+    """[nrows x ncols] row-major -> [nrows / 64][ncols][64], canonical, a row at the bit-reversal of its index inside the tile
+    (include/mi_stark.h: mi_chelpers_set_tiled_section)."""
+    return (np.asarray(a, dtype=np.uint64).reshape(nrows // 64, 64, ncols) % np.uint64(glo.P)).transpose(0, 2, 1)[:, :, REV6].reshape(-1).copy()
 
 
 def test_tiled_section_is_declared_before_the_build_and_never_stored_into(tmp_path):

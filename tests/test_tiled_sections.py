@@ -18,8 +18,12 @@ def ctx():
     c.close()
 
 
+REV6 = np.array([int(format(i, "06b")[::-1], 2) for i in range(64)])
+
+
 def tile_major(a, nrows, ncols):
-    return np.asarray(a, dtype=np.uint64).reshape(nrows // 64, 64, ncols).transpose(0, 2, 1).reshape(-1).copy()
+    """element (row, col) at (row // 64 * ncols + col) * 64 + bit-reversal of (row % 64): include/mi_stark.h"""
+    return np.asarray(a, dtype=np.uint64).reshape(nrows // 64, 64, ncols).transpose(0, 2, 1)[:, :, REV6].reshape(-1).copy()
 
 
 @pytest.mark.parametrize("log_n,blow,ncols", [(5, 1, 5), (6, 1, 8), (10, 1, 9), (10, 1, 96), (10, 1, 97), (10, 1, 130), (11, 2, 200), (12, 1, 371), (10, 4, 24), (13, 1, 17)])
