@@ -245,7 +245,7 @@ def proof_kernel_rooflines(stats_csv, proofs_in_profile, zk):
         "evmap": 8.0 * N * zk["n_evals"],
     }
     bound = {"leaf_hashing": "hbm (VALU-issue-bound in fact: see valu)", "ntt_passes": "hbm", "constraint_kernels": "hbm (co-limited by integer issue)",
-             "operand_transpose": "hbm: pure data movement the algorithm does not ask for (tile-major copies of the operands per batch of rows; the witness is written tile-major ONCE, behind its upload, by the same kernel: 23 of these launches)", "linear_kernel": "hbm",
+             "operand_transpose": "hbm: pure data movement the algorithm does not ask for (tile-major copies, per batch of rows, of the operands that are still row-major: the computed base-domain sections and the extended constants; the witness is written tile-major ONCE, behind its upload, by the same kernel -- 22 of these launches --, the wide extended sections by the leaf kernel while it absorbs them)", "linear_kernel": "hbm",
              "evmap": "hbm"}
     out = {}
     for k in fam:
