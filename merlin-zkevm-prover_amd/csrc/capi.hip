@@ -184,6 +184,8 @@ extern "C" void mi_ctx_destroy(mi_ctx *c)
     else if (c->workspace) (void)hipFree(c->workspace);
     if (c->w256) (void)hipFree(c->w256);
     if (c->small) (void)hipFree(c->small);
+    if (c->tr_stream) { (void)hipStreamSynchronize(c->tr_stream); (void)hipStreamDestroy(c->tr_stream); }
+    if (c->tr_dev) (void)hipFree(c->tr_dev);
     if (c->own_pool.scratch) (void)hipFree(c->own_pool.scratch);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->chelpers_scratch) (void)hipFree(c->chelpers_scratch);
@@ -443,17 +445,26 @@ extern "C" int mi_transcript_put(mi_ctx *c, uint64_t state[4], uint64_t pending[
     // no allocation on this path (a proof makes dozens of these calls): the context's 4 KiB words when they suffice, its scratch otherwise
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     const bool fits = (32 + n) * 8 <= 4096;
-    u64 *dev = c->small;
-    if (!fits) MI_TRY(mi_scratch(c, (32 + n) * 8, (void **)&dev));
+    if (!c->tr_stream) MI_HIP_CHECK(hipStreamCreateWithFlags(&c->tr_stream, hipStreamNonBlocking));
+    if (c->tr_dev_bytes < (32 + n) * 8) { // (its own words: the context's scratch may be in use by kernels queued on the main stream)
+        MI_HIP_CHECK(hipStreamSynchronize(c->tr_stream));
+        if (c->tr_dev) MI_HIP_CHECK(hipFree(c->tr_dev));
+        c->tr_dev = nullptr;
+        c->tr_dev_bytes = 0;
+        const uint64_t want = std::max<uint64_t>(1 << 16, (32 + n) * 8);
+        MI_HIP_CHECK(hipMalloc((void **)&c->tr_dev, want));
+        c->tr_dev_bytes = want;
+    }
+    u64 *dev = c->tr_dev;
     std::vector<uint64_t> big(fits ? 0 : 32 + n);
     uint64_t *h = fits ? (uint64_t *)c->pinned : big.data();
     memcpy(&h[0], state, 32); memcpy(&h[4], pending, 64); memcpy(&h[12], out, 96);
     h[24] = *pending_cursor; h[25] = *out_cursor;
     memcpy(&h[32], input, n * 8);
-    MI_HIP_CHECK(hipMemcpyAsync(dev, h, (32 + n) * 8, hipMemcpyHostToDevice, c->stream));
-    MI_TRY(launch_transcript_put(c, dev, (const u64 *)dev + 32, n));
-    MI_HIP_CHECK(hipMemcpyAsync(h, dev, 26 * 8, hipMemcpyDeviceToHost, c->stream));
-    MI_HIP_CHECK(hipStreamSynchronize(c->stream));
+    MI_HIP_CHECK(hipMemcpyAsync(dev, h, (32 + n) * 8, hipMemcpyHostToDevice, c->tr_stream));
+    MI_TRY(launch_transcript_put(c, dev, (const u64 *)dev + 32, n, c->tr_stream));
+    MI_HIP_CHECK(hipMemcpyAsync(h, dev, 26 * 8, hipMemcpyDeviceToHost, c->tr_stream));
+    MI_HIP_CHECK(hipStreamSynchronize(c->tr_stream));
     memcpy(state, &h[0], 32); memcpy(pending, &h[4], 64); memcpy(out, &h[12], 96);
     *pending_cursor = (uint32_t)h[24]; *out_cursor = (uint32_t)h[25];
     return MI_OK;

@@ -129,6 +129,12 @@ struct mi_ctx {
     u64 *chelpers_scratch = nullptr; // challenges / public inputs / ZhInv of the running constraint-evaluator program
     // mi_lde_merkle_host: upload stream, two staging buffers [n x chunk] and their hand-over events
     hipStream_t copy_stream[2] = {};
+    // Transcript::put runs on a stream of its own (mi_transcript_put): its operands come from the host, so it depends on nothing that is
+    // queued on `stream`, and a long absorb (the 5 304 words of a zkEVM proof's evaluations: 663 chained permutations, 10 ms on one
+    // wave) runs beside whatever the caller queued before it instead of behind it
+    hipStream_t tr_stream = nullptr;
+    u64 *tr_dev = nullptr;
+    uint64_t tr_dev_bytes = 0;
     u64 *stage = nullptr;
     uint64_t stage_bytes = 0;
     static constexpr int N_STAGE = 3; // device staging buffers of the upload: the copy of chunk k + 2 must not wait for the kernels of chunk k
@@ -176,7 +182,7 @@ static inline bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
 
 // ---- internal launchers (defined in the .hip files)
 int launch_permute(mi_ctx *ctx, u64 *out, const u64 *in, uint64_t count);
-int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n);
+int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n, hipStream_t stream);
 int launch_linear_hash_rows(mi_ctx *ctx, u64 *digests, const u64 *src, uint64_t pitch, uint64_t ncols, uint64_t nrows);
 int launch_linear_hash_absorb(mi_ctx *ctx, u64 *digests, uint32_t nslabs, const u64 *const *bases, const uint64_t *pitches,
                               const uint64_t *widths, uint64_t nrows, bool first, bool final);

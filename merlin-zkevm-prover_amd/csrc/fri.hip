@@ -177,9 +177,9 @@ __global__ __launch_bounds__(256) void k_evmap_partial(u64 *__restrict__ partial
                                                        uint32_t n_evals, uint64_t n, uint32_t ext_bits, uint64_t rows_per_slice,
                                                        const u64 *__restrict__ lev, const u64 *__restrict__ lpev, uint64_t row0)
 {
-    // LEv / LpEv of 64 rows at a time through LDS: the same three words for every lane, which as vector loads cost an address-path slot
+    // LEv / LpEv of 128 rows at a time through LDS: the same three words for every lane, which as vector loads cost an address-path slot
     // each (12 a four-row step against 4 for the polynomial values: the kernel was bound there, not by HBM or issue)
-    constexpr uint32_t CH = 64, LW = CH * 3 + 2; // (+2: the two tables' rows fall into different banks)
+    constexpr uint32_t CH = 128, LW = CH * 3 + 2; // (+2: the two tables' rows fall into different banks)
     __shared__ u64 sL[2][LW];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint64_t k0 = row0 + (uint64_t)blockIdx.y * rows_per_slice; // rows [row0, n) of the base domain (row0 > 0: a row shard's partial sums)
@@ -318,22 +318,29 @@ __global__ __launch_bounds__(256) void k_evmap_partial_tiled(u64 *__restrict__ p
     }
 }
 
-// evaluations [0, n_rm): the row-major kernel's s_rm slices; the others: the tile-major kernels' s_t slices
-__global__ __launch_bounds__(256) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ p_rm, uint32_t s_rm, uint32_t n_rm,
-                                                      const u64 *__restrict__ p_t, uint32_t s_t, uint32_t n_t, const EvDesc *__restrict__ desc, uint32_t n_evals)
+// evaluations [0, n_rm): the row-major kernel's s_rm slices; the others: the tile-major kernels' s_t slices.  A wave per evaluation, its
+// lanes over the slices (up to 8 192 of them: one thread adding them up one after the other took 2 ms).
+__global__ __launch_bounds__(64) void k_evmap_reduce(u64 *__restrict__ evals, const u64 *__restrict__ p_rm, uint32_t s_rm, uint32_t n_rm,
+                                                     const u64 *__restrict__ p_t, uint32_t s_t, uint32_t n_t, const EvDesc *__restrict__ desc, uint32_t n_evals)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
     if (i >= n_evals) return;
     const bool rm = i < n_rm;
     const u64 *partial = rm ? p_rm + (uint64_t)i * 3 : p_t + (uint64_t)(i - n_rm) * 3;
     const uint32_t n_slices = rm ? s_rm : s_t, pitch = rm ? n_rm : n_t;
     E3 acc = {{0, 0, 0}};
-    for (uint32_t s = 0; s < n_slices; s++) {
+    for (uint32_t s = lane; s < n_slices; s += 64) {
         const u64 *p = partial + (uint64_t)s * pitch * 3;
         acc = gl::e3_add(acc, E3{{p[0], p[1], p[2]}});
     }
-    u64 *o = evals + (uint64_t)desc[i].out_index * 3;
-    o[0] = acc.v[0]; o[1] = acc.v[1]; o[2] = acc.v[2];
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+#pragma unroll
+        for (int o = 32; o; o >>= 1) acc.v[e] = gl::add(acc.v[e], (u64)__shfl_xor((unsigned long long)acc.v[e], o));
+    if (lane == 0) {
+        u64 *o = evals + (uint64_t)desc[i].out_index * 3;
+        o[0] = acc.v[0]; o[1] = acc.v[1]; o[2] = acc.v[2];
+    }
 }
 
 int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, unsigned ext_bits, const u64 *const *pol_ptr,
@@ -384,7 +391,6 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, un
     u64 *p_t0 = p_t - 3 * (uint64_t)n_rm; // the tile-major kernels index by descriptor: descriptor n_rm is the family's first
     MI_HIP_CHECK(hipMemcpyAsync(ddesc, d.data(), n_evals * sizeof(EvDesc), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // d is a stack-lifetime host buffer
-    const unsigned gx = (unsigned)((n_evals + 255) / 256);
     if (n_rm)
         hipLaunchKernelGGL(k_evmap_partial, dim3((n_rm + 255) / 256, s_rm), dim3(256), 0, ctx->stream, p_rm, ddesc, n_rm, n_rm, row0 + nrows,
                            (uint32_t)ext_bits, rps_rm, lev, lpev, row0);
@@ -398,7 +404,7 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, un
         hipLaunchKernelGGL((k_evmap_partial_tiled<CG, UR, true>), dim3((n_t - n_t1 + 4 * CG - 1) / (4 * CG), s_t), dim3(256), 0, ctx->stream, p_t0, ddesc,
                            n_rm + n_t1, n_t - n_t1, n_t, row0 + nrows, (uint32_t)ext_bits, rps_t, lev, lpev, row0);
     }
-    hipLaunchKernelGGL(k_evmap_reduce, dim3(gx), dim3(256), 0, ctx->stream, evals, p_rm, s_rm, n_rm, p_t, s_t, n_t, ddesc, (uint32_t)n_evals);
+    hipLaunchKernelGGL(k_evmap_reduce, dim3((unsigned)n_evals), dim3(64), 0, ctx->stream, evals, p_rm, s_rm, n_rm, p_t, s_t, n_t, ddesc, (uint32_t)n_evals);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

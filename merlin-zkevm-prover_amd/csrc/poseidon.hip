@@ -138,10 +138,10 @@ __global__ __launch_bounds__(64) void k_transcript_put(u64 *io, const u64 *__res
     if (threadIdx.x == 0) { io[24] = pc; io[25] = oc; }
 }
 
-int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n)
+int launch_transcript_put(mi_ctx *ctx, u64 *io, const u64 *input, uint64_t n, hipStream_t stream)
 {
     MI_TRY(upload_rc_once(ctx));
-    hipLaunchKernelGGL(k_transcript_put, dim3(1), dim3(64), 0, ctx->stream, io, input, n);
+    hipLaunchKernelGGL(k_transcript_put, dim3(1), dim3(64), 0, stream, io, input, n);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

@@ -1145,11 +1145,8 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     }
     TimerStopAndLog(STARK_STEP_5_EVMAP);
     TimerStart(STARK_STEP_5_XDIVXSUB);
-    // starks.cpp:342-345 puts evals[i] one by one; they are contiguous, so one put absorbs the same elements in the same order
-    if (evals.offset() == FIELD_EXTENSION) { if (nEvals) transcript.put(evals[0], nEvals * FIELD_EXTENSION); }
-    else for (uint64_t i = 0; i < nEvals; i++) transcript.put(evals[i], 3);
-    transcript.getField(challenges[5]); // v1
-    transcript.getField(challenges[6]); // v2
+    // x / (x - xi), x / (x - w xi) (:350-365) depend on xi alone: queued BEFORE the evaluations go into the transcript -- that absorb is 663
+    // chained permutations on one wave (10 ms at zkEVM size), on the transcript's own stream (mi_transcript_put), and these kernels run beside it
     for (const mi::StarkMirror::RowShard &S : m.rowShards) { // the other devices build their own tables (full height: addressing as here), beside this one
         mi::check(mi_multi_set_device(mm, S.shard), "Starks::genProof (row shards: device)");
         mi_ctx *cg = mi_multi_ctx(mm, S.shard);
@@ -1159,8 +1156,13 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     }
     if (!m.rowShards.empty()) mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
     const uint64_t xdivRows = m.rowShards.empty() ? NExtended : m.rowShards[0].row0; // row shards: this device's rows only
-    mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, xdivRows, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");    // :350-365
+    mi::check(mi_x_div_x_sub_dev(c, m.d_xdiv, m.d_x2ns, xdivRows, (const uint64_t *)xi), "Starks::genProof (xDivXSubXi)");
     mi::check(mi_x_div_x_sub_dev(c, m.d_xdivw, m.d_x2ns, xdivRows, (const uint64_t *)wxi), "Starks::genProof (xDivXSubWXi)");
+    // starks.cpp:342-345 puts evals[i] one by one; they are contiguous, so one put absorbs the same elements in the same order
+    if (evals.offset() == FIELD_EXTENSION) { if (nEvals) transcript.put(evals[0], nEvals * FIELD_EXTENSION); }
+    else for (uint64_t i = 0; i < nEvals; i++) transcript.put(evals[i], 3);
+    transcript.getField(challenges[5]); // v1
+    transcript.getField(challenges[6]); // v2
     TimerStopAndLog(STARK_STEP_5_XDIVXSUB);
     TimerStart(STARK_STEP_5_CALCULATE_EXPS);
     if (nrowsStepBatch == 4) steps->step52ns_parser_first_avx(params, NExtended, nrowsStepBatch);
