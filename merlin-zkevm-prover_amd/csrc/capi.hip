@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 
 static thread_local char g_err[512] = "";
 
@@ -723,11 +724,18 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
             c->pack_stage_bytes = need;
         }
     }
+    static const bool timing = getenv("MI_UPLOAD_TIMING") != nullptr; // stderr: where the host thread's time goes, per call
+    double t_wait = 0, t_pack = 0, t_enq = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct Report { const bool on; double &w, &p, &e; uint64_t n; ~Report() { if (on) fprintf(stderr, "mi_lde_merkle_host: %llu chunks; host thread: waiting for a staging buffer %.1f ms, packing %.1f ms, enqueueing copies %.1f ms\n", (unsigned long long)n, w * 1e3, p * 1e3, e * 1e3); } } report{timing, t_wait, t_pack, t_enq, n_chunks};
     auto upload_packed = [&](uint64_t k) -> int {
         const uint64_t cw = cws[k], slot = k % 3;
         u64 *hs = c->pack_stage[slot];
+        const double t0 = now();
         MI_HIP_CHECK(hipEventSynchronize(c->ev_pack_sent[slot])); // the copy that last read this staging buffer (three chunks ago, or in
                                                                    // an earlier call) is done; a never-recorded event is complete
+        const double t1 = now();
+        t_wait += t1 - t0;
         const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pack_threads, (n * cw * 8) >> 22)); // at least 4 MiB per thread
         std::vector<std::thread> th;
         const uint64_t rows_per = (n + T - 1) / T;
@@ -755,10 +763,13 @@ static int lde_merkle_host_impl(mi_ctx *c, uint64_t *nodes, uint64_t *ext, uint6
             else th.emplace_back(work);
         }
         for (auto &t : th) t.join();
+        const double t2 = now();
+        t_pack += t2 - t1;
         MI_HIP_CHECK(hipStreamWaitEvent(c->copy_stream[0], c->ev_consumed[k % NS], 0)); // the LDE that read this device buffer is done
         MI_HIP_CHECK(hipMemcpyAsync(st[k % NS], hs, n * cw * 8, hipMemcpyHostToDevice, c->copy_stream[0]));
         MI_HIP_CHECK(hipEventRecord(c->ev_pack_sent[slot], c->copy_stream[0]));
         for (int s = 0; s < 2; s++) MI_HIP_CHECK(hipEventRecord(c->ev_uploaded[k % NS][s], c->copy_stream[0]));
+        t_enq += now() - t2;
         return MI_OK;
     };
     // A PAGE-LOCKED trace (hipHostMalloc / mi_host_register) could let some chunks skip the host's packers -- the packed form moves at the
