@@ -26,10 +26,10 @@ def tile_major(a, nrows, ncols):
     return np.asarray(a, dtype=np.uint64).reshape(nrows // 64, 64, ncols).transpose(0, 2, 1)[:, :, REV6].reshape(-1).copy()
 
 
-@pytest.mark.parametrize("log_n,blow,ncols", [(5, 1, 5), (6, 1, 8), (10, 1, 9), (10, 1, 96), (10, 1, 97), (10, 1, 130), (11, 2, 200), (12, 1, 371), (10, 4, 24), (13, 1, 17)])
+@pytest.mark.parametrize("log_n,blow,ncols", [(5, 1, 5), (6, 1, 8), (10, 1, 9), (10, 1, 96), (10, 1, 128), (10, 1, 130), (11, 2, 200), (12, 1, 371), (10, 4, 24), (13, 1, 17)])
 def test_lde_merkle_dev_tiled_is_the_row_major_commit_in_another_layout(ctx, log_n, blow, ncols):
     """extendPol + merkelize of a device section (starks.cpp:133-138): the nodes are the oracle's tree over the oracle's extension, the
-    section holds that extension tile-major; widths below / at / above a chunk (96) and not a multiple of 8, blowups 2..16, the
+    section holds that extension tile-major; widths below / at / above a chunk (128) and not a multiple of 8, blowups 2..16, the
     smallest extension a tile allows (64 rows), a source at a wider pitch."""
     rng = np.random.default_rng(1000 + log_n * 7 + ncols)
     n, n_ext = 1 << log_n, 1 << (log_n + blow)
@@ -74,14 +74,16 @@ def test_lde_merkle_dev_tiled_with_a_lent_workspace_and_twice_in_a_row(ctx):
     ctx.lde(ext_r, d_src, n_ext, n, ncols)
     ctx.merkle_build(nodes_r, ext_r, ncols, n_ext)
     want_t, want_nodes = tile_major(ctx.to_host(ext_r), n_ext, ncols), ctx.to_host(nodes_r)
-    loan = torch.zeros(64 << 20, dtype=torch.int64, device="cuda")  # 512 MiB
-    for lent in (True, False):
-        ctx.lend_workspace(loan if lent else None)
+    # 512 MiB: the widest chunk (128 columns: 8 MiB of compact extension + 12 MiB of transform scratch); 14 and 7 MiB: the loan holds
+    # narrower chunks only (64, 32 columns) -- the call narrows them instead of allocating
+    for loan_mib in (512, 14, 7, 0):
+        loan = torch.zeros(loan_mib << 17, dtype=torch.int64, device="cuda") if loan_mib else None
+        ctx.lend_workspace(loan)
         for _ in range(2):
             nodes, ext_t = ctx.empty((2 * n_ext - 1) * 4), ctx.empty(n_ext * ncols)
             ctx.lde_merkle_dev_tiled(nodes, ext_t, d_src, n, n_ext, ncols)
-            assert np.array_equal(ctx.to_host(ext_t), want_t) and np.array_equal(ctx.to_host(nodes), want_nodes), lent
-    ctx.lend_workspace(None)
+            assert np.array_equal(ctx.to_host(ext_t), want_t) and np.array_equal(ctx.to_host(nodes), want_nodes), loan_mib
+        ctx.lend_workspace(None)
 
 
 @pytest.mark.parametrize("log_n,ncols,pack", [(10, 70, -1), (12, 665, -1), (10, 33, 0), (11, 128, 0), (6, 12, -1)])
