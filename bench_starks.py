@@ -238,6 +238,11 @@ def tiled_ext(ne, w):
     return os.environ.get("MI_STARK_TILED_EXT", "1")[:1] != "0" and ne >= 64 and w > 4 and not os.environ.get("MI_STARK_DEVICES", "")
 
 
+def tiled_consts(n):
+    """host/starks.hpp's rule for keeping the resident constant polynomials tile-major: one device, at least one tile of rows."""
+    return os.environ.get("MI_STARK_TILED_CONSTS", "1")[:1] != "0" and n >= 64 and not os.environ.get("MI_STARK_DEVICES", "")
+
+
 def compiled_programs(args, shard=None):
     """The five programs through mi_chelpers_compile + the native build with the in-tree code-object cache (no GPU needed): what
     Starks does on first use, done ahead so that the GPU box finds every kernel in the cache."""
@@ -250,6 +255,8 @@ def compiled_programs(args, shard=None):
         p = mi_stark.ChelpersProgram(None, ops, ar, sections=secs[name], n_const=args.n_const, nrows_ext=n if base else ne, step=STEP_ID[name])
         if base and tiled_witness(si, n, cols["cm1_n"]):
             p.set_tiled_section(off["cm1_n"])
+        if base and args.n_const and tiled_consts(n):
+            p.set_tiled_consts()
         if not base:
             for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns"):
                 if tiled_ext(ne, cols[k]):

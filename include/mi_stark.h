@@ -436,6 +436,10 @@ int mi_chelpers_build_native(mi_chelpers_prog *prog, const char *cache_dir, uint
  * mi_chelpers_build_native / _precompile_shard / _lower_stats, once per tile-major section, named by its offset; the program then runs
  * through the compiled kernels only, over rows from a multiple of 64. */
 int mi_chelpers_set_tiled_section(mi_chelpers_prog *prog, uint64_t section_offset);
+/* ... and the constant polynomials: const_pols of mi_chelpers_run_dev is then [nrows / 64][n_const][64] (rows bit-reversed inside a tile
+ * as above) -- a proving key's constants never change, so they can be kept that way for good.  Same call order; a program that reads no
+ * constant polynomial is left as it is. */
+int mi_chelpers_set_tiled_consts(mi_chelpers_prog *prog);
 /* dst (tile-major as above, nrows x ncols_total) <- src (row-major, src_pitch words per row, ncols columns), placed at column col0 of
  * the tiles; nrows a multiple of 64; values canonicalised. */
 int mi_tile_major_dev(mi_ctx *ctx, uint64_t *dst, uint64_t ncols_total, uint64_t col0, const uint64_t *src, uint64_t src_pitch,

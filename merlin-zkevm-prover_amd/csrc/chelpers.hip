@@ -1105,6 +1105,29 @@ extern "C" int mi_chelpers_set_tiled_section(mi_chelpers_prog *p, uint64_t secti
     MI_REQUIRE(hit, "no declared section starts at this offset");
     MI_REQUIRE(hit->nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
     hit->tiled = true;
+    chp::renumber_staged_columns(p);
+    return MI_OK;
+}
+
+// ... and the constant polynomials the program reads (const_pols of mi_chelpers_run_dev: [nrows / 64][n_const][64] then): a proving key's
+// constants never change, so a caller can keep them that way for good (host/starks.hpp does, for the base-domain steps).  A program that
+// reads no constant polynomial is left as it is.
+extern "C" int mi_chelpers_set_tiled_consts(mi_chelpers_prog *p)
+{
+    if (!p) return MI_ERR_INVALID;
+    MI_REQUIRE(!p->native, "mi_chelpers_set_tiled_consts comes before mi_chelpers_build_native");
+    for (HostSection &S : p->sections)
+        if (S.role == 1) {
+            MI_REQUIRE(S.nrows % 64 == 0, "a tile-major section has a multiple of 64 rows");
+            S.tiled = true;
+        }
+    chp::renumber_staged_columns(p);
+    return MI_OK;
+}
+
+namespace chp {
+void renumber_staged_columns(mi_chelpers_prog *p)
+{
     // the per-batch tile-major copy holds the other sections' columns only (a batch of rows is sized by them): renumber the staged
     // columns, the sections read in place behind them (a column keeps a number of its own: the operand statistics go by it)
     uint32_t c0 = 0;
@@ -1113,8 +1136,8 @@ extern "C" int mi_chelpers_set_tiled_section(mi_chelpers_prog *p, uint64_t secti
     p->staged_cols = c0 ? c0 : 1;
     for (HostSection &S : p->sections)
         if (S.tiled) { S.col0 = c0; c0 += (uint32_t)S.ncols; }
-    return MI_OK;
 }
+} // namespace chp
 
 // Parallel builds: process `shard` of `nshards` compiles every nshards-th kernel into the cache and keeps nothing; a final
 // mi_chelpers_build_native then finds every kernel in the cache.

@@ -206,6 +206,7 @@ struct mi_chelpers_prog {
 };
 
 namespace chp {
+void renumber_staged_columns(mi_chelpers_prog *p); // chelpers.hip: after a section was declared tile-major
 // chelpers_native.hip
 int native_build(mi_chelpers_prog *P, const char *cache_dir, uint64_t chunk_cost, uint32_t shard, uint32_t nshards);
 int native_host_run(const mi_chelpers_prog *P, const mi_chelpers_params *a, const uint64_t *rows, uint64_t nrows, uint64_t chunk_cost);

@@ -947,12 +947,15 @@ static int generate(const mi_chelpers_prog *P, const NativeProg *N, size_t k, st
         src += line;
     }
     for (const auto &xs : g.xshifts) {
-        // a section kept tile-major (a part of the polynomial area): tile = row / 64 of the whole section (row_base is a multiple of 64),
-        // rows wrap at its end
+        // a section kept tile-major (a part of the polynomial area, or the constant polynomials): tile = row / 64 of the whole section
+        // (row_base is a multiple of 64), rows wrap at its end
         const HostSection &S = P->sections[xs.first];
         const uint32_t s = xs.second;
-        snprintf(line, sizeof line, "  const u64 *__restrict__ X%u_%u = pols + %lluULL + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + gl::tile_pos((lane + %uu) & 63u);\n",
-                 xs.first, s, (unsigned long long)S.offset, s, (unsigned long long)(S.nrows / 64 - 1), (unsigned long long)S.ncols * 64, s);
+        char where[64];
+        if (S.role == 0) snprintf(where, sizeof where, "pols + %lluULL", (unsigned long long)S.offset);
+        else snprintf(where, sizeof where, "cpols"); // (role 1: the constant polynomials, mi_chelpers_set_tiled_consts)
+        snprintf(line, sizeof line, "  const u64 *__restrict__ X%u_%u = %s + (((row_base >> 6) + tile + ((lane + %uu) >> 6)) & %lluULL) * %lluULL + gl::tile_pos((lane + %uu) & 63u);\n",
+                 xs.first, s, where, s, (unsigned long long)(S.nrows / 64 - 1), (unsigned long long)S.ncols * 64, s);
         src += line;
     }
     if (g.uses_zh) {
@@ -1200,9 +1203,34 @@ __global__ __launch_bounds__(256) void k_untile(u64 *__restrict__ dst, uint64_t 
         dst[r * dst_pitch + cc] = src[((row >> 6) * ncols_total + col0 + cc) * 64 + gl::tile_pos((uint32_t)(row & 63))];
     }
 }
+// whole tiles: 64 rows x 64 columns through LDS, 512-byte runs in (a column's words of a tile) and out (a row's 64 columns) -- the
+// constants' LDE reads its source through this (host/starks.hpp keeps them tile-major)
+__global__ __launch_bounds__(256) void k_untile_tiles(u64 *__restrict__ dst, uint64_t dst_pitch, const u64 *__restrict__ src, uint64_t ncols_total, uint64_t col0,
+                                                       uint64_t tile0, uint32_t ncols)
+{
+    __shared__ u64 t[64][65];
+    const uint32_t l = threadIdx.x & 63, q = threadIdx.x >> 6, c0 = blockIdx.y * 64;
+    const uint64_t tile = blockIdx.x;
+    const u64 *s = src + ((tile0 + tile) * ncols_total + col0 + c0) * 64 + l;
+    const uint32_t row = gl::tile_pos(l); // word l of a run is this row of the tile
+#pragma unroll 4
+    for (uint32_t cc = q; cc < 64; cc += 4)
+        if (c0 + cc < ncols) t[row][cc] = s[(uint64_t)cc * 64];
+    __syncthreads();
+    if (c0 + l < ncols) {
+#pragma unroll 4
+        for (uint32_t r = q; r < 64; r += 4) dst[(tile * 64 + r) * dst_pitch + c0 + l] = t[r][l];
+    }
+}
 int launch_untile(mi_ctx *ctx, u64 *dst, uint64_t dst_pitch, const u64 *src, uint64_t ncols_total, uint64_t col0, uint64_t row0, uint64_t nrows, uint64_t ncols)
 {
     if (!nrows || !ncols) return MI_OK;
+    if (row0 % 64 == 0 && nrows % 64 == 0 && nrows / 64 < (1ull << 31) && ncols < (1ull << 22)) {
+        hipLaunchKernelGGL(k_untile_tiles, dim3((unsigned)(nrows / 64), (unsigned)((ncols + 63) / 64)), dim3(256), 0, ctx->stream, dst, dst_pitch, src, ncols_total, col0,
+                           row0 / 64, (uint32_t)ncols);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
     hipLaunchKernelGGL(k_untile, dim3(mi_grid_256(nrows * ncols)), dim3(256), 0, ctx->stream, dst, dst_pitch, src, ncols_total, col0, row0, nrows, ncols);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;

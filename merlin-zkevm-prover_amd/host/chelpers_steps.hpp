@@ -33,6 +33,7 @@ struct StarkMirror
     Sec cmN[4] = {}, cm2ns[4] = {}; // cm1_n cm2_n cm3_n tmpExp_n / cm1_2ns .. cm4_2ns
     bool tiledWitness = false;      // cm1_n lies tile-major in the image (host/starks.hpp): the base-domain steps read it in place
     bool tiledExt[4] = {};          // cm1_2ns .. cm4_2ns lie tile-major in the image: step42ns / step52ns read them in place
+    bool tiledConstN = false;       // d_constN is tile-major (kept that way by the Starks for good): the base-domain steps read it in place
     bool anyTiledExt() const { return tiledExt[0] || tiledExt[1] || tiledExt[2] || tiledExt[3]; }
     uint64_t qOffset = 0, fOffset = 0;
     uint64_t *d_constN = nullptr, *d_const2ns = nullptr, nConst = 0;
@@ -65,9 +66,12 @@ inline StarkMirror *&currentMirror()
 }
 
 inline bool isBaseStep(int step) { return step == MI_CHELPERS_STEP2PREV || step == MI_CHELPERS_STEP3PREV || step == MI_CHELPERS_STEP3; }
-constexpr int MI_STEP_KEY_TRACED = 0x10000, MI_STEP_KEY_TILED = 0x20000; // flags in the first half of a program-cache key
-// a program is compiled for the layout of the sections it reads: one entry per layout (base-domain steps: the witness; the others: the extension)
-inline int stepLayoutKey(const StarkMirror *m, int step) { return (isBaseStep(step) ? m->tiledWitness : m->anyTiledExt()) ? MI_STEP_KEY_TILED : 0; }
+constexpr int MI_STEP_KEY_TRACED = 0x10000, MI_STEP_KEY_TILED = 0x20000, MI_STEP_KEY_TILED_CONST = 0x40000; // flags in the first half of a program-cache key
+// a program is compiled for the layout of what it reads: one entry per layout (base-domain steps: the witness, the constants; the others: the extension)
+inline int stepLayoutKey(const StarkMirror *m, int step)
+{
+    return ((isBaseStep(step) ? m->tiledWitness : m->anyTiledExt()) ? MI_STEP_KEY_TILED : 0) | (isBaseStep(step) && m->tiledConstN ? MI_STEP_KEY_TILED_CONST : 0);
+}
 
 inline StarkMirror *mirrorOf(StepsParams &params)
 {
@@ -96,6 +100,7 @@ inline void buildStepProgram(const StarkMirror *m, int step, mi_chelpers_prog *p
 {
     if (isBaseStep(step) && m->tiledWitness && m->cmN[0].cols)
         check(mi_chelpers_set_tiled_section(prog, m->cmN[0].offset), "Steps (the witness section is tile-major)");
+    if (isBaseStep(step) && m->tiledConstN) check(mi_chelpers_set_tiled_consts(prog), "Steps (the constant polynomials are tile-major)");
     if (!isBaseStep(step))
         for (unsigned s = 0; s < (step == MI_CHELPERS_STEP52NS ? 4u : 3u); s++)
             if (m->tiledExt[s] && m->cm2ns[s].cols) check(mi_chelpers_set_tiled_section(prog, m->cm2ns[s].offset), "Steps (an extended section is tile-major)");

@@ -204,6 +204,7 @@ private:
     void *pAddress;
     // device side
     uint64_t *d_constN = nullptr; // constant polynomials over the base domain: resident for the life of this object
+    bool constNTiled = false;     // ... tile-major ([N / 64][nConstants][64]): what the base-domain steps read in place (init())
     uint64_t treeElems = 0, scratchElems = 0;
     std::map<std::pair<int, const void *>, mi_chelpers_prog *> progs;
 
@@ -304,7 +305,7 @@ public:
     // step's tables in place (the reference's tables are constants of the binary and never change)
     void forgetProgram(int step, const void *opsTable)
     {
-        for (int key : {step, step | mi::MI_STEP_KEY_TILED}) {
+        for (int key : {step, step | mi::MI_STEP_KEY_TILED, step | mi::MI_STEP_KEY_TILED_CONST, step | mi::MI_STEP_KEY_TILED | mi::MI_STEP_KEY_TILED_CONST}) {
             auto it = progs.find({key, opsTable});
             if (it == progs.end()) continue;
             if (it->second) mi_chelpers_free(mi::ctx(), it->second);
@@ -412,7 +413,20 @@ private:
         if (starkInfo.nConstants) {
             d_constN = (uint64_t *)mi_dev_alloc(mi::ctx(), starkInfo.nConstants * N * 8);
             if (!d_constN) mi::fail("Starks::Starks (constant polynomials)");
-            mi::check(mi_copy_h2d(mi::ctx(), d_constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (constant polynomials h2d)");
+            // Kept TILE-MAJOR on one device: every base-domain step reads them (the zkEVM's 218: three tile-major copies of 14.6 GB per
+            // proof, 19 ms), nothing writes them, and their one other reader -- the extension of stage 4 -- takes them through an untiling
+            // pass per column chunk (6 ms).  Row-major with several devices (the shards extend their own copies from it) and with
+            // MI_STARK_TILED_CONSTS=0.
+            const char *e = std::getenv("MI_STARK_TILED_CONSTS");
+            constNTiled = !mi::multi() && N >= 64 && !(e && e[0] == '0');
+            if (constNTiled) {
+                uint64_t *tmp = (uint64_t *)mi_dev_alloc(mi::ctx(), starkInfo.nConstants * N * 8); // (before the image is reserved: there is room)
+                if (!tmp) mi::fail("Starks::Starks (constant polynomials, staging)");
+                mi::check(mi_copy_h2d(mi::ctx(), tmp, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (constant polynomials h2d)");
+                mi::check(mi_tile_major_dev(mi::ctx(), d_constN, starkInfo.nConstants, 0, tmp, starkInfo.nConstants, N, starkInfo.nConstants), "Starks::Starks (constant polynomials, tile-major)");
+                mi::check(mi_ctx_sync(mi::ctx()), "Starks::Starks (constant polynomials, tile-major)");
+                mi_dev_free(mi::ctx(), tmp);
+            } else mi::check(mi_copy_h2d(mi::ctx(), d_constN, pConstPolsAddress, starkInfo.nConstants * N * 8), "Starks::Starks (constant polynomials h2d)");
         }
         // the proof's HBM now, not inside the first genProof: like the reference, which allocates pAddress when the prover starts
         // (prover.cpp:99-120).  273 GB of fresh device memory take the driver 5.7 s; a later, larger Starks grows the arena once more.
@@ -691,7 +705,7 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     const eSection sN[4] = {cm1_n, cm2_n, cm3_n, tmpExp_n}, s2[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
     for (int i = 0; i < 4; i++) { m.cmN[i] = {off(sN[i]), cols(sN[i])}; m.cm2ns[i] = {off(s2[i]), cols(s2[i])}; }
     m.qOffset = off(q_2ns); m.fOffset = off(f_2ns);
-    m.d_constN = d_constN; m.nConst = starkInfo.nConstants;
+    m.d_constN = d_constN; m.nConst = starkInfo.nConstants; m.tiledConstN = constNTiled;
     m.zhinv.resize(1ULL << extendBits);
     for (uint64_t i = 0; i < m.zhinv.size(); i++) m.zhinv[i] = Goldilocks::toU64(zi.zhInv(i));
     m.progs = &progs;
@@ -1023,6 +1037,23 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         mi::check(mi_multi_set_device(mm, 0), "Starks::genProof (row shards: device)");
         constRowsOnly = true;
         constRowsFrom = (int)tableOwners[0];
+    } else if (nConst && constNTiled) {
+        // the resident constants are tile-major: a column chunk at a time goes row-major into the head of the remaining scratch and is extended from there
+        // (a small STARK's remainder does not hold a chunk beside the transform's scratch -- lend() hands the context nothing then --: an allocation)
+        const uint64_t cw0 = std::min<uint64_t>(nConst, 96), stage = (N * cw0 + 15) & ~15ULL;
+        const bool fromRest = restElems >= stage + 16 * 2 * (N + NExtended);
+        uint64_t *chunk = fromRest ? rest : mi::devAlloc(stage, "Starks::genProof (constant polynomials: a chunk row-major)");
+        if (fromRest) lend(rest + stage, restElems - stage);
+        for (uint64_t c0 = 0; c0 < nConst; c0 += cw0) {
+            const uint64_t cw = std::min(cw0, nConst - c0);
+            mi::check(mi_untile_dev(c, chunk, cw, d_constN, nConst, N, c0, 0, N, cw), "Starks::genProof (constant polynomials: a chunk row-major)");
+            mi::check(mi_lde_dev(c, m.d_const2ns + c0, nConst, chunk, cw, NExtended, N, cw), "Starks::genProof (constant polynomials, extended)");
+        }
+        if (fromRest) lend(rest, restElems);
+        else {
+            mi::check(mi_ctx_sync(c), "Starks::genProof (constant polynomials, extended)");
+            mi::devFree(chunk);
+        }
     } else if (nConst) mi::check(mi_lde_dev(c, m.d_const2ns, nConst, d_constN, nConst, NExtended, N, nConst), "Starks::genProof (constant polynomials, extended)");
     mi::check(mi_geom_seq_dev(c, m.d_x2ns, NExtended, Goldilocks::toU64(Goldilocks::shift()), Goldilocks::toU64(Goldilocks::w(nBitsExt))),
               "Starks::genProof (x_2ns)"); // starks.hpp:155-160

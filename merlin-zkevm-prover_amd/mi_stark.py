@@ -65,7 +65,7 @@ EXPORTS = [
     "mi_set_poseidon_variant", "mi_set_poseidon_coop_max", "mi_set_ntt_tile", "mi_set_lde_fuse", "mi_set_leaf_mode", "mi_timer_start", "mi_timer_stop", "mi_timer_elapsed_ms",
     "mi_dbg_field_ops_dev", "mi_dbg_host_poseidon_permute", "mi_dbg_host_mul", "mi_dbg_host_e3_mul", "mi_dbg_host_e3_inv",
     "mi_dbg_host_dft16", "mi_dbg_lincomb_cols_dev", "mi_dbg_ntt_colmajor_dev",
-    "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_get_host_pack_threads",
+    "mi_ctx_lend_workspace", "mi_dev_mem_info", "mi_lde_merkle_host_keep", "mi_lde_merkle_host_keep_tiled", "mi_tile_major_dev", "mi_chelpers_set_tiled_section", "mi_chelpers_set_tiled_consts", "mi_get_host_pack_threads",
     "mi_ctx_device", "mi_multi_lend", "mi_multi_plan_debug", "mi_multi_create", "mi_multi_create2", "mi_multi_lead", "mi_multi_set_transient", "mi_multi_transient_need", "mi_multi_windowed_need", "mi_multi_check_stats", "mi_multi_own", "mi_vmm_reserve", "mi_vmm_back", "mi_vmm_allow_peer", "mi_vmm_backed_bytes", "mi_vmm_free", "mi_multi_destroy", "mi_multi_shards", "mi_multi_peer_access", "mi_multi_ctx", "mi_multi_set_pack_threads", "mi_multi_set_upload_mode", "mi_multi_set_row_images", "mi_multi_set_device", "mi_multi_copy", "mi_multi_sync", "mi_multi_last_upload_mode", "mi_multi_commit", "mi_multi_group_proofs",
     "mi_multi_tree_release_rows", "mi_multi_tree_free", "mi_multi_tree_info", "mi_multi_tree_nodes", "mi_multi_gather_rows", "mi_multi_last_stats",
     "mi_lde_merkle_host", "mi_set_host_pack_threads", "mi_host_register", "mi_host_unregister", "mi_set_chelpers_min_words", "mi_chelpers_compile", "mi_chelpers_compile_micro", "mi_chelpers_free", "mi_chelpers_stats", "mi_chelpers_run_dev", "mi_dbg_host_chelpers_run", "mi_chelpers_build_native", "mi_chelpers_precompile_shard", "mi_chelpers_lower_stats", "mi_dbg_host_chelpers_run_lowered", "mi_chelpers_native_stats", "mi_set_chelpers_batch_rows", "mi_chelpers_reserve",
@@ -532,6 +532,10 @@ class ChelpersProgram:
 
     NATIVE_STAT_NAMES = ("kernels", "code_bytes", "build_ms", "cache_hits", "estimated_valu_per_row", "spill_words_moved_per_row",
                          "horner_chain_steps", "constant_words")
+
+    def set_tiled_consts(self):
+        """The constant polynomials handed to run_* are TILE-MAJOR ([nrows / 64][n_const][64], rows bit-reversed inside a tile)."""
+        _check(lib().mi_chelpers_set_tiled_consts(self.h))
 
     def reserve(self, nrows):
         _check(lib().mi_chelpers_reserve(self.ctx.h, self.h, u64(nrows)))

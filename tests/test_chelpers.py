@@ -608,6 +608,44 @@ def test_tiled_section_is_declared_before_the_build_and_never_stored_into(tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,witness_tiled", [(23, True), (24, False)])
+def test_base_step_program_reads_tile_major_constants_in_place(seed, witness_tiled, tmp_path):
+    """The resident constant polynomials kept tile-major (host/starks.hpp; mi_chelpers_set_tiled_consts): a base-domain program reads
+    them in place -- shifted rows across tile borders and around the end included --, with the witness section tile-major as well or
+    row-major, in one batch and in many, from row 0 and from a later multiple of 64."""
+    import mi_stark
+    ctx = mi_stark.Context(0)
+    nrows = 1 << 12
+    ops, args, pols, cpols, chal, pub, x, sections = _base_case(seed, nrows)
+    want = pols.copy()
+    glo.chelpers_stepbase(ops, args, want, cpols, 7, chal, pub, x, 2, np.arange(nrows))
+    img = pols.copy()
+    if witness_tiled:
+        img[:nrows * 40] = _tile_major(pols[:nrows * 40], nrows, 40)
+    d_ct = ctx.to_device(_tile_major(cpols, nrows, 7))
+    prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=sections, n_const=7, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP3PREV)
+    if witness_tiled:
+        prog.set_tiled_section(0)
+    prog.set_tiled_consts()
+    assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=2500)["kernels"] >= 2
+    with pytest.raises(mi_stark.MiStarkError, match="comes before mi_chelpers_build_native"):
+        prog.set_tiled_consts()
+    d_x = ctx.to_device(x)
+    for batch in (0, 512):
+        ctx.set_chelpers_batch_rows(batch)
+        d_pols = ctx.to_device(img)
+        prog.run_base(d_pols, d_ct, 7, chal, pub, d_x, 2, 0, nrows)
+        assert np.array_equal(ctx.to_host(d_pols)[nrows * 40:], want[nrows * 40:]), batch
+    d_pols = ctx.to_device(img)                    # rows [1024, 4096) only
+    prog.run_base(d_pols, d_ct, 7, chal, pub, d_x, 2, 1024, nrows - 1024)
+    part = pols.copy()
+    glo.chelpers_stepbase(ops, args, part, cpols, 7, chal, pub, x, 2, np.arange(1024, nrows))
+    assert np.array_equal(ctx.to_host(d_pols)[nrows * 40:], part[nrows * 40:])
+    prog.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", [21, 22])
 def test_base_step_program_reads_a_tile_major_section_in_place(seed, tmp_path):
     """The witness kept tile-major (host/starks.hpp): mi_tile_major_dev writes [tile][column][64 rows]; a base-domain program compiled

@@ -42,11 +42,11 @@ def precompile_starks(jobs, only):
         if only >= 0 and ci != only:
             continue
         t0 = time.time()
-        # both layouts of the image: the witness and the wide extended sections tile-major (one device), and row-major (MI_STARK_DEVICES,
-        # MI_STARK_TILED_WITNESS=0 / MI_STARK_TILED_EXT=0, a STARK whose lookups read witness columns); for the default configuration the
-        # A/B form too (witness tile-major, extension row-major).  Kernels that do not differ are found in the cache the second time.
-        for tiled, tiled_ext in (("1", "1"), ("0", "0")) + ((("1", "0"),) if ci == 0 else ()):
-            env = dict(os.environ, MI_STARK_TILED_WITNESS=tiled, MI_STARK_TILED_EXT=tiled_ext)
+        # both layouts of the image: the witness, the wide extended sections and the resident constants tile-major (one device), and all
+        # row-major (MI_STARK_DEVICES, MI_STARK_TILED_WITNESS / _EXT / _CONSTS = 0, a STARK whose lookups read witness columns); for the
+        # default configuration the A/B forms too (extension row-major; constants row-major).  Kernels that do not differ are found in the cache the second time.
+        for tiled, tiled_ext, tiled_c in (("1", "1", "1"), ("0", "0", "0")) + ((("1", "0", "1"), ("1", "1", "0")) if ci == 0 else ()):
+            env = dict(os.environ, MI_STARK_TILED_WITNESS=tiled, MI_STARK_TILED_EXT=tiled_ext, MI_STARK_TILED_CONSTS=tiled_c)
             procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench_starks.py")] + argv + ["--precompile", str(s), str(jobs)], env=env) for s in range(jobs)]
             if any(p.wait() for p in procs):
                 raise SystemExit("a precompile shard of bench_starks.py failed")
