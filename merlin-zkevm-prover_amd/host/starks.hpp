@@ -737,7 +737,8 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     // MI_STARK_TILED_EXT=0: row-major as before.
     {
         const char *e = std::getenv("MI_STARK_TILED_EXT");
-        const bool on = deviceSteps && !(e && e[0] == '0') && !mm && NExtended >= 64;
+        const char *be = std::getenv("MI_CHELPERS_BACKEND"); // (the interpreter, an A/B switch of the extended-domain steps, reads row-major sections)
+        const bool on = deviceSteps && !(e && e[0] == '0') && !mm && NExtended >= 64 && !(be && std::string(be) == "interpreter");
         for (int i = 0; i < 3; i++) m.tiledExt[i] = on && cols(s2[i]) > 4;
         for (int i = 0; i < 4; i++) tiledExtLast[i] = m.tiledExt[i];
     }

@@ -692,10 +692,11 @@ def test_base_step_program_reads_a_tile_major_section_in_place(seed, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiled_secs", [(0,), (0, 1), (0, 1, 2)])
-def test_native_step42ns_reads_tile_major_sections_in_place(tmp_path, tiled_secs):
+@pytest.mark.parametrize("tiled_secs,tiled_consts", [((0,), False), ((0, 1), False), ((0, 1, 2), False), ((0, 1, 2), True), ((), True)])
+def test_native_step42ns_reads_tile_major_sections_in_place(tmp_path, tiled_secs, tiled_consts):
     """The extended sections as Starks::genProof keeps them (mi_lde_merkle_dev_tiled): one, two or all of a step42ns program's sections
-    tile-major, the others row-major through the per-batch copy; shifted rows across tile borders and around the end; batches; a row range."""
+    tile-major, the others row-major through the per-batch copy, the extended constants tile-major or not; shifted rows across tile
+    borders and around the end; batches; a row range."""
     import mi_stark
     ctx = mi_stark.Context(0)
     nrows = 1 << 13
@@ -710,8 +711,10 @@ def test_native_step42ns_reads_tile_major_sections_in_place(tmp_path, tiled_secs
     prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=secs, n_const=n_const, nrows_ext=nrows)
     for i in tiled_secs:
         prog.set_tiled_section(secs[i][0])
+    if tiled_consts:
+        prog.set_tiled_consts()
     assert prog.build_native(cache_dir=str(tmp_path), chunk_cost=7000)["kernels"] >= 3
-    d_pols, d_c, d_x = ctx.to_device(img), ctx.to_device(cpols), ctx.to_device(x)
+    d_pols, d_c, d_x = ctx.to_device(img), ctx.to_device(_tile_major(cpols, nrows, n_const) if tiled_consts else cpols), ctx.to_device(x)
     for batch in (0, 1024, 64):
         ctx.set_chelpers_batch_rows(batch)
         q = ctx.to_device(np.full(nrows * 3 + 6, 0xABCD, dtype=np.uint64))
@@ -729,8 +732,8 @@ def test_native_step42ns_reads_tile_major_sections_in_place(tmp_path, tiled_secs
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lin_min,tiled_secs", [(None, (0, 1, 2)), (1, (0, 1, 2)), (1, (0, 2)), (1, (1,))])
-def test_native_step52ns_reads_tile_major_sections_in_place(tmp_path, lin_min, tiled_secs, monkeypatch):
+@pytest.mark.parametrize("lin_min,tiled_secs,tiled_consts", [(None, (0, 1, 2), False), (1, (0, 1, 2), False), (1, (0, 2), False), (1, (1,), False), (1, (0, 1, 2), True), (None, (0,), True)])
+def test_native_step52ns_reads_tile_major_sections_in_place(tmp_path, lin_min, tiled_secs, tiled_consts, monkeypatch):
     """... and step52ns, whose polynomial terms the linear kernel sums: out of tile-major sections it takes a lane's own row, out of
     row-major ones it turns a slab through LDS -- both in one program."""
     import mi_stark
@@ -749,11 +752,14 @@ def test_native_step52ns_reads_tile_major_sections_in_place(tmp_path, lin_min, t
     prog = mi_stark.ChelpersProgram(ctx, ops, args, sections=secs, n_const=n_const, nrows_ext=nrows, step=mi_stark.MI_CHELPERS_STEP52NS)
     for i in tiled_secs:
         prog.set_tiled_section(secs[i][0])
+    if tiled_consts:
+        prog.set_tiled_consts()
     prog.build_native(cache_dir=str(tmp_path), chunk_cost=1500)
     f = ctx.zeros(nrows * 3)
+    d_c = ctx.to_device(_tile_major(cpols, nrows, n_const) if tiled_consts else cpols)
     for batch in (2048, 0):
         ctx.set_chelpers_batch_rows(batch)
-        prog.run52(ctx.to_device(img), ctx.to_device(cpols), n_const, chal, evals, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
+        prog.run52(ctx.to_device(img), d_c, n_const, chal, evals, ctx.to_device(xd), ctx.to_device(xdw), f, 0, nrows)
         assert np.array_equal(ctx.to_host(f), want), batch
     prog.close()
     ctx.close()

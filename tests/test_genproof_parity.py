@@ -150,11 +150,12 @@ def test_starks_genproof_equals_the_oracle_prover_shaped_starks(name, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,layout", [("zkevm_small", {"MI_STARK_TILED_EXT": "0"}), ("recursive_12", {"MI_STARK_TILED_EXT": "0"}),
-                                         ("zkevm_14", {"MI_STARK_TILED_EXT": "0", "MI_STARK_TILED_WITNESS": "0"}), ("zkevm_small", {"MI_STARK_TILED_WITNESS": "0"})])
+                                         ("zkevm_14", {"MI_STARK_TILED_EXT": "0", "MI_STARK_TILED_WITNESS": "0", "MI_STARK_TILED_CONSTS": "0"}), ("zkevm_small", {"MI_STARK_TILED_WITNESS": "0"}),
+                                         ("recursive_small", {"MI_STARK_TILED_CONSTS": "0"})])
 def test_starks_genproof_with_a_row_major_image_equals_the_oracle_prover(name, layout, tmp_path):
-    """The image's layout is the device's own business (host/starks.hpp: the witness and the wide extended sections tile-major, the rows
-    of a tile bit-reversed): with either or both kept row-major (the switches a maintainer has; what a multi-device proof uses) the proof
-    is the same proof."""
+    """The image's layout is the device's own business (host/starks.hpp: the witness, the wide extended sections and the constants
+    tile-major, the rows of a tile bit-reversed): with any of them kept row-major (the switches a maintainer has; what a multi-device
+    proof uses) the proof is the same proof."""
     inputs, want = shaped_case(name)
     got, = sr.gen_proof_on_device(*inputs, workdir=str(tmp_path), batches=(4,), env=dict(os.environ, **layout))
     assert got == want, first_difference(got, want)
