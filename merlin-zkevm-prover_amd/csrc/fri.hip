@@ -394,7 +394,7 @@ int launch_evmap(mi_ctx *ctx, u64 *evals, uint64_t n_evals, uint64_t n_total, un
     if (n_rm)
         hipLaunchKernelGGL(k_evmap_partial, dim3((n_rm + 255) / 256, s_rm), dim3(256), 0, ctx->stream, p_rm, ddesc, n_rm, n_rm, row0 + nrows,
                            (uint32_t)ext_bits, rps_rm, lev, lpev, row0);
-    if (n_t1) { // (UR = 2: 164 VGPRs, three waves per SIMD, 23.0 ms at zkEVM size; UR = 4: 180 VGPRs, two waves, 27.2 ms)
+    if (n_t1) { // (CG x UR = 4 x 2: 164 VGPRs, three waves per SIMD, 22.4 ms at zkEVM size; 4 x 4: 180 VGPRs, two waves, 27.2; 3 x 2: 128 VGPRs, 21.6; 2 x 4: 100 VGPRs, 23.6)
         constexpr int CG = 4, UR = 2;
         hipLaunchKernelGGL((k_evmap_partial_tiled<CG, UR, false>), dim3((n_t1 + 4 * CG - 1) / (4 * CG), s_t), dim3(256), 0, ctx->stream, p_t0, ddesc, n_rm, n_t1,
                            n_t, row0 + nrows, (uint32_t)ext_bits, rps_t, lev, lpev, row0);
