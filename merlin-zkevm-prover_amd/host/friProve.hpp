@@ -22,7 +22,7 @@ public:
     {
         proveImpl(fproof, treesGL, transcript, &friPol, nullptr, polBits, starkInfo, nTrees);
     }
-    // the same with the FRI polynomial already in HBM (f_2ns as StarksDevice::step52ns leaves it: 2^polBits x 3, read only): no
+    // the same with the FRI polynomial already in HBM (f_2ns as step52ns leaves it in the image of host/starks.hpp: 2^polBits x 3, read only): no
     // upload, and nothing is written back but the proof
     static void prove(FRIProof &fproof, MerkleTreeGL **treesGL, Transcript transcript, const uint64_t *d_friPol, uint64_t polBits, StarkInfo starkInfo,
                       uint64_t nTrees = 5)

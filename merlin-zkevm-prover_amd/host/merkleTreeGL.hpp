@@ -74,7 +74,7 @@ public:
         d_source = dev_source;
         d_source_borrowed = true;
     }
-    // a tree that was built in HBM by someone else (StarksDevice): leaves and nodes borrowed, ready for getRoot / getGroupProofs
+    // a tree that was built in HBM by someone else (host/starks.hpp): leaves and nodes borrowed, ready for getRoot / getGroupProofs
     // tiled: the leaves' rows lie TILE-MAJOR ([height / 64][width][64], mi_lde_merkle_dev_tiled) -- the openings gather a row's values
     void setDeviceTree(uint64_t *dev_source, uint64_t *dev_nodes, bool tiled = false)
     {

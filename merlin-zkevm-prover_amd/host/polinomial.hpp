@@ -113,7 +113,7 @@ public:
 
     // polinomial.hpp:230-584 -- the plookup columns.  The reference has four bodies (map-based calculateH1H2 / calculateH1H2_, the
     // hash-table _opt1 for dim 1 and _opt3 for dim 3) that produce the same h1 / h2; all of them run on the GPU here.  Host views in
-    // and out (packed copies cross PCIe: with the polynomials already in HBM use mi_calculate_h1h2_dev / StarksDevice instead);
+    // and out (packed copies cross PCIe: with the polynomials already in HBM use mi_calculate_h1h2_dev instead, as host/starks.hpp does);
     // buffer / size_keys / size_values are the reference's hash-table scratch and are not used.  A value of f that t does not hold
     // ends the process with "number not included: w=<row>", like the reference.
     static void calculateH1H2(Polinomial &h1, Polinomial &h2, Polinomial &fPol, Polinomial &tPol)
