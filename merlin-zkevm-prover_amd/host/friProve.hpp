@@ -4,6 +4,7 @@
 // (stark_info.hpp:21-35); the proof container is friProof.hpp.
 #ifndef FRI_PROVE
 #define FRI_PROVE
+#include <utility>
 #include <vector>
 #include "transcript.hpp"
 #include "polinomial.hpp"
@@ -91,12 +92,13 @@ private:
                 }
                 for (uint64_t i = 0; i < ys.size(); i++) {
                     std::vector<MerkleProof> vMkProof;
+                    vMkProof.reserve(nTrees);
                     for (uint64_t t = 0; t < nTrees; t++) {
                         if (!treesGL[t]) continue;
                         const uint64_t stride = treesGL[t]->width + treesGL[t]->MerkleProofSize() * HASH_SIZE;
                         vMkProof.push_back(MerkleProof(treesGL[t]->width, treesGL[t]->MerkleProofSize(), &buffs[t][i * stride]));
                     }
-                    fproof.proofs.fri.trees[0].polQueries.push_back(vMkProof);
+                    fproof.proofs.fri.trees[0].polQueries.push_back(std::move(vMkProof)); // (moved: a MerkleProof holds one small vector per opened value, as the reference's does)
                 }
             } else {
                 MerkleTreeGL *t = treesFRIGL[si];
@@ -106,7 +108,7 @@ private:
                 for (uint64_t i = 0; i < ys.size(); i++) {
                     std::vector<MerkleProof> vMkProof;
                     vMkProof.push_back(MerkleProof(t->width, t->MerkleProofSize(), &buff[i * stride]));
-                    fproof.proofs.fri.trees[si].polQueries.push_back(vMkProof);
+                    fproof.proofs.fri.trees[si].polQueries.push_back(std::move(vMkProof)); // (moved: a MerkleProof holds one small vector per opened value, as the reference's does)
                 }
             }
             if (si < steps.size() - 1)
