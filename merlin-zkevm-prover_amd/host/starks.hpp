@@ -696,8 +696,16 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
     // (starks.cpp:133,214); a real starkinfo leaves none unwritten, but a map with a column no step stores into (the synthetic shapes
     // have them) must not commit what the PREVIOUS proof's stage-4 plan left there -- the region is scratch between proofs.  Zeros are
     // what the reference's calloc'ed pAddress holds in a column nothing writes (prover.cpp:113).  52 GB at zkEVM size: 17 ms of HBM
-    // writes on this stream, beside a stage 1 that is bound by the PCIe link.
-    mi::check(mi_dev_zero(c, sec(cm2_n), (off(cm1_2ns) - off(cm2_n)) * 8), "Starks::genProof (zero the computed base-domain sections)");
+    // writes on this stream, beside a stage 1 that is bound by the PCIe link -- queued where nothing waits for them: on one device that
+    // is after stage 1 has lent its scratch (lending synchronises the stream: queued here, STARK_INITIALIZATION was 8.8 ms of waiting for
+    // this fill), while the host packs the first chunk of the witness; with several devices here, ahead of the shards' buffers.
+    bool zeroed = false;
+    auto zeroComputed = [&]() {
+        if (zeroed) return;
+        mi::check(mi_dev_zero(c, sec(cm2_n), (off(cm1_2ns) - off(cm2_n)) * 8), "Starks::genProof (zero the computed base-domain sections)");
+        zeroed = true;
+    };
+    if (mi::multi()) zeroComputed();
     lend(nullptr, 0); // whatever the previous proof lent last (the tail of ITS stage-4 plan: inside what are live sections again now) is not this proof's
     mi::StarkMirror m;
     m.hostPols = mem; m.d_mem = d_mem; m.N = N; m.NExtended = NExtended; m.nBits = nBits; m.nBitsExt = nBitsExt;
@@ -843,7 +851,9 @@ inline void Starks::genProof(FRIProof &proof, Goldilocks::Element *publicInputs,
         commitSharded(0, (const uint64_t *)(mem + off(cm1_n)), -1, cols(cm1_n), sec(cm1_2ns), sec(cm1_n), stageScratch(1), root0.address());
     } else {
         const Scratch scr = stageScratch(1);
+        if (scr.rezero) zeroComputed(); // (the scratch IS part of those sections: zeros first, and again when the stage is done)
         lend(scr.p, scr.elems);
+        zeroComputed();
         if (m.tiledExt[0])
             mi::check(mi_lde_merkle_host_tiled(c, d_nodes[0], sec(cm1_2ns), sec(cm1_n), m.tiledWitness ? 0 : cols(cm1_n), (const uint64_t *)(mem + off(cm1_n)), N, NExtended,
                                                cols(cm1_n), 0), "Starks::genProof (stage 1: extendPol + merkelize)");
